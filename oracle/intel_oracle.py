@@ -1,0 +1,384 @@
+"""CPU oracle for the IntEL hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A functional PyTorch (CPU, fp32/fp64) restatement of the reference's per-session forward,
+its BPR / Plackett-Luce / intent losses and its NDCG evaluation.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this file; the
+product (``intel_sigir2023_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity is PINNED: ``tests/test_oracle_golden.py`` checks every function here against the
+fixtures in ``tests/golden/*.npz`` that ``tests/golden/make_golden.py`` produced by running
+the reference itself (/root/reference, imported unmodified) in the build container.
+
+Each function cites the reference lines it restates (paths relative to
+/root/reference/IntEL/src).  Parameters are taken from a plain ``state_dict``-style mapping
+``sd`` whose keys are the reference's (``models/IntEL/IntEL.py:36-115``).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------
+# configuration
+# ----------------------------------------------------------------------------------------
+class Config(object):
+    """The subset of CLI flags the hot path depends on (models/IntEL/IntEL.py:17-34)."""
+
+    def __init__(self, **kw):
+        self.model_num = 3
+        self.history_max = 20
+        self.encoder = 'BERT4Rec'
+        self.context_emb_size = 16
+        self.i_emb_size = 16
+        self.u_emb_size = 32
+        self.s_emb_size = 32
+        self.im_emb_size = 16
+        self.intent_emb_size = 16
+        self.cross_attn_qsize = 32
+        self.num_heads = 1
+        self.num_layers = 1
+        self.cross_attention = 1
+        self.dropout = 0.0
+        # loss flags (loss/Baseloss.py:9-12, loss/BaseIntloss.py:13-20)
+        self.intent_weight = 0.1
+        self.ensemble_weight = 1.0
+        self.kl_temp = 2.0
+        self.kl_weight = 0.5
+        self.cal_diversity = 0
+        self.diversity_alpha = 0.01
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _lin(x, sd, name, bias=True):
+    b = sd.get(name + '.bias') if bias else None
+    return F.linear(x, sd[name + '.weight'], b)
+
+
+# ----------------------------------------------------------------------------------------
+# attention blocks
+# ----------------------------------------------------------------------------------------
+def mha(x, sd, prefix, heads, key_mask=None):
+    """modules/layers.py:31-60.  No output projection; softmax over keys after subtracting the
+    tensor-global max (a no-op unless a row sits ~88 below it); all-masked rows -> 0."""
+    B, T, D = x.shape
+    dk = D // heads
+
+    def split(t):
+        return t.view(B, T, heads, dk).transpose(1, 2)
+    q = split(_lin(x, sd, prefix + '.q_linear'))
+    k = split(_lin(x, sd, prefix + '.k_linear'))
+    v = split(_lin(x, sd, prefix + '.v_linear'))
+    s = torch.matmul(q, k.transpose(-1, -2)) / dk ** 0.5
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, :], float('-inf'))
+    p = torch.softmax(s - s.max(), dim=-1)
+    p = torch.where(torch.isnan(p), torch.zeros_like(p), p)
+    o = torch.matmul(p, v)
+    return o.transpose(1, 2).reshape(B, T, D)
+
+
+def tied_tower(h, sd, attn, w1, w2, ln, heads, layers):
+    """models/IntEL/IntEL.py:182-188 / 191-197: the SAME weights are applied ``layers`` times,
+    attention is unmasked (padded rows act as keys and queries)."""
+    for _ in range(layers):
+        res = h
+        h = mha(h, sd, attn, heads)
+        h = _lin(h, sd, w1)
+        h = _lin(torch.relu(h), sd, w2)
+        h = F.layer_norm(h + res, (h.shape[-1],), sd[ln + '.weight'], sd[ln + '.bias'], 1e-5)
+    return h
+
+
+def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2):
+    """models/GeneralSeq.py:89-106 with modules/layers.py:82-88 blocks (bias=True, d_ff=d_model)."""
+    B, T, D = seq.shape
+    ar = torch.arange(T)
+    valid = ar[None, :] < lengths[:, None]
+    pos = ar[None, :] * valid.long()                      # pads -> position 0
+    x = seq + sd[prefix + '.p_embeddings.weight'][pos]
+    for l in range(layers):
+        p = '%s.transformer_block.%d' % (prefix, l)
+        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid)
+        ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
+        y = _lin(torch.relu(_lin(ctx, sd, p + '.linear1')), sd, p + '.linear2')
+        x = F.layer_norm(y + ctx, (D,), sd[p + '.layer_norm2.weight'], sd[p + '.layer_norm2.bias'], 1e-5)
+    x = x * valid[:, :, None].float()
+    return x[torch.arange(B), lengths - 1]
+
+
+def gru4rec(seq, lengths, sd, prefix):
+    """models/GeneralSeq.py:64-78: one-layer GRU (gate order r,z,n as torch.nn.GRU), hidden state
+    after each session's own last step, then a bias-free projection."""
+    B, T, D = seq.shape
+    w_ih, w_hh = sd[prefix + '.rnn.weight_ih_l0'], sd[prefix + '.rnn.weight_hh_l0']
+    b_ih, b_hh = sd[prefix + '.rnn.bias_ih_l0'], sd[prefix + '.rnn.bias_hh_l0']
+    Hd = w_hh.shape[1]
+    h = seq.new_zeros(B, Hd)
+    for t in range(T):
+        gi = F.linear(seq[:, t], w_ih, b_ih)
+        gh = F.linear(h, w_hh, b_hh)
+        r = torch.sigmoid(gi[:, :Hd] + gh[:, :Hd])
+        z = torch.sigmoid(gi[:, Hd:2 * Hd] + gh[:, Hd:2 * Hd])
+        n = torch.tanh(gi[:, 2 * Hd:] + r * gh[:, 2 * Hd:])
+        hn = (1 - z) * n + z * h
+        live = (t < lengths)[:, None]
+        h = torch.where(live, hn, h)
+    return F.linear(h, sd[prefix + '.out.weight'])
+
+
+def single_query_pool(intent, h, valid, sd, prefix, scale):
+    """modules/attention.py:149-161 + 48-63 as called from IntEL.py:201-204.  The query has one
+    row, the mask is [B,L,L]; every VALID row therefore receives the same pooled vector and every
+    padded row receives 0.  The row max is taken over ALL L positions before
+    masking (attention.py:57)."""
+    q = F.linear(intent, sd[prefix + '.query_layer.weight'])            # [B,a]
+    k = F.linear(h, sd[prefix + '.key_layer.weight'])                    # [B,L,a]
+    v = F.linear(h, sd[prefix + '.value_layer.weight'])                  # [B,L,v]
+    att = torch.einsum('ba,bla->bl', q, k) * scale
+    att = att - att.max(dim=-1, keepdim=True)[0]
+    att = att.masked_fill(~valid, float('-inf'))
+    w = torch.softmax(att, dim=-1)
+    w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
+    pooled = torch.einsum('bl,blv->bv', w, v)                            # [B,v]
+    return pooled[:, None, :] * valid[:, :, None].float()
+
+
+# ----------------------------------------------------------------------------------------
+# forward
+# ----------------------------------------------------------------------------------------
+def predict_intent(sd, data, cfg):
+    """models/IntEL/IntEL.py:126-155."""
+    his = torch.cat([sd['context_embeddings.weight'][data['his_context_mh']],
+                     _lin(data['his_intents'].float(), sd, 'intent_embeddings')], dim=-1)
+    his_item = torch.cat([sd['iid_embeddings.weight'][data['his_item_id']],
+                          _lin(data['his_item_int'].float(), sd, 'intent_embeddings')], dim=-1)
+    if cfg.encoder == 'BERT4Rec':
+        hv = bert4rec(his, data['history_len'], sd, 'encoder')
+        hiv = bert4rec(his_item, data['history_item_len'], sd, 'item_encoder')
+    elif cfg.encoder == 'GRU4Rec':
+        hv = gru4rec(his, data['history_len'], sd, 'encoder')
+        hiv = gru4rec(his_item, data['history_item_len'], sd, 'item_encoder')
+    else:
+        raise ValueError('Invalid sequence encoder.')
+    cur = torch.cat([sd['context_embeddings.weight'][data['context_mh']],
+                     sd['uid_embeddings.weight'][data['u_id_c']]], dim=-1)
+    logits = _lin(torch.cat([cur, hiv, hv], dim=-1), sd, 'pred_layer')
+    return torch.softmax(logits, dim=-1)
+
+
+def predict_ensemble(sd, data, intent, cfg):
+    """models/IntEL/IntEL.py:158-217."""
+    scores = data['scores'].float()
+    B, L, K = scores.shape
+    valid = torch.arange(L)[None, :] < data['session_len'][:, None]
+    h_i = torch.cat([sd['iid_embeddings.weight'][data['i_id_s']],
+                     sd['item_embeddings.weight'][data['i_class_c']]], dim=-1)
+    h_u = torch.relu(sd['uid_embeddings.weight'][data['u_id_c']])[:, None, :].expand(B, L, -1)
+    h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers)
+    h_s = _lin(scores, sd, 'score_embeddings')
+    h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers)
+    if cfg.cross_attention:
+        scale = 1.0 / math.sqrt(cfg.cross_attn_qsize)
+        item_x = single_query_pool(intent, h_i, valid, sd, 'intent_item_attention', scale)
+        score_x = single_query_pool(intent, h_s, valid, sd, 'intent_score_attention', scale)
+    else:
+        def mlp(p):
+            t = torch.relu(_lin(intent, sd, p + '.0'))
+            return F.linear(t, sd[p + '.2.weight'])
+        item_x = h_i * mlp('intent_item_embeddings')[:, None, :]
+        score_x = h_s * mlp('intent_score_embeddings')[:, None, :]
+    h_int = torch.relu(_lin(intent, sd, 'intent_embeddings'))[:, None, :].expand(B, L, -1)
+    feat = torch.cat([item_x, score_x, h_u, h_int], dim=-1)
+    weights = _lin(feat, sd, 'weight_embeddings')            # NO softmax (IntEL.py:214)
+    ens = (weights * scores).sum(-1)
+    return weights, ens
+
+
+def forward(sd, data, cfg):
+    """models/IntEL/IntEL.py:117-124."""
+    intent = predict_intent(sd, data, cfg)
+    weights, ens = predict_ensemble(sd, data, intent, cfg)
+    return {'weights': weights, 'ens_score': ens, 'intents': intent}
+
+
+# ----------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------
+def _pair_setup(ens, ranking, session_len):
+    L = ens.shape[1]
+    valid = torch.arange(L)[None, :] < session_len[:, None]
+    vv = valid[:, :, None] & valid[:, None, :]
+    r = ranking.clamp(min=0)
+    z = ens[:, :, None] - ens[:, None, :]
+    return vv, r, z
+
+
+def bpr_select(ranking, session_len, noise):
+    """loss/BPRloss.py:20-30: index of the sampled negative for every row; candidates are the
+    valid items of the closest lower rank tier, ties broken by ``noise/10``; a row without any
+    lower-ranked valid item picks argmax(noise) over ALL L columns."""
+    L = ranking.shape[1]
+    valid = torch.arange(L)[None, :] < session_len[:, None]
+    vv = (valid[:, :, None] & valid[:, None, :]).long()
+    r = ranking.clamp(min=0)
+    D = (r[:, :, None] - r[:, None, :]) * vv
+    sim = (D.max() + 1 - D) * (D > 0)
+    best = sim.max(dim=-1, keepdim=True)[0]
+    cand = ((sim == best) & (D > 0)).int()
+    return (cand + noise / 10).argmax(dim=-1)
+
+
+def bpr_loss(ens, ranking, session_len, noise, scores=None, weights=None, cal_diversity=0, alpha=0.01):
+    """loss/BPRloss.py:37-56 (+ diversity :12-18, float64 base-score differences)."""
+    vv, r, z = _pair_setup(ens, ranking, session_len)
+    sel = bpr_select(ranking, session_len, noise)
+    pos = (r > 0)
+    npos = pos.sum(-1)
+    zs = torch.gather(z, 2, sel[:, :, None]).squeeze(2)
+    loss = ((-torch.log(torch.sigmoid(zs)) * pos).sum(-1) / npos).mean()
+    if cal_diversity:
+        sg = torch.sigmoid(zs)
+        sig = sg * (1 - sg)
+        bsel = torch.gather(scores, 1, sel[:, :, None].expand(-1, -1, scores.shape[2]))
+        bd = scores - bsel                                              # float64 [B,L,K]
+        zd = sig[:, :, None] * (bd - zs[:, :, None]) ** 2
+        A = (zd * weights).sum(-1) * pos
+        div = -(A.sum(-1) / npos).mean()
+        loss = (loss.double() + div * alpha).float()     # in-place += keeps float32 (BPRloss.py:54)
+    return loss
+
+
+def list_loss(ens, ranking, session_len, scores=None, weights=None, cal_diversity=0, alpha=0.01):
+    """loss/Listloss.py:25-43 (+ diversity :17-23).  No max-subtraction in the exponent."""
+    vv, r, z = _pair_setup(ens, ranking, session_len)
+    M = (r[:, :, None] > r[:, None, :]) & vv
+    pos = (r > 0)
+    npos = pos.sum(-1)
+    e = torch.exp(-z) * M
+    loss = (((e.sum(2) + 1) * pos).clamp(min=1).log().sum(1) / npos).mean()
+    if cal_diversity:
+        bd = scores[:, :, None, :] - scores[:, None, :, :]             # float64 [B,L,L,K]
+        ez = torch.exp(-z)
+        up = ((ez[..., None] * (bd - z[..., None]) * M[..., None]).sum(2)) ** 2
+        Aw = (weights * up).sum(-1)
+        bo = 2 * (1 + (ez * M).sum(2)) ** 2
+        div = -((Aw / bo * pos).sum(-1) / npos).mean()
+        loss = (loss.double() + div * alpha).float()     # in-place += keeps float32 (Listloss.py:41)
+    return loss
+
+
+def intent_loss(pred, label, kl_weight=0.5, kl_temp=2.0):
+    """loss/BaseIntloss.py:30-67.  ``label`` float64; CE uses the float64 label, KL the float32
+    cast; per-class weights are all ones."""
+    if float(pred.min()) == 0.0:
+        soft = pred + 1e-6
+        soft = soft / soft.sum(-1, keepdim=True)
+    else:
+        soft = pred
+    ce = -(((label > 0) * label * soft.log()) + ((label == 0) * (1 - soft).log())).sum(-1).mean()
+    lab32 = label.float()
+    kl_el = torch.where(lab32 > 0, lab32 * (lab32.log() - soft.log()), torch.zeros_like(lab32))
+    kl = kl_el.double().sum(-1).mean() * kl_temp * kl_temp
+    return ce * (1 - kl_weight) + kl * kl_weight, ce, kl
+
+
+def int_bpr_loss(out, batch, cfg, noise):
+    """loss/IntBPRloss.py:15-20."""
+    il, _, _ = intent_loss(out['intents'], batch['intents'], cfg.kl_weight, cfg.kl_temp)
+    el = bpr_loss(out['ens_score'], batch['ranking'], batch['session_len'], noise,
+                  batch['scores'], out['weights'], cfg.cal_diversity, cfg.diversity_alpha)
+    return el * cfg.ensemble_weight + il * cfg.intent_weight, el, il
+
+
+def int_list_loss(out, batch, cfg):
+    """loss/IntListloss.py:14-19."""
+    il, _, _ = intent_loss(out['intents'], batch['intents'], cfg.kl_weight, cfg.kl_temp)
+    el = list_loss(out['ens_score'], batch['ranking'], batch['session_len'],
+                   batch['scores'], out['weights'], cfg.cal_diversity, cfg.diversity_alpha)
+    return el * cfg.ensemble_weight + il * cfg.intent_weight, el, il
+
+
+# ----------------------------------------------------------------------------------------
+# optimizer semantics
+# ----------------------------------------------------------------------------------------
+def adam_groups(named_params, l2):
+    """models/BaseModel.py:53-62 + helpers/BaseRunner.py:182-188: names containing 'bias' get no
+    weight decay, everything else (LayerNorm weights and embedding tables included) gets ``l2``."""
+    decay, no_decay = [], []
+    for name, p in named_params:
+        (no_decay if 'bias' in name else decay).append(p)
+    return [{'params': decay, 'weight_decay': l2}, {'params': no_decay, 'weight_decay': 0.0}]
+
+
+# ----------------------------------------------------------------------------------------
+# evaluation
+# ----------------------------------------------------------------------------------------
+def evaluate_method(prediction_scores, ranking_lists, pos_nums, topk, metrics, session_len):
+    """helpers/BaseRunner.py:56-131 in numpy: pad predictions with 0 and labels with -2 (->0) up to
+    max(max(session_len), max(topk)); stable pre-sort by label; per-behaviour HR/NDCG with binary
+    gains over 'the first all_pos columns'; overall NDCG@k with LINEAR gains (3/2/1/0)."""
+    n = min(len(session_len), len(prediction_scores))
+    session_len = np.asarray(session_len[:n])
+    pos_nums = {k: np.asarray(v[:n]) for k, v in pos_nums.items()}
+    width = int(max(session_len.max(), max(topk)))
+    P = np.zeros((n, width), dtype=np.float64)
+    R = np.full((n, width), -2, dtype=np.int64)
+    for i in range(n):
+        m = min(int(session_len[i]), len(prediction_scores[i]))
+        P[i, :m] = np.asarray(prediction_scores[i][:m], dtype=np.float64)
+        m2 = min(int(session_len[i]), len(ranking_lists[i]))
+        R[i, :m2] = np.asarray(ranking_lists[i][:m2])
+    order = np.argsort(R, axis=1)[:, ::-1]
+    rows = np.arange(n)[:, None]
+    R = R[rows, order]
+    P = P[rows, order]
+    R[R < 0] = 0
+    asc = P.argsort(axis=1)
+    disc = 1.0 / np.log2(np.arange(width) + 2.0)
+    res = {}
+    total_pos = np.sum(np.array(list(pos_nums.values())), axis=0).reshape(-1, 1)
+    for btype, cnt in pos_nums.items():
+        beh = btype.split('_')[1].split('num')[0]
+        allp = total_pos if 'click' in btype else cnt.reshape(-1, 1)
+        hitmat = asc < allp
+        keep = np.nonzero(allp[:, 0] > 0)[0]
+        hitmat, allp_k = hitmat[keep], allp[keep]
+        for k in topk:
+            kk = min(k, width)
+            for metric in metrics:
+                key = '%s_%s@%d' % (beh, metric, k)
+                if metric == 'HR':
+                    res[key] = (hitmat[:, -kk:].sum(1) > 0).mean()
+                elif metric == 'NDCG':
+                    if k == 1:
+                        continue
+                    dcg = (hitmat[:, -kk:] * disc[:kk][::-1]).sum(1)
+                    ideal = (np.arange(kk).reshape(1, -1) < allp_k)
+                    idcg = (ideal * disc[:kk]).sum(1)
+                    res[key] = (dcg / idcg).mean()
+                else:
+                    raise ValueError('Undefined evaluation metric: {}.'.format(metric))
+    desc = np.argsort(P, axis=1)[:, ::-1]
+    Rs = R[rows, desc]
+    Rp = np.sort(R, axis=1)[:, ::-1]
+    for k in topk:
+        dcg = (Rs[:, :k] * disc[:k]).sum(1)
+        idcg = (Rp[:, :k] * disc[:k]).sum(1)
+        res['NDCG@%d' % k] = (dcg / idcg).mean()
+    return res
+
+
+def ndcg_at_k(ens_score, ranking, session_len, k=3):
+    """The overall ``NDCG@k`` key of evaluate_method for a padded [B,L] batch (numpy in/out)."""
+    B = ens_score.shape[0]
+    preds = [np.asarray(ens_score[i]) for i in range(B)]
+    ranks = [np.asarray(ranking[i]) for i in range(B)]
+    pos = {'c_x_i': np.ones(B, dtype=np.int64)}
+    # evaluate_method's overall NDCG does not depend on pos_nums; reuse its padding/sorting path
+    out = evaluate_method(preds, ranks, {'c_clicknum_i': np.ones(B, dtype=np.int64)}, [k], [],
+                          np.asarray(session_len))
+    del pos
+    return out['NDCG@%d' % k]
