@@ -1,0 +1,213 @@
+/*
+ * intel_hip.h -- C ABI of the MI355X-native IntEL hot path (libintel_hip.so).
+ *
+ * The reference (JiayuLi-997/IntEL-SIGIR2023) is pure Python and has no FFI: its extension point
+ * is class lookup by name (IntEL/src/main.py:127-130).  This header is therefore the boundary a
+ * maintainer binds from Python with ctypes; every entry point cites the
+ * reference code it replaces (paths relative to IntEL/src).
+ *
+ * Conventions
+ *   - plain C: device pointers are passed as void* / typed pointers, sizes as int / long long,
+ *     the HIP stream as void* (hipStream_t); no torch types.
+ *   - all tensors are dense row-major; float = fp32, ids/lengths = int32.
+ *   - every function returns 0 on success, a negative INTEL_E_* code or a positive hipError_t
+ *     otherwise; intel_last_error() returns a message for the calling thread.
+ *   - nothing here allocates device memory or synchronises: the caller provides a workspace of
+ *     intel_workspace_bytes() bytes and owns all ordering through the stream (graph-capturable).
+ */
+#ifndef INTEL_HIP_H
+#define INTEL_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define INTEL_ABI_VERSION 1
+
+enum {
+  INTEL_OK = 0,
+  INTEL_E_ARG = -1,        /* bad argument / unsupported shape */
+  INTEL_E_WORKSPACE = -2,  /* workspace too small */
+  INTEL_E_STATE = -3       /* backward without a matching training forward */
+};
+
+enum { INTEL_ENC_BERT4REC = 0, INTEL_ENC_GRU4REC = 1 };
+
+/* Model hyper-parameters: the flags of IntEL.parse_model_args (models/IntEL/IntEL.py:17-34),
+ * GeneralSeq (models/GeneralSeq.py:15-17) and the corpus sizes read in IntEL.__init__ (:36-115). */
+typedef struct IntelDesc {
+  int model_num;        /* K  --model_num                     */
+  int intent_num;       /* I  len(corpus.zero_int)            */
+  int item_num;         /* rows of iid_embeddings             */
+  int class_num;        /* rows of item_embeddings (itemfnum) */
+  int user_num;         /* rows of uid_embeddings             */
+  int ctx_num;          /* rows of context_embeddings         */
+  int d_id, d_im, d_u, d_s, d_c, d_int; /* --i/im/u/s/context/intent_emb_size */
+  int q_size;           /* --cross_attn_qsize                 */
+  int heads, layers;    /* --num_heads / --num_layers (tied)  */
+  int cross_attention;  /* --cross_attention                  */
+  int encoder;          /* INTEL_ENC_*                        */
+  int history_max;      /* --history_max                      */
+  int enc_layers, enc_heads; /* BERT4Rec: hard-coded 2/2 (IntEL.py:108-109) */
+  int gru_hidden;       /* GRU4Rec: hard-coded 128 (IntEL.py:105-106)       */
+} IntelDesc;
+
+/* Parameter slots.  Each maps 1:1 to a reference state_dict key.  The arrays
+ * passed as `params` / `grads` have INTEL_P_COUNT entries; unused slots are NULL. */
+enum IntelParam {
+  INTEL_P_IID_EMB = 0,   /* iid_embeddings.weight      [item_num, d_id]  */
+  INTEL_P_ITEM_EMB,      /* item_embeddings.weight     [class_num, d_im] */
+  INTEL_P_UID_EMB,       /* uid_embeddings.weight      [user_num, d_u]   */
+  INTEL_P_CTX_EMB,       /* context_embeddings.weight  [ctx_num, d_c]    */
+  INTEL_P_INTENT_W,      /* intent_embeddings.weight   [d_int, I]        */
+  INTEL_P_INTENT_B,      /* intent_embeddings.bias     [d_int]           */
+  INTEL_P_SCORE_W,       /* score_embeddings.weight    [d_s, K]          */
+  INTEL_P_SCORE_B,
+  /* item tower: i_attn_head.{q,k,v}_linear.weight, i_W1, i_W2, i_layer_norm */
+  INTEL_P_I_WQ, INTEL_P_I_WK, INTEL_P_I_WV, INTEL_P_I_W1, INTEL_P_I_B1, INTEL_P_I_W2, INTEL_P_I_B2,
+  INTEL_P_I_LNG, INTEL_P_I_LNB,
+  /* score tower: s_* */
+  INTEL_P_S_WQ, INTEL_P_S_WK, INTEL_P_S_WV, INTEL_P_S_W1, INTEL_P_S_B1, INTEL_P_S_W2, INTEL_P_S_B2,
+  INTEL_P_S_LNG, INTEL_P_S_LNB,
+  /* cross attention: intent_{item,score}_attention.{query,key,value}_layer.weight */
+  INTEL_P_XI_WQ, INTEL_P_XI_WK, INTEL_P_XI_WV,
+  INTEL_P_XS_WQ, INTEL_P_XS_WK, INTEL_P_XS_WV,
+  /* --cross_attention 0: intent_{item,score}_embeddings.{0.weight,0.bias,2.weight} */
+  INTEL_P_MI_W0, INTEL_P_MI_B0, INTEL_P_MI_W2,
+  INTEL_P_MS_W0, INTEL_P_MS_B0, INTEL_P_MS_W2,
+  INTEL_P_WE_W, INTEL_P_WE_B,     /* weight_embeddings */
+  INTEL_P_PRED_W, INTEL_P_PRED_B, /* pred_layer        */
+  /* sequence encoders: slot = INTEL_P_ENC0 + e*INTEL_ENC_STRIDE + offset, e = 0 ("encoder"),
+   * 1 ("item_encoder").  BERT4Rec: POS then per block l: INTEL_ENC_BLOCK0 + l*INTEL_ENC_BLOCK_STRIDE
+   * + {WQ,BQ,WK,BK,WV,BV,LN1G,LN1B,W1,B1,W2,B2,LN2G,LN2B}.  GRU4Rec: WIH,WHH,BIH,BHH,OUT. */
+  INTEL_P_ENC0
+};
+enum {
+  INTEL_ENC_POS = 0,
+  INTEL_ENC_GRU_WIH = 1, INTEL_ENC_GRU_WHH, INTEL_ENC_GRU_BIH, INTEL_ENC_GRU_BHH, INTEL_ENC_GRU_OUT,
+  INTEL_ENC_BLOCK0 = 6,
+  INTEL_ENC_WQ = 0, INTEL_ENC_BQ, INTEL_ENC_WK, INTEL_ENC_BK, INTEL_ENC_WV, INTEL_ENC_BV,
+  INTEL_ENC_LN1G, INTEL_ENC_LN1B, INTEL_ENC_W1, INTEL_ENC_B1, INTEL_ENC_W2, INTEL_ENC_B2,
+  INTEL_ENC_LN2G, INTEL_ENC_LN2B,
+  INTEL_ENC_BLOCK_STRIDE = 14,
+  INTEL_ENC_MAX_BLOCKS = 4,
+  INTEL_ENC_STRIDE = 6 + 14 * 4,
+  INTEL_P_COUNT = INTEL_P_ENC0 + 2 * (6 + 14 * 4)
+};
+
+/* One collated batch: the tensors of BaseModel.Dataset.collate_batch (models/BaseModel.py:121-142)
+ * that IntEL.forward reads (IntEL.py:126-217), ids narrowed to int32 and scores to fp32 by the host.
+ * L / H / Hi are the PADDED lengths of this batch (pad rows are real rows: SURVEY.md §0.5). */
+typedef struct IntelBatch {
+  int B, L, H, Hi;
+  const int* i_id_s;            /* [B,L]            */
+  const int* i_class_c;         /* [B,L]            */
+  const float* scores;          /* [B,L,K]          */
+  const int* session_len;       /* [B]              */
+  const int* u_id_c;            /* [B]              */
+  const int* context_mh;        /* [B]              */
+  const int* his_context_mh;    /* [B,H]            */
+  const float* his_intents;     /* [B,H,I]          */
+  const int* history_len;       /* [B]              */
+  const int* his_item_id;       /* [B,Hi]           */
+  const int* his_item_idx;      /* [B,Hi] intent index of each history item, -1 = all-zero row;
+                                   NULL when his_item_int is given                       */
+  const float* his_item_int;    /* [B,Hi,I] dense form (reference layout) or NULL        */
+  const int* history_item_len;  /* [B]              */
+} IntelBatch;
+
+/* Outputs of IntEL.forward (IntEL.py:117-124). */
+typedef struct IntelOut {
+  float* weights;    /* [B,L,K] */
+  float* ens_score;  /* [B,L]   */
+  float* intents;    /* [B,I]   */
+} IntelOut;
+
+typedef struct IntelCtx IntelCtx;
+
+const char* intel_last_error(void);
+int intel_abi_version(void);
+
+/* Context = desc + host-side plan.  Holds no device memory. */
+IntelCtx* intel_create(const IntelDesc* desc);
+void intel_destroy(IntelCtx* ctx);
+
+/* Bytes of workspace intel_forward/intel_backward need for a batch of this shape.  `train` != 0
+ * also reserves the activation stash the backward pass reads. */
+size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train);
+
+/* IntEL.forward (IntEL.py:117-124) = predict_intent (:126-155) + predict_ensemble (:158-217). */
+int intel_forward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                  size_t workspace_bytes, const IntelOut* out, int train, void* stream);
+
+/* loss.backward() for the model part (helpers/BaseRunner.py:288): given d(loss)/d(out) computes
+ * d(loss)/d(param) for every parameter.  `grads[slot]` must be zero-initialised for the embedding
+ * tables (row grads are accumulated with atomics) -- all other slots are overwritten.  Must follow
+ * an intel_forward(train=1) on the same ctx / batch / workspace. */
+int intel_backward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                   size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                   const float* d_intents, void* const* grads, void* stream);
+
+/* ---- losses ------------------------------------------------------------------------------- */
+/* BPRloss.forward (loss/BPRloss.py:37-56) incl. bpr_loss (:20-34) and diversity (:12-18).
+ *   noise [B,L,L] replaces torch.rand_like (BPRloss.py:26); scores_f64 may be NULL (then scores_f32
+ *   is used for the diversity term).  Outputs: loss[1] (fp32), select[B,L] (int32).  When d_ens /
+ *   d_weights are non-NULL the gradients of `loss * grad_scale` are written too. */
+int intel_bpr_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                   const float* noise, const double* scores_f64, const float* scores_f32,
+                   const float* weights, int cal_diversity, double alpha, float grad_scale,
+                   float* loss, int* select, float* d_ens, float* d_weights, void* workspace,
+                   size_t workspace_bytes, void* stream);
+/* Listloss.forward (loss/Listloss.py:25-43) incl. list_loss (:12-15) and diversity (:17-23). */
+int intel_list_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                    const double* scores_f64, const float* scores_f32, const float* weights,
+                    int cal_diversity, double alpha, float grad_scale, float* loss, float* d_ens,
+                    float* d_weights, void* workspace, size_t workspace_bytes, void* stream);
+/* BaseIntloss.get_intloss (loss/BaseIntloss.py:57-67): out3 = {intent_loss, ce, kl} (fp64);
+ * d_pred (optional) = grad_scale * d(intent_loss)/d(pred). */
+int intel_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
+                      float grad_scale, double* out3, float* d_pred, void* workspace, size_t workspace_bytes,
+                      void* stream);
+size_t intel_loss_workspace_bytes(int B, int L, int K);
+
+/* ---- optimizer ---------------------------------------------------------------------------- */
+/* torch.optim.Adam.step as configured by BaseRunner._build_optimizer (helpers/BaseRunner.py:182-188)
+ * with the groups of BaseModel.customize_parameters (models/BaseModel.py:53-62): coupled L2
+ * (g += wd*p), bias-corrected moments, dense over all n elements.  zero_grad != 0 also clears g. */
+int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* ---- evaluation --------------------------------------------------------------------------- */
+/* Overall NDCG@k of BaseRunner.evaluate_method (helpers/BaseRunner.py:117-126) for a padded batch:
+ * ndcg[b] per session (linear gains, pads scored 0 / labelled 0, width = max(L, k)). */
+int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
+               float* ndcg, void* stream);
+
+/* ---- building blocks (exported for unit tests; see tests/test_ops_gpu.py) ------------------ */
+/* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (relu) -- torch.nn.Linear. */
+int intel_op_linear(const float* x, int M, int K, const float* w, int N, const float* bias, int relu,
+                    float* y, void* workspace, size_t workspace_bytes, void* stream);
+/* dx[M,K] = dy[M,N] @ w[N,K]. */
+int intel_op_linear_dgrad(const float* dy, int M, int N, const float* w, int K, float* dx, void* workspace,
+                          size_t workspace_bytes, void* stream);
+/* dw[N,K] = dy^T x, db[N] = colsum(dy) (db may be NULL). */
+int intel_op_linear_wgrad(const float* dy, const float* x, int M, int N, int K, float* dw, float* db,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* softmax(QK^T/sqrt(dk)) V per (session, head) on a packed [B*T, 3*d] QKV buffer
+ * (modules/layers.py:50-60); key_len NULL = all T rows are keys. */
+int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,
+                       float* lse, void* stream);
+int intel_op_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, int B,
+                           int T, int d, int heads, const int* key_len, float* d_qkv, float* dsum_ws,
+                           void* stream);
+/* y = LayerNorm(x + r) (r may be NULL), eps 1e-5; xhat/rstd optional stash. */
+int intel_op_add_layernorm(const float* x, const float* r, int M, int N, const float* gamma, const float* beta,
+                           float* y, float* xhat, float* rstd, void* stream);
+size_t intel_op_workspace_bytes(int M, int N, int K);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INTEL_HIP_H */

@@ -1,0 +1,72 @@
+"""Builds libintel_hip.so (the C-ABI library of include/intel_hip.h) in-tree with hipcc for gfx950.
+
+No torch headers are involved: the library is plain HIP + extern "C", bound from Python with ctypes
+(intel_sigir2023_amd/_lib.py).  hipcc cross-compiles without a GPU.
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB = os.path.join(HERE, 'libintel_hip.so')
+OBJ = os.path.join(HERE, 'build')
+ARCH = 'gfx950'
+FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError('hipcc not found (need ROCm with gfx950 support)')
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.cpp')))
+
+
+def _stamp():
+    h = hashlib.sha256()
+    files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    files.append(os.path.join(HERE, '..', 'include', 'intel_hip.h'))
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode())
+            h.update(fh.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=False):
+    """Compile every csrc/*.hip|*.cpp and link libintel_hip.so.  Returns the library path."""
+    stamp_file = os.path.join(OBJ, 'stamp')
+    stamp = _stamp()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, os.path.basename(src) + '.o')
+        cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    r = subprocess.run([hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    with open(stamp_file, 'w') as fh:
+        fh.write(stamp)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,390 @@
+// Per-(session, head) softmax attention, forward and backward, fp32 MFMA (gfx950).
+//
+// Restates modules/layers.py:50-60 (scaled_dot_product_attention) for
+//   - the item / score towers: NO mask, padded rows are keys and queries (IntEL.py:184,193),
+//   - the BERT4Rec blocks: key mask j < history_len (models/GeneralSeq.py:100).
+// The reference's "minus tensor-global max" (layers.py:57) is a mathematical no-op and is not
+// reproduced; rows with no valid key give 0 (NaN->0, layers.py:58).
+//
+// Layout: one packed activation buffer qkv[B*T, 3d] = [q | k | v] per row (the fused QKV GEMM's
+// output); head h owns columns h*dk..(h+1)*dk-1 of each third.
+//
+// Forward (flash-style, one workgroup = 64 queries of one (session, head), wave = 16 queries):
+//   S^T = K Q^T is computed with the KEY on the accumulator rows and the QUERY on the lane, so the
+//   probabilities sit in registers exactly in the B-operand layout of the following O^T = V^T P^T
+//   product: no LDS round trip for P (cdna guide §3 "accumulator tile as the next operand").
+// Backward = two kernels with the same structure (S and dP are recomputed from the saved
+//   log-sum-exp): attn_bwd_dq (wave owns 16 queries, sweeps keys) and attn_bwd_dkv (wave owns 16
+//   keys, sweeps queries); neither needs a cross-wave reduction or atomics.
+#include "kernels.h"
+
+#define AT_KB 64   // keys (or queries) staged per LDS block
+
+template <int DKT>
+struct AttnSmem {
+  static constexpr int LD = DKT * 16 + 4;   // ld % 8 == 4: b128 row reads and b32 column reads conflict-free
+};
+
+// stage rows [r0, r0+64) of one third of qkv (column offset coff) into LDS, zero padded
+template <int DKT>
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ base, int ldg, int coff, int dk,
+                                           int r0, int T, int tid) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  constexpr int C4 = DKT * 4;   // float4 per row
+  for (int i = tid; i < AT_KB * C4; i += 256) {
+    const int r = i / C4, c4 = i - r * C4;
+    const int row = r0 + r, col = c4 * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < T && col < dk) v = *reinterpret_cast<const f32x4*>(base + (size_t)row * ldg + coff + col);
+    *reinterpret_cast<f32x4*>(dst + r * LD + col) = v;
+  }
+}
+
+// fragment of one row (B-operand / "row on the lane" form): element s of group g = x[row][g*16+4*(lane>>4)+s]
+template <int DKT>
+__device__ __forceinline__ void load_row_frags(f32x4 (&f)[DKT], const float* __restrict__ rowp, bool rowok, int dk, int lane) {
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) {
+    const int col = g * 16 + 4 * (lane >> 4);
+    f[g] = (rowok && col < dk) ? *reinterpret_cast<const f32x4*>(rowp + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__device__ __forceinline__ float group_max16(float v) {   // over the 4 lane groups sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float group_sum16(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int T, int d, int heads,
+                                                       const int* __restrict__ key_len, float scale,
+                                                       float* __restrict__ out, float* __restrict__ lse) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + AT_KB * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int dk = d / heads, ldg = 3 * d;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const float* base = qkv + (size_t)b * T * ldg;
+  const int q = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  f32x4 qf[DKT];
+  load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < T, dk, lane);
+  f32x4 oT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kb = 0; kb < nkeys; kb += AT_KB) {
+    __syncthreads();
+    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
+    stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
+    __syncthreads();
+    f32x4 st[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kb + kt * 16 < nkeys) {
+#pragma unroll
+        for (int g = 0; g < DKT; ++g) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + (lane & 15)) * LD + g * 16 + 4 * (lane >> 4));
+#pragma unroll
+          for (int s = 0; s < 4; ++s) st[kt] = mfma16(kf[s], qf[g][s], st[kt]);
+        }
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + kt * 16 + 4 * (lane >> 4) + r;
+        const float v = key < nkeys ? st[kt][r] * scale : -INFINITY;
+        st[kt][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = group_max16(mx);
+    const float m_new = fmaxf(m_run, mx);        // finite: this block holds >= 1 valid key
+    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(st[kt][r] - m_new);   // exp(-inf) = 0 for masked keys
+        st[kt][r] = p;
+        ps += p;
+      }
+    ps = group_sum16(ps);
+    l_run = l_run * corr + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DKT; ++i) oT[i] *= corr;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kb + kt * 16 < nkeys) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const float* vrow = Vs + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
+#pragma unroll
+          for (int dt = 0; dt < DKT; ++dt) oT[dt] = mfma16(vrow[dt * 16], st[kt][s], oT[dt]);
+        }
+      }
+    }
+  }
+  if (q < T) {
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    float* orow = out + ((size_t)b * T + q) * d + h * dk;
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const int col = dt * 16 + 4 * (lane >> 4);
+      if (col < dk) *reinterpret_cast<f32x4*>(orow + col) = oT[dt] * inv;
+    }
+    if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dQ: wave owns 16 queries, sweeps key blocks.  Also writes dsum[q] = sum_d dO*O.
+// ------------------------------------------------------------------------------------------
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                          const float* __restrict__ dout, const float* __restrict__ lse,
+                                                          int T, int d, int heads, const int* __restrict__ key_len,
+                                                          float scale, float* __restrict__ dqkv, float* __restrict__ dsum) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + AT_KB * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int dk = d / heads, ldg = 3 * d;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const float* base = qkv + (size_t)b * T * ldg;
+  const int q = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  const bool qok = q < T;
+  f32x4 qf[DKT], dof[DKT];
+  load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, qok, dk, lane);
+  load_row_frags<DKT>(dof, dout + ((size_t)b * T + q) * d + h * dk, qok, dk, lane);
+  float dsm = 0.f;
+  {
+    f32x4 of[DKT];
+    load_row_frags<DKT>(of, out + ((size_t)b * T + q) * d + h * dk, qok, dk, lane);
+#pragma unroll
+    for (int g = 0; g < DKT; ++g)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dsm += of[g][s] * dof[g][s];
+    dsm = group_sum16(dsm);
+  }
+  const float lq = qok ? lse[((size_t)b * heads + h) * T + q] : INFINITY;
+  if (qok && lane < 16) dsum[((size_t)b * heads + h) * T + q] = dsm;
+  f32x4 dqT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < nkeys; kb += AT_KB) {
+    __syncthreads();
+    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
+    stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      if (kb + kt * 16 >= nkeys) continue;
+      f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        const int off = (kt * 16 + (lane & 15)) * LD + g * 16 + 4 * (lane >> 4);
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + off);
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + off);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sT = mfma16(kf[s], qf[g][s], sT);
+          dpT = mfma16(vf[s], dof[g][s], dpT);
+        }
+      }
+      f32x4 dsT;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + kt * 16 + 4 * (lane >> 4) + r;
+        const float p = key < nkeys ? expf(sT[r] * scale - lq) : 0.f;
+        dsT[r] = p * (dpT[r] - dsm) * scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* krow = Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < DKT; ++dt) dqT[dt] = mfma16(krow[dt * 16], dsT[s], dqT[dt]);
+      }
+    }
+  }
+  if (qok) {
+    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * dk;
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const int col = dt * 16 + 4 * (lane >> 4);
+      if (col < dk) *reinterpret_cast<f32x4*>(drow + col) = dqT[dt];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dK/dV: wave owns 16 keys, sweeps query blocks (Q and dO staged in LDS).
+// ------------------------------------------------------------------------------------------
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ dsum,
+                                                           int T, int d, int heads, const int* __restrict__ key_len,
+                                                           float scale, float* __restrict__ dqkv) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Os = smem + AT_KB * LD;
+  float* Ls = smem + 2 * AT_KB * LD;   // [64] lse
+  float* Ds = Ls + AT_KB;              // [64] dsum
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int dk = d / heads, ldg = 3 * d;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const float* base = qkv + (size_t)b * T * ldg;
+  const int key = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  const bool kok = key < T;
+  f32x4 kf[DKT], vf[DKT];
+  load_row_frags<DKT>(kf, base + (size_t)key * ldg + d + h * dk, kok, dk, lane);
+  load_row_frags<DKT>(vf, base + (size_t)key * ldg + 2 * d + h * dk, kok, dk, lane);
+  f32x4 dkT[DKT], dvT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) {
+    dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool key_live = key < nkeys;          // masked keys get exactly zero gradient
+  const bool wave_live = (blockIdx.y * AT_KB + wave * 16) < nkeys;
+
+  for (int qb = 0; qb < T; qb += AT_KB) {
+    __syncthreads();
+    stage_rows<DKT>(Qs, base, ldg, h * dk, dk, qb, T, tid);
+    stage_rows<DKT>(Os, dout + (size_t)b * T * d, d, h * dk, dk, qb, T, tid);
+    if (tid < AT_KB) {
+      const int qq = qb + tid;
+      Ls[tid] = qq < T ? lse[((size_t)b * heads + h) * T + qq] : INFINITY;
+      Ds[tid] = qq < T ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
+    }
+    __syncthreads();
+    if (!wave_live) continue;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      if (qb + qt * 16 >= T) continue;
+      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        const int off = (qt * 16 + (lane & 15)) * LD + g * 16 + 4 * (lane >> 4);
+        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + off);
+        const f32x4 of = *reinterpret_cast<const f32x4*>(Os + off);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sa = mfma16(qf[s], kf[g][s], sa);     // S[query][key]
+          dp = mfma16(of[s], vf[g][s], dp);     // dP[query][key]
+        }
+      }
+      f32x4 pr, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = qt * 16 + 4 * (lane >> 4) + r;
+        const float p = key_live ? expf(sa[r] * scale - Ls[ql]) : 0.f;
+        pr[r] = p;
+        ds[r] = p * (dp[r] - Ds[ql]) * scale;
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int roff = (qt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < DKT; ++dt) {
+          dvT[dt] = mfma16(Os[roff + dt * 16], pr[s], dvT[dt]);   // dV^T[dim][key] += dO^T P
+          dkT[dt] = mfma16(Qs[roff + dt * 16], ds[s], dkT[dt]);   // dK^T[dim][key] += Q^T dS
+        }
+      }
+    }
+  }
+  if (kok) {
+    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * dk;
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const int col = dt * 16 + 4 * (lane >> 4);
+      if (col < dk) {
+        *reinterpret_cast<f32x4*>(drow + d + col) = dkT[dt];
+        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = dvT[dt];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static int check_attn_shape(int T, int d, int heads) {
+  INTEL_CHECK_ARG(heads > 0 && d % heads == 0, "attention: d=%d not divisible by heads=%d", d, heads);
+  const int dk = d / heads;
+  INTEL_CHECK_ARG(dk % 4 == 0 && dk <= 128 && d % 4 == 0, "attention: head dim %d unsupported (need multiple of 4, <= 128)", dk);
+  INTEL_CHECK_ARG(T > 0, "attention: empty sequence");
+  return 0;
+}
+
+#define ATTN_DISPATCH(DKT_RT, CALL)               \
+  switch (DKT_RT) {                               \
+    case 1: { constexpr int DKT = 1; CALL; } break; \
+    case 2: { constexpr int DKT = 2; CALL; } break; \
+    case 3: { constexpr int DKT = 3; CALL; } break; \
+    case 4: { constexpr int DKT = 4; CALL; } break; \
+    case 5: case 6: { constexpr int DKT = 6; CALL; } break; \
+    default: { constexpr int DKT = 8; CALL; } break; \
+  }
+
+int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
+                    hipStream_t st) {
+  if (B <= 0) return 0;
+  int rc = check_attn_shape(T, d, heads);
+  if (rc) return rc;
+  const int dk = d / heads, dkt = cdiv(dk, 16);
+  const float scale = 1.0f / sqrtf((float)dk);
+  dim3 grid(B * heads, cdiv(T, AT_KB));
+  ATTN_DISPATCH(dkt, {
+    size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
+    allow_lds(attn_fwd_kernel<DKT>, smem);
+    hipLaunchKernelGGL(attn_fwd_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse);
+  });
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
+                    int heads, const int* key_len, float* dqkv, float* dsum, hipStream_t st) {
+  if (B <= 0) return 0;
+  int rc = check_attn_shape(T, d, heads);
+  if (rc) return rc;
+  const int dk = d / heads, dkt = cdiv(dk, 16);
+  const float scale = 1.0f / sqrtf((float)dk);
+  dim3 grid(B * heads, cdiv(T, AT_KB));
+  ATTN_DISPATCH(dkt, {
+    size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
+    allow_lds(attn_bwd_dq_kernel<DKT>, smem);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DKT>, grid, dim3(256), smem, st, qkv, out, dout, lse, T, d, heads, key_len,
+                       scale, dqkv, dsum);
+  });
+  INTEL_CHECK_LAUNCH();
+  ATTN_DISPATCH(dkt, {
+    size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
+    allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
+                       scale, dqkv);
+  });
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,71 @@
+// Internal launcher API shared by the kernel files, the model plan (model.cpp) and the C ABI.
+// Every launcher enqueues on `st`, never synchronises, returns 0 or an error code.
+#pragma once
+#include "common.h"
+
+// ---- fp32 MFMA GEMM family (gemm.hip) -------------------------------------------------------
+// Packed B operand: tiles of 16 k x 16 n in the register order of v_mfma_f32_16x16x4_f32,
+// P[((nt*KG + g)*64 + lane)*4 + s] = B[g*16 + 4*(lane>>4) + s][nt*16 + (lane&15)], zero padded.
+static inline size_t packed_floats(int Kd, int Nd) { return (size_t)rup(Kd, 16) * rup(Nd, 16); }
+// trans=0: B[k][n] = W[n*ldw + k]  (y = x W^T, W is [Nd,Kd]);  trans=1: B[k][n] = W[k*ldw + n].
+// Writes tiles nt_off .. nt_off+ceil(Nd/16)-1 of a packed matrix whose k extent is Kd.
+int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st);
+
+struct GemmEpilogue {
+  const float* bias = nullptr;    // [N]
+  int relu = 0;                   // max(.,0) after bias
+  const float* mask = nullptr;    // multiply by (mask[m][n] > 0) after bias/relu (relu backward)
+  int ldmask = 0;
+  const float* res = nullptr;     // + res[m][n]
+  int ldres = 0;
+  const float* gamma = nullptr;   // LayerNorm over the N columns (N <= 128) when non-null
+  const float* beta = nullptr;
+  float* xhat = nullptr;          // optional stash for LayerNorm backward
+  int ldxhat = 0;
+  float* rstd = nullptr;          // [M]
+  int accumulate = 0;             // C += value instead of C = value
+};
+// C[M,N] = epilogue(A[M,K] @ B) with B packed by launch_pack_b (k extent K, n extent N).
+int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc,
+                     const GemmEpilogue& ep, hipStream_t st);
+// dW[N,K] (+)= dY[M,N]^T X[M,K];  db[N] (+)= colsum(dY) when db != null.  `slabs` needs
+// wgrad_slab_floats(M,N,K) floats.
+size_t wgrad_slab_floats(int M, int N, int K);
+int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
+                 float* db, int accumulate, float* slabs, hipStream_t st);
+
+// ---- attention (attn.hip) -------------------------------------------------------------------
+// qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
+int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
+                    hipStream_t st);
+// dsum: scratch [B*heads*T]
+int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
+                    int heads, const int* key_len, float* dqkv, float* dsum, hipStream_t st);
+
+// ---- row / session kernels (rowops.hip) -----------------------------------------------------
+// dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu
+int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,
+                       hipStream_t st);
+// dst[b*T+t, col0:col0+d] = src[b, :]  broadcast of a per-session vector
+int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st);
+// grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics
+int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st);
+// y = LN(x + r) rows
+int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
+                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st);
+// dz = LN backward; dgamma/dbeta (+)= column sums (via slabs: needs ln_bwd_slab_floats(M,N))
+size_t ln_bwd_slab_floats(int M, int N);
+int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
+                         const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
+                         float* slabs, hipStream_t st);
+// softmax over rows of length N (in place allowed)
+int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st);
+// dx = y * (dy - sum(dy*y))
+int launch_softmax_rows_bwd(const float* y, const float* dy, int M, int N, float* dx, hipStream_t st);
+// generic elementwise: y = a (+ b)
+int launch_add2(const float* a, const float* b, long long n, float* y, hipStream_t st);
+int launch_fill(float* p, long long n, float v, hipStream_t st);
+// column sums: out[N] (+)= sum_m x[m][n]  (small M*N; single pass with atomics-free two-level)
+int launch_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate, float* slabs, hipStream_t st);
+size_t colsum_slab_floats(int M, int N);

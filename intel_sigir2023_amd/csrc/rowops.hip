@@ -1,0 +1,314 @@
+// Row-wise HBM-bound kernels: embedding row gather / scatter-add, LayerNorm fwd/bwd, row softmax,
+// small reductions.  One wave per row wherever a row reduction is needed (wave shuffles only).
+#include "kernels.h"
+
+int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
+                       int accumulate, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// gather: dst[m, col0:col0+d] = table[idx[m]]   (nn.Embedding forward, IntEL.py:135,141,147-148,170-172)
+// A row of d floats is read by d/4 consecutive lanes with 16-byte loads (d=64 -> 256 B per row).
+// ------------------------------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ table, int d, const int* __restrict__ idx, int M,
+                                   float* __restrict__ dst, int ldd, int col0, int relu) {
+  const int d4 = d >> 2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d4) return;
+  const int m = (int)(i / d4), c = (int)(i - (long long)m * d4);
+  const int row = idx[m];
+  f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (row >= 0) v = *reinterpret_cast<const f32x4*>(table + (size_t)row * d + c * 4);
+  if (relu) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+  }
+  *reinterpret_cast<f32x4*>(dst + (size_t)m * ldd + col0 + c * 4) = v;
+}
+__global__ void gather_rows_scalar_kernel(const float* __restrict__ table, int d, const int* __restrict__ idx, int M,
+                                          float* __restrict__ dst, int ldd, int col0, int relu) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d) return;
+  const int m = (int)(i / d), c = (int)(i - (long long)m * d);
+  const int row = idx[m];
+  float v = row >= 0 ? table[(size_t)row * d + c] : 0.f;
+  if (relu) v = fmaxf(v, 0.f);
+  dst[(size_t)m * ldd + col0 + c] = v;
+}
+
+int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,
+                       hipStream_t st) {
+  if (M <= 0 || d <= 0) return 0;
+  const bool vec = (d % 4 == 0) && (ldd % 4 == 0) && (col0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(table) & 15) == 0);
+  if (vec) {
+    long long n = (long long)M * (d / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+  } else {
+    long long n = (long long)M * d;
+    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+  }
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+__global__ void bcast_rows_kernel(const float* __restrict__ src, int lds, int d, int B, int T, float* __restrict__ dst,
+                                  int ldd, int col0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T * d) return;
+  const int c = (int)(i % d);
+  const long long m = i / d;
+  const int b = (int)(m / T);
+  dst[(size_t)m * ldd + col0 + c] = src[(size_t)b * lds + c];
+}
+int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st) {
+  long long n = (long long)B * T * d;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, d, B, T, dst, ldd, col0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// scatter-add: grad_table[idx[m]] += src[m, col0:col0+d]   (dense embedding backward)
+// One lane per element: a wave adds 64 consecutive floats = whole 256-B rows, the shape global
+// float atomics run fastest at (MI355X guide, "Global float atomics").
+// ------------------------------------------------------------------------------------------
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, int lds, int col0, int d,
+                                        const int* __restrict__ idx, int M, float* __restrict__ grad_table,
+                                        const float* __restrict__ relu_out, int ldr, int rcol0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d) return;
+  const int m = (int)(i / d), c = (int)(i - (long long)m * d);
+  const int row = idx[m];
+  if (row < 0) return;
+  float v = src[(size_t)m * lds + col0 + c];
+  if (relu_out && !(relu_out[(size_t)m * ldr + rcol0 + c] > 0.f)) v = 0.f;
+  if (v != 0.f) atomicAdd(grad_table + (size_t)row * d + c, v);
+}
+int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st) {
+  long long n = (long long)M * d;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, col0, d, idx, M,
+                     grad_table, relu_out, ldr, rcol0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// y = LayerNorm(x + r), eps = 1e-5, biased variance (torch.nn.LayerNorm).  One wave per row.
+// ------------------------------------------------------------------------------------------
+#define LN_MAXPL 8   // columns per lane: N <= 512
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r,
+                                                            int ldr, int M, int N, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                            float* __restrict__ xhat, int ldxh, float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[LN_MAXPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    float t = 0.f;
+    if (c < N) {
+      t = x[(size_t)row * ldx + c];
+      if (r) t += r[(size_t)row * ldr + c];
+    }
+    v[i] = t;
+    s += t;
+  }
+  const float mean = wave_sum(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    const float dlt = c < N ? v[i] - mean : 0.f;
+    v[i] = dlt;
+    q += dlt * dlt;
+  }
+  const float rs = 1.f / sqrtf(wave_sum(q) / (float)N + 1e-5f);
+  if (rstd && lane == 0) rstd[row] = rs;
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    const int c = lane + 64 * i;
+    if (c < N) {
+      const float xh = v[i] * rs;
+      if (xhat) xhat[(size_t)row * ldxh + c] = xh;
+      y[(size_t)row * ldy + c] = xh * gamma[c] + beta[c];
+    }
+  }
+}
+int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
+                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st) {
+  if (M <= 0) return 0;
+  INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm: N=%d > %d unsupported", N, 64 * LN_MAXPL);
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, ldx, r, ldr, M, N, gamma, beta, y, ldy, xhat,
+                     ldxh, rstd);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm backward.  dz = rstd * (g - mean(g) - xhat*mean(g*xhat)), g = gamma*dy.
+// dgamma/dbeta: per-block column partials (each block owns LNB_ROWS rows) -> slabs -> reduce.
+// ------------------------------------------------------------------------------------------
+#define LNB_ROWS 64
+static inline int ln_bwd_blocks(int M) { return cdiv(M, LNB_ROWS); }
+size_t ln_bwd_slab_floats(int M, int N) { return (size_t)ln_bwd_blocks(M) * 2 * N; }
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ xhat,
+                                                            int ldxh, const float* __restrict__ rstd, int M, int N,
+                                                            const float* __restrict__ gamma, float* __restrict__ dz, int lddz,
+                                                            float* __restrict__ slabs) {
+  __shared__ float sg[4][64 * LN_MAXPL];
+  __shared__ float sb[4][64 * LN_MAXPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[LN_MAXPL], ab[LN_MAXPL];
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) ag[i] = ab[i] = 0.f;
+  const int r0 = blockIdx.x * LNB_ROWS;
+  for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+    const int row = r0 + rr;
+    if (row >= M) break;
+    float g[LN_MAXPL], xh[LN_MAXPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPL; ++i) {
+      const int c = lane + 64 * i;
+      float d = 0.f, h = 0.f, gm = 0.f;
+      if (c < N) {
+        d = dy[(size_t)row * lddy + c];
+        h = xhat[(size_t)row * ldxh + c];
+        gm = gamma[c];
+      }
+      ag[i] += d * h;
+      ab[i] += d;
+      g[i] = d * gm;
+      xh[i] = h;
+      s1 += g[i];
+      s2 += g[i] * h;
+    }
+    const float m1 = wave_sum(s1) / (float)N, m2 = wave_sum(s2) / (float)N;
+    const float rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < LN_MAXPL; ++i) {
+      const int c = lane + 64 * i;
+      if (c < N) dz[(size_t)row * lddz + c] = rs * (g[i] - m1 - xh[i] * m2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LN_MAXPL; ++i) {
+    sg[wave][lane + 64 * i] = ag[i];
+    sb[wave][lane + 64 * i] = ab[i];
+  }
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * 2 * N;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    slab[c] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+    slab[N + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+  }
+}
+int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
+                         const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
+                         float* slabs, hipStream_t st) {
+  if (M <= 0) return 0;
+  INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm_bwd: N=%d unsupported", N);
+  const int nb = ln_bwd_blocks(M);
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
+  INTEL_CHECK_LAUNCH();
+  int rc = launch_slab_reduce(slabs, (size_t)2 * N, nb, 1, N, dgamma, N, accumulate, st);
+  if (rc) return rc;
+  return launch_slab_reduce(slabs + N, (size_t)2 * N, nb, 1, N, dbeta, N, accumulate, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// row softmax (pred_layer(...).softmax(-1), IntEL.py:153) and its backward.  One wave per row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, int M, int N, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * N;
+  float mx = -INFINITY;
+  for (int c = lane; c < N; c += 64) mx = fmaxf(mx, xr[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += expf(xr[c] - mx);
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < N; c += 64) y[(size_t)row * N + c] = expf(xr[c] - mx) * inv;
+}
+int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, N, y);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+__global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, int M,
+                                                               int N, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane; c < N; c += 64) s += y[(size_t)row * N + c] * dy[(size_t)row * N + c];
+  s = wave_sum(s);
+  for (int c = lane; c < N; c += 64) dx[(size_t)row * N + c] = y[(size_t)row * N + c] * (dy[(size_t)row * N + c] - s);
+}
+int launch_softmax_rows_bwd(const float* y, const float* dy, int M, int N, float* dx, hipStream_t st) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, y, dy, M, N, dx);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ y) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = a[i] + (b ? b[i] : 0.f);
+}
+int launch_add2(const float* a, const float* b, long long n, float* y, hipStream_t st) {
+  if (n <= 0) return 0;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, y);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+int launch_fill(float* p, long long n, float v, hipStream_t st) {
+  if (n <= 0) return 0;
+  long long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// column sums of a [M,N] matrix -> out[N]; per-block partials then deterministic reduce
+#define CS_ROWS 256
+size_t colsum_slab_floats(int M, int N) { return (size_t)cdiv(M, CS_ROWS) * N; }
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M, int N, float* __restrict__ slabs) {
+  const int r0 = blockIdx.x * CS_ROWS;
+  const int r1 = min(M, r0 + CS_ROWS);
+  for (int c = threadIdx.x; c < N; c += 256) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + c];
+    slabs[(size_t)blockIdx.x * N + c] = s;
+  }
+}
+int launch_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate, float* slabs, hipStream_t st) {
+  if (N <= 0) return 0;
+  const int nb = cdiv(M, CS_ROWS);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, x, ldx, M, N, slabs);
+  INTEL_CHECK_LAUNCH();
+  return launch_slab_reduce(slabs, (size_t)N, nb, 1, N, out, N, accumulate, st);
+}

@@ -1,0 +1,29 @@
+// Launchers of session.hip / loss.hip / optim.hip (internal).
+#pragma once
+#include "common.h"
+
+int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
+                         float* xbar, float* attw, hipStream_t st);
+int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, const float* attw, const float* dxbar,
+                         int ldxb, float scale, float* dX, float* dqk, hipStream_t st);
+int launch_ens_fwd(const float* wv, const float* wpad, const float* scores, const int* slen, int B, int L, int K,
+                   int per_item, float* weights, float* ens, hipStream_t st);
+int launch_ens_bwd(const float* d_weights, const float* d_ens, const float* scores, const int* slen, int B, int L, int K,
+                   int per_item, float* dwv, float* dwpad, float* dwt, hipStream_t st);
+int launch_gate_fwd(const float* x, int d, const float* vec, int B, int L, float* dst, int ldd, int col0, hipStream_t st);
+int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d, const float* vec, int B, int L, float* dx,
+                    float* dvec, hipStream_t st);
+int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int L, float* out, int ldo, int ocol0,
+                          int accumulate, hipStream_t st);
+int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st);
+int launch_add_pos_bwd(const float* dE, int dm, const int* len, int B, int T, float* dpos, hipStream_t st);
+int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
+                         int col0, hipStream_t st);
+int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int I, const int* idx, int M, float* dW,
+                             float* db, hipStream_t st);
+int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st);
+int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st);
+int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,
+                     const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st);
+int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
+                       int accumulate, hipStream_t st);

@@ -1,0 +1,415 @@
+// Per-session kernels of predict_ensemble (models/IntEL/IntEL.py:158-217) that are not GEMMs:
+//   - single-query cross-attention pooling (IntEL.py:201-204 -> modules/attention.py:48-63)
+//   - fusion weights broadcast + weighted-sum score aggregation (IntEL.py:212-215)
+//   - the --cross_attention 0 elementwise gating (IntEL.py:206-209)
+// One wave (64 lanes) per session, four sessions per 256-thread workgroup, wave shuffles for every
+// per-list reduction; the candidate-list tile X[b] (L x d floats) is streamed twice from L1/L2.
+#include "kernels.h"
+#include "session.h"
+
+#define XP_MAXL 512
+
+// ------------------------------------------------------------------------------------------
+// Cross-attention with ONE query row per session:
+//   att_l = scale * <qk_b, x_l>   (qk_b = Wk^T Wq intent_b, computed by two small GEMMs)
+//   att  -= max over ALL L rows (attention.py:57, before masking)
+//   w_l   = softmax over valid l (l < session_len), NaN -> 0
+//   xbar  = sum_l w_l x_l         (value projection Wv applied afterwards to xbar: linear)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void xatt_pool_fwd_kernel(const float* __restrict__ X, int L, int d,
+                                                            const float* __restrict__ qk, const int* __restrict__ slen,
+                                                            float scale, int B, float* __restrict__ xbar,
+                                                            float* __restrict__ attw) {
+  __shared__ float s_att[4][XP_MAXL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float* Xb = X + (size_t)b * L * d;
+  const float* q = qk + (size_t)b * d;
+  const int len = min(slen[b], L);
+  float* att = s_att[wave];
+  // scores: 16 lanes per row, 4 rows per pass
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int l0 = 0; l0 < L; l0 += 4) {
+    const int l = l0 + grp;
+    float s = 0.f;
+    if (l < L) {
+      for (int c = sub * 4; c < d; c += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(Xb + (size_t)l * d + c);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(q + c);
+        s += xv[0] * qv[0] + xv[1] * qv[1] + xv[2] * qv[2] + xv[3] * qv[3];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (l < L && sub == 0) att[l] = s * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int l = lane; l < L; l += 64) mx = fmaxf(mx, att[l]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int l = lane; l < len; l += 64) sum += expf(att[l] - mx);
+  sum = wave_sum(sum);
+  // sum == 0 (underflow or len == 0): softmax row is NaN in the reference and replaced by 0
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const float w = l < len ? expf(att[l] - mx) * inv : 0.f;
+    att[l] = w;
+    attw[(size_t)b * L + l] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    float acc = 0.f;
+    for (int l = 0; l < len; ++l) acc += att[l] * Xb[(size_t)l * d + c];
+    xbar[(size_t)b * d + c] = acc;
+  }
+}
+
+int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
+                         float* xbar, float* attw, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool: list length %d > %d unsupported", L, XP_MAXL);
+  INTEL_CHECK_ARG(d % 4 == 0, "xatt_pool: width %d must be a multiple of 4", d);
+  hipLaunchKernelGGL(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward: given dxbar[b,:], produces dX[b,l,:] (written, all L rows) and dqk[b,:]
+//   g_l = <dxbar, x_l>;  datt_l = w_l (g_l - sum_j w_j g_j);  dx_l = w_l dxbar + datt_l*scale*qk
+//   dqk = scale * sum_l datt_l x_l
+__global__ __launch_bounds__(256) void xatt_pool_bwd_kernel(const float* __restrict__ X, int L, int d,
+                                                            const float* __restrict__ qk, const float* __restrict__ attw,
+                                                            const float* __restrict__ dxbar, int ldxb, float scale, int B,
+                                                            float* __restrict__ dX, float* __restrict__ dqk) {
+  __shared__ float s_g[4][XP_MAXL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float* Xb = X + (size_t)b * L * d;
+  const float* q = qk + (size_t)b * d;
+  const float* dxb = dxbar + (size_t)b * ldxb;
+  const float* w = attw + (size_t)b * L;
+  float* g = s_g[wave];
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int l0 = 0; l0 < L; l0 += 4) {
+    const int l = l0 + grp;
+    float s = 0.f;
+    if (l < L) {
+      for (int c = sub * 4; c < d; c += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(Xb + (size_t)l * d + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dxb + c);
+        s += xv[0] * gv[0] + xv[1] * gv[1] + xv[2] * gv[2] + xv[3] * gv[3];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (l < L && sub == 0) g[l] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float wg = 0.f;
+  for (int l = lane; l < L; l += 64) wg += w[l] * g[l];
+  wg = wave_sum(wg);
+  __builtin_amdgcn_wave_barrier();
+  for (int l = lane; l < L; l += 64) g[l] = w[l] * (g[l] - wg) * scale;   // = datt_l * scale
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < d; c += 64) {
+    const float dxc = dxb[c], qc = q[c];
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float da = g[l];
+      dX[((size_t)b * L + l) * d + c] = w[l] * dxc + da * qc;
+      acc += da * Xb[(size_t)l * d + c];
+    }
+    dqk[(size_t)b * d + c] = acc;
+  }
+}
+
+int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, const float* attw, const float* dxbar,
+                         int ldxb, float scale, float* dX, float* dqk, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool_bwd: list length %d > %d unsupported", L, XP_MAXL);
+  hipLaunchKernelGGL(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// weights[b,l,:] = l < len ? wv[b,:] : wpad[b,:];  ens[b,l] = sum_k weights*scores (IntEL.py:214-215)
+// (cross_attention=1: the fusion weights are session-constant for valid rows, SURVEY.md §0.4;
+//  padded rows see [0,0,h_u,h_intent] -> wpad.)  per_item != 0: weights already hold per-item values.
+// ------------------------------------------------------------------------------------------
+__global__ void ens_fwd_kernel(const float* __restrict__ wv, const float* __restrict__ wpad, const float* __restrict__ scores,
+                               const int* __restrict__ slen, int B, int L, int K, int per_item,
+                               float* __restrict__ weights, float* __restrict__ ens) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * L) return;
+  const int b = i / L, l = i - b * L;
+  const float* src = per_item ? (weights + (size_t)i * K) : ((l < slen[b]) ? wv + (size_t)b * K : wpad + (size_t)b * K);
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = src[k];
+    if (!per_item) weights[(size_t)i * K + k] = w;
+    acc += w * scores[(size_t)i * K + k];
+  }
+  ens[i] = acc;
+}
+int launch_ens_fwd(const float* wv, const float* wpad, const float* scores, const int* slen, int B, int L, int K,
+                   int per_item, float* weights, float* ens, hipStream_t st) {
+  if (B * L <= 0) return 0;
+  hipLaunchKernelGGL(ens_fwd_kernel, dim3(cdiv(B * L, 256)), dim3(256), 0, st, wv, wpad, scores, slen, B, L, K, per_item, weights, ens);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dwt[b,l,k] = d_weights + d_ens*scores;  dwv[b,k] = sum_{l<len} dwt, dwpad[b,k] = sum_{l>=len} dwt.
+// per_item: writes dwt[M,K] instead (dwv/dwpad unused).
+__global__ __launch_bounds__(256) void ens_bwd_kernel(const float* __restrict__ d_weights, const float* __restrict__ d_ens,
+                                                      const float* __restrict__ scores, const int* __restrict__ slen, int B,
+                                                      int L, int K, int per_item, float* __restrict__ dwv,
+                                                      float* __restrict__ dwpad, float* __restrict__ dwt) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int len = slen[b];
+  for (int k = 0; k < K; ++k) {
+    float sv = 0.f, sp = 0.f;
+    for (int l = lane; l < L; l += 64) {
+      const size_t i = (size_t)b * L + l;
+      float v = 0.f;
+      if (d_weights) v += d_weights[i * K + k];
+      if (d_ens) v += d_ens[i] * scores[i * K + k];
+      if (per_item) dwt[i * K + k] = v;
+      if (l < len) sv += v; else sp += v;
+    }
+    if (!per_item) {
+      sv = wave_sum(sv);
+      sp = wave_sum(sp);
+      if (lane == 0) {
+        dwv[(size_t)b * K + k] = sv;
+        dwpad[(size_t)b * K + k] = sp;
+      }
+    }
+  }
+}
+int launch_ens_bwd(const float* d_weights, const float* d_ens, const float* scores, const int* slen, int B, int L, int K,
+                   int per_item, float* dwv, float* dwpad, float* dwt, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(ens_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, d_weights, d_ens, scores, slen, B, L, K, per_item, dwv, dwpad, dwt);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// --cross_attention 0 gating (IntEL.py:206-209): dst[m, col0+c] = x[m,c] * vec[b,c]
+// backward: dx[m,c] (+)= dfeat[m,col0+c]*vec[b,c];  dvec[b,c] = sum_l dfeat[m,col0+c]*x[m,c]
+// ------------------------------------------------------------------------------------------
+__global__ void gate_fwd_kernel(const float* __restrict__ x, int d, const float* __restrict__ vec, int B, int L,
+                                float* __restrict__ dst, int ldd, int col0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * L * d) return;
+  const int c = (int)(i % d);
+  const long long m = i / d;
+  const int b = (int)(m / L);
+  dst[(size_t)m * ldd + col0 + c] = x[i] * vec[(size_t)b * d + c];
+}
+int launch_gate_fwd(const float* x, int d, const float* vec, int B, int L, float* dst, int ldd, int col0, hipStream_t st) {
+  long long n = (long long)B * L * d;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d, vec, B, L, dst, ldd, col0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dfeat, int ldf, int col0, const float* __restrict__ x,
+                                                       int d, const float* __restrict__ vec, int B, int L,
+                                                       float* __restrict__ dx, float* __restrict__ dvec) {
+  // one block per session; thread c loops over rows
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float vc = vec[(size_t)b * d + c];
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const size_t m = (size_t)b * L + l;
+      const float g = dfeat[m * ldf + col0 + c];
+      dx[m * d + c] = g * vc;
+      acc += g * x[m * d + c];
+    }
+    dvec[(size_t)b * d + c] = acc;
+  }
+}
+int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d, const float* vec, int B, int L, float* dx,
+                    float* dvec, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(256), 0, st, dfeat, ldf, col0, x, d, vec, B, L, dx, dvec);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// out[b, c] = sum_l src[(b*L + l), col0 + c]   (gradient of a per-session vector broadcast over the list)
+__global__ __launch_bounds__(256) void session_colsum_kernel(const float* __restrict__ src, int lds, int col0, int d, int B, int L,
+                                                             float* __restrict__ out, int ldo, int ocol0, int accumulate) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += src[((size_t)b * L + l) * lds + col0 + c];
+    float* dst = out + (size_t)b * ldo + ocol0 + c;
+    *dst = accumulate ? *dst + acc : acc;
+  }
+}
+int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int L, float* out, int ldo, int ocol0,
+                          int accumulate, hipStream_t st) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(session_colsum_kernel, dim3(B), dim3(256), 0, st, src, lds, col0, d, B, L, out, ldo, ocol0, accumulate);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder helpers (models/GeneralSeq.py:89-106, IntEL.py:135-143)
+// ------------------------------------------------------------------------------------------
+// E[b*T+t, :] += pos_emb[t < len_b ? t : 0, :]   (position ids: forward order, pads -> 0)
+__global__ void add_pos_kernel(float* __restrict__ E, int dm, const float* __restrict__ pos, const int* __restrict__ len,
+                               int B, int T) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T * dm) return;
+  const int c = (int)(i % dm);
+  const long long m = i / dm;
+  const int b = (int)(m / T), t = (int)(m - (long long)b * T);
+  const int p = t < len[b] ? t : 0;
+  E[i] += pos[(size_t)p * dm + c];
+}
+int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st) {
+  long long n = (long long)B * T * dm;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E, dm, pos, len, B, T);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+// dpos[p,:] += sum over (b,t) with position p of dE[b*T+t,:]  (atomics; tiny table)
+__global__ void add_pos_bwd_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ len, int B, int T,
+                                   float* __restrict__ dpos) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T * dm) return;
+  const int c = (int)(i % dm);
+  const long long m = i / dm;
+  const int b = (int)(m / T), t = (int)(m - (long long)b * T);
+  const int p = t < len[b] ? t : 0;
+  const float v = dE[i];
+  if (v != 0.f) atomicAdd(dpos + (size_t)p * dm + c, v);
+}
+int launch_add_pos_bwd(const float* dE, int dm, const int* len, int B, int T, float* dpos, hipStream_t st) {
+  long long n = (long long)B * T * dm;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_pos_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, dm, len, B, T, dpos);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// one-hot intent rows of the item history (IntEL.py:142 with his_item_int one-hot):
+// E[m, col0:col0+d_int] = Wint[:, idx[m]] + bint   (idx < 0: bias only)
+__global__ void onehot_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int d_int, int I,
+                                     const int* __restrict__ idx, int M, float* __restrict__ E, int lde, int col0) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d_int) return;
+  const int c = (int)(i % d_int);
+  const int m = (int)(i / d_int);
+  const int j = idx[m];
+  float v = bias[c];
+  if (j >= 0) v += W[(size_t)c * I + j];
+  E[(size_t)m * lde + col0 + c] = v;
+}
+int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
+                         int col0, hipStream_t st) {
+  long long n = (long long)M * d_int;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(onehot_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, bias, d_int, I, idx, M, E, lde, col0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+// dW[c, idx[m]] += dE[m, col0+c];  db[c] += dE[m, col0+c]   (atomics; [d_int, I] is tiny)
+__global__ void onehot_linear_bwd_kernel(const float* __restrict__ dE, int lde, int col0, int d_int, int I,
+                                         const int* __restrict__ idx, int M, float* __restrict__ dW, float* __restrict__ db) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d_int) return;
+  const int c = (int)(i % d_int);
+  const int m = (int)(i / d_int);
+  const float v = dE[(size_t)m * lde + col0 + c];
+  if (v == 0.f) return;
+  const int j = idx[m];
+  if (j >= 0) atomicAdd(dW + (size_t)c * I + j, v);
+  atomicAdd(db + c, v);
+}
+int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int I, const int* idx, int M, float* dW,
+                             float* db, hipStream_t st) {
+  long long n = (long long)M * d_int;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(onehot_linear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, lde, col0, d_int, I, idx, M, dW, db);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// vec[b,:] = E[b*T + len_b - 1, :] * 1   (GeneralSeq.py:103-105; the selected row is always valid)
+__global__ void select_last_kernel(const float* __restrict__ E, int dm, const int* __restrict__ len, int B, int T,
+                                   float* __restrict__ out, int ldo, int col0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dm) return;
+  const int b = i / dm, c = i - b * dm;
+  int t = len[b] - 1;
+  t = t < 0 ? T + t : t;            // torch negative indexing when len == 0
+  t = min(max(t, 0), T - 1);
+  const float valid = (t < len[b]) ? 1.f : 0.f;
+  out[(size_t)b * ldo + col0 + c] = E[((size_t)b * T + t) * dm + c] * valid;
+}
+int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st) {
+  if (B * dm <= 0) return 0;
+  hipLaunchKernelGGL(select_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, E, dm, len, B, T, out, ldo, col0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+// dE = 0 except dE[b*T + len_b - 1, :] = dvec[b, col0:col0+dm]
+__global__ void select_last_bwd_kernel(const float* __restrict__ dvec, int ldv, int col0, int dm, const int* __restrict__ len,
+                                       int B, int T, float* __restrict__ dE) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * T * dm) return;
+  const int c = (int)(i % dm);
+  const long long m = i / dm;
+  const int b = (int)(m / T), t = (int)(m - (long long)b * T);
+  int tl = len[b] - 1;
+  tl = tl < 0 ? T + tl : tl;
+  tl = min(max(tl, 0), T - 1);
+  dE[i] = (t == tl && tl < len[b]) ? dvec[(size_t)b * ldv + col0 + c] : 0.f;
+}
+int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st) {
+  long long n = (long long)B * T * dm;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(select_last_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dvec, ldv, col0, dm, len, B, T, dE);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// copy a column block: dst[m, dcol0 + c] = src[m, scol0 + c] (optionally * (mask>0))
+__global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int scol0, int d, long long M, float* __restrict__ dst,
+                                 int ldd, int dcol0, const float* __restrict__ relu_out, int ldr, int rcol0, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * d) return;
+  const int c = (int)(i % d);
+  const long long m = i / d;
+  float v = src[(size_t)m * lds + scol0 + c];
+  if (relu_out && !(relu_out[(size_t)m * ldr + rcol0 + c] > 0.f)) v = 0.f;
+  float* p = dst + (size_t)m * ldd + dcol0 + c;
+  *p = accumulate ? *p + v : v;
+}
+int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,
+                     const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st) {
+  long long n = M * d;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, scol0, d, M, dst, ldd, dcol0,
+                     relu_out, ldr, rcol0, accumulate);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

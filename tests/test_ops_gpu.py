@@ -1,0 +1,95 @@
+"""GPU parity of the building-block kernels (through the C ABI) against torch fp32/fp64 on CPU.
+
+These are floating-point kernels: the comparison is against a float64 torch evaluation of the same
+op with tolerance 2e-5 relative to the output scale (fp32 re-association only; the MFMA used is the
+exact-fp32 v_mfma_f32_16x16x4_f32).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def _close(got, ref, tol=2e-5, name=''):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, '%s: max err %.3e (scale %.3e)' % (name, err, scale)
+
+
+@pytest.mark.parametrize('M,K,N', [(64, 16, 16), (200, 128, 128), (130, 3, 64), (77, 30, 64), (300, 384, 30),
+                                   (1000, 128, 384), (65, 1071, 16), (50, 64, 200)])
+def test_linear_fwd_dgrad_wgrad(M, K, N):
+    from intel_sigir2023_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + K * 3 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev))
+    _close(y, x.double() @ w.double().t() + b.double(), name='linear')
+    y = ops.linear(x.to(dev), w.to(dev), None, relu=True)
+    _close(y, torch.relu(x.double() @ w.double().t()), name='linear+relu')
+    dx = ops.linear_dgrad(dy.to(dev), w.to(dev))
+    _close(dx, dy.double() @ w.double(), name='dgrad')
+    dw, db = ops.linear_wgrad(dy.to(dev), x.to(dev))
+    _close(dw, dy.double().t() @ x.double(), tol=5e-5, name='wgrad')
+    _close(db, dy.double().sum(0), tol=5e-5, name='bgrad')
+
+
+def _attn_ref(qkv, B, T, d, heads, key_len):
+    dk = d // heads
+    x = qkv.double().view(B, T, 3, heads, dk)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / dk ** 0.5
+    if key_len is not None:
+        mask = torch.arange(T)[None, :] < key_len[:, None]
+        s = s.masked_fill(~mask[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, -1)
+    o = p @ v
+    return o.transpose(1, 2).reshape(B * T, d)
+
+
+@pytest.mark.parametrize('B,T,d,heads,masked', [(3, 50, 128, 1, False), (2, 50, 64, 2, False), (4, 20, 128, 2, True),
+                                                (2, 200, 128, 2, False), (2, 200, 128, 2, True), (3, 37, 32, 2, True),
+                                                (2, 70, 32, 1, False), (2, 100, 96, 2, True), (3, 9, 16, 2, False)])
+def test_attention_fwd_bwd(B, T, d, heads, masked):
+    from intel_sigir2023_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + T * 10 + d + heads)
+    qkv = torch.randn(B * T, 3 * d, generator=g)
+    key_len = None
+    if masked:
+        key_len = torch.randint(1, T + 1, (B,), generator=g)
+        key_len[0] = T
+        key_len[-1] = 1
+    dout = torch.randn(B * T, d, generator=g)
+    qkv_r = qkv.clone().double().requires_grad_(True)
+    ref = _attn_ref(qkv_r, B, T, d, heads, key_len)
+    (ref * dout.double()).sum().backward()
+    kl = key_len.to(torch.int32).to(dev) if masked else None
+    out, lse = ops.attention(qkv.to(dev), B, T, d, heads, kl)
+    _close(out, ref, name='attn fwd')
+    dqkv = ops.attention_bwd(qkv.to(dev), out, dout.to(dev), lse, B, T, d, heads, kl)
+    _close(dqkv, qkv_r.grad, tol=5e-5, name='attn bwd')
+
+
+@pytest.mark.parametrize('M,N', [(10, 32), (130, 128), (77, 64), (5, 200)])
+def test_add_layernorm(M, N):
+    from intel_sigir2023_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    x, r = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    gamma, beta = torch.randn(N, generator=g), torch.randn(N, generator=g)
+    y, xhat, rstd = ops.add_layernorm(x.to(dev), r.to(dev), gamma.to(dev), beta.to(dev), stash=True)
+    ref = torch.nn.functional.layer_norm((x + r).double(), (N,), gamma.double(), beta.double(), 1e-5)
+    _close(y, ref, name='ln')
+    _close(xhat * gamma.to(dev) + beta.to(dev), ref, name='xhat')
