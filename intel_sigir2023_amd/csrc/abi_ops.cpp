@@ -70,3 +70,51 @@ extern "C" int intel_op_add_layernorm(const float* x, const float* r, int M, int
                                       const float* beta, float* y, float* xhat, float* rstd, void* stream) {
   return launch_add_layernorm(x, N, r, N, M, N, gamma, beta, y, N, xhat, N, rstd, (hipStream_t)stream);
 }
+
+// ---- losses / optimizer / evaluation ------------------------------------------------------------
+#include "session.h"
+
+extern "C" size_t intel_loss_workspace_bytes(int B, int L, int K) {
+  (void)L; (void)K;
+  size_t a = loss_ws_bytes(B), b = intent_ws_bytes(B);
+  return (a > b ? a : b) + 256;
+}
+
+extern "C" int intel_bpr_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                              const float* noise, const double* scores_f64, const float* scores_f32,
+                              const float* weights, int cal_diversity, double alpha, float grad_scale, float* loss,
+                              int* select, float* d_ens, float* d_weights, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  INTEL_CHECK_ARG(B > 0 && L > 0 && K > 0 && ens_score && ranking && session_len && loss && workspace, "bpr loss: bad argument");
+  return launch_bpr_loss(B, L, K, ens_score, ranking, session_len, noise, scores_f64, scores_f32, weights, cal_diversity, alpha,
+                         grad_scale, loss, select, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int intel_list_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                               const double* scores_f64, const float* scores_f32, const float* weights,
+                               int cal_diversity, double alpha, float grad_scale, float* loss, float* d_ens,
+                               float* d_weights, void* workspace, size_t workspace_bytes, void* stream) {
+  INTEL_CHECK_ARG(B > 0 && L > 0 && K > 0 && ens_score && ranking && session_len && loss && workspace, "list loss: bad argument");
+  return launch_list_loss(B, L, K, ens_score, ranking, session_len, scores_f64, scores_f32, weights, cal_diversity, alpha,
+                          grad_scale, loss, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int intel_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
+                                 float grad_scale, double* out3, float* d_pred, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  INTEL_CHECK_ARG(B > 0 && I > 0 && pred && label && out3 && workspace, "intent loss: bad argument");
+  return launch_intent_loss(B, I, pred, label, kl_weight, kl_temp, grad_scale, out3, d_pred, workspace, workspace_bytes,
+                            (hipStream_t)stream);
+}
+
+extern "C" int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream) {
+  INTEL_CHECK_ARG(p && g && m && v, "adam: null tensor");
+  return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, (hipStream_t)stream);
+}
+
+extern "C" int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
+                          float* ndcg, void* stream) {
+  INTEL_CHECK_ARG(ens_score && ranking && session_len && ndcg, "ndcg: null tensor");
+  return launch_ndcg(B, L, k, ens_score, ranking, session_len, ndcg, (hipStream_t)stream);
+}

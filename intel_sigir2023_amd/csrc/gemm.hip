@@ -16,7 +16,7 @@
 // pack
 // ------------------------------------------------------------------------------------------
 __global__ void pack_b_kernel(const float* __restrict__ W, int ldw, int Kd, int Nd, int trans,
-                              float* __restrict__ P, int nt_off, int KG, int NT) {
+                              float* __restrict__ P, int nt_off, int KG, int NT, int g_off, int KG_total) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (nt, g, lane)
   int total = NT * KG * 64;
   if (idx >= total) return;
@@ -32,13 +32,15 @@ __global__ void pack_b_kernel(const float* __restrict__ W, int ldw, int Kd, int 
     if (k < Kd && n < Nd) x = trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k];
     v[s] = x;
   }
-  *reinterpret_cast<f32x4*>(P + ((size_t)((nt_off + nt) * KG + g) * 64 + lane) * 4) = v;
+  *reinterpret_cast<f32x4*>(P + ((size_t)((nt_off + nt) * KG_total + g_off + g) * 64 + lane) * 4) = v;
 }
 
-int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st) {
+int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st, int g_off,
+                  int KG_total) {
   int KG = rup(Kd, 16) / 16, NT = rup(Nd, 16) / 16;
   int total = NT * KG * 64;
-  hipLaunchKernelGGL(pack_b_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, ldw, Kd, Nd, trans, P, nt_off, KG, NT);
+  if (KG_total <= 0) KG_total = KG;
+  hipLaunchKernelGGL(pack_b_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, ldw, Kd, Nd, trans, P, nt_off, KG, NT, g_off, KG_total);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -9,7 +9,10 @@
 static inline size_t packed_floats(int Kd, int Nd) { return (size_t)rup(Kd, 16) * rup(Nd, 16); }
 // trans=0: B[k][n] = W[n*ldw + k]  (y = x W^T, W is [Nd,Kd]);  trans=1: B[k][n] = W[k*ldw + n].
 // Writes tiles nt_off .. nt_off+ceil(Nd/16)-1 of a packed matrix whose k extent is Kd.
-int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st);
+// g_off / KG_total: place this matrix's k groups at offset g_off of a packed matrix with KG_total
+// k groups (stacking several weights along k; Kd of each must then be a multiple of 16).
+int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st,
+                  int g_off = 0, int KG_total = 0);
 
 struct GemmEpilogue {
   const float* bias = nullptr;    // [N]

@@ -1,0 +1,898 @@
+// Host-side plan of the IntEL forward / backward: which kernels run, on which buffers, in which
+// order.  Restates models/IntEL/IntEL.py:117-217 (forward) and derives its backward by hand (the
+// reference relies on torch autograd, helpers/BaseRunner.py:288).  Everything is enqueued on one
+// HIP stream without synchronisation or allocation, so a whole step is graph-capturable.
+//
+// Workspace layout (one caller-provided allocation, carved by `Layout`):
+//   [ packed weights | forward activations (stash) | backward temporaries | reduction slabs ]
+// Activations are fp32 row-major [rows, width]; "rows" are B*L candidate rows or B*T history rows.
+#include <string.h>
+
+#include <new>
+
+#include "../../include/intel_hip.h"
+#include "kernels.h"
+#include "session.h"
+#include "gru.h"
+
+#define MAX_TOWER_LAYERS 8
+
+namespace {
+
+struct Arena {
+  char* base;
+  size_t off;
+  float* f(size_t n) {
+    off = rup_sz(off, 256);
+    float* p = reinterpret_cast<float*>(base + off);
+    off += n * sizeof(float);
+    return p;
+  }
+};
+
+// tower parameter offsets relative to INTEL_P_I_WQ / INTEL_P_S_WQ
+enum { T_WQ = 0, T_WK, T_WV, T_W1, T_B1, T_W2, T_B2, T_LNG, T_LNB };
+
+struct TowerLayerBufs { float *QKV, *A, *LSE, *R1, *XH, *RSTD, *Xout; };
+struct TowerBufs {
+  int d, pbase, xbase, feat_off;
+  float* X0;
+  TowerLayerBufs layer[MAX_TOWER_LAYERS];
+  float *QV, *QK, *XBAR, *ATTW;
+  float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T;
+  float *pXq, *pXqT, *pXk, *pXkT, *pXv, *pXvT;
+  // --cross_attention 0
+  float *MH, *MV, *pM0, *pM2, *pM2T, *pM0T;
+};
+struct EncBlockBufs {
+  float *QKV, *A, *LSE, *C, *XH1, *RSTD1, *F1, *Eout, *XH2, *RSTD2;
+  float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T, *bQKV;
+};
+struct EncBufs {
+  int T, dm, d_tab, pbase, predin_off;
+  float* E0;
+  EncBlockBufs blk[INTEL_ENC_MAX_BLOCKS];
+  GruBufs gru;
+};
+
+struct Layout {
+  int B, L, H, Hi, M;
+  TowerBufs tw[2];          // 0 = item tower, 1 = score tower
+  EncBufs enc[2];           // 0 = "encoder" (session history), 1 = "item_encoder"
+  int F, Pin;               // width of the fusion feature / pred_layer input
+  float *FEAT, *WV, *WPAD, *FEATFULL, *PREDIN, *LOGITS, *INTENTS;
+  float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
+  // backward temporaries
+  float *dXa, *dXb, *dZ, *dF1, *dA, *dQKV, *DSUM, *SLABS;
+  float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN, *dVB1, *dVB2, *dVB3;
+  size_t total;
+};
+
+}  // namespace
+
+struct IntelCtx {
+  IntelDesc d;
+  Layout lay;
+  bool have_layout;
+  bool fwd_done;
+  int fB, fL, fH, fHi;
+  const void* f_ws;
+  unsigned char touched[INTEL_P_COUNT];
+};
+
+namespace {
+
+inline int enc_slot(int e, int off) { return INTEL_P_ENC0 + e * INTEL_ENC_STRIDE + off; }
+inline int enc_blk_slot(int e, int l, int off) { return enc_slot(e, INTEL_ENC_BLOCK0 + l * INTEL_ENC_BLOCK_STRIDE + off); }
+
+void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, Layout& y) {
+  Arena ar{base, 0};
+  y.B = B; y.L = L; y.H = H; y.Hi = Hi; y.M = B * L;
+  const int M = y.M;
+  const int d_i = D.d_id + D.d_im, d_s = D.d_s;
+  y.F = d_i + d_s + D.d_u + D.d_int;
+  const int dm0 = D.d_c + D.d_int, dm1 = D.d_id + D.d_int;
+  y.Pin = D.d_c + D.d_u + dm1 + dm0;
+  const int I = D.intent_num, K = D.model_num;
+  // ---- packed weights
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    w.d = t == 0 ? d_i : d_s;
+    w.pbase = t == 0 ? INTEL_P_I_WQ : INTEL_P_S_WQ;
+    w.xbase = t == 0 ? INTEL_P_XI_WQ : INTEL_P_XS_WQ;
+    w.feat_off = t == 0 ? 0 : d_i;
+    const int d = w.d;
+    w.pWqkv = ar.f(packed_floats(d, 3 * d));
+    w.pW1 = ar.f(packed_floats(d, d));
+    w.pW2 = ar.f(packed_floats(d, d));
+    w.pWqkvT = ar.f(packed_floats(3 * rup(d, 16), d));
+    w.pW1T = ar.f(packed_floats(d, d));
+    w.pW2T = ar.f(packed_floats(d, d));
+    if (D.cross_attention) {
+      w.pXq = ar.f(packed_floats(I, d));
+      w.pXqT = ar.f(packed_floats(d, I));
+      w.pXk = ar.f(packed_floats(d, d));
+      w.pXkT = ar.f(packed_floats(d, d));
+      w.pXv = ar.f(packed_floats(d, d));
+      w.pXvT = ar.f(packed_floats(d, d));
+    } else {
+      w.pM0 = ar.f(packed_floats(I, D.q_size));
+      w.pM0T = ar.f(packed_floats(D.q_size, I));
+      w.pM2 = ar.f(packed_floats(D.q_size, d));
+      w.pM2T = ar.f(packed_floats(d, D.q_size));
+    }
+  }
+  y.pInt = ar.f(packed_floats(I, D.d_int));
+  y.pIntT = ar.f(packed_floats(D.d_int, I));
+  y.pScore = ar.f(packed_floats(K, d_s));
+  y.pWe = ar.f(packed_floats(y.F, K));
+  y.pWePad = ar.f(packed_floats(D.d_u + D.d_int, K));
+  y.pWeT = ar.f(packed_floats(K, y.F));
+  y.pWePadT = ar.f(packed_floats(K, D.d_u + D.d_int));
+  y.pPred = ar.f(packed_floats(y.Pin, I));
+  y.pPredT = ar.f(packed_floats(I, y.Pin));
+  for (int e = 0; e < 2; ++e) {
+    EncBufs& n = y.enc[e];
+    n.T = e == 0 ? H : Hi;
+    n.dm = e == 0 ? dm0 : dm1;
+    n.d_tab = e == 0 ? D.d_c : D.d_id;
+    n.pbase = enc_slot(e, 0);
+    n.predin_off = e == 0 ? (D.d_c + D.d_u + dm1) : (D.d_c + D.d_u);
+    const int dm = n.dm;
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      for (int l = 0; l < D.enc_layers; ++l) {
+        EncBlockBufs& k = n.blk[l];
+        k.pWqkv = ar.f(packed_floats(dm, 3 * dm));
+        k.pW1 = ar.f(packed_floats(dm, dm));
+        k.pW2 = ar.f(packed_floats(dm, dm));
+        k.pWqkvT = ar.f(packed_floats(3 * rup(dm, 16), dm));
+        k.pW1T = ar.f(packed_floats(dm, dm));
+        k.pW2T = ar.f(packed_floats(dm, dm));
+        k.bQKV = ar.f(3 * dm);
+      }
+    } else {
+      gru_layout_packed(n.gru, dm, D.gru_hidden, ar.base, ar.off);
+    }
+  }
+  // ---- forward activations
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    const size_t md = (size_t)M * w.d;
+    w.X0 = ar.f(md);
+    for (int l = 0; l < D.layers; ++l) {
+      TowerLayerBufs& b = w.layer[l];
+      b.QKV = ar.f(3 * md);
+      b.A = ar.f(md);
+      b.LSE = ar.f((size_t)B * D.heads * L);
+      b.R1 = ar.f(md);
+      b.XH = ar.f(md);
+      b.RSTD = ar.f(M);
+      b.Xout = ar.f(md);
+    }
+    if (D.cross_attention) {
+      w.QV = ar.f((size_t)B * w.d);
+      w.QK = ar.f((size_t)B * w.d);
+      w.XBAR = ar.f((size_t)B * w.d);
+      w.ATTW = ar.f((size_t)B * L);
+    } else {
+      w.MH = ar.f((size_t)B * D.q_size);
+      w.MV = ar.f((size_t)B * w.d);
+    }
+  }
+  y.FEAT = ar.f((size_t)B * y.F);
+  y.WV = ar.f((size_t)B * K);
+  y.WPAD = ar.f((size_t)B * K);
+  y.FEATFULL = D.cross_attention ? nullptr : ar.f((size_t)M * y.F);
+  y.PREDIN = ar.f((size_t)B * y.Pin);
+  y.LOGITS = ar.f((size_t)B * I);
+  y.INTENTS = ar.f((size_t)B * I);
+  size_t maxMD = (size_t)M * (d_i > d_s ? d_i : d_s);
+  size_t maxLSE = (size_t)B * D.heads * L;
+  for (int e = 0; e < 2; ++e) {
+    EncBufs& n = y.enc[e];
+    const size_t rows = (size_t)B * n.T, md = rows * n.dm;
+    n.E0 = ar.f(md);
+    if (md > maxMD) maxMD = md;
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      for (int l = 0; l < D.enc_layers; ++l) {
+        EncBlockBufs& k = n.blk[l];
+        k.QKV = ar.f(3 * md);
+        k.A = ar.f(md);
+        k.LSE = ar.f((size_t)B * D.enc_heads * n.T);
+        k.C = ar.f(md);
+        k.XH1 = ar.f(md);
+        k.RSTD1 = ar.f(rows);
+        k.F1 = ar.f(md);
+        k.Eout = ar.f(md);
+        k.XH2 = ar.f(md);
+        k.RSTD2 = ar.f(rows);
+      }
+      if ((size_t)B * D.enc_heads * n.T > maxLSE) maxLSE = (size_t)B * D.enc_heads * n.T;
+    } else {
+      gru_layout_act(n.gru, B, n.T, n.dm, D.gru_hidden, ar.base, ar.off);
+    }
+  }
+  // ---- backward temporaries
+  y.dXa = ar.f(maxMD);
+  y.dXb = ar.f(maxMD);
+  y.dZ = ar.f(maxMD);
+  y.dF1 = ar.f(maxMD);
+  y.dA = ar.f(maxMD);
+  y.dQKV = ar.f(3 * maxMD);
+  y.DSUM = ar.f(maxLSE);
+  y.dFEAT = ar.f((size_t)B * y.F);
+  y.dWV = ar.f((size_t)B * K);
+  y.dWPAD = ar.f((size_t)B * K);
+  y.dWT = D.cross_attention ? nullptr : ar.f((size_t)M * K);
+  y.dFEATFULL = D.cross_attention ? nullptr : ar.f((size_t)M * y.F);
+  y.dINTENT = ar.f((size_t)B * I);
+  y.dLOGITS = ar.f((size_t)B * I);
+  y.dPREDIN = ar.f((size_t)B * y.Pin);
+  const int dmax = d_i > d_s ? (d_i > dm0 ? (d_i > dm1 ? d_i : dm1) : (dm0 > dm1 ? dm0 : dm1))
+                             : (d_s > dm0 ? (d_s > dm1 ? d_s : dm1) : (dm0 > dm1 ? dm0 : dm1));
+  const int vmax = dmax > I ? (dmax > D.q_size ? dmax : D.q_size) : (I > D.q_size ? I : D.q_size);
+  y.dVB1 = ar.f((size_t)B * vmax);
+  y.dVB2 = ar.f((size_t)B * vmax);
+  y.dVB3 = ar.f((size_t)B * vmax);
+  // slabs: the largest weight-gradient / LayerNorm / column-sum reduction
+  size_t maxNK = (size_t)dmax * dmax;
+  auto upd = [&](size_t v) { if (v > maxNK) maxNK = v; };
+  upd((size_t)I * y.Pin); upd((size_t)K * y.F); upd((size_t)D.d_int * I); upd((size_t)d_s * K); upd((size_t)D.q_size * I);
+  upd((size_t)dmax * D.q_size); upd((size_t)dmax * I);
+  const int gh = D.gru_hidden;
+  if (D.encoder == INTEL_ENC_GRU4REC) { upd((size_t)3 * gh * dmax); upd((size_t)3 * gh * gh); upd((size_t)dmax * gh); }
+  size_t maxN = (size_t)(dmax > I ? dmax : I);
+  if ((size_t)3 * gh > maxN && D.encoder == INTEL_ENC_GRU4REC) maxN = 3 * gh;
+  if ((size_t)y.Pin > maxN) maxN = y.Pin;
+  if ((size_t)y.F > maxN) maxN = y.F;
+  size_t rowsmax = (size_t)M;
+  if ((size_t)B * H > rowsmax) rowsmax = (size_t)B * H;
+  if ((size_t)B * Hi > rowsmax) rowsmax = (size_t)B * Hi;
+  size_t slab = 256 * (maxNK + maxN);
+  size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;
+  if (lnslab > slab) slab = lnslab;
+  y.SLABS = ar.f(slab + 1024);
+  y.total = rup_sz(ar.off, 256) + 256;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Run {
+  IntelCtx* ctx;
+  const IntelDesc& D;
+  Layout& y;
+  const void* const* params;
+  void* const* grads;
+  const IntelBatch* bt;
+  hipStream_t st;
+  int rc;
+  const float* P(int slot) const { return static_cast<const float*>(params[slot]); }
+  float* G(int slot) const { return static_cast<float*>(grads[slot]); }
+  // 0 the first time a gradient slot is written in this backward, 1 afterwards (accumulate)
+  int acc(int slot) {
+    int a = ctx->touched[slot];
+    ctx->touched[slot] = 1;
+    return a;
+  }
+  bool ok(int r) {
+    if (r != 0 && rc == 0) rc = r;
+    return rc == 0;
+  }
+};
+
+#define RUN(expr)             \
+  do {                        \
+    if (!r.ok(expr)) return;  \
+  } while (0)
+
+bool need(Run& r, int slot, const char* name) {
+  if (r.params[slot] == nullptr) {
+    intel_set_error("missing parameter %s (slot %d)", name, slot);
+    r.rc = INTEL_E_ARG;
+    return false;
+  }
+  return true;
+}
+
+void lin(Run& r, const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc, const GemmEpilogue& ep) {
+  RUN(launch_gemm_rows(A, lda, M, K, Bp, N, C, ldc, ep, r.st));
+}
+
+// dW (+)= dY^T X for parameter slots (w_slot, b_slot or -1)
+void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, int w_slot, int b_slot) {
+  float* dW = r.G(w_slot);
+  float* db = b_slot >= 0 ? r.G(b_slot) : nullptr;
+  if (!dW) return;
+  int a = r.acc(w_slot);
+  if (b_slot >= 0) { int ab = r.acc(b_slot); (void)ab; }
+  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, r.y.SLABS, r.st));
+}
+
+// ---- weight packing -------------------------------------------------------------------------
+void pack_tower(Run& r, TowerBufs& w) {
+  const int d = w.d, pb = w.pbase;
+  const int nt = rup(d, 16) / 16;
+  for (int j = 0; j < 3; ++j) {
+    RUN(launch_pack_b(r.P(pb + T_WQ + j), d, d, d, 0, w.pWqkv, j * nt, r.st));
+    // dX = dQKV @ [Wq;Wk;Wv]: reduction index = 3 stacked output dims (each padded to 16)
+    RUN(launch_pack_b(r.P(pb + T_WQ + j), d, d, d, 1, w.pWqkvT, 0, r.st, j * nt, 3 * nt));
+  }
+  RUN(launch_pack_b(r.P(pb + T_W1), d, d, d, 0, w.pW1, 0, r.st));
+  RUN(launch_pack_b(r.P(pb + T_W2), d, d, d, 0, w.pW2, 0, r.st));
+  RUN(launch_pack_b(r.P(pb + T_W1), d, d, d, 1, w.pW1T, 0, r.st));
+  RUN(launch_pack_b(r.P(pb + T_W2), d, d, d, 1, w.pW2T, 0, r.st));
+  const int I = r.D.intent_num;
+  if (r.D.cross_attention) {
+    const int xb = w.xbase;
+    RUN(launch_pack_b(r.P(xb + 0), I, I, d, 0, w.pXq, 0, r.st));    // QV = intent Wq^T
+    RUN(launch_pack_b(r.P(xb + 0), I, d, I, 1, w.pXqT, 0, r.st));   // dintent = dQV Wq
+    RUN(launch_pack_b(r.P(xb + 1), d, d, d, 1, w.pXkT, 0, r.st));   // QK = QV Wk
+    RUN(launch_pack_b(r.P(xb + 1), d, d, d, 0, w.pXk, 0, r.st));    // dQV = dQK Wk^T
+    RUN(launch_pack_b(r.P(xb + 2), d, d, d, 0, w.pXv, 0, r.st));    // pooled = xbar Wv^T
+    RUN(launch_pack_b(r.P(xb + 2), d, d, d, 1, w.pXvT, 0, r.st));   // dxbar = dpooled Wv
+  } else {
+    const int mb = (w.pbase == INTEL_P_I_WQ) ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
+    const int q = r.D.q_size;
+    RUN(launch_pack_b(r.P(mb + 0), I, I, q, 0, w.pM0, 0, r.st));
+    RUN(launch_pack_b(r.P(mb + 0), I, q, I, 1, w.pM0T, 0, r.st));
+    RUN(launch_pack_b(r.P(mb + 2), q, q, d, 0, w.pM2, 0, r.st));
+    RUN(launch_pack_b(r.P(mb + 2), q, d, q, 1, w.pM2T, 0, r.st));
+  }
+}
+
+void pack_all(Run& r) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const int I = D.intent_num, K = D.model_num;
+  for (int t = 0; t < 2; ++t) {
+    pack_tower(r, y.tw[t]);
+    if (r.rc) return;
+  }
+  const int off = y.F - (D.d_u + D.d_int);
+  RUN(launch_pack_b(r.P(INTEL_P_INTENT_W), I, I, D.d_int, 0, y.pInt, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_INTENT_W), I, D.d_int, I, 1, y.pIntT, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_SCORE_W), K, K, D.d_s, 0, y.pScore, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_WE_W), y.F, y.F, K, 0, y.pWe, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_WE_W) + off, y.F, D.d_u + D.d_int, K, 0, y.pWePad, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_WE_W), y.F, K, y.F, 1, y.pWeT, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_WE_W) + off, y.F, K, D.d_u + D.d_int, 1, y.pWePadT, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_PRED_W), y.Pin, y.Pin, I, 0, y.pPred, 0, r.st));
+  RUN(launch_pack_b(r.P(INTEL_P_PRED_W), y.Pin, I, y.Pin, 1, y.pPredT, 0, r.st));
+  for (int e = 0; e < 2; ++e) {
+    EncBufs& n = y.enc[e];
+    const int dm = n.dm, nt = rup(dm, 16) / 16;
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      for (int l = 0; l < D.enc_layers; ++l) {
+        EncBlockBufs& k = n.blk[l];
+        for (int j = 0; j < 3; ++j) {
+          const float* W = r.P(enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j));
+          RUN(launch_pack_b(W, dm, dm, dm, 0, k.pWqkv, j * nt, r.st));
+          RUN(launch_pack_b(W, dm, dm, dm, 1, k.pWqkvT, 0, r.st, j * nt, 3 * nt));
+          RUN(launch_copy_cols(r.P(enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j)), dm, 0, dm, 1, k.bQKV, 3 * dm, j * dm, nullptr, 0, 0, 0, r.st));
+        }
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W1)), dm, dm, dm, 0, k.pW1, 0, r.st));
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W2)), dm, dm, dm, 0, k.pW2, 0, r.st));
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W1)), dm, dm, dm, 1, k.pW1T, 0, r.st));
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W2)), dm, dm, dm, 1, k.pW2T, 0, r.st));
+      }
+    } else {
+      RUN(gru_pack(n.gru, r.P(enc_slot(e, INTEL_ENC_GRU_WIH)), r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
+                   r.P(enc_slot(e, INTEL_ENC_GRU_OUT)), dm, D.gru_hidden, r.st));
+    }
+  }
+}
+
+// ---- towers (IntEL.py:182-197) ----------------------------------------------------------------
+void tower_fwd(Run& r, TowerBufs& w) {
+  const IntelDesc& D = r.D;
+  const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
+  const float* X = w.X0;
+  for (int l = 0; l < D.layers; ++l) {
+    TowerLayerBufs& b = w.layer[l];
+    GemmEpilogue e0;
+    lin(r, X, d, M, d, w.pWqkv, 3 * d, b.QKV, 3 * d, e0);                       // q,k,v (bias=False, IntEL.py:60)
+    if (r.rc) return;
+    RUN(launch_attn_fwd(b.QKV, B, L, d, D.heads, nullptr, b.A, b.LSE, r.st));    // no mask (IntEL.py:184)
+    GemmEpilogue e1;
+    e1.bias = r.P(pb + T_B1);
+    e1.relu = 1;                                                                 // stores relu(W1 h + b1)
+    lin(r, b.A, d, M, d, w.pW1, d, b.R1, d, e1);
+    if (r.rc) return;
+    GemmEpilogue e2;
+    e2.bias = r.P(pb + T_B2);
+    e2.res = X; e2.ldres = d;
+    e2.gamma = r.P(pb + T_LNG); e2.beta = r.P(pb + T_LNB);
+    e2.xhat = b.XH; e2.ldxhat = d; e2.rstd = b.RSTD;
+    if (d <= 128) {
+      lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2);
+    } else {
+      GemmEpilogue e2b;
+      e2b.bias = e2.bias;
+      lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2b);
+      if (r.rc) return;
+      RUN(launch_add_layernorm(b.Xout, d, X, d, M, d, e2.gamma, e2.beta, b.Xout, d, b.XH, d, b.RSTD, r.st));
+    }
+    if (r.rc) return;
+    X = b.Xout;
+  }
+}
+
+// dXout (in r.y.dXa) -> dX0 (returned pointer, one of dXa/dXb)
+float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const int M = y.M, d = w.d, B = y.B, L = y.L, pb = w.pbase;
+  for (int l = D.layers - 1; l >= 0; --l) {
+    TowerLayerBufs& b = w.layer[l];
+    const float* Xin = l == 0 ? w.X0 : w.layer[l - 1].Xout;
+    {
+      int a = r.acc(pb + T_LNG);
+      r.acc(pb + T_LNB);
+      if (!r.ok(launch_layernorm_bwd(dX, d, b.XH, d, b.RSTD, M, d, r.P(pb + T_LNG), y.dZ, d, r.G(pb + T_LNG), r.G(pb + T_LNB), a,
+                                     y.SLABS, r.st)))
+        return nullptr;
+    }
+    wgrad(r, y.dZ, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
+    GemmEpilogue em;
+    em.mask = b.R1; em.ldmask = d;
+    lin(r, y.dZ, d, M, d, w.pW2T, d, y.dF1, d, em);                 // d(pre-relu) = (dZ W2) * [R1 > 0]
+    wgrad(r, y.dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1);
+    GemmEpilogue e0;
+    lin(r, y.dF1, d, M, d, w.pW1T, d, y.dA, d, e0);
+    if (r.rc) return nullptr;
+    if (!r.ok(launch_attn_bwd(b.QKV, b.A, y.dA, b.LSE, B, L, d, D.heads, nullptr, y.dQKV, y.DSUM, r.st))) return nullptr;
+    for (int j = 0; j < 3; ++j) wgrad(r, y.dQKV + j * d, 3 * d, Xin, d, M, d, d, pb + T_WQ + j, -1);
+    // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
+    GemmEpilogue er;
+    er.res = y.dZ; er.ldres = d;
+    lin(r, y.dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
+    if (r.rc) return nullptr;
+    float* t = dX; dX = dXalt; dXalt = t;
+  }
+  return dX;
+}
+
+// ---- BERT4Rec encoder (GeneralSeq.py:89-106) -----------------------------------------------------
+void bert_fwd(Run& r, int e) {
+  const IntelDesc& D = r.D;
+  EncBufs& n = r.y.enc[e];
+  const int B = r.y.B, T = n.T, dm = n.dm, rows = B * T;
+  const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
+  RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
+  const float* X = n.E0;
+  for (int l = 0; l < D.enc_layers; ++l) {
+    EncBlockBufs& k = n.blk[l];
+    {   // fused q/k/v projection (bias=True in TransformerLayer, layers.py:70)
+      GemmEpilogue eb;
+      eb.bias = k.bQKV;
+      lin(r, X, dm, rows, dm, k.pWqkv, 3 * dm, k.QKV, 3 * dm, eb);
+      if (r.rc) return;
+    }
+    RUN(launch_attn_fwd(k.QKV, B, T, dm, D.enc_heads, len, k.A, k.LSE, r.st));
+    RUN(launch_add_layernorm(k.A, dm, X, dm, rows, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)),
+                             r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), k.C, dm, k.XH1, dm, k.RSTD1, r.st));
+    GemmEpilogue e1;
+    e1.bias = r.P(enc_blk_slot(e, l, INTEL_ENC_B1));
+    e1.relu = 1;
+    lin(r, k.C, dm, rows, dm, k.pW1, dm, k.F1, dm, e1);
+    if (r.rc) return;
+    GemmEpilogue e2;
+    e2.bias = r.P(enc_blk_slot(e, l, INTEL_ENC_B2));
+    e2.res = k.C; e2.ldres = dm;
+    if (dm <= 128) {
+      e2.gamma = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)); e2.beta = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B));
+      e2.xhat = k.XH2; e2.ldxhat = dm; e2.rstd = k.RSTD2;
+      lin(r, k.F1, dm, rows, dm, k.pW2, dm, k.Eout, dm, e2);
+    } else {
+      GemmEpilogue e2b;
+      e2b.bias = e2.bias;
+      lin(r, k.F1, dm, rows, dm, k.pW2, dm, k.Eout, dm, e2b);
+      if (r.rc) return;
+      RUN(launch_add_layernorm(k.Eout, dm, k.C, dm, rows, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)),
+                               r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B)), k.Eout, dm, k.XH2, dm, k.RSTD2, r.st));
+    }
+    if (r.rc) return;
+    X = k.Eout;
+  }
+  RUN(launch_select_last(X, dm, len, B, T, r.y.PREDIN, r.y.Pin, n.predin_off, r.st));
+}
+
+// returns dE0 (gradient w.r.t. the encoder input rows, pos-emb already handled)
+float* bert_bwd(Run& r, int e) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  EncBufs& n = y.enc[e];
+  const int B = y.B, T = n.T, dm = n.dm, rows = B * T;
+  const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
+  float *dX = y.dXa, *dXalt = y.dXb;
+  if (!r.ok(launch_select_last_bwd(y.dPREDIN, y.Pin, n.predin_off, dm, len, B, T, dX, r.st))) return nullptr;
+  for (int l = D.enc_layers - 1; l >= 0; --l) {
+    EncBlockBufs& k = n.blk[l];
+    const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
+    // LN2: Eout = LN2(F2 + C)
+    {
+      const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
+      int a = r.acc(sg);
+      r.acc(sb);
+      if (!r.ok(launch_layernorm_bwd(dX, dm, k.XH2, dm, k.RSTD2, rows, dm, r.P(sg), y.dZ, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+        return nullptr;
+    }
+    wgrad(r, y.dZ, dm, k.F1, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
+    GemmEpilogue em;
+    em.mask = k.F1; em.ldmask = dm;
+    lin(r, y.dZ, dm, rows, dm, k.pW2T, dm, y.dF1, dm, em);
+    wgrad(r, y.dF1, dm, k.C, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
+    // dC = dF1 W1 + dZ (residual into LN2)
+    GemmEpilogue ec;
+    ec.res = y.dZ; ec.ldres = dm;
+    lin(r, y.dF1, dm, rows, dm, k.pW1T, dm, y.dA, dm, ec);
+    if (r.rc) return nullptr;
+    // LN1: C = LN1(A + Xin): dS = LN1bwd(dC)  -> dA_attn = dS, residual dXin += dS
+    {
+      const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
+      int a = r.acc(sg);
+      r.acc(sb);
+      if (!r.ok(launch_layernorm_bwd(y.dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), y.dZ, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+        return nullptr;
+    }
+    if (!r.ok(launch_attn_bwd(k.QKV, k.A, y.dZ, k.LSE, B, T, dm, D.enc_heads, len, y.dQKV, y.DSUM, r.st))) return nullptr;
+    for (int j = 0; j < 3; ++j)
+      wgrad(r, y.dQKV + j * dm, 3 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j),
+            enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j));
+    {
+      GemmEpilogue er;
+      er.res = y.dZ; er.ldres = dm;
+      lin(r, y.dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);   // dm % 16 == 0 (check_desc)
+    }
+    if (r.rc) return nullptr;
+    float* t = dX; dX = dXalt; dXalt = t;
+  }
+  // position embedding gradient
+  if (r.G(enc_slot(e, INTEL_ENC_POS))) {
+    if (!r.acc(enc_slot(e, INTEL_ENC_POS))) {
+      if (!r.ok(launch_fill(r.G(enc_slot(e, INTEL_ENC_POS)), (long long)(D.history_max + 1) * dm, 0.f, r.st))) return nullptr;
+    }
+    if (!r.ok(launch_add_pos_bwd(dX, dm, len, B, T, r.G(enc_slot(e, INTEL_ENC_POS)), r.st))) return nullptr;
+  }
+  return dX;
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+void forward_impl(Run& r, const IntelOut* out) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const IntelBatch& bt = *r.bt;
+  const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
+  pack_all(r);
+  if (r.rc) return;
+  // ===== predict_intent (IntEL.py:126-155)
+  for (int e = 0; e < 2; ++e) {
+    EncBufs& n = y.enc[e];
+    const int rows = B * n.T, dm = n.dm;
+    GemmEpilogue eb;
+    eb.bias = r.P(INTEL_P_INTENT_B);
+    if (e == 0) {
+      RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st));
+      lin(r, bt.his_intents, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
+    } else {
+      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
+      if (bt.his_item_idx)
+        RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st));
+      else
+        lin(r, bt.his_item_int, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_id, dm, eb);
+    }
+    if (r.rc) return;
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      bert_fwd(r, e);
+    } else {
+      const int* len = e == 0 ? bt.history_len : bt.history_item_len;
+      RUN(gru_fwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_BIH)),
+                  r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st));
+    }
+    if (r.rc) return;
+  }
+  RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
+  RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
+  {
+    GemmEpilogue ep;
+    ep.bias = r.P(INTEL_P_PRED_B);
+    lin(r, y.PREDIN, y.Pin, B, y.Pin, y.pPred, I, y.LOGITS, I, ep);
+    if (r.rc) return;
+    RUN(launch_softmax_rows(y.LOGITS, B, I, y.INTENTS, r.st));
+  }
+  // ===== predict_ensemble (IntEL.py:158-217)
+  TowerBufs& ti = y.tw[0];
+  TowerBufs& ts = y.tw[1];
+  RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, r.st));
+  if (D.d_im > 0) RUN(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, r.st));
+  tower_fwd(r, ti);
+  if (r.rc) return;
+  {
+    GemmEpilogue es;
+    es.bias = r.P(INTEL_P_SCORE_B);
+    lin(r, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
+    if (r.rc) return;
+  }
+  tower_fwd(r, ts);
+  if (r.rc) return;
+  const int off_u = ti.d + ts.d, off_int = off_u + D.d_u;
+  const float scale = 1.0f / sqrtf((float)D.q_size);
+  GemmEpilogue e0;
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
+    if (D.cross_attention) {
+      lin(r, y.INTENTS, I, B, I, w.pXq, w.d, w.QV, w.d, e0);
+      lin(r, w.QV, w.d, B, w.d, w.pXkT, w.d, w.QK, w.d, e0);
+      if (r.rc) return;
+      RUN(launch_xatt_pool_fwd(Xf, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, r.st));
+      lin(r, w.XBAR, w.d, B, w.d, w.pXv, w.d, y.FEAT + w.feat_off, y.F, e0);
+    } else {
+      const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
+      GemmEpilogue eh;
+      eh.bias = r.P(mb + 1);
+      eh.relu = 1;
+      lin(r, y.INTENTS, I, B, I, w.pM0, D.q_size, w.MH, D.q_size, eh);
+      lin(r, w.MH, D.q_size, B, D.q_size, w.pM2, w.d, w.MV, w.d, e0);
+      if (r.rc) return;
+      RUN(launch_gate_fwd(Xf, w.d, w.MV, B, L, y.FEATFULL, y.F, w.feat_off, r.st));
+    }
+    if (r.rc) return;
+  }
+  RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.FEAT, y.F, off_u, 1, r.st));     // relu(h_u)
+  {
+    GemmEpilogue eh;
+    eh.bias = r.P(INTEL_P_INTENT_B);
+    eh.relu = 1;
+    lin(r, y.INTENTS, I, B, I, y.pInt, D.d_int, y.FEAT + off_int, y.F, eh);                             // relu(h_intent)
+    if (r.rc) return;
+  }
+  GemmEpilogue ew;
+  ew.bias = r.P(INTEL_P_WE_B);
+  if (D.cross_attention) {
+    lin(r, y.FEAT, y.F, B, y.F, y.pWe, K, y.WV, K, ew);
+    lin(r, y.FEAT + off_u, y.F, B, D.d_u + D.d_int, y.pWePad, K, y.WPAD, K, ew);
+    if (r.rc) return;
+    RUN(launch_ens_fwd(y.WV, y.WPAD, bt.scores, bt.session_len, B, L, K, 0, out->weights, out->ens_score, r.st));
+  } else {
+    RUN(launch_bcast_rows(y.FEAT + off_u, y.F, D.d_u + D.d_int, B, L, y.FEATFULL, y.F, off_u, r.st));
+    lin(r, y.FEATFULL, y.F, M, y.F, y.pWe, K, out->weights, K, ew);
+    if (r.rc) return;
+    RUN(launch_ens_fwd(nullptr, nullptr, bt.scores, bt.session_len, B, L, K, 1, out->weights, out->ens_score, r.st));
+  }
+  hipError_t e = hipMemcpyAsync(out->intents, y.INTENTS, (size_t)B * I * sizeof(float), hipMemcpyDeviceToDevice, r.st);
+  if (e != hipSuccess) {
+    intel_set_error("intents copy failed: %s", hipGetErrorString(e));
+    r.rc = (int)e;
+  }
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+void backward_impl(Run& r, const float* d_weights, const float* d_ens, const float* d_intents) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const IntelBatch& bt = *r.bt;
+  const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
+  TowerBufs& ti = y.tw[0];
+  TowerBufs& ts = y.tw[1];
+  const int off_u = ti.d + ts.d, off_int = off_u + D.d_u, npad = D.d_u + D.d_int;
+  const float scale = 1.0f / sqrtf((float)D.q_size);
+  GemmEpilogue e0;
+  GemmEpilogue eacc;
+  eacc.accumulate = 1;
+  memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
+  // embedding tables accumulate with atomics into caller-zeroed buffers
+  r.ctx->touched[INTEL_P_IID_EMB] = r.ctx->touched[INTEL_P_ITEM_EMB] = 1;
+  r.ctx->touched[INTEL_P_UID_EMB] = r.ctx->touched[INTEL_P_CTX_EMB] = 1;
+
+  // ===== fusion weights + aggregation (IntEL.py:212-215)
+  if (D.cross_attention) {
+    RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 0, y.dWV, y.dWPAD, nullptr, r.st));
+    wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+    if (r.rc) return;
+    if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
+      RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, y.SLABS, r.st));
+    }
+    lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
+    lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
+  } else {
+    RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 1, nullptr, nullptr, y.dWT, r.st));
+    wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+    lin(r, y.dWT, K, M, K, y.pWeT, y.F, y.dFEATFULL, y.F, e0);
+    if (r.rc) return;
+    // per-session parts of the feature: h_u, h_intent are broadcast over the list
+    RUN(launch_session_colsum(y.dFEATFULL, y.F, off_u, npad, B, L, y.dFEAT, y.F, off_u, 0, r.st));
+  }
+  if (r.rc) return;
+  // h_u = relu(uid_emb[u])
+  if (r.G(INTEL_P_UID_EMB))
+    RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
+  // h_intent = relu(intent_embeddings(intent)): dpre -> dVB1 [B, d_int]
+  RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
+  wgrad(r, y.dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+  lin(r, y.dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
+  if (r.rc) return;
+
+  // ===== towers: cross attention + tied self-attention layers
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    const int d = w.d;
+    const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
+    float* dX = y.dXa;
+    if (D.cross_attention) {
+      const int xb = w.xbase;
+      // pooled = xbar Wv^T
+      wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1);
+      lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, y.dVB1, d, e0);          // dxbar
+      if (r.rc) return;
+      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, y.dVB1, d, scale, dX, y.dVB2, r.st));   // dX, dQK
+      // QK = QV Wk  (QK[b][j] = sum_i QV[b][i] Wk[i][j])
+      wgrad(r, w.QV, d, y.dVB2, d, B, d, d, xb + 1, -1);
+      lin(r, y.dVB2, d, B, d, w.pXk, d, y.dVB3, d, e0);                            // dQV
+      wgrad(r, y.dVB3, d, y.INTENTS, I, B, d, I, xb + 0, -1);
+      lin(r, y.dVB3, d, B, d, w.pXqT, I, y.dINTENT, I, eacc);
+    } else {
+      const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
+      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dX, y.dVB1, r.st));    // dX, dMV
+      wgrad(r, y.dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
+      GemmEpilogue em;
+      em.mask = w.MH; em.ldmask = D.q_size;
+      lin(r, y.dVB1, d, B, d, w.pM2T, D.q_size, y.dVB2, D.q_size, em);            // d(pre-relu hidden)
+      wgrad(r, y.dVB2, D.q_size, y.INTENTS, I, B, D.q_size, I, mb + 0, mb + 1);
+      lin(r, y.dVB2, D.q_size, B, D.q_size, w.pM0T, I, y.dINTENT, I, eacc);
+    }
+    if (r.rc) return;
+    float* dX0 = tower_bwd(r, w, dX, y.dXb);
+    if (r.rc || !dX0) return;
+    if (t == 0) {
+      if (r.G(INTEL_P_IID_EMB))
+        RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+      if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
+        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
+    } else {
+      wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
+    }
+    if (r.rc) return;
+  }
+
+  // ===== predict_intent backward
+  if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
+  RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
+  wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+  lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+  if (r.rc) return;
+  if (r.G(INTEL_P_CTX_EMB))
+    RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+  if (r.G(INTEL_P_UID_EMB))
+    RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
+  for (int e = 0; e < 2; ++e) {
+    EncBufs& n = y.enc[e];
+    const int rows = B * n.T, dm = n.dm;
+    float* dE = nullptr;
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      dE = bert_bwd(r, e);
+    } else {
+      const int* len = e == 0 ? bt.history_len : bt.history_item_len;
+      GruGrads gg;
+      gg.dWih = r.G(enc_slot(e, INTEL_ENC_GRU_WIH)); gg.dWhh = r.G(enc_slot(e, INTEL_ENC_GRU_WHH));
+      gg.dbih = r.G(enc_slot(e, INTEL_ENC_GRU_BIH)); gg.dbhh = r.G(enc_slot(e, INTEL_ENC_GRU_BHH));
+      gg.dWout = r.G(enc_slot(e, INTEL_ENC_GRU_OUT));
+      dE = y.dXa;
+      r.ok(gru_bwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
+                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, y.dXb, y.SLABS, r.st));
+    }
+    if (r.rc || !dE) return;
+    // input rows: [table row | intent_embeddings(intent rows)]
+    if (e == 0) {
+      if (r.G(INTEL_P_CTX_EMB))
+        RUN(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+      wgrad(r, dE + D.d_c, dm, bt.his_intents, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+    } else {
+      if (r.G(INTEL_P_IID_EMB))
+        RUN(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+      if (bt.his_item_idx) {
+        if (r.G(INTEL_P_INTENT_W))
+          RUN(launch_onehot_linear_bwd(dE, dm, D.d_id, D.d_int, I, bt.his_item_idx, rows, r.G(INTEL_P_INTENT_W), r.G(INTEL_P_INTENT_B), r.st));
+      } else {
+        wgrad(r, dE + D.d_id, dm, bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+      }
+    }
+    if (r.rc) return;
+  }
+}
+
+int check_desc(const IntelDesc& d) {
+  INTEL_CHECK_ARG(d.model_num >= 1 && d.model_num <= 16, "model_num %d unsupported (1..16)", d.model_num);
+  INTEL_CHECK_ARG(d.intent_num >= 1, "intent_num must be positive");
+  INTEL_CHECK_ARG(d.layers >= 0 && d.layers <= MAX_TOWER_LAYERS, "num_layers %d unsupported (0..%d)", d.layers, MAX_TOWER_LAYERS);
+  INTEL_CHECK_ARG(d.heads >= 1, "num_heads must be >= 1");
+  const int d_i = d.d_id + d.d_im;
+  INTEL_CHECK_ARG(d_i % 4 == 0 && d.d_s % 4 == 0 && d.d_id % 4 == 0 && d.d_im % 4 == 0, "embedding sizes must be multiples of 4");
+  INTEL_CHECK_ARG(d.d_u % 4 == 0 && d.d_c % 4 == 0 && d.d_int % 4 == 0, "embedding sizes must be multiples of 4");
+  INTEL_CHECK_ARG(d_i % d.heads == 0 && d.d_s % d.heads == 0, "tower widths must be divisible by num_heads");
+  INTEL_CHECK_ARG(d_i % 16 == 0 && d.d_s % 16 == 0, "tower widths (i_emb+im_emb=%d, s_emb=%d) must be multiples of 16", d_i, d.d_s);
+  INTEL_CHECK_ARG(d.encoder == INTEL_ENC_BERT4REC || d.encoder == INTEL_ENC_GRU4REC, "Invalid sequence encoder.");
+  if (d.encoder == INTEL_ENC_BERT4REC) {
+    INTEL_CHECK_ARG(d.enc_layers >= 1 && d.enc_layers <= INTEL_ENC_MAX_BLOCKS, "encoder blocks %d unsupported", d.enc_layers);
+    INTEL_CHECK_ARG((d.d_c + d.d_int) % 16 == 0 && (d.d_id + d.d_int) % 16 == 0, "encoder widths must be multiples of 16");
+    INTEL_CHECK_ARG((d.d_c + d.d_int) % d.enc_heads == 0 && (d.d_id + d.d_int) % d.enc_heads == 0, "encoder widths must be divisible by heads");
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
+  if (!desc) {
+    intel_set_error("intel_create: null descriptor");
+    return nullptr;
+  }
+  if (check_desc(*desc) != 0) return nullptr;
+  IntelCtx* c = new (std::nothrow) IntelCtx();
+  if (!c) return nullptr;
+  c->d = *desc;
+  c->have_layout = false;
+  c->fwd_done = false;
+  return c;
+}
+
+extern "C" void intel_destroy(IntelCtx* ctx) { delete ctx; }
+
+extern "C" size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train) {
+  (void)train;
+  if (!ctx || B <= 0 || L <= 0 || H <= 0 || Hi <= 0) return 0;
+  Layout y;
+  make_layout(ctx->d, B, L, H, Hi, nullptr, y);
+  return y.total;
+}
+
+static int check_batch(const IntelCtx* ctx, const IntelBatch* b) {
+  INTEL_CHECK_ARG(b && b->B > 0 && b->L > 0 && b->H > 0 && b->Hi > 0, "bad batch shape");
+  INTEL_CHECK_ARG(b->i_id_s && b->i_class_c && b->scores && b->session_len && b->u_id_c && b->context_mh, "batch: null tensor");
+  INTEL_CHECK_ARG(b->his_context_mh && b->his_intents && b->history_len && b->his_item_id && b->history_item_len, "batch: null history tensor");
+  INTEL_CHECK_ARG(b->his_item_idx || b->his_item_int, "batch: need his_item_idx or his_item_int");
+  INTEL_CHECK_ARG(b->H <= ctx->d.history_max + 1 && b->Hi <= ctx->d.history_max + 1 || ctx->d.encoder != INTEL_ENC_BERT4REC,
+                  "history longer than history_max+1 position embeddings");
+  return 0;
+}
+
+extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                             size_t workspace_bytes, const IntelOut* out, int train, void* stream) {
+  INTEL_CHECK_ARG(ctx && params && out && workspace, "intel_forward: null argument");
+  int rc = check_batch(ctx, batch);
+  if (rc) return rc;
+  INTEL_CHECK_ARG(out->weights && out->ens_score && out->intents, "intel_forward: null output");
+  INTEL_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
+  make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay);
+  if (workspace_bytes < ctx->lay.total) {
+    intel_set_error("intel_forward: workspace %zu < %zu bytes", workspace_bytes, ctx->lay.total);
+    return INTEL_E_WORKSPACE;
+  }
+  ctx->have_layout = true;
+  Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0};
+  forward_impl(r, out);
+  ctx->fwd_done = (r.rc == 0) && train;
+  ctx->fB = batch->B; ctx->fL = batch->L; ctx->fH = batch->H; ctx->fHi = batch->Hi;
+  ctx->f_ws = workspace;
+  return r.rc;
+}
+
+extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                              size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                              const float* d_intents, void* const* grads, void* stream) {
+  INTEL_CHECK_ARG(ctx && params && grads && workspace, "intel_backward: null argument");
+  int rc = check_batch(ctx, batch);
+  if (rc) return rc;
+  if (!ctx->fwd_done || ctx->fB != batch->B || ctx->fL != batch->L || ctx->fH != batch->H || ctx->fHi != batch->Hi ||
+      ctx->f_ws != workspace) {
+    intel_set_error("intel_backward: no matching intel_forward(train=1) on this context/workspace");
+    return INTEL_E_STATE;
+  }
+  if (workspace_bytes < ctx->lay.total) return INTEL_E_WORKSPACE;
+  INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
+  Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0};
+  backward_impl(r, d_weights, d_ens_score, d_intents);
+  return r.rc;
+}

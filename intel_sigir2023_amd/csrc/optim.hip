@@ -1,0 +1,148 @@
+// Fused Adam (dense, coupled L2) and on-device NDCG@k.
+#include "kernels.h"
+#include "session.h"
+
+// torch.optim.Adam single-tensor update (helpers/BaseRunner.py:182-188 builds it with
+// weight_decay = --l2 on non-bias parameters, models/BaseModel.py:53-62):
+//   g += wd*p;  m = m + (g-m)*(1-b1);  v = b2*v + (1-b2)*g*g;
+//   p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// Dense over the whole tensor: rows with zero gradient still decay.
+// Pure HBM stream: 4 reads + 3 writes (+1 write when the gradient is cleared in the same pass).
+struct AdamArgs {
+  float* p; float* g; float* m; float* v; long long n;
+  float step_size, beta1, beta2, eps, wd, inv_bc2_sqrt, grad_scale; int zero_grad;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
+  g = g * a.grad_scale + a.wd * p;
+  m = m + (g - m) * (1.f - a.beta1);
+  v = v * a.beta2 + (1.f - a.beta2) * g * g;
+  const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+  p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
+  const long long n4 = a.n >> 2;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+    f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = p[k], mk = m[k], vk = v[k];
+      adam_one(pk, g[k], mk, vk, a);
+      p[k] = pk; m[k] = mk; v[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(a.p)[i] = p;
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+    if (a.zero_grad) reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // tail
+  const long long t0 = n4 << 2;
+  for (long long i = t0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+    float p = a.p[i], m = a.m[i], v = a.v[i];
+    adam_one(p, a.g[i], m, v, a);
+    a.p[i] = p; a.m[i] = m; a.v[i] = v;
+    if (a.zero_grad) a.g[i] = 0.f;
+  }
+}
+
+int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                float wd, int step, float grad_scale, int zero_grad, hipStream_t st) {
+  if (n <= 0) return 0;
+  INTEL_CHECK_ARG(step >= 1, "adam: step must be >= 1");
+  INTEL_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                    reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adam: tensors must be 16-byte aligned");
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+  long long blocks = ((n >> 2) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);     // grid-stride: 256 CUs x 8
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// NDCG@k, "All" key of BaseRunner.evaluate_method (helpers/BaseRunner.py:117-126):
+//   width = max(L, k); predictions padded with 0, labels with 0 (negatives / pads / unlabelled);
+//   gains are LINEAR in the label (3/2/1/0); ties in the prediction resolve to the lower label
+//   first (what the reference's label-descending pre-sort + reversed argsort yields).
+// One wave per session; top-k by k rounds of wave arg-max.
+// ------------------------------------------------------------------------------------------
+#define ND_MAXPL 8
+__global__ __launch_bounds__(256) void ndcg_kernel(const float* __restrict__ ens, const int* __restrict__ ranking,
+                                                   const int* __restrict__ slen, int B, int L, int k, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int len = min(slen[b], L);
+  const int width = max(L, k);
+  float pv[ND_MAXPL];
+  int lb[ND_MAXPL];
+  bool used[ND_MAXPL];
+  int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // label histogram (labels 0..7; Tmall uses 0..3)
+#pragma unroll
+  for (int i = 0; i < ND_MAXPL; ++i) {
+    const int l = lane + 64 * i;
+    const bool in = l < len;
+    pv[i] = in ? ens[(size_t)b * L + l] : 0.f;
+    int r = in ? ranking[(size_t)b * L + l] : 0;
+    r = r < 0 ? 0 : r;
+    lb[i] = r;
+    used[i] = !(l < width);
+    if (l < width) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cnt[q] += (min(r, 7) == q);
+    }
+  }
+  double dcg = 0.0;
+  for (int p = 0; p < k; ++p) {
+    // best = max prediction; ties -> smaller label, then larger index (any order: equal gain)
+    float bv = -INFINITY;
+    int bl = 0x7fffffff, bi = -1;
+#pragma unroll
+    for (int i = 0; i < ND_MAXPL; ++i) {
+      if (!used[i] && (pv[i] > bv || (pv[i] == bv && lb[i] < bl))) { bv = pv[i]; bl = lb[i]; bi = lane + 64 * i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int ol = __shfl_xor(bl, o), oi = __shfl_xor(bi, o);
+      const bool take = (oi >= 0) && (bi < 0 || ov > bv || (ov == bv && (ol < bl || (ol == bl && oi > bi))));
+      if (take) { bv = ov; bl = ol; bi = oi; }
+    }
+    if (bi < 0) break;
+#pragma unroll
+    for (int i = 0; i < ND_MAXPL; ++i)
+      if (lane + 64 * i == bi) used[i] = true;
+    dcg += (double)bl / log2((double)p + 2.0);
+  }
+  // ideal: labels sorted descending
+#pragma unroll
+  for (int q = 0; q < 8; ++q) cnt[q] = wave_sum_i(cnt[q]);
+  double idcg = 0.0;
+  {
+    int p = 0;
+#pragma unroll
+    for (int q = 7; q >= 1; --q)
+      for (int c = 0; c < cnt[q] && p < k; ++c, ++p) idcg += (double)q / log2((double)p + 2.0);
+  }
+  if (lane == 0) out[b] = (float)(dcg / idcg);    // 0/0 -> NaN like the reference
+}
+
+int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const int* slen, float* out, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(max(L, k) <= 64 * ND_MAXPL, "ndcg: list length %d > %d unsupported", L, 64 * ND_MAXPL);
+  INTEL_CHECK_ARG(k >= 1 && k <= 64, "ndcg: k=%d unsupported", k);
+  hipLaunchKernelGGL(ndcg_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, ens, ranking, slen, B, L, k, out);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

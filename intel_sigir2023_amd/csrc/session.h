@@ -27,3 +27,20 @@ int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, f
                      const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st);
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
                        int accumulate, hipStream_t st);
+
+// loss.hip
+size_t loss_ws_bytes(int B);
+size_t intent_ws_bytes(int B);
+int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const float* noise,
+                    const double* sc64, const float* sc32, const float* weights, int cal_div, double alpha,
+                    float grad_scale, float* loss, int* select, float* d_ens, float* d_weights, void* ws, size_t ws_bytes,
+                    hipStream_t st);
+int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
+                     const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
+                     float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
+                       float grad_scale, double* out3, float* d_pred, void* ws, size_t ws_bytes, hipStream_t st);
+// optim.hip
+int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                float wd, int step, float grad_scale, int zero_grad, hipStream_t st);
+int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const int* slen, float* out, hipStream_t st);

@@ -1,0 +1,424 @@
+"""IntEL model -- host-side mirror of the reference's ``models/IntEL/IntEL.py`` (class ``IntEL``).
+
+Same constructor contract (``IntEL(args, corpus)``), same CLI flags (``parse_model_args``), same
+``state_dict`` keys and shapes, same ``forward(data) -> {"weights","ens_score","intents"}``; the
+arithmetic runs in hand-written gfx950 HIP kernels behind the C ABI (include/intel_hip.h).  The
+sub-modules below are parameter containers only (their ``forward`` is never called): there is no
+PyTorch / CPU fallback -- calling the model without the HIP library or off-GPU raises.
+"""
+import ctypes as C
+import logging
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+def _list_product(xs):
+    p = 1
+    for x in xs:
+        p *= int(x)
+    return p
+
+
+class _AttnHead(nn.Module):
+    """Parameters of modules/layers.py:11-29 (MultiHeadAttention; no output projection)."""
+
+    def __init__(self, d_model, n_heads, bias=True):
+        super().__init__()
+        self.d_model, self.h = d_model, n_heads
+        self.q_linear = nn.Linear(d_model, d_model, bias=bias)
+        self.k_linear = nn.Linear(d_model, d_model, bias=bias)
+        self.v_linear = nn.Linear(d_model, d_model, bias=bias)
+
+
+class _TransformerLayer(nn.Module):
+    """Parameters of modules/layers.py:62-80 (TransformerLayer)."""
+
+    def __init__(self, d_model, d_ff, n_heads):
+        super().__init__()
+        self.masked_attn_head = _AttnHead(d_model, n_heads)
+        self.layer_norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear2 = nn.Linear(d_ff, d_model)
+        self.layer_norm2 = nn.LayerNorm(d_model)
+
+
+class _BERT4RecEncoder(nn.Module):
+    """Parameters of models/GeneralSeq.py:80-87."""
+
+    def __init__(self, emb_size, max_his, num_layers=2, num_heads=2):
+        super().__init__()
+        self.p_embeddings = nn.Embedding(max_his + 1, emb_size)
+        self.transformer_block = nn.ModuleList(
+            [_TransformerLayer(emb_size, emb_size, num_heads) for _ in range(num_layers)])
+
+
+class _GRU4RecEncoder(nn.Module):
+    """Parameters of models/GeneralSeq.py:58-62."""
+
+    def __init__(self, emb_size, hidden_size=128):
+        super().__init__()
+        self.rnn = nn.GRU(input_size=emb_size, hidden_size=hidden_size, batch_first=True)
+        self.out = nn.Linear(hidden_size, emb_size, bias=False)
+
+
+class _CrossAtt(nn.Module):
+    """Parameters of modules/attention.py:121-147 (CrossAtt, bias-free q/k/v)."""
+
+    def __init__(self, input_qsize, input_vsize, size):
+        super().__init__()
+        self.query_layer = nn.Linear(input_qsize, size, bias=False)
+        self.key_layer = nn.Linear(input_vsize, size, bias=False)
+        self.value_layer = nn.Linear(input_vsize, size, bias=False)
+
+
+class IntEL(nn.Module):
+    reader, runner = 'SeqReader', 'BaseRunner'
+    extra_log_args = ['cross_attn_qsize', 'num_heads', 'num_layers', 'encoder', 'intent_emb_size']
+
+    # ---- CLI contract (IntEL.py:17-34, GeneralSeq.py:15-17, BaseModel.py:20-27) ----------------
+    @staticmethod
+    def parse_model_args(parser):
+        parser.add_argument('--encoder', type=str, default='BERT4Rec', help='A sequence encoder for intent prediction.')
+        parser.add_argument('--context_emb_size', type=int, default=16, help='Embedding size for context.')
+        parser.add_argument('--i_emb_size', type=int, default=16, help='Embedding size for item id.')
+        parser.add_argument('--u_emb_size', type=int, default=32, help='Embedding size for user.')
+        parser.add_argument('--s_emb_size', type=int, default=32, help='Embedding size for score.')
+        parser.add_argument('--im_emb_size', type=int, default=16, help='Embedding size for item metadata.')
+        parser.add_argument('--intent_emb_size', type=int, default=16, help='Embedding size for intent.')
+        parser.add_argument('--cross_attn_qsize', type=int, default=32, help='Embedding size for cross-attention query.')
+        parser.add_argument('--num_heads', type=int, default=1, help='Number of attention heads.')
+        parser.add_argument('--dropout', type=float, default=0, help='Dropout probability for each deep layer')
+        parser.add_argument('--num_layers', type=int, default=1, help='Number of self-attention layers.')
+        parser.add_argument('--cross_attention', type=int, default=1,
+                            help='Using cross-attention structure or direct attention.')
+        parser.add_argument('--history_max', type=int, default=20)
+        parser.add_argument('--model_path', type=str, default='', help='Model save path.')
+        parser.add_argument('--buffer', type=int, default=1, help='Whether to buffer feed dicts for dev/test')
+        parser.add_argument('--model_num', type=int, default=2, help='Number of base models.')
+        return parser
+
+    def __init__(self, args, corpus):
+        super().__init__()
+        # BaseModel / GeneralModel / GeneralSeq attributes (BaseModel.py:38-45,151-155; GeneralSeq.py:19-21)
+        self.intent_num = len(corpus.zero_int)
+        self.device = getattr(args, 'device', torch.device('cpu'))
+        self.model_path = getattr(args, 'model_path', '')
+        self.buffer = getattr(args, 'buffer', 1)
+        self.optimizer = None
+        self.check_list = list()
+        self.user_num = int(corpus.max_uid + 1)
+        self.item_num = int(corpus.max_iid + 1)
+        self.max_his = args.history_max
+        self.itemfnum = _list_product(corpus.itemfnum)
+        self.model_num = args.model_num
+        self.dropout = float(getattr(args, 'dropout', 0))
+
+        # parameters, created in the reference's order (IntEL.py:43-115) so that a given
+        # torch.manual_seed yields the same default initialisation
+        self.iid_embeddings = nn.Embedding(self.item_num, args.i_emb_size)
+        self.im_emb_size = 0
+        if self.itemfnum > 0:
+            self.item_embeddings = nn.Embedding(self.itemfnum, args.im_emb_size)
+            self.im_emb_size = args.im_emb_size
+        self.uid_embeddings = nn.Embedding(self.user_num, args.u_emb_size)
+        self.intent_embeddings = nn.Linear(self.intent_num, args.intent_emb_size)
+        self.score_embeddings = nn.Linear(args.model_num, args.s_emb_size)
+        self.head_num, self.layer_num = args.num_heads, args.num_layers
+        self.item_emb_size = args.i_emb_size + self.im_emb_size
+        self.i_attn_head = _AttnHead(self.item_emb_size, self.head_num, bias=False)
+        self.i_W1 = nn.Linear(self.item_emb_size, self.item_emb_size)
+        self.i_W2 = nn.Linear(self.item_emb_size, self.item_emb_size)
+        self.i_layer_norm = nn.LayerNorm(self.item_emb_size)
+        self.score_emb_size = args.s_emb_size
+        self.s_attn_head = _AttnHead(self.score_emb_size, self.head_num, bias=False)
+        self.s_W1 = nn.Linear(self.score_emb_size, self.score_emb_size)
+        self.s_W2 = nn.Linear(self.score_emb_size, self.score_emb_size)
+        self.s_layer_norm = nn.LayerNorm(self.score_emb_size)
+        self.cross_attn_qsize = args.cross_attn_qsize
+        self.cross_attention = args.cross_attention
+        if self.cross_attention:
+            self.intent_score_attention = _CrossAtt(self.intent_num, self.score_emb_size, self.score_emb_size)
+            self.intent_item_attention = _CrossAtt(self.intent_num, self.item_emb_size, self.item_emb_size)
+        else:
+            self.intent_score_embeddings = nn.Sequential(
+                nn.Linear(self.intent_num, self.cross_attn_qsize), nn.ReLU(),
+                nn.Linear(self.cross_attn_qsize, self.score_emb_size, bias=False))
+            self.intent_item_embeddings = nn.Sequential(
+                nn.Linear(self.intent_num, self.cross_attn_qsize), nn.ReLU(),
+                nn.Linear(self.cross_attn_qsize, self.item_emb_size, bias=False))
+        self.weight_embeddings = nn.Linear(
+            self.item_emb_size + args.s_emb_size + args.intent_emb_size + args.u_emb_size, args.model_num)
+        self.context_embeddings = nn.Embedding(_list_product(corpus.contextfnum), args.context_emb_size)
+        self.encoder_name = args.encoder
+        self.intent_pred_size = args.intent_emb_size + args.context_emb_size
+        self.his_item_dim = args.intent_emb_size + args.i_emb_size
+        if self.encoder_name == 'GRU4Rec':
+            self.encoder = _GRU4RecEncoder(self.intent_pred_size, hidden_size=128)
+            self.item_encoder = _GRU4RecEncoder(self.his_item_dim, hidden_size=128)
+        elif self.encoder_name == 'BERT4Rec':
+            self.encoder = _BERT4RecEncoder(self.intent_pred_size, self.max_his, num_layers=2, num_heads=2)
+            self.item_encoder = _BERT4RecEncoder(self.his_item_dim, self.max_his, num_layers=2, num_heads=2)
+        else:
+            raise ValueError('Invalid sequence encoder.')
+        self.pred_layer = nn.Linear(
+            self.intent_pred_size + self.his_item_dim + args.context_emb_size + args.u_emb_size, self.intent_num)
+
+        self._desc = L.IntelDesc(
+            model_num=args.model_num, intent_num=self.intent_num, item_num=self.item_num,
+            class_num=max(self.itemfnum, 1), user_num=self.user_num,
+            ctx_num=_list_product(corpus.contextfnum), d_id=args.i_emb_size, d_im=self.im_emb_size,
+            d_u=args.u_emb_size, d_s=args.s_emb_size, d_c=args.context_emb_size, d_int=args.intent_emb_size,
+            q_size=args.cross_attn_qsize, heads=args.num_heads, layers=args.num_layers,
+            cross_attention=int(bool(args.cross_attention)),
+            encoder=0 if self.encoder_name == 'BERT4Rec' else 1, history_max=self.max_his,
+            enc_layers=2, enc_heads=2, gru_hidden=128)
+        self._ctx = None
+        self._ws = None
+        self._slot_names = self._build_slot_map()
+
+    # ---- reference auxiliary API (BaseModel.py:53-78) -------------------------------------------
+    def customize_parameters(self, define_dict={}):
+        weight_p, bias_p = [], []
+        for name, p in filter(lambda x: x[1].requires_grad, self.named_parameters()):
+            (bias_p if 'bias' in name else weight_p).append(p)
+        return [{'params': weight_p}, {'params': bias_p, 'weight_decay': 0}]
+
+    def save_model(self, model_path=None):
+        model_path = model_path or self.model_path
+        d = os.path.dirname(model_path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        torch.save(self.state_dict(), model_path)
+
+    def load_model(self, model_path=None):
+        model_path = model_path or self.model_path
+        self.load_state_dict(torch.load(model_path, map_location=self.device))
+        logging.info('Load model from ' + model_path)
+
+    def count_variables(self):
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def to(self, *a, **k):
+        m = super().to(*a, **k)
+        try:
+            self.device = next(self.parameters()).device
+        except StopIteration:
+            pass
+        return m
+
+    # ---- parameter slots of the C ABI -------------------------------------------------------------
+    def _build_slot_map(self):
+        P = L.P
+        m = {
+            P['IID_EMB']: 'iid_embeddings.weight', P['UID_EMB']: 'uid_embeddings.weight',
+            P['CTX_EMB']: 'context_embeddings.weight',
+            P['INTENT_W']: 'intent_embeddings.weight', P['INTENT_B']: 'intent_embeddings.bias',
+            P['SCORE_W']: 'score_embeddings.weight', P['SCORE_B']: 'score_embeddings.bias',
+            P['WE_W']: 'weight_embeddings.weight', P['WE_B']: 'weight_embeddings.bias',
+            P['PRED_W']: 'pred_layer.weight', P['PRED_B']: 'pred_layer.bias',
+        }
+        if self.itemfnum > 0:
+            m[P['ITEM_EMB']] = 'item_embeddings.weight'
+        for t, pre in (('I', 'i'), ('S', 's')):
+            m[P[t + '_WQ']] = pre + '_attn_head.q_linear.weight'
+            m[P[t + '_WK']] = pre + '_attn_head.k_linear.weight'
+            m[P[t + '_WV']] = pre + '_attn_head.v_linear.weight'
+            m[P[t + '_W1']] = pre + '_W1.weight'
+            m[P[t + '_B1']] = pre + '_W1.bias'
+            m[P[t + '_W2']] = pre + '_W2.weight'
+            m[P[t + '_B2']] = pre + '_W2.bias'
+            m[P[t + '_LNG']] = pre + '_layer_norm.weight'
+            m[P[t + '_LNB']] = pre + '_layer_norm.bias'
+        if self.cross_attention:
+            for t, pre in (('XI', 'intent_item_attention'), ('XS', 'intent_score_attention')):
+                m[P[t + '_WQ']] = pre + '.query_layer.weight'
+                m[P[t + '_WK']] = pre + '.key_layer.weight'
+                m[P[t + '_WV']] = pre + '.value_layer.weight'
+        else:
+            for t, pre in (('MI', 'intent_item_embeddings'), ('MS', 'intent_score_embeddings')):
+                m[P[t + '_W0']] = pre + '.0.weight'
+                m[P[t + '_B0']] = pre + '.0.bias'
+                m[P[t + '_W2']] = pre + '.2.weight'
+        for e, pre in ((0, 'encoder'), (1, 'item_encoder')):
+            base = L.P_ENC0 + e * L.ENC_STRIDE
+            if self.encoder_name == 'BERT4Rec':
+                m[base + L.ENC_POS] = pre + '.p_embeddings.weight'
+                for l in range(2):
+                    b = base + L.ENC_BLOCK0 + l * L.ENC_BLOCK_STRIDE
+                    tb = '%s.transformer_block.%d.' % (pre, l)
+                    names = {'WQ': 'masked_attn_head.q_linear.weight', 'BQ': 'masked_attn_head.q_linear.bias',
+                             'WK': 'masked_attn_head.k_linear.weight', 'BK': 'masked_attn_head.k_linear.bias',
+                             'WV': 'masked_attn_head.v_linear.weight', 'BV': 'masked_attn_head.v_linear.bias',
+                             'LN1G': 'layer_norm1.weight', 'LN1B': 'layer_norm1.bias',
+                             'W1': 'linear1.weight', 'B1': 'linear1.bias', 'W2': 'linear2.weight', 'B2': 'linear2.bias',
+                             'LN2G': 'layer_norm2.weight', 'LN2B': 'layer_norm2.bias'}
+                    for i, nm in enumerate(L.ENC_BLOCK_NAMES):
+                        m[b + i] = tb + names[nm]
+            else:
+                m[base + L.ENC_GRU_WIH] = pre + '.rnn.weight_ih_l0'
+                m[base + L.ENC_GRU_WHH] = pre + '.rnn.weight_hh_l0'
+                m[base + L.ENC_GRU_BIH] = pre + '.rnn.bias_ih_l0'
+                m[base + L.ENC_GRU_BHH] = pre + '.rnn.bias_hh_l0'
+                m[base + L.ENC_GRU_OUT] = pre + '.out.weight'
+        return m
+
+    def slot_items(self):
+        """[(slot, name, parameter)] for every parameter the kernels read."""
+        named = dict(self.named_parameters())
+        return [(s, n, named[n]) for s, n in sorted(self._slot_names.items())]
+
+    def _param_array(self, tensors_by_slot):
+        arr = (C.c_void_p * L.P_COUNT)()
+        for s, t in tensors_by_slot.items():
+            arr[s] = t.data_ptr() if t is not None else None
+        return arr
+
+    def _context(self):
+        if self._ctx is None:
+            ctx = L.lib().intel_create(C.byref(self._desc))
+            if not ctx:
+                raise L.IntelHipError('intel_create failed: ' + L.lib().intel_last_error().decode())
+            self._ctx = ctx
+        return self._ctx
+
+    def __del__(self):
+        try:
+            if getattr(self, '_ctx', None):
+                L.lib().intel_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ---- batch conversion ---------------------------------------------------------------------------
+    @staticmethod
+    def _i32(t):
+        return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+
+    @staticmethod
+    def _f32(t):
+        return t if t.dtype == torch.float32 and t.is_contiguous() else t.to(torch.float32).contiguous()
+
+    def prepare_batch(self, data):
+        """Narrow a reference-layout batch dict (BaseModel.py:121-142) to the ABI layout.  Returns
+        (IntelBatch struct, dict of tensors kept alive).  Already-converted batches pass through."""
+        if '_intel' in data:
+            return data['_intel']
+        dev = data['i_id_s'].device
+        L.require_gpu(data['i_id_s'])
+        keep = {}
+        keep['i_id_s'] = self._i32(data['i_id_s'])
+        Bsz, Lmax = keep['i_id_s'].shape
+        if 'i_class_c' in data and data['i_class_c'] is not None:
+            keep['i_class_c'] = self._i32(data['i_class_c'])
+        else:
+            keep['i_class_c'] = torch.zeros(Bsz, Lmax, dtype=torch.int32, device=dev)
+        keep['scores'] = self._f32(data['scores'])
+        for k in ('session_len', 'u_id_c', 'context_mh', 'his_context_mh', 'history_len', 'his_item_id',
+                  'history_item_len'):
+            keep[k] = self._i32(data[k])
+        keep['his_intents'] = self._f32(data['his_intents'])
+        if 'his_item_idx' in data:
+            keep['his_item_idx'] = self._i32(data['his_item_idx'])
+        else:
+            keep['his_item_int'] = self._f32(data['his_item_int'])
+        H, Hi = keep['his_context_mh'].shape[1], keep['his_item_id'].shape[1]
+        b = L.IntelBatch(B=Bsz, L=Lmax, H=H, Hi=Hi)
+        for k, v in keep.items():
+            setattr(b, k, v.data_ptr())
+        prepared = (b, keep)
+        return prepared
+
+    def _workspace(self, nbytes, device):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != device:
+            self._ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        off = (-self._ws.data_ptr()) % 256
+        return self._ws[off:]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, data):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError('dropout > 0 is not implemented in the HIP path (BPR / P-L scripts use --dropout 0)')
+        batch, keep = self.prepare_batch(data)
+        items = self.slot_items()
+        params = [p for _, _, p in items]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if need_grad:
+            w, e, i = _IntELFunction.apply(self, batch, keep, *params)
+        else:
+            w, e, i = self.run_forward(batch, keep, [p.detach() for p in params], train=False)
+            self._generation = getattr(self, '_generation', 0) + 1
+        return {'weights': w, 'ens_score': e, 'intents': i}
+
+    def run_forward(self, batch, keep, param_tensors, train):
+        items = self.slot_items()
+        dev = keep['i_id_s'].device
+        for t in param_tensors:
+            L.require_gpu(t)
+        lib = L.lib()
+        ctx = self._context()
+        nb = lib.intel_workspace_bytes(ctx, batch.B, batch.L, batch.H, batch.Hi, int(train))
+        ws = self._workspace(nb, dev)
+        K, I = self.model_num, self.intent_num
+        weights = torch.empty(batch.B, batch.L, K, dtype=torch.float32, device=dev)
+        ens = torch.empty(batch.B, batch.L, dtype=torch.float32, device=dev)
+        intents = torch.empty(batch.B, I, dtype=torch.float32, device=dev)
+        out = L.IntelOut(weights=weights.data_ptr(), ens_score=ens.data_ptr(), intents=intents.data_ptr())
+        parr = self._param_array({s: t.contiguous() for (s, _, _), t in zip(items, param_tensors)})
+        L.check(lib.intel_forward(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), C.byref(out), int(train),
+                                  L.stream_ptr(dev)), 'intel_forward')
+        return weights, ens, intents
+
+    def run_backward(self, batch, keep, param_tensors, d_weights, d_ens, d_intents, grad_tensors=None):
+        """d(out) -> d(param).  grad_tensors: optional {slot: tensor} of persistent buffers (embedding
+        tables must arrive zeroed); otherwise fresh ones are allocated."""
+        items = self.slot_items()
+        dev = keep['i_id_s'].device
+        lib = L.lib()
+        ctx = self._context()
+        nb = lib.intel_workspace_bytes(ctx, batch.B, batch.L, batch.H, batch.Hi, 1)
+        ws = self._workspace(nb, dev)
+        table_slots = (L.P['IID_EMB'], L.P['ITEM_EMB'], L.P['UID_EMB'], L.P['CTX_EMB'])
+        if grad_tensors is None:
+            grad_tensors = {}
+            for (s, _, p), t in zip(items, param_tensors):
+                if not p.requires_grad:
+                    continue
+                grad_tensors[s] = torch.zeros_like(t) if s in table_slots else torch.empty_like(t)
+        parr = self._param_array({s: t.contiguous() for (s, _, _), t in zip(items, param_tensors)})
+        garr = self._param_array(grad_tensors)
+        L.check(lib.intel_backward(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(d_weights), L.ptr(d_ens),
+                                   L.ptr(d_intents), garr, L.stream_ptr(dev)), 'intel_backward')
+        return grad_tensors
+
+
+class _IntELFunction(torch.autograd.Function):
+    """Makes ``loss.backward()`` (helpers/BaseRunner.py:288) drive the hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, model, batch, keep, *params):
+        ctx.model, ctx.batch, ctx.keep = model, batch, keep
+        ctx.save_for_backward(*params)
+        out = model.run_forward(batch, keep, [p.detach() for p in params], train=True)
+        model._generation = getattr(model, '_generation', 0) + 1    # the stash lives in ONE workspace
+        ctx.generation = model._generation
+        return out
+
+    @staticmethod
+    def backward(ctx, d_weights, d_ens, d_intents):
+        params = ctx.saved_tensors
+        model = ctx.model
+        if ctx.generation != model._generation:
+            raise L.IntelHipError('backward of a stale forward: the activation stash was overwritten by a later '
+                                  'training forward of the same model (one forward/backward pair at a time)')
+
+        def c(t):
+            return None if t is None else t.contiguous().float()
+        grads = model.run_backward(ctx.batch, ctx.keep, [p.detach() for p in params], c(d_weights), c(d_ens), c(d_intents))
+        items = model.slot_items()
+        out = [grads.get(s) if p.requires_grad else None for (s, _, p) in items]
+        return (None, None, None) + tuple(out)

@@ -41,3 +41,27 @@ def grad_projection(g):
     r = np.random.default_rng(PROJ_SEED).standard_normal(g.shape)
     g64 = np.asarray(g, dtype=np.float64)
     return np.array([(g64 * r).sum(), np.sqrt((g64 * g64).sum())])
+
+
+def make_args(fx_args, device):
+    import argparse
+    ns = argparse.Namespace(**fx_args)
+    ns.device = device
+    return ns
+
+
+def make_corpus(shape):
+    import types
+    return types.SimpleNamespace(itemfnum=[shape['classes']], contextfnum=[shape['ctx']],
+                                 zero_int=np.zeros(shape['I']), max_uid=shape['users'] - 1,
+                                 max_iid=shape['items'] - 1)
+
+
+def build_model(fx, device):
+    """The product model initialised from a fixture's reference state_dict."""
+    from intel_sigir2023_amd.model import IntEL
+    args = make_args(fx.args, device)
+    model = IntEL(args, make_corpus(fx.shape))
+    missing = model.load_state_dict(fx.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model.to(device), args
