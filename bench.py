@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training sessions/sec of the IntEL hot path on synthetic Tmall-shape data
+(BASELINE.json: list=50, K=3 base rankers, 64-d embeddings, 1M-item table) at 1/2/4/8 MI355X.
+
+A "step" = one pass of the hot path over one batch per GPU: forward -> BPR loss (+intent loss) ->
+hand-written backward -> gradient all-reduce (N>1) -> dense Adam over all parameters, inputs resident
+in HBM.  Prints ONE JSON line (rank 0).  `python bench.py --gpus N --steps K --warmup W`; for N>1 launch
+with torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
+F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
+MFMA_KERNELS = ('gemm_rows_kernel', 'wgrad_kernel', 'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel')
+
+
+def algorithmic_bytes_per_session(flags, corpus, shape, train, e=4):
+    """bytes a session's forward (and training extras) must move, fp32 (e=4)."""
+    L, H, Hi = shape['L'], shape['H'], shape['H']
+    K, I = flags['model_num'], corpus['I']
+    d_id, d_im, d_u, d_c = flags['i_emb_size'], flags['im_emb_size'], flags['u_emb_size'], flags['context_emb_size']
+    fwd = e * ((L + Hi) * d_id + d_u) + e * (L * d_im + (1 + H) * d_c) + 4 * (2 * L + 2 * Hi + H + 5) + 4 * L * K \
+        + 4 * H * I + 4 * (L + L * K + I)
+    if not train:
+        return fwd
+    return fwd + 4 * (L + I) + 4 * ((L + Hi) * d_id + d_u)
+
+
+def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
+    """The oracle (CPU restatement, kind='port') timed on this host: full training step on a bounded
+    sample (B=512 sessions per step, same synthetic generator), ~budget_s seconds of CPU work."""
+    import torch
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.model import IntEL
+    from oracle import intel_oracle as O
+    torch.manual_seed(0)
+    cpu = torch.device('cpu')
+    B = 512
+    flags = {k: v for k, v in vars(args_ns).items() if k != 'device'}
+    cfg = O.Config(**flags)
+    # parameters with the product's default init (CPU copy)
+    a = argparse.Namespace(**vars(args_ns))
+    a.device = cpu
+    m = IntEL(a, corpus)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    del m
+    batch = synth.to_reference_layout(synth.make_batch(workload, B, cpu, seed=99), cinfo['I'])
+    opt = torch.optim.Adam(O.adam_groups(list(sd.items()), 1e-4), lr=1e-3)
+
+    def step():
+        opt.zero_grad()
+        out = O.forward(sd, batch, cfg)
+        if 'BPR' in loss_name:
+            noise = torch.rand(B, batch['i_id_s'].shape[1], batch['i_id_s'].shape[1])
+            loss, _, _ = O.int_bpr_loss(out, batch, cfg, noise)
+        else:
+            loss, _, _ = O.int_list_loss(out, batch, cfg)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+    step()                                  # warm-up (allocations, lazy init)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 50:
+            break
+    return {'value': round(B * n / el, 2), 'unit': 'sessions/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
+            'sample': '%d training steps of B=%d synthetic %s sessions (oracle/intel_oracle.py: fwd+loss+autograd+torch Adam), %.1f s'
+                      % (n, B, workload, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', type=str, default='tmall', help='tmall | lifedata | stress | tiny')
+    ap.add_argument('--batch', type=int, default=4096, help='sessions per GPU per step (weak scaling)')
+    ap.add_argument('--loss', type=str, default='IntBPRloss')
+    ap.add_argument('--cal_diversity', type=int, default=0)
+    ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_roofline', action='store_true')
+    ap.add_argument('--cpu_budget', type=float, default=20.0)
+    ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
+    a = ap.parse_args()
+
+    import torch
+    from intel_sigir2023_amd import _lib, parallel, synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    rank, world, local_rank = parallel.init_distributed()
+    if world != a.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (a.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    _lib.lib()
+    w = synth.WORKLOADS[a.workload]
+    args_ns = synth.make_args(a.workload, dev, cal_diversity=a.cal_diversity)
+    corpus, cinfo = synth.make_corpus(a.workload)
+    torch.manual_seed(0)
+    model = IntEL(args_ns, corpus).to(dev)
+    eng = IntELEngine(model, a.loss, args_ns, lr=1e-3, l2=1e-4)
+    parallel.broadcast_(eng.param_buckets())
+    B = a.batch
+    nbatches = 2
+    batches = [synth.make_batch(a.workload, B, dev, seed=rank * 1000 + i, zipf=bool(a.zipf)) for i in range(nbatches)]
+    Lmax = w['batch']['L']
+
+    def one_step(i):
+        return eng.train_step(batches[i % nbatches])
+    for i in range(a.warmup):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = one_step(i)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    el = parallel.allreduce_max_float(el, dev)
+    last_loss = float(loss[0])
+
+    # ---- eval throughput (forward + on-device NDCG@3), not part of `value`
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ev_steps = max(3, a.steps // 2)
+    for i in range(ev_steps):
+        out, nd = eng.eval_step(batches[i % nbatches], k=3)
+    torch.cuda.synchronize()
+    ev_el = parallel.allreduce_max_float(time.perf_counter() - t1, dev)
+    ndcg3 = float(nd.float().nan_to_num(0).mean())
+
+    if rank != 0:
+        return
+    res = {
+        'metric': 'train sessions/sec, IntEL fwd+BPR loss+bwd+Adam, synthetic Tmall-shape list=%d K=%d d=64' % (Lmax, w['flags']['model_num']),
+        'value': round(world * B * a.steps / el, 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': round(1e3 * el / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, d=64, fp32, %s loss, cal_diversity=%d, %s item ids'
+                               % (a.workload, cinfo['items'], Lmax, w['flags']['model_num'], cinfo['I'], w['batch']['H'], a.loss,
+                                  a.cal_diversity, 'zipf' if a.zipf else 'uniform'),
+                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world},
+        'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
+        'loss_last_step': round(last_loss, 6),
+    }
+    bytes_train = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], True)
+    res['gather_roofline'] = {'bytes_per_session': bytes_train, 'achieved_GBps': round(bytes_train * res['value'] / world / 1e9, 3),
+                              'peak_GBps': HBM_PEAK / 1e9, 'frac': round(bytes_train * res['value'] / world / HBM_PEAK, 6)}
+    if not a.no_roofline:
+        lib = _lib.lib()
+        lib.intel_prof_enable(1)
+        psteps = 3
+        for i in range(psteps):
+            one_step(i)
+        prof_shapes = json.loads(lib.intel_prof_collect().decode())
+        lib.intel_prof_enable(0)
+        prof = {}                       # aggregate the shape-tagged GEMM records by kernel
+        for k, v in prof_shapes.items():
+            d = prof.setdefault(k.split('[')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            for f in d:
+                d[f] += v[f]
+        tot = sum(v['ms'] for v in prof.values())
+        name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+        avg_ms = dom['ms'] / dom['launches']
+        if name.split('<')[0] in MFMA_KERNELS:
+            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                    'frac': round(ach / (F32_MFMA_PEAK / 1e12), 5), 'traffic': None}
+        else:
+            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+            roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': round(ach / (HBM_PEAK / 1e9), 5), 'traffic': None}
+        roof.update({'kernel': name, 'launches_per_step': dom['launches'] / psteps, 'avg_launch_ms': round(avg_ms, 5),
+                     'share_of_kernel_time': round(dom['ms'] / tot, 4),
+                     'algorithmic_per_launch': (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches']})
+        res['roofline'] = roof
+        res['kernel_ms_per_step'] = {k: round(v['ms'] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16]}
+        res['kernel_rate'] = {k: ('%.1f TF/s' % (v['flops'] / v['ms'] / 1e9) if v['flops'] > 0 else '%.0f GB/s' % (v['bytes'] / v['ms'] / 1e6))
+                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16] if v['flops'] > 0 or v['bytes'] > 0}
+        if a.shapes:
+            res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f TF/s' % (v['ms'] / psteps, v['launches'] // psteps, v['flops'] / v['ms'] / 1e9)
+                                  for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01}
+        res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
+    if world == 1 and not a.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

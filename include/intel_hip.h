@@ -185,6 +185,13 @@ int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float l
 int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
                float* ndcg, void* stream);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+/* Per-kernel HIP-event timing on the launch stream (used by bench.py for the `roofline` block; the
+ * reference only has wall-clock _check_time, helpers/BaseRunner.py:174-180).  intel_prof_collect()
+ * synchronises the device and returns a JSON object {"kernel": {"launches","ms","flops","bytes"}}. */
+void intel_prof_enable(int on);
+const char* intel_prof_collect(void);
+
 /* ---- building blocks (exported for unit tests; see tests/test_ops_gpu.py) ------------------ */
 /* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (relu) -- torch.nn.Linear. */
 int intel_op_linear(const float* x, int M, int K, const float* w, int N, const float* bias, int relu,

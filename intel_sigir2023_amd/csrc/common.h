@@ -5,6 +5,8 @@
 #include <stddef.h>
 #include <math.h>
 
+#include "prof.h"
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define INTEL_WAVE 64

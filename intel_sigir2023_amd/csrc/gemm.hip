@@ -10,6 +10,8 @@
 // 128 output columns; wave w owns column tiles {w, w+4} x all four 16-row tiles (8 accumulators).
 // The k index inside a 16-wide k group is permuted (lane group j holds k = 4j..4j+3) identically
 // in A fragments and in the packed B, which is what lets both sides use 16-byte loads.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------
@@ -40,7 +42,7 @@ int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, 
   int KG = rup(Kd, 16) / 16, NT = rup(Nd, 16) / 16;
   int total = NT * KG * 64;
   if (KG_total <= 0) KG_total = KG;
-  hipLaunchKernelGGL(pack_b_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, ldw, Kd, Nd, trans, P, nt_off, KG, NT, g_off, KG_total);
+  LAUNCH(pack_b_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, ldw, Kd, Nd, trans, P, nt_off, KG, NT, g_off, KG_total);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -54,16 +56,179 @@ int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, 
 #define GR_LDE (128 + 4)
 
 struct GemmRowsArgs {
+  int vec_ep;   // epilogue operands are 16-byte aligned with leading dimensions % 4 == 0
+  int dbg;   // ablation bits (INTEL_DEBUG_GEMM): 1 no epilogue, 2 no MFMA, 4 no LDS staging, 8 no A prefetch
   const float* A; int lda; int M; int K;
   const float* Bp; int N;
   float* C; int ldc;
   GemmEpilogue ep;
 };
 
+// Epilogues.  The MFMAs are issued with the WEIGHT fragment as the A operand and the activation
+// fragment as the B operand, so an accumulator register quad holds 4 CONSECUTIVE OUTPUT COLUMNS of
+// one row (row = lane&15 of the tile): every epilogue load/store is a 16-byte access.
+//   acc[rt][c][r]  <->  row m0 + rt*16 + (lane&15),  column n0 + ct*16 + 4*(lane>>4) + r
+//
+// vmcnt counts loads AND stores in issue order, so a load issued after a store cannot be waited for
+// without also draining that store.  Both epilogues therefore issue EVERY global load (bias and the
+// one auxiliary operand: residual, relu mask or the accumulate destination) before the first store.
+__device__ __forceinline__ void gr_epilogue_direct(const GemmRowsArgs& a, const f32x4 (&acc)[4][2], int m0, int n0, int ntc,
+                                                   int wave, int lane) {
+  const GemmEpilogue& ep = a.ep;
+  // one auxiliary operand per call (the plan never combines them): 1 mask, 2 residual, 3 accumulate
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const bool late_acc = ep.accumulate && mode != 3;      // accumulate combined with mask/res (unused by the plan)
+  if (a.vec_ep) {
+    f32x4 bias[2], aux[4][2];
+    bool okc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ct = wave + 4 * c;
+      const int col = n0 + ct * 16 + 4 * (lane >> 4);
+      okc[c] = ct < ntc && col + 3 < a.N;
+      bias[c] = (ep.bias && okc[c]) ? *reinterpret_cast<const f32x4*>(ep.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = m0 + rt * 16 + (lane & 15);
+        aux[rt][c] = (mode && okc[c] && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ct = wave + 4 * c;
+      const int col = n0 + ct * 16 + 4 * (lane >> 4);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = m0 + rt * 16 + (lane & 15);
+        f32x4 x = acc[rt][c] + bias[c];
+        if (ep.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+        }
+        if (mode == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = aux[rt][c][r] > 0.f ? x[r] : 0.f;
+        } else {
+          x += aux[rt][c];                      // residual / accumulate (zeros when unused)
+        }
+        if (okc[c] && row < a.M) {
+          f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col);
+          if (late_acc) x += *dst;
+          *dst = x;
+        }
+      }
+    }
+    // ragged right edge (N % 4 != 0 never happens with vec_ep unless N % 16 != 0): scalar tail
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ct = wave + 4 * c;
+      const int col = n0 + ct * 16 + 4 * (lane >> 4);
+      if (ct >= ntc || okc[c] || col >= a.N) continue;
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = m0 + rt * 16 + (lane & 15);
+        if (row >= a.M) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cc = col + r;
+          if (cc >= a.N) continue;
+          float x = acc[rt][c][r] + (ep.bias ? ep.bias[cc] : 0.f);
+          if (ep.relu) x = fmaxf(x, 0.f);
+          if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + cc] > 0.f) ? x : 0.f;
+          if (ep.res) x += ep.res[(size_t)row * ep.ldres + cc];
+          float* dst = a.C + (size_t)row * a.ldc + cc;
+          *dst = ep.accumulate ? (*dst + x) : x;
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int ct = wave + 4 * c;
+    if (ct >= ntc) continue;
+    const int col = n0 + ct * 16 + 4 * (lane >> 4);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int row = m0 + rt * 16 + (lane & 15);
+      if (row >= a.M) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = col + r;
+        if (cc >= a.N) continue;
+        float x = acc[rt][c][r] + (ep.bias ? ep.bias[cc] : 0.f);
+        if (ep.relu) x = fmaxf(x, 0.f);
+        if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + cc] > 0.f) ? x : 0.f;
+        if (ep.res) x += ep.res[(size_t)row * ep.ldres + cc];
+        float* dst = a.C + (size_t)row * a.ldc + cc;
+        *dst = ep.accumulate ? (*dst + x) : x;
+      }
+    }
+  }
+}
+
+// LayerNorm epilogue through an LDS tile Es[64][GR_LDE] (caller syncs before; N <= 128).  One wave
+// normalises 16 rows; the residual rows are all loaded before the first store (see above).
+__device__ __forceinline__ void gr_epilogue_ln(const GemmRowsArgs& a, const f32x4 (&acc)[4][2], float* Es, int m0, int ntc,
+                                               int wave, int lane) {
+  const GemmEpilogue& ep = a.ep;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int ct = wave + 4 * c;
+    if (ct < ntc) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        *reinterpret_cast<f32x4*>(Es + (rt * 16 + (lane & 15)) * GR_LDE + ct * 16 + 4 * (lane >> 4)) = acc[rt][c];
+    }
+  }
+  const int ncols = min(128, a.N);
+  const bool ok0 = lane < ncols, ok1 = lane + 64 < ncols;
+  float res0[16], res1[16];
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int row = m0 + wave * 16 + rr;
+    const bool rok = row < a.M && ep.res != nullptr;
+    res0[rr] = (rok && ok0) ? ep.res[(size_t)row * ep.ldres + lane] : 0.f;
+    res1[rr] = (rok && ok1) ? ep.res[(size_t)row * ep.ldres + lane + 64] : 0.f;
+  }
+  const float bias0 = (ep.bias && ok0) ? ep.bias[lane] : 0.f, bias1 = (ep.bias && ok1) ? ep.bias[lane + 64] : 0.f;
+  const float g0 = ok0 ? ep.gamma[lane] : 0.f, g1 = ok1 ? ep.gamma[lane + 64] : 0.f;
+  const float be0 = ok0 ? ep.beta[lane] : 0.f, be1 = ok1 ? ep.beta[lane + 64] : 0.f;
+  __syncthreads();
+  const float inv_n = 1.f / (float)a.N;
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int r = wave * 16 + rr;
+    const int row = m0 + r;
+    float v0 = 0.f, v1 = 0.f;
+    if (ok0) { v0 = Es[r * GR_LDE + lane] + bias0; if (ep.relu) v0 = fmaxf(v0, 0.f); v0 += res0[rr]; }
+    if (ok1) { v1 = Es[r * GR_LDE + lane + 64] + bias1; if (ep.relu) v1 = fmaxf(v1, 0.f); v1 += res1[rr]; }
+    const float mean = wave_sum(v0 + v1) * inv_n;
+    const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
+    const float rs = 1.f / sqrtf(var + 1e-5f);
+    if (row < a.M) {
+      if (ep.rstd && lane == 0) ep.rstd[row] = rs;
+      if (ok0) {
+        const float xh = d0 * rs;
+        if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
+        a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+      }
+      if (ok1) {
+        const float xh = d1 * rs;
+        if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
+        a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRowsArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                       // [64][GR_LDA]
-  float* Es = smem + GR_BM * GR_LDA;      // [64][GR_LDE]
+  float* As = smem;                       // [64][GR_LDA]; re-used as the LayerNorm epilogue tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * GR_BM;
   const int Kp = (a.K + 15) & ~15, KG = Kp >> 4;
@@ -78,6 +243,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRowsArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool has0 = wave < ntc, has1 = wave + 4 < ntc;
 
     for (int kc = 0; kc < Kp; kc += GR_KC) {
       const int kcl = min(GR_KC, Kp - kc);
@@ -105,86 +271,256 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRowsArgs a) {
       }
       const int ng = kcl >> 4;
       const int gbase = kc >> 4;
+      // B fragments come straight from L2 in MFMA order; prefetch one k group ahead
+      const f32x4* bp0 = reinterpret_cast<const f32x4*>(a.Bp) + ((size_t)(nc + wave) * KG + gbase) * 64 + lane;
+      const f32x4* bp1 = reinterpret_cast<const f32x4*>(a.Bp) + ((size_t)(nc + wave + 4) * KG + gbase) * 64 + lane;
+      f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (has0) b0 = bp0[0];
+      if (has1) b1 = bp1[0];
       for (int g = 0; g < ng; ++g) {
+        f32x4 n0v = b0, n1v = b1;
+        if (g + 1 < ng) {
+          if (has0) n0v = bp0[(size_t)(g + 1) * 64];
+          if (has1) n1v = bp1[(size_t)(g + 1) * 64];
+        }
         f32x4 af[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
           af[rt] = *reinterpret_cast<const f32x4*>(As + (rt * 16 + (lane & 15)) * GR_LDA + g * 16 + 4 * (lane >> 4));
+        if (has0) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int ct = wave + 4 * c;
-          if (ct < ntc) {
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(a.Bp + ((size_t)((nc + ct) * KG + gbase + g) * 64 + lane) * 4);
+          for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-              for (int rt = 0; rt < 4; ++rt) acc[rt][c] = mfma16(af[rt][s], bf[s], acc[rt][c]);
-          }
+            for (int rt = 0; rt < 4; ++rt) acc[rt][0] = mfma16(b0[s], af[rt][s], acc[rt][0]);
         }
+        if (has1) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[rt][1] = mfma16(b1[s], af[rt][s], acc[rt][1]);
+        }
+        b0 = n0v;
+        b1 = n1v;
       }
     }
-    // ---- epilogue: accumulators -> LDS -> row-wise processing, coalesced stores
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ct = wave + 4 * c;
-      if (ct < ntc) {
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Es[(rt * 16 + 4 * (lane >> 4) + r) * GR_LDE + ct * 16 + (lane & 15)] = acc[rt][c][r];
-      }
+    if (!ep.gamma) {
+      gr_epilogue_direct(a, acc, m0, nc * 16, ntc, wave, lane);
+      continue;
     }
+    // LayerNorm epilogue (N <= 128: single chunk): the A tile is dead, re-use it
     __syncthreads();
-    const int n0 = nc * 16;
-    const int ncols = min(128, a.N - n0);
-    for (int rr = 0; rr < 16; ++rr) {
-      const int r = wave * 16 + rr;
-      const int row = m0 + r;
-      if (row >= a.M) break;
-      float v[2];
-      bool ok[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int cl = lane + 64 * h;
-        ok[h] = cl < ncols;
-        float x = 0.f;
-        if (ok[h]) {
-          const int col = n0 + cl;
-          x = Es[r * GR_LDE + cl];
-          if (ep.bias) x += ep.bias[col];
-          if (ep.relu) x = fmaxf(x, 0.f);
-          if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + col] > 0.f) ? x : 0.f;
-          if (ep.res) x += ep.res[(size_t)row * ep.ldres + col];
-        }
-        v[h] = x;
-      }
-      if (ep.gamma) {   // LayerNorm over the row (host guarantees N <= 128 -> single chunk)
-        const float inv_n = 1.f / (float)a.N;
-        const float mean = wave_sum(v[0] + v[1]) * inv_n;
-        const float d0 = ok[0] ? v[0] - mean : 0.f, d1 = ok[1] ? v[1] - mean : 0.f;
-        const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
-        const float rs = 1.f / sqrtf(var + 1e-5f);
-        if (ep.rstd && lane == 0) ep.rstd[row] = rs;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (ok[h]) {
-            const int col = n0 + lane + 64 * h;
-            const float xh = (h ? d1 : d0) * rs;
-            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + col] = xh;
-            v[h] = xh * ep.gamma[col] + ep.beta[col];
-          }
-        }
-      }
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        if (ok[h]) {
-          float* dst = a.C + (size_t)row * a.ldc + n0 + lane + 64 * h;
-          *dst = ep.accumulate ? (*dst + v[h]) : v[h];
-        }
-      }
-    }
+    gr_epilogue_ln(a, acc, As, m0, ntc, wave, lane);
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// gemm_rows, B-stationary persistent form (K <= 128, 16-byte aligned A).
+//
+// 512-thread workgroup = 8 waves; wave (ct, rg) owns ONE 16-column tile and RT of the four 16-row
+// tiles of a 64-row A tile, and keeps its B fragments for the whole K extent in registers (32
+// VGPRs) while the workgroup sweeps row tiles: weights are read from L2 once per workgroup.  The
+// next A tile is prefetched global -> registers under the MFMAs of the current one (two LDS
+// buffers, one barrier per tile).  ~100 VGPRs -> 2 workgroups (16 waves) per CU.
+//   RT = 4: 128-column chunks;  RT = 2: 64-column chunks;  RT = 1: 32-column chunks.
+// Per-iteration order: MFMA(t) -> LDS write of tile t+S -> epilogue stores of tile t -> barrier ->
+// issue loads of tile t+2S; the only wait for loads sits before the stores are issued, so stores
+// drain under the next tile's MFMAs (vmcnt counts loads and stores in order).
+// ------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 2) void gemm_rows_w8_kernel(GemmRowsArgs a) {
+  constexpr int RG = 4 / RT;            // row groups
+  constexpr int CT = 8 / RG;            // column tiles per chunk
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave / RG, rg = wave % RG;
+  const int Kp = (a.K + 15) & ~15, KG = Kp >> 4;      // KG <= 8
+  const int NT = (a.N + 15) >> 4;
+  const int nc = blockIdx.y * CT;
+  const int ntc = min(CT, NT - nc);
+  const bool active = ct < ntc;
+  const GemmEpilogue& ep = a.ep;
+  f32x4 bfr[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    bfr[g] = (g < KG && active) ? reinterpret_cast<const f32x4*>(a.Bp)[((size_t)(nc + ct) * KG + g) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  const int c4n = Kp >> 2;                    // float4 per tile row
+  const int tot4 = GR_BM * c4n;               // float4 per tile
+  f32x4 pre[4];
+  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  auto load_tile = [&](int tt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 512 * j;
+      if (i < tot4) {
+        const int r = i / c4n, c = (i - r * c4n) * 4;
+        const int row = tt * GR_BM + r;
+        pre[j] = (row < a.M && c < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  auto store_tile = [&](float* As) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 512 * j;
+      if (i < tot4) {
+        const int r = i / c4n, c = (i - r * c4n) * 4;
+        *reinterpret_cast<f32x4*>(As + r * GR_LDA + c) = pre[j];
+      }
+    }
+  };
+  // auxiliary epilogue operand (the plan never combines them): 1 relu mask, 2 residual, 3 accumulate
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
+  const bool colok = active && col + 3 < a.N;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!ep.gamma && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+
+  load_tile(t);
+  store_tile(smem);
+  __syncthreads();
+  if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    float* As = smem + buf * (GR_BM * GR_LDA);
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active && !(a.dbg & 2)) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g < KG) {
+          f32x4 af[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            af[rt] = *reinterpret_cast<const f32x4*>(As + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDA + g * 16 + 4 * (lane >> 4));
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(bfr[g][s], af[rt][s], acc[rt]);
+        }
+      }
+    }
+    if (t + (int)gridDim.x < ntiles) store_tile(smem + (buf ^ 1) * (GR_BM * GR_LDA));
+    const int m0 = t * GR_BM;
+    if (a.dbg & 1) {
+      if (acc[0][0] == 12345.678f) a.C[0] = 1.f;
+    } else if (!ep.gamma) {
+      if (a.vec_ep && colok) {
+        f32x4 aux[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          f32x4 x = acc[rt] + bias;
+          if (ep.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
+          } else {
+            x += aux[rt];
+          }
+          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+        }
+      } else if (active && col < a.N) {       // unaligned operands / ragged right edge: scalar
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          if (row >= a.M) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int cc = col + r;
+            if (cc >= a.N) continue;
+            float x = acc[rt][r] + (ep.bias ? ep.bias[cc] : 0.f);
+            if (ep.relu) x = fmaxf(x, 0.f);
+            if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + cc] > 0.f) ? x : 0.f;
+            if (ep.res) x += ep.res[(size_t)row * ep.ldres + cc];
+            float* dst = a.C + (size_t)row * a.ldc + cc;
+            *dst = ep.accumulate ? (*dst + x) : x;
+          }
+        }
+      }
+    } else {
+      // LayerNorm epilogue (one chunk covers all N <= 128 columns): accumulators -> LDS tile ->
+      // one wave per 8 rows; every residual row is loaded before the first store
+      __syncthreads();                 // all waves are done reading this A buffer
+      float* Es = As;
+      if (active) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          *reinterpret_cast<f32x4*>(Es + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDE + ct * 16 + 4 * (lane >> 4)) = acc[rt];
+      }
+      const int ncols = a.N;
+      const bool ok0 = lane < ncols, ok1 = lane + 64 < ncols;
+      float res0[8], res1[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = m0 + wave * 8 + rr;
+        const bool rok = row < a.M && ep.res != nullptr;
+        res0[rr] = (rok && ok0) ? ep.res[(size_t)row * ep.ldres + lane] : 0.f;
+        res1[rr] = (rok && ok1) ? ep.res[(size_t)row * ep.ldres + lane + 64] : 0.f;
+      }
+      const float bias0 = (ep.bias && ok0) ? ep.bias[lane] : 0.f, bias1 = (ep.bias && ok1) ? ep.bias[lane + 64] : 0.f;
+      const float g0 = ok0 ? ep.gamma[lane] : 0.f, g1 = ok1 ? ep.gamma[lane + 64] : 0.f;
+      const float be0 = ok0 ? ep.beta[lane] : 0.f, be1 = ok1 ? ep.beta[lane + 64] : 0.f;
+      __syncthreads();
+      const float inv_n = 1.f / (float)a.N;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr;
+        const int row = m0 + r;
+        float v0 = 0.f, v1 = 0.f;
+        if (ok0) { v0 = Es[r * GR_LDE + lane] + bias0; if (ep.relu) v0 = fmaxf(v0, 0.f); v0 += res0[rr]; }
+        if (ok1) { v1 = Es[r * GR_LDE + lane + 64] + bias1; if (ep.relu) v1 = fmaxf(v1, 0.f); v1 += res1[rr]; }
+        const float mean = wave_sum(v0 + v1) * inv_n;
+        const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
+        const float rs = 1.f / sqrtf(var + 1e-5f);
+        if (row < a.M) {
+          if (ep.rstd && lane == 0) ep.rstd[row] = rs;
+          if (ok0) {
+            const float xh = d0 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
+            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+          }
+          if (ok1) {
+            const float xh = d1 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
+            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (t + 2 * (int)gridDim.x < ntiles) load_tile(t + 2 * gridDim.x);
+    buf ^= 1;
+  }
+}
+
+template <int RT>
+static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
+  constexpr int CT = 8 / (4 / RT);
+  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
+  int gx = ntiles < 512 ? ntiles : 512;
+  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
+  allow_lds(gemm_rows_w8_kernel<RT>, smem);
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+           gemm_rows_w8_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
 }
 
 int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc,
@@ -193,19 +529,44 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   INTEL_CHECK_ARG(K > 0, "gemm_rows: K must be positive");
   INTEL_CHECK_ARG(!(ep.gamma && N > 128), "gemm_rows: fused LayerNorm needs N <= 128 (got %d)", N);
   GemmRowsArgs a;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("INTEL_DEBUG_GEMM"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
+  {
+    uintptr_t bits = reinterpret_cast<uintptr_t>(C) | (uintptr_t)(ldc & 3) << 60;
+    bool ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && ((ldc & 3) == 0);
+    if (ep.bias) ok = ok && ((reinterpret_cast<uintptr_t>(ep.bias) & 15) == 0);
+    if (ep.mask) ok = ok && ((reinterpret_cast<uintptr_t>(ep.mask) & 15) == 0) && ((ep.ldmask & 3) == 0);
+    if (ep.res) ok = ok && ((reinterpret_cast<uintptr_t>(ep.res) & 15) == 0) && ((ep.ldres & 3) == 0);
+    (void)bits;
+    a.vec_ep = ok ? 1 : 0;
+  }
   a.A = A; a.lda = lda; a.M = M; a.K = K; a.Bp = Bp; a.N = N; a.C = C; a.ldc = ldc; a.ep = ep;
-  size_t smem = (size_t)(GR_BM * GR_LDA + GR_BM * GR_LDE) * sizeof(float);
+  const bool vecA = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  INTEL_CHECK_ARG(!(ep.gamma && (ep.mask || ep.accumulate)), "gemm_rows: LayerNorm epilogue cannot be combined with mask/accumulate");
+  if (rup(K, 16) <= GR_KC && vecA && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
+    if (N > 64) return launch_w8<4>(a, st);
+    if (N > 32) return launch_w8<2>(a, st);
+    return launch_w8<1>(a, st);
+  }
+  size_t smem = (size_t)(GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_kernel, smem);
-  hipLaunchKernelGGL(gemm_rows_kernel, dim3(cdiv(M, GR_BM)), dim3(256), smem, st, a);
+  LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), gemm_rows_kernel, dim3(cdiv(M, GR_BM)), dim3(256), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
 
 // ------------------------------------------------------------------------------------------
 // wgrad: dW[N,K] = sum_m dY[m,n] X[m,k]; db[n] = sum_m dY[m,n]
+//
+// The reduction runs over the B*L rows: every workgroup sweeps a strided set of 32-row tiles and
+// keeps a full (<=128 x <=128) partial product in accumulators (wave (wn,wk) owns a 4x4 block of
+// 16x16 tiles).  Per 32 rows a CU moves 32 KB from HBM and issues 1 MFLOP: balanced against both
+// roofs, so the grid is sized for 4 workgroups per CU (1024 slabs) to overlap loads and MFMAs.
+// Partials go to per-workgroup slabs and are summed in a fixed order (bitwise reproducible).
 // ------------------------------------------------------------------------------------------
 #define WG_RT 32          // rows per LDS tile
-#define WG_MAXS 256       // max slabs
+#define WG_MAXS 1024      // max slabs (4 workgroups per CU)
 
 static inline int wgrad_num_slabs(int M) {
   int s = cdiv(M, 4 * WG_RT);
@@ -218,8 +579,7 @@ struct WgradArgs {
   float* slabs; int S; int want_db;
 };
 
-// grid: (S, ceil(N/128), ceil(K/128)); each block: rows tiles s, s+S, ... ; wave (wn,wk) owns a
-// 4x4 block of 16x16 output tiles.
+// generic path (any alignment): stage -> sync -> MFMA, single LDS buffer
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -299,32 +659,177 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
   if (a.want_db && blockIdx.z == 0 && tid < nb) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
 }
 
-// out[i] (+)= sum_s slabs[s][i]; i < n.  Fixed summation order -> bitwise reproducible.
-__global__ void slab_reduce_kernel(const float* __restrict__ slabs, size_t stride, int S, int n, int rows, int cols,
-                                   float* __restrict__ out, int ldo, int accumulate) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int s = 0;
-  for (; s + 3 < S; s += 4) {
-    s0 += slabs[(size_t)s * stride + i];
-    s1 += slabs[(size_t)(s + 1) * stride + i];
-    s2 += slabs[(size_t)(s + 2) * stride + i];
-    s3 += slabs[(size_t)(s + 3) * stride + i];
+// pipelined path (16-byte aligned operands): the next 32-row tile is prefetched global -> registers
+// while the MFMAs of the current tile run from LDS; two LDS buffers, one barrier per tile.
+__global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
+  const int nb = min(128, a.N - n0), kb = min(128, a.K - k0);
+  const int NTb = (nb + 15) >> 4, KTb = (kb + 15) >> 4;
+  const int ldy = ((NTb * 16 + 31) & ~31) + 16, ldx = ((KTb * 16 + 31) & ~31) + 16;
+  const int bufsz = WG_RT * (ldy + ldx);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int ntw = (NTb + 1) >> 1, ktw = (KTb + 1) >> 1;
+  const int nt0 = wn * ntw, kt0 = wk * ktw;
+  const int cy = NTb * 4, cx = KTb * 4;                  // float4 per row
+  const int njy = (WG_RT * cy + 255) >> 8, njx = (WG_RT * cx + 255) >> 8;   // float4 per thread (<= 4 each)
+  f32x4 py[4], px[4];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;
+  const int ntiles = (a.M + WG_RT - 1) / WG_RT;
+  int t = blockIdx.x;
+  auto load_tile = [&](int tt) {
+    const int m0 = tt * WG_RT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      py[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < njy) {
+        const int i = tid + 256 * j;
+        const int r = i / cy, c = (i - r * cy) * 4;
+        const int row = m0 + r;
+        if (r < WG_RT && row < a.M && c < nb) py[j] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)row * a.lddy + n0 + c);
+      }
+      px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j < njx) {
+        const int i = tid + 256 * j;
+        const int r = i / cx, c = (i - r * cx) * 4;
+        const int row = m0 + r;
+        if (r < WG_RT && row < a.M && c < kb) px[j] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0 + c);
+      }
+    }
+  };
+  if (t < ntiles) load_tile(t);
+  int buf = 0;
+  for (; t < ntiles; t += a.S) {
+    float* Ys = smem + buf * bufsz;
+    float* Xs = Ys + WG_RT * ldy;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < njy) {
+        const int i = tid + 256 * j;
+        const int r = i / cy, c = (i - r * cy) * 4;
+        if (r < WG_RT) *reinterpret_cast<f32x4*>(Ys + r * ldy + c) = py[j];
+      }
+      if (j < njx) {
+        const int i = tid + 256 * j;
+        const int r = i / cx, c = (i - r * cx) * 4;
+        if (r < WG_RT) *reinterpret_cast<f32x4*>(Xs + r * ldx + c) = px[j];
+      }
+    }
+    __syncthreads();
+    if (t + a.S < ntiles) load_tile(t + a.S);
+    if (a.want_db && blockIdx.z == 0 && tid < nb) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WG_RT; ++r) s += Ys[r * ldy + tid];
+      dbacc += s;
+    }
+#pragma unroll 2
+    for (int ms = 0; ms < WG_RT / 4; ++ms) {
+      const int rr = ms * 4 + (lane >> 4);
+      float af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = (nt0 + i < NTb && i < ntw) ? Ys[rr * ldy + (nt0 + i) * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = (kt0 + j < KTb && j < ktw) ? Xs[rr * ldx + (kt0 + j) * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (nt0 + i < NTb && i < ntw) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (kt0 + j < KTb && j < ktw) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+      }
+    }
+    buf ^= 1;
   }
-  for (; s < S; ++s) s0 += slabs[(size_t)s * stride + i];
-  float v = (s0 + s1) + (s2 + s3);
-  int r = i / cols, c = i - r * cols;
-  (void)rows;
-  float* dst = out + (size_t)r * ldo + c;
-  *dst = accumulate ? (*dst + v) : v;
+  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (!(nt0 + i < NTb && i < ntw)) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!(kt0 + j < KTb && j < ktw)) continue;
+      const int k = k0 + (kt0 + j) * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + (nt0 + i) * 16 + 4 * (lane >> 4) + r;
+        if (n < a.N && k < a.K) slab[(size_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+  }
+  if (a.want_db && blockIdx.z == 0 && tid < nb) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
+}
+
+// out[i] (+)= sum_s slabs[s][i]; i < n.  16 slab lanes x 16 output groups per workgroup; each lane
+// sums its strided slabs with 4 independent accumulators, then a fixed-order LDS tree: reproducible.
+template <int VEC>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, size_t stride, int S, int n, int cols,
+                                                          float* __restrict__ out, int ldo, int accumulate) {
+  __shared__ float red[16][16 * VEC + 1];
+  const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int i0 = (blockIdx.x * 16 + o) * VEC;
+  float s0[VEC], s1[VEC], s2[VEC], s3[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) s0[v] = s1[v] = s2[v] = s3[v] = 0.f;
+  if (i0 < n) {
+    int s = q;
+    if (VEC == 4) {
+      for (; s + 48 < S; s += 64) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride + i0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 16) * stride + i0);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 32) * stride + i0);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 48) * stride + i0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { s0[v] += a0[v]; s1[v] += a1[v]; s2[v] += a2[v]; s3[v] += a3[v]; }
+      }
+      for (; s < S; s += 16) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride + i0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) s0[v] += a0[v];
+      }
+    } else {
+      for (; s + 48 < S; s += 64) {
+        s0[0] += slabs[(size_t)s * stride + i0];
+        s1[0] += slabs[(size_t)(s + 16) * stride + i0];
+        s2[0] += slabs[(size_t)(s + 32) * stride + i0];
+        s3[0] += slabs[(size_t)(s + 48) * stride + i0];
+      }
+      for (; s < S; s += 16) s0[0] += slabs[(size_t)s * stride + i0];
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) red[q][o * VEC + v] = (s0[v] + s1[v]) + (s2[v] + s3[v]);
+  __syncthreads();
+  if (q == 0 && i0 < n) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int i = i0 + v;
+      if (i >= n) break;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += red[k][o * VEC + v];
+      const int r = i / cols, c = i - r * cols;
+      float* dst = out + (size_t)r * ldo + c;
+      *dst = accumulate ? (*dst + acc) : acc;
+    }
+  }
 }
 
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
                        int accumulate, hipStream_t st) {
   int n = rows * cols;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, slabs, stride, S, n, rows, cols, out, ldo, accumulate);
+  const bool vec = ((stride & 3) == 0) && ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) && n >= 1024;
+  if (vec)
+    LAUNCH_W(0.0, 4.0 * (double)S * n, slab_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, slabs, stride, S, n, cols, out, ldo, accumulate);
+  else
+    LAUNCH_W(0.0, 4.0 * (double)S * n, slab_reduce_kernel<1>, dim3(cdiv(n, 16)), dim3(256), 0, st, slabs, stride, S, n, cols, out, ldo, accumulate);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -338,7 +843,14 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   const int nbm = min(128, N), kbm = min(128, K);
   const int ldy = (rup(rup(nbm, 16), 32)) + 16, ldxs = (rup(rup(kbm, 16), 32)) + 16;
   size_t smem = (size_t)WG_RT * (ldy + ldxs) * sizeof(float);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), smem, st, a);
+  const bool al = ((lddy & 3) == 0) && ((ldx & 3) == 0) && ((N & 3) == 0) && ((K & 3) == 0) &&
+                  (((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0);
+  if (al) {
+    allow_lds(wgrad_pipe_kernel, 2 * smem);
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), wgrad_pipe_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), 2 * smem, st, a);
+  } else {
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), wgrad_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), smem, st, a);
+  }
   INTEL_CHECK_LAUNCH();
   size_t stride = (size_t)N * K + N;
   int rc = launch_slab_reduce(slabs, stride, a.S, N, K, dW, lddw, accumulate, st);

@@ -120,7 +120,7 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     GemmEpilogue eh;
     eh.bias = bhh;
     if ((rc = launch_gemm_rows(g.HP + (size_t)t * Hd, T * Hd, B, Hd, g.pWhh, 3 * Hd, g.GH, 3 * Hd, eh, st))) return rc;
-    hipLaunchKernelGGL(gru_gate_fwd_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, g.GI, g.GH, g.HP, g.HCUR, g.GATES, g.GHN, len,
+    LAUNCH(gru_gate_fwd_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, g.GI, g.GH, g.HP, g.HCUR, g.GATES, g.GHN, len,
                        B, T, Hd, t);
     INTEL_CHECK_LAUNCH();
   }
@@ -139,7 +139,7 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
   float *dH = g.dHa, *dHn = g.dHb;
   if ((rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
   for (int t = T - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(gru_gate_bwd_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, dH, g.HP, g.GATES, g.GHN, len, B, T, Hd, t,
+    LAUNCH(gru_gate_bwd_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, dH, g.HP, g.GATES, g.GHN, len, B, T, Hd, t,
                        g.dGI, g.dGH, dHn);
     INTEL_CHECK_LAUNCH();
     // dh_{t-1} += dGH_t Whh

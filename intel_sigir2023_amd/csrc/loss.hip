@@ -296,15 +296,15 @@ static int run_pair_loss(bool bpr, LossArgs& a, float* loss, void* ws, size_t ws
   if (bpr) {
     smem = (size_t)a.L * 4 * sizeof(float);
     allow_lds(bpr_loss_kernel, smem);
-    hipLaunchKernelGGL(bpr_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
+    LAUNCH(bpr_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
   } else {
     smem = (size_t)a.L * 3 * sizeof(float) + (a.cal_div ? ((size_t)2 * a.L * a.K + a.L) * sizeof(double) : 0);
     INTEL_CHECK_ARG(smem <= 150 * 1024, "list loss: L=%d K=%d does not fit LDS", a.L, a.K);
     allow_lds(list_loss_kernel, smem);
-    hipLaunchKernelGGL(list_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
+    LAUNCH(list_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
   }
   INTEL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a.lossb, a.divb, a.B, a.cal_div, a.alpha, loss);
+  LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a.lossb, a.divb, a.B, a.cal_div, a.alpha, loss);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -427,13 +427,13 @@ int launch_intent_loss(int B, int I, const float* pred, const double* label, dou
   const long long n = (long long)B * I;
   int blocks = (int)((n + 1023) / 1024);
   blocks = blocks < 1 ? 1 : (blocks > 512 ? 512 : blocks);
-  hipLaunchKernelGGL(min_bits_kernel, dim3(blocks), dim3(256), 0, st, pred, n, minbits);
+  LAUNCH(min_bits_kernel, dim3(blocks), dim3(256), 0, st, pred, n, minbits);
   INTEL_CHECK_LAUNCH();
   const double T2 = kl_temp * kl_temp;
-  hipLaunchKernelGGL(intent_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, pred, label, B, I, minbits, kl_weight, T2, grad_scale,
+  LAUNCH(intent_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, pred, label, B, I, minbits, kl_weight, T2, grad_scale,
                      rowout, d_pred);
   INTEL_CHECK_LAUNCH();
-  hipLaunchKernelGGL(intent_finalize_kernel, dim3(1), dim3(256), 0, st, rowout, B, kl_weight, T2, out3);
+  LAUNCH(intent_finalize_kernel, dim3(1), dim3(256), 0, st, rowout, B, kl_weight, T2, out3);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -248,7 +248,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   size_t rowsmax = (size_t)M;
   if ((size_t)B * H > rowsmax) rowsmax = (size_t)B * H;
   if ((size_t)B * Hi > rowsmax) rowsmax = (size_t)B * Hi;
-  size_t slab = 256 * (maxNK + maxN);
+  size_t slab = 1024 * (maxNK + maxN);
   size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;
   if (lnslab > slab) slab = lnslab;
   y.SLABS = ar.f(slab + 1024);
@@ -747,7 +747,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       if (r.G(INTEL_P_IID_EMB))
         RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
       if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
-        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
+        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st, D.class_num));
     } else {
       wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
     }

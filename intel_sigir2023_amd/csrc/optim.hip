@@ -65,7 +65,7 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
   long long blocks = ((n >> 2) + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);     // grid-stride: 256 CUs x 8
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  LAUNCH_W(0.0, (zero_grad ? 32.0 : 28.0) * (double)n, adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -142,7 +142,7 @@ int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(max(L, k) <= 64 * ND_MAXPL, "ndcg: list length %d > %d unsupported", L, 64 * ND_MAXPL);
   INTEL_CHECK_ARG(k >= 1 && k <= 64, "ndcg: k=%d unsupported", k);
-  hipLaunchKernelGGL(ndcg_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, ens, ranking, slen, B, L, k, out);
+  LAUNCH(ndcg_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, ens, ranking, slen, B, L, k, out);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

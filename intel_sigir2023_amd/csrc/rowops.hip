@@ -42,10 +42,10 @@ int launch_gather_rows(const float* table, int d, const int* idx, int M, float* 
                    ((reinterpret_cast<uintptr_t>(table) & 15) == 0);
   if (vec) {
     long long n = (long long)M * (d / 4);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+    LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
   } else {
     long long n = (long long)M * d;
-    hipLaunchKernelGGL(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+    LAUNCH(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
   }
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -63,7 +63,7 @@ __global__ void bcast_rows_kernel(const float* __restrict__ src, int lds, int d,
 int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st) {
   long long n = (long long)B * T * d;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, d, B, T, dst, ldd, col0);
+  LAUNCH(bcast_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, d, B, T, dst, ldd, col0);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -85,11 +85,69 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int lds, 
   if (relu_out && !(relu_out[(size_t)m * ldr + rcol0 + c] > 0.f)) v = 0.f;
   if (v != 0.f) atomicAdd(grad_table + (size_t)row * d + c, v);
 }
+// Small destination tables (item classes, positions, the [d_int, I] intent weight): thousands of
+// rows hit the same few destination rows, so global atomics serialise on them (measured 1.6 ms for
+// a 64x30 table).  Each workgroup instead accumulates its slice of rows in an LDS image of the whole
+// table (ds_add_f32) and flushes it with one global atomic per touched element.
+struct SmallScatterArgs {
+  const float* src; int lds, col0, d;
+  const int* idx;        // row index per source row, or null
+  const int* len; int T; // when idx == null && len != null: position index (t < len[b] ? t : 0)
+  int M, R;              // source rows, table rows
+  float* out; int rs, cs; // out[row*rs + c*cs]
+  const float* relu_out; int ldr, rcol0;
+  int rows_per_block;
+};
+__global__ __launch_bounds__(256) void scatter_add_small_kernel(SmallScatterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float tab[];
+  const int n = a.R * a.d;
+  for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * a.rows_per_block;
+  const int r1 = min(a.M, r0 + a.rows_per_block);
+  const int cnt = (r1 - r0) * a.d;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int m = r0 + i / a.d, c = i % a.d;
+    int row = 0;
+    if (a.idx) row = a.idx[m];
+    else if (a.len) { const int b = m / a.T, t = m - b * a.T; row = t < a.len[b] ? t : 0; }
+    if (row < 0 || row >= a.R) continue;
+    float v = a.src[(size_t)m * a.lds + a.col0 + c];
+    if (a.relu_out && !(a.relu_out[(size_t)m * a.ldr + a.rcol0 + c] > 0.f)) v = 0.f;
+    if (v != 0.f) atomicAdd(&tab[row * a.d + c], v);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(a.out + (size_t)(i / a.d) * a.rs + (size_t)(i % a.d) * a.cs, v);
+  }
+}
+#define SMALL_SCATTER_MAX_FLOATS 24576   // 96 KB LDS image
+int launch_scatter_add_small(const float* src, int lds, int col0, int d, const int* idx, const int* len, int T, int M, int R,
+                             float* out, int rs, int cs, const float* relu_out, int ldr, int rcol0, hipStream_t st) {
+  if (M <= 0 || d <= 0) return 0;
+  INTEL_CHECK_ARG((size_t)R * d <= SMALL_SCATTER_MAX_FLOATS, "scatter_add_small: table %d x %d too large", R, d);
+  SmallScatterArgs a;
+  a.src = src; a.lds = lds; a.col0 = col0; a.d = d; a.idx = idx; a.len = len; a.T = T; a.M = M; a.R = R; a.out = out;
+  a.rs = rs; a.cs = cs; a.relu_out = relu_out; a.ldr = ldr; a.rcol0 = rcol0;
+  int blocks = cdiv(M, 64);
+  if (blocks > 512) blocks = 512;
+  a.rows_per_block = cdiv(M, blocks);
+  blocks = cdiv(M, a.rows_per_block);
+  size_t smem = (size_t)R * d * sizeof(float);
+  allow_lds(scatter_add_small_kernel, smem);
+  LAUNCH_W(0.0, 4.0 * (double)M * d, scatter_add_small_kernel, dim3(blocks), dim3(256), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
-                            const float* relu_out, int ldr, int rcol0, hipStream_t st) {
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st, int table_rows) {
   long long n = (long long)M * d;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, col0, d, idx, M,
+  if (table_rows > 0 && (size_t)table_rows * d <= SMALL_SCATTER_MAX_FLOATS && M >= 8 * table_rows)
+    return launch_scatter_add_small(src, lds, col0, d, idx, nullptr, 0, M, table_rows, grad_table, d, 1, relu_out, ldr, rcol0, st);
+  LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, col0, d, idx, M,
                      grad_table, relu_out, ldr, rcol0);
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -144,7 +202,7 @@ int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M
                          const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st) {
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm: N=%d > %d unsupported", N, 64 * LN_MAXPL);
-  hipLaunchKernelGGL(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, ldx, r, ldr, M, N, gamma, beta, y, ldy, xhat,
+  LAUNCH(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, ldx, r, ldr, M, N, gamma, beta, y, ldy, xhat,
                      ldxh, rstd);
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -216,7 +274,7 @@ int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh,
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm_bwd: N=%d unsupported", N);
   const int nb = ln_bwd_blocks(M);
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
+  LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
   INTEL_CHECK_LAUNCH();
   int rc = launch_slab_reduce(slabs, (size_t)2 * N, nb, 1, N, dgamma, N, accumulate, st);
   if (rc) return rc;
@@ -242,7 +300,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, N, y);
+  LAUNCH(softmax_rows_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, M, N, y);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -258,7 +316,7 @@ __global__ __launch_bounds__(256) void softmax_rows_bwd_kernel(const float* __re
 }
 int launch_softmax_rows_bwd(const float* y, const float* dy, int M, int N, float* dx, hipStream_t st) {
   if (M <= 0) return 0;
-  hipLaunchKernelGGL(softmax_rows_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, y, dy, M, N, dx);
+  LAUNCH(softmax_rows_bwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, y, dy, M, N, dx);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -275,7 +333,7 @@ int launch_add2(const float* a, const float* b, long long n, float* y, hipStream
   if (n <= 0) return 0;
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, y);
+  LAUNCH(add2_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, b, n, y);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -288,7 +346,7 @@ int launch_fill(float* p, long long n, float v, hipStream_t st) {
   if (n <= 0) return 0;
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+  LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -308,7 +366,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 int launch_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate, float* slabs, hipStream_t st) {
   if (N <= 0) return 0;
   const int nb = cdiv(M, CS_ROWS);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, st, x, ldx, M, N, slabs);
+  LAUNCH(colsum_kernel, dim3(nb), dim3(256), 0, st, x, ldx, M, N, slabs);
   INTEL_CHECK_LAUNCH();
   return launch_slab_reduce(slabs, (size_t)N, nb, 1, N, out, N, accumulate, st);
 }

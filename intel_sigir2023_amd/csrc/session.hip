@@ -73,7 +73,7 @@ int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, c
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool: list length %d > %d unsupported", L, XP_MAXL);
   INTEL_CHECK_ARG(d % 4 == 0, "xatt_pool: width %d must be a multiple of 4", d);
-  hipLaunchKernelGGL(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
+  LAUNCH(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -134,7 +134,7 @@ int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, c
                          int ldxb, float scale, float* dX, float* dqk, hipStream_t st) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool_bwd: list length %d > %d unsupported", L, XP_MAXL);
-  hipLaunchKernelGGL(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
+  LAUNCH(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -162,7 +162,7 @@ __global__ void ens_fwd_kernel(const float* __restrict__ wv, const float* __rest
 int launch_ens_fwd(const float* wv, const float* wpad, const float* scores, const int* slen, int B, int L, int K,
                    int per_item, float* weights, float* ens, hipStream_t st) {
   if (B * L <= 0) return 0;
-  hipLaunchKernelGGL(ens_fwd_kernel, dim3(cdiv(B * L, 256)), dim3(256), 0, st, wv, wpad, scores, slen, B, L, K, per_item, weights, ens);
+  LAUNCH(ens_fwd_kernel, dim3(cdiv(B * L, 256)), dim3(256), 0, st, wv, wpad, scores, slen, B, L, K, per_item, weights, ens);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void ens_bwd_kernel(const float* __restrict__ 
 int launch_ens_bwd(const float* d_weights, const float* d_ens, const float* scores, const int* slen, int B, int L, int K,
                    int per_item, float* dwv, float* dwpad, float* dwt, hipStream_t st) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(ens_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, d_weights, d_ens, scores, slen, B, L, K, per_item, dwv, dwpad, dwt);
+  LAUNCH(ens_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, d_weights, d_ens, scores, slen, B, L, K, per_item, dwv, dwpad, dwt);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -221,7 +221,7 @@ __global__ void gate_fwd_kernel(const float* __restrict__ x, int d, const float*
 int launch_gate_fwd(const float* x, int d, const float* vec, int B, int L, float* dst, int ldd, int col0, hipStream_t st) {
   long long n = (long long)B * L * d;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d, vec, B, L, dst, ldd, col0);
+  LAUNCH(gate_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, d, vec, B, L, dst, ldd, col0);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d, const float* vec, int B, int L, float* dx,
                     float* dvec, hipStream_t st) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(gate_bwd_kernel, dim3(B), dim3(256), 0, st, dfeat, ldf, col0, x, d, vec, B, L, dx, dvec);
+  LAUNCH(gate_bwd_kernel, dim3(B), dim3(256), 0, st, dfeat, ldf, col0, x, d, vec, B, L, dx, dvec);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void session_colsum_kernel(const float* __rest
 int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int L, float* out, int ldo, int ocol0,
                           int accumulate, hipStream_t st) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(session_colsum_kernel, dim3(B), dim3(256), 0, st, src, lds, col0, d, B, L, out, ldo, ocol0, accumulate);
+  LAUNCH(session_colsum_kernel, dim3(B), dim3(256), 0, st, src, lds, col0, d, B, L, out, ldo, ocol0, accumulate);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -286,7 +286,7 @@ __global__ void add_pos_kernel(float* __restrict__ E, int dm, const float* __res
 int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st) {
   long long n = (long long)B * T * dm;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E, dm, pos, len, B, T);
+  LAUNCH(add_pos_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E, dm, pos, len, B, T);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -305,7 +305,9 @@ __global__ void add_pos_bwd_kernel(const float* __restrict__ dE, int dm, const i
 int launch_add_pos_bwd(const float* dE, int dm, const int* len, int B, int T, float* dpos, hipStream_t st) {
   long long n = (long long)B * T * dm;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(add_pos_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, dm, len, B, T, dpos);
+  if ((size_t)T * dm <= 24576)   // positions 0..T-1 only: stage the table in LDS
+    return launch_scatter_add_small(dE, dm, 0, dm, nullptr, len, T, B * T, T, dpos, dm, 1, nullptr, 0, 0, st);
+  LAUNCH(add_pos_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, dm, len, B, T, dpos);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -327,7 +329,7 @@ int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, co
                          int col0, hipStream_t st) {
   long long n = (long long)M * d_int;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(onehot_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, bias, d_int, I, idx, M, E, lde, col0);
+  LAUNCH(onehot_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, bias, d_int, I, idx, M, E, lde, col0);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -348,7 +350,12 @@ int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int 
                              float* db, hipStream_t st) {
   long long n = (long long)M * d_int;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(onehot_linear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, lde, col0, d_int, I, idx, M, dW, db);
+  if ((size_t)I * d_int <= 24576) {
+    int rc = launch_scatter_add_small(dE, lde, col0, d_int, idx, nullptr, 0, M, I, dW, 1, I, nullptr, 0, 0, st);   // dW[c*I + j]
+    if (rc) return rc;
+    return launch_scatter_add_small(dE, lde, col0, d_int, nullptr, nullptr, 0, M, 1, db, 0, 1, nullptr, 0, 0, st);  // db[c]
+  }
+  LAUNCH(onehot_linear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, lde, col0, d_int, I, idx, M, dW, db);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -367,7 +374,7 @@ __global__ void select_last_kernel(const float* __restrict__ E, int dm, const in
 }
 int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st) {
   if (B * dm <= 0) return 0;
-  hipLaunchKernelGGL(select_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, E, dm, len, B, T, out, ldo, col0);
+  LAUNCH(select_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, E, dm, len, B, T, out, ldo, col0);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -387,7 +394,7 @@ __global__ void select_last_bwd_kernel(const float* __restrict__ dvec, int ldv, 
 int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st) {
   long long n = (long long)B * T * dm;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(select_last_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dvec, ldv, col0, dm, len, B, T, dE);
+  LAUNCH(select_last_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dvec, ldv, col0, dm, len, B, T, dE);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -408,7 +415,7 @@ int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, f
                      const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st) {
   long long n = M * d;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, scol0, d, M, dst, ldd, dcol0,
+  LAUNCH(copy_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, scol0, d, M, dst, ldd, dcol0,
                      relu_out, ldr, rcol0, accumulate);
   INTEL_CHECK_LAUNCH();
   return 0;

@@ -1,0 +1,157 @@
+"""Training / evaluation engine: the fast path around BaseRunner.fit's hot loop
+(helpers/BaseRunner.py:279-290: forward -> criterion -> backward -> optimizer.step).
+
+Compared with driving the module through autograd + torch.optim (which also works and is what the
+parity tests exercise), the engine keeps every parameter, gradient and Adam moment in flat buffers:
+  * gradients are persistent (no per-step allocation; embedding-table gradients stay dense like
+    nn.Embedding(sparse=False) but are re-zeroed inside the Adam sweep that consumes them),
+  * data parallelism is one all-reduce per flat bucket (parallel.py),
+  * Adam is two launches (decayed bucket, bias bucket) with the reference's param-group semantics
+    (models/BaseModel.py:53-62, helpers/BaseRunner.py:182-188).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import parallel
+
+
+class IntELEngine(object):
+    def __init__(self, model, loss_name='IntBPRloss', args=None, lr=1e-3, l2=0.0, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.loss_name = loss_name
+        if loss_name not in ('IntBPRloss', 'IntListloss', 'BPRloss', 'Listloss'):
+            raise ValueError('unsupported loss ' + loss_name)
+        self.kind = 'bpr' if 'BPR' in loss_name else 'list'
+        self.with_intent = loss_name.startswith('Int')
+        g = lambda k, d: getattr(args, k, d) if args is not None else d
+        self.intent_weight = float(g('intent_weight', 0.1))
+        self.ensemble_weight = float(g('ensemble_weight', 1.0))
+        self.kl_weight, self.kl_temp = float(g('kl_weight', 0.5)), float(g('kl_temp', 2.0))
+        self.cal_diversity, self.alpha = int(g('cal_diversity', 0)), float(g('diversity_alpha', 0.01))
+        self.lr, self.l2, self.betas, self.eps = float(lr), float(l2), betas, float(eps)
+        self.step_count = 0
+        self.device = next(model.parameters()).device
+        L.require_gpu(next(model.parameters()))
+        self._flatten()
+        self._bufs = {}
+
+    # ---- flat parameter / gradient / moment buckets -------------------------------------------------
+    def _flatten(self):
+        items = self.model.slot_items()
+        groups = {'decay': [], 'nodecay': []}
+        for s, name, p in items:
+            groups['nodecay' if 'bias' in name else 'decay'].append((s, name, p))
+        self.flat, self.gflat, self.m, self.v = {}, {}, {}, {}
+        self.grad_by_slot = {}
+        for gname, lst in groups.items():
+            sizes = [((p.numel() + 63) // 64) * 64 for _, _, p in lst]      # 256-byte aligned slices
+            total = sum(sizes)
+            flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+            gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
+            off = 0
+            for (s, name, p), sz in zip(lst, sizes):
+                n = p.numel()
+                flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = flat[off:off + n].view_as(p)
+                gview = gflat[off:off + n].view_as(p)
+                p.grad = gview
+                self.grad_by_slot[s] = gview
+                off += sz
+            self.flat[gname], self.gflat[gname] = flat, gflat
+            self.m[gname] = torch.zeros_like(flat)
+            self.v[gname] = torch.zeros_like(flat)
+
+    def buckets(self):
+        return [self.gflat['decay'], self.gflat['nodecay']]
+
+    def param_buckets(self):
+        return [self.flat['decay'], self.flat['nodecay']]
+
+    def _buf(self, name, shape, dtype):
+        t = self._bufs.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t
+
+    # ---- one training step ---------------------------------------------------------------------------
+    def train_step(self, batch, noise=None):
+        """forward + loss + backward + gradient all-reduce + Adam on one (local) batch.
+        Returns (loss, ensemble_loss, intent_loss) as device tensors (no host sync)."""
+        model = self.model
+        lib = L.lib()
+        dev = self.device
+        world = parallel.world_size()
+        ib, keep = model.prepare_batch(batch)
+        B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
+        params = [p.detach() for _, _, p in model.slot_items()]
+        weights, ens, intents = model.run_forward(ib, keep, params, train=True)
+        model._generation = getattr(model, '_generation', 0) + 1
+        st = L.stream_ptr(dev)
+        nb = lib.intel_loss_workspace_bytes(B, Lmax, K)
+        ws = self._buf('loss_ws', (int(nb),), torch.uint8)
+        loss_e = self._buf('loss_e', (1,), torch.float32)
+        d_ens = self._buf('d_ens', (B, Lmax), torch.float32)
+        d_w = self._buf('d_w', (B, Lmax, K), torch.float32)
+        ranking, slen = keep.get('ranking_i32'), keep['session_len']
+        if ranking is None:
+            ranking = batch['ranking'] if batch['ranking'].dtype == torch.int32 else batch['ranking'].to(torch.int32)
+            ranking = ranking.contiguous()
+        sc = batch['scores']
+        sc64 = sc.contiguous() if sc.dtype == torch.float64 else None
+        sc32 = keep['scores']
+        gs_e = self.ensemble_weight / world
+        if self.kind == 'bpr':
+            if noise is None:
+                noise = torch.rand(B, Lmax, Lmax, dtype=torch.float32, device=dev)      # BPRloss.py:26
+            select = self._buf('select', (B, Lmax), torch.int32)
+            L.check(lib.intel_bpr_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(noise), L.ptr(sc64),
+                                       L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
+                                       L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss')
+        else:
+            L.check(lib.intel_list_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(sc64), L.ptr(sc32),
+                                        L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e), L.ptr(d_ens),
+                                        L.ptr(d_w), L.ptr(ws), nb, st), 'intel_list_loss')
+        d_int, out3 = None, None
+        if self.with_intent:
+            out3 = self._buf('out3', (3,), torch.float64)
+            d_int = self._buf('d_int', (B, I), torch.float32)
+            label = batch['intents']
+            label = label if label.dtype == torch.float64 else label.double()
+            L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label.contiguous()), self.kl_weight, self.kl_temp,
+                                          self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws), nb, st),
+                    'intel_intent_loss')
+        model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+        parallel.allreduce_sum_(self.buckets())
+        self.step_count += 1
+        b1, b2 = self.betas
+        for gname, wd in (('decay', self.l2), ('nodecay', 0.0)):
+            n = self.flat[gname].numel()
+            if n:
+                L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
+                                            L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
+                                            1, st), 'intel_adam_step')
+        ens_loss = loss_e.reshape(()).clone()
+        if self.with_intent:
+            int_loss = out3[0].clone()
+            return ens_loss.double() * self.ensemble_weight + int_loss * self.intent_weight, ens_loss, int_loss
+        return ens_loss, ens_loss, ens_loss
+
+    # ---- evaluation -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def eval_step(self, batch, k=3):
+        """forward + on-device NDCG@k (helpers/BaseRunner.py:328-343 + :117-126).  Returns
+        (out_dict, ndcg[B] device tensor)."""
+        model = self.model
+        ib, keep = model.prepare_batch(batch)
+        params = [p.detach() for _, _, p in model.slot_items()]
+        weights, ens, intents = model.run_forward(ib, keep, params, train=False)
+        model._generation = getattr(model, '_generation', 0) + 1
+        ndcg = self._buf('ndcg', (ib.B,), torch.float32)
+        ranking = batch['ranking'] if batch['ranking'].dtype == torch.int32 else batch['ranking'].to(torch.int32)
+        ranking = ranking.contiguous()
+        L.check(L.lib().intel_ndcg(ib.B, ib.L, k, L.ptr(ens), L.ptr(ranking), L.ptr(keep['session_len']), L.ptr(ndcg),
+                                   L.stream_ptr(self.device)), 'intel_ndcg')
+        return {'weights': weights, 'ens_score': ens, 'intents': intents}, ndcg

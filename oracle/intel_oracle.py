@@ -273,7 +273,7 @@ def list_loss(ens, ranking, session_len, scores=None, weights=None, cal_diversit
 def intent_loss(pred, label, kl_weight=0.5, kl_temp=2.0):
     """loss/BaseIntloss.py:30-67.  ``label`` float64; CE uses the float64 label, KL the float32
     cast; per-class weights are all ones."""
-    if float(pred.min()) == 0.0:
+    if float(pred.detach().min()) == 0.0:
         soft = pred + 1e-6
         soft = soft / soft.sum(-1, keepdim=True)
     else:
