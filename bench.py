@@ -197,7 +197,7 @@ def main():
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16] if v['flops'] > 0 or v['bytes'] > 0}
         if a.shapes:
             res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f TF/s' % (v['ms'] / psteps, v['launches'] // psteps, v['flops'] / v['ms'] / 1e9)
-                                  for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01}
+                                  for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01 and v['flops'] > 0}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)

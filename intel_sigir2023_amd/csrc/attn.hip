@@ -358,7 +358,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_fwd_kernel<DKT>, smem);
-    LAUNCH_W(4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, attn_fwd_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse);
+    LAUNCH_S(B * heads, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, attn_fwd_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse);
   });
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -375,14 +375,14 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_bwd_dq_kernel<DKT>, smem);
-    LAUNCH_W(6.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dq_kernel<DKT>, grid, dim3(256), smem, st, qkv, out, dout, lse, T, d, heads, key_len,
+    LAUNCH_S(B * heads, T, dk, 6.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dq_kernel<DKT>, grid, dim3(256), smem, st, qkv, out, dout, lse, T, d, heads, key_len,
                        scale, dqkv, dsum);
   });
   INTEL_CHECK_LAUNCH();
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
     allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
-    LAUNCH_W(8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
+    LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
                        scale, dqkv);
   });
   INTEL_CHECK_LAUNCH();

@@ -15,36 +15,88 @@
 #include "kernels.h"
 
 // ------------------------------------------------------------------------------------------
-// pack
+// pack: weights -> MFMA fragment order.  A model step re-packs ~80 small matrices (the parameters
+// change every step); they are batched into job tables passed by value so that a whole model is
+// packed in two launches instead of eighty.
 // ------------------------------------------------------------------------------------------
-__global__ void pack_b_kernel(const float* __restrict__ W, int ldw, int Kd, int Nd, int trans,
-                              float* __restrict__ P, int nt_off, int KG, int NT, int g_off, int KG_total) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (nt, g, lane)
-  int total = NT * KG * 64;
+struct PackJob {
+  const float* W; float* P;
+  int ldw, Kd, Nd, trans, nt_off, g_off, KG_total, KG, NT, block0;
+};
+#define PACK_MAX_JOBS 56
+struct PackJobs { int n; PackJob j[PACK_MAX_JOBS]; };
+
+__global__ void pack_b_kernel(PackJobs jobs) {
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].block0) ++ji;
+  const PackJob& jb = jobs.j[ji];
+  const int idx = ((int)blockIdx.x - jb.block0) * blockDim.x + threadIdx.x;   // one thread per (nt, g, lane)
+  const int total = jb.NT * jb.KG * 64;
   if (idx >= total) return;
-  int lane = idx & 63;
-  int g = (idx >> 6) % KG;
-  int nt = (idx >> 6) / KG;
-  int n = nt * 16 + (lane & 15);
+  const int lane = idx & 63;
+  const int g = (idx >> 6) % jb.KG;
+  const int nt = (idx >> 6) / jb.KG;
+  const int n = nt * 16 + (lane & 15);
   f32x4 v;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    int k = g * 16 + 4 * (lane >> 4) + s;
+    const int k = g * 16 + 4 * (lane >> 4) + s;
     float x = 0.f;
-    if (k < Kd && n < Nd) x = trans ? W[(size_t)k * ldw + n] : W[(size_t)n * ldw + k];
+    if (k < jb.Kd && n < jb.Nd) x = jb.trans ? jb.W[(size_t)k * jb.ldw + n] : jb.W[(size_t)n * jb.ldw + k];
     v[s] = x;
   }
-  *reinterpret_cast<f32x4*>(P + ((size_t)((nt_off + nt) * KG_total + g_off + g) * 64 + lane) * 4) = v;
+  *reinterpret_cast<f32x4*>(jb.P + ((size_t)((jb.nt_off + nt) * jb.KG_total + jb.g_off + g) * 64 + lane) * 4) = v;
+}
+
+static thread_local PackJobs* g_pack_batch = nullptr;
+static thread_local int g_pack_blocks = 0;
+
+static int pack_flush(PackJobs& jobs, int blocks, hipStream_t st) {
+  if (jobs.n == 0) return 0;
+  LAUNCH(pack_b_kernel, dim3(blocks), dim3(256), 0, st, jobs);
+  INTEL_CHECK_LAUNCH();
+  jobs.n = 0;
+  return 0;
+}
+
+// Between pack_batch_begin / pack_batch_end launch_pack_b only records jobs.
+static thread_local PackJobs g_pack_storage;
+void pack_batch_begin() {
+  g_pack_storage.n = 0;
+  g_pack_blocks = 0;
+  g_pack_batch = &g_pack_storage;
+}
+int pack_batch_end(hipStream_t st) {
+  int rc = g_pack_batch ? pack_flush(*g_pack_batch, g_pack_blocks, st) : 0;
+  g_pack_batch = nullptr;
+  g_pack_blocks = 0;
+  return rc;
 }
 
 int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st, int g_off,
                   int KG_total) {
-  int KG = rup(Kd, 16) / 16, NT = rup(Nd, 16) / 16;
-  int total = NT * KG * 64;
-  if (KG_total <= 0) KG_total = KG;
-  LAUNCH(pack_b_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, W, ldw, Kd, Nd, trans, P, nt_off, KG, NT, g_off, KG_total);
-  INTEL_CHECK_LAUNCH();
-  return 0;
+  PackJob jb;
+  jb.W = W; jb.P = P; jb.ldw = ldw; jb.Kd = Kd; jb.Nd = Nd; jb.trans = trans; jb.nt_off = nt_off; jb.g_off = g_off;
+  jb.KG = rup(Kd, 16) / 16; jb.NT = rup(Nd, 16) / 16;
+  jb.KG_total = KG_total > 0 ? KG_total : jb.KG;
+  const int blocks = cdiv(jb.NT * jb.KG * 64, 256);
+  if (g_pack_batch) {
+    if (g_pack_batch->n == PACK_MAX_JOBS) {
+      int rc = pack_flush(*g_pack_batch, g_pack_blocks, st);
+      if (rc) return rc;
+      g_pack_blocks = 0;
+    }
+    jb.block0 = g_pack_blocks;
+    g_pack_batch->j[g_pack_batch->n++] = jb;
+    g_pack_blocks += blocks;
+    return 0;
+  }
+  PackJobs one;
+  one.n = 1;
+  jb.block0 = 0;
+  one.j[0] = jb;
+  int tmp = blocks;
+  return pack_flush(one, tmp, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -821,10 +873,41 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// few outputs, many slabs (bias / LayerNorm parameter gradients): 4 outputs x 64 slab lanes per workgroup
+__global__ __launch_bounds__(256) void slab_reduce_small_kernel(const float* __restrict__ slabs, size_t stride, int S, int n, int cols,
+                                                                float* __restrict__ out, int ldo, int accumulate) {
+  __shared__ float red[64][5];
+  const int o = threadIdx.x & 3, q = threadIdx.x >> 2;
+  const int i = blockIdx.x * 4 + o;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < n) {
+    int s = q;
+    for (; s + 64 < S; s += 128) {
+      s0 += slabs[(size_t)s * stride + i];
+      s1 += slabs[(size_t)(s + 64) * stride + i];
+    }
+    for (; s < S; s += 64) s0 += slabs[(size_t)s * stride + i];
+  }
+  red[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && i < n) {
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) acc += red[k][o];
+    const int r = i / cols, c = i - r * cols;
+    float* dst = out + (size_t)r * ldo + c;
+    *dst = accumulate ? (*dst + acc) : acc;
+  }
+}
+
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
                        int accumulate, hipStream_t st) {
   int n = rows * cols;
   if (n <= 0) return 0;
+  if (n < 1024 && S > 32) {
+    LAUNCH_W(0.0, 4.0 * (double)S * n, slab_reduce_small_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, slabs, stride, S, n, cols, out, ldo, accumulate);
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   const bool vec = ((stride & 3) == 0) && ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) && n >= 1024;
   if (vec)
     LAUNCH_W(0.0, 4.0 * (double)S * n, slab_reduce_kernel<4>, dim3(cdiv(n, 64)), dim3(256), 0, st, slabs, stride, S, n, cols, out, ldo, accumulate);

@@ -14,6 +14,10 @@ static inline size_t packed_floats(int Kd, int Nd) { return (size_t)rup(Kd, 16) 
 int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, int nt_off, hipStream_t st,
                   int g_off = 0, int KG_total = 0);
 
+// batch mode: between begin/end launch_pack_b only records jobs; end launches them together
+void pack_batch_begin();
+int pack_batch_end(hipStream_t st);
+
 struct GemmEpilogue {
   const float* bias = nullptr;    // [N]
   int relu = 0;                   // max(.,0) after bias

@@ -64,7 +64,7 @@ struct Layout {
   float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
   // backward temporaries
   float *dXa, *dXb, *dZ, *dF1, *dA, *dQKV, *DSUM, *SLABS;
-  float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN, *dVB1, *dVB2, *dVB3;
+  float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN, *dVB1, *dVB2, *dVB3, *ONEHOT;
   size_t total;
 };
 
@@ -234,6 +234,11 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   y.dVB1 = ar.f((size_t)B * vmax);
   y.dVB2 = ar.f((size_t)B * vmax);
   y.dVB3 = ar.f((size_t)B * vmax);
+  {
+    const int Tm = H > Hi ? H : Hi;
+    const int Rm = I > Tm ? I : Tm;
+    y.ONEHOT = ar.f((size_t)B * Tm * Rm);
+  }
   // slabs: the largest weight-gradient / LayerNorm / column-sum reduction
   size_t maxNK = (size_t)dmax * dmax;
   auto upd = [&](size_t v) { if (v > maxNK) maxNK = v; };
@@ -343,6 +348,11 @@ void pack_all(Run& r) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const int I = D.intent_num, K = D.model_num;
+  struct BatchGuard {     // every launch_pack_b below is recorded and issued as one job table
+    Run& r;
+    explicit BatchGuard(Run& rr) : r(rr) { pack_batch_begin(); }
+    ~BatchGuard() { r.ok(pack_batch_end(r.st)); }
+  } guard(r);
   for (int t = 0; t < 2; ++t) {
     pack_tower(r, y.tw[t]);
     if (r.rc) return;
@@ -546,12 +556,13 @@ float* bert_bwd(Run& r, int e) {
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
   }
-  // position embedding gradient
+  // position embedding gradient: dpos[p,:] = sum over rows at position p = onehot^T dE (MFMA wgrad)
   if (r.G(enc_slot(e, INTEL_ENC_POS))) {
-    if (!r.acc(enc_slot(e, INTEL_ENC_POS))) {
-      if (!r.ok(launch_fill(r.G(enc_slot(e, INTEL_ENC_POS)), (long long)(D.history_max + 1) * dm, 0.f, r.st))) return nullptr;
-    }
-    if (!r.ok(launch_add_pos_bwd(dX, dm, len, B, T, r.G(enc_slot(e, INTEL_ENC_POS)), r.st))) return nullptr;
+    const int ps = enc_slot(e, INTEL_ENC_POS);
+    if (!r.ok(launch_make_onehot(nullptr, len, T, rows, T, y.ONEHOT, r.st))) return nullptr;
+    if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
+    r.acc(ps);
+    if (!r.ok(launch_wgrad(y.ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, y.SLABS, r.st))) return nullptr;
   }
   return dX;
 }
@@ -747,7 +758,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       if (r.G(INTEL_P_IID_EMB))
         RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
       if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
-        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st, D.class_num));
+        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
     } else {
       wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
     }
@@ -790,8 +801,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       if (r.G(INTEL_P_IID_EMB))
         RUN(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
       if (bt.his_item_idx) {
-        if (r.G(INTEL_P_INTENT_W))
-          RUN(launch_onehot_linear_bwd(dE, dm, D.d_id, D.d_int, I, bt.his_item_idx, rows, r.G(INTEL_P_INTENT_W), r.G(INTEL_P_INTENT_B), r.st));
+        if (r.G(INTEL_P_INTENT_W)) {   // dW[c][j] = sum_m dE[m][c] onehot[m][j]: the dense wgrad on a materialised one-hot
+          RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows, I, y.ONEHOT, r.st));
+          wgrad(r, dE + D.d_id, dm, y.ONEHOT, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+        }
       } else {
         wgrad(r, dE + D.d_id, dm, bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
       }

@@ -130,8 +130,8 @@ int launch_scatter_add_small(const float* src, int lds, int col0, int d, const i
   SmallScatterArgs a;
   a.src = src; a.lds = lds; a.col0 = col0; a.d = d; a.idx = idx; a.len = len; a.T = T; a.M = M; a.R = R; a.out = out;
   a.rs = rs; a.cs = cs; a.relu_out = relu_out; a.ldr = ldr; a.rcol0 = rcol0;
-  int blocks = cdiv(M, 64);
-  if (blocks > 512) blocks = 512;
+  int blocks = cdiv(M, 256);
+  if (blocks > 128) blocks = 128;     // every workgroup flushes the whole table: keep the flush count low
   a.rows_per_block = cdiv(M, blocks);
   blocks = cdiv(M, a.rows_per_block);
   size_t smem = (size_t)R * d * sizeof(float);

@@ -360,6 +360,28 @@ int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int 
   return 0;
 }
 
+// oh[m, :] = one_hot(row index of m) over R columns: idx[m] when idx != null, else the BERT4Rec
+// position of row m (t < len[b] ? t : 0).  The small-table gradients (position embeddings, the
+// one-hot intent rows) are then plain dY^T X products on the MFMA wgrad kernel: deterministic and
+// free of same-address atomics.
+__global__ void make_onehot_kernel(const int* __restrict__ idx, const int* __restrict__ len, int T, int M, int R,
+                                   float* __restrict__ oh) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * R) return;
+  const int m = (int)(i / R), c = (int)(i - (long long)m * R);
+  int row;
+  if (idx) row = idx[m];
+  else { const int b = m / T, t = m - b * T; row = t < len[b] ? t : 0; }
+  oh[i] = (row == c) ? 1.f : 0.f;
+}
+int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, float* oh, hipStream_t st) {
+  long long n = (long long)M * R;
+  if (n <= 0) return 0;
+  LAUNCH(make_onehot_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, len, T, M, R, oh);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 // vec[b,:] = E[b*T + len_b - 1, :] * 1   (GeneralSeq.py:103-105; the selected row is always valid)
 __global__ void select_last_kernel(const float* __restrict__ E, int dm, const int* __restrict__ len, int B, int T,
                                    float* __restrict__ out, int ldo, int col0) {
