@@ -129,6 +129,8 @@ typedef struct IntelCtx IntelCtx;
 
 const char* intel_last_error(void);
 int intel_abi_version(void);
+/* out4 = {sizeof(IntelDesc), sizeof(IntelBatch), sizeof(IntelOut), INTEL_P_COUNT}: lets a binding check its mirror */
+void intel_abi_sizes(int* out4);
 
 /* Context = desc + host-side plan.  Holds no device memory. */
 IntelCtx* intel_create(const IntelDesc* desc);

@@ -33,6 +33,11 @@ def lib():
         _declare(_lib)
         if _lib.intel_abi_version() != 1:
             raise IntelHipError('ABI version mismatch')
+        sizes = (C.c_int * 4)()
+        _lib.intel_abi_sizes(sizes)
+        mine = [C.sizeof(IntelDesc), C.sizeof(IntelBatch), C.sizeof(IntelOut), P_COUNT]
+        if list(sizes) != mine:
+            raise IntelHipError('struct layout mismatch between _lib.py and intel_hip.h: %s vs %s' % (list(sizes), mine))
     return _lib
 
 
@@ -92,7 +97,7 @@ ENC_STRIDE = 6 + ENC_BLOCK_STRIDE * ENC_MAX_BLOCKS
 P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 
 EXPORTS = [
-    'intel_last_error', 'intel_abi_version', 'intel_create', 'intel_destroy', 'intel_workspace_bytes',
+    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_bpr_loss', 'intel_list_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd',
@@ -110,6 +115,7 @@ def _declare(l):
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+    sig('intel_abi_sizes', None, [C.POINTER(C.c_int)])
     sig('intel_create', vp, [C.POINTER(IntelDesc)])
     sig('intel_destroy', None, [vp])
     sig('intel_workspace_bytes', sz, [vp, i, i, i, i, i])

@@ -16,6 +16,13 @@ void intel_set_error(const char* fmt, ...) {
 
 extern "C" const char* intel_last_error(void) { return g_err; }
 extern "C" int intel_abi_version(void) { return INTEL_ABI_VERSION; }
+// sizeof of the public structs, so that a binding can verify its mirror of the header
+extern "C" void intel_abi_sizes(int* out4) {
+  out4[0] = (int)sizeof(IntelDesc);
+  out4[1] = (int)sizeof(IntelBatch);
+  out4[2] = (int)sizeof(IntelOut);
+  out4[3] = (int)INTEL_P_COUNT;
+}
 
 // workspace: packed weight + wgrad slabs
 extern "C" size_t intel_op_workspace_bytes(int M, int N, int K) {

@@ -1,0 +1,80 @@
+"""CLI counterpart of the reference's ``main.py`` for the hot path:
+``python -m intel_sigir2023_amd.main --model_name IntEL --loss_name IntBPRloss --workload tmall ...``
+
+Classes are resolved by name like the reference (main.py:127-130); flags come from the same
+``parse_*_args`` hooks.  Data: synthetic workloads (synth.py) -- the CSV/JSON reader is outside the hot
+path.  Needs an MI355X; there is no CPU path.
+"""
+import argparse
+import logging
+import sys
+
+import numpy as np
+import torch
+
+from . import loss as loss_mod
+from . import synth
+from .model import IntEL
+from .runner import BaseRunner
+
+MODELS = {'IntEL': IntEL}
+LOSSES = {n: getattr(loss_mod, n) for n in ('BPRloss', 'Listloss', 'IntBPRloss', 'IntListloss')}
+RUNNERS = {'BaseRunner': BaseRunner}
+
+
+def parse_global_args(parser):
+    parser.add_argument('--gpu', type=str, default='0', help='device index')
+    parser.add_argument('--verbose', type=int, default=logging.INFO)
+    parser.add_argument('--random_seed', type=int, default=0)
+    parser.add_argument('--train', type=int, default=1)
+    parser.add_argument('--workload', type=str, default='tiny', help='synthetic workload: ' + ', '.join(synth.WORKLOADS))
+    parser.add_argument('--train_batches', type=int, default=8, help='synthetic batches per epoch')
+    parser.add_argument('--use_engine', type=int, default=1)
+    return parser
+
+
+def build_parser(argv=None):
+    init = argparse.ArgumentParser(add_help=False)
+    init.add_argument('--model_name', type=str, default='IntEL')
+    init.add_argument('--loss_name', type=str, default='IntBPRloss')
+    init.add_argument('--runner_name', type=str, default='BaseRunner')
+    init_args, _ = init.parse_known_args(argv)
+    for name, table in ((init_args.model_name, MODELS), (init_args.loss_name, LOSSES), (init_args.runner_name, RUNNERS)):
+        if name not in table:
+            raise SystemExit('unknown class %s (available: %s)' % (name, ', '.join(table)))
+    parser = argparse.ArgumentParser(description='IntEL on MI355X')
+    parse_global_args(parser)
+    MODELS[init_args.model_name].parse_model_args(parser)
+    RUNNERS[init_args.runner_name].parse_runner_args(parser)
+    LOSSES[init_args.loss_name].parse_loss_args(parser)
+    return init_args, parser
+
+
+def main(argv=None):
+    init_args, parser = build_parser(argv)
+    w0, _ = parser.parse_known_args(argv)
+    parser.set_defaults(**{k: v for k, v in synth.WORKLOADS[w0.workload]['flags'].items()})
+    args, extras = parser.parse_known_args(argv)
+    logging.basicConfig(level=args.verbose, stream=sys.stdout)
+    np.random.seed(args.random_seed)
+    torch.manual_seed(args.random_seed)
+    if not torch.cuda.is_available():
+        raise SystemExit('intel_sigir2023_amd needs an MI355X (no CPU path)')
+    args.device = torch.device('cuda', int(args.gpu or 0))
+    corpus, cinfo = synth.make_corpus(args.workload)
+    model = MODELS[init_args.model_name](args, corpus).to(args.device)
+    logging.info('#params: %d' % model.count_variables())
+    criterion = LOSSES[init_args.loss_name](args)
+    runner = RUNNERS[init_args.runner_name](args, use_engine=bool(args.use_engine))
+    dev = [synth.make_batch(args.workload, args.eval_batch_size, args.device, seed=10_000 + i, ragged=True) for i in range(2)]
+    data = {'train': lambda ep: [synth.make_batch(args.workload, args.batch_size, args.device, seed=ep * 1000 + i, ragged=True)
+                                 for i in range(args.train_batches)], 'dev': dev, 'test': dev}
+    if args.train > 0:
+        runner.train(model, data, criterion, init_args.loss_name)
+    loss, res = runner.evaluate(model, data['test'], runner.topk, runner.metrics, criterion)
+    logging.info('test loss= %.4f, metrics: %s' % (loss, ', '.join('%s:%.4f' % kv for kv in sorted(res.items()))))
+    return res
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,257 @@
+"""Train / evaluate loop -- host-side counterpart of the reference's ``helpers/BaseRunner.py``.
+
+Same CLI flags (``parse_runner_args``), same loop semantics (epoch loop, dev-metric model selection
+with ``stop_tol = 1e-4``, early stop, best-model reload, NaN check) and a bit-for-bit restatement of
+``evaluate_method`` (the source of the NDCG@3 numbers).  Two ways to drive the HIP path:
+  * ``use_engine=False``: exactly the reference's hot loop -- ``model(batch)``, ``criterion(...)``,
+    ``loss.backward()``, ``torch.optim`` step (helpers/BaseRunner.py:279-290);
+  * ``use_engine=True`` (default): ``IntELEngine.train_step`` (flat buffers + fused Adam + DP all-reduce).
+"""
+import gc
+import logging
+import os
+from time import time
+
+import numpy as np
+import torch
+
+from .engine import IntELEngine
+
+
+def format_metric(result_dict):
+    """utils/utils.py:64-89."""
+    keys = sorted(result_dict.keys(), key=lambda k: (int(k.split('@')[1]) if '@' in k else 0, k.split('@')[0]))
+    out = []
+    for k in keys:
+        m = result_dict[k]
+        if isinstance(m, (float, np.floating)):
+            out.append('{}:{:<.4f}'.format(k, m))
+        elif isinstance(m, (int, np.integer)):
+            out.append('{}:{}'.format(k, m))
+    return ','.join(out)
+
+
+class BaseRunner(object):
+    @staticmethod
+    def parse_runner_args(parser):
+        """helpers/BaseRunner.py:22-54."""
+        parser.add_argument('--epoch', type=int, default=200, help='Number of epochs.')
+        parser.add_argument('--test_epoch', type=int, default=-1, help='Print test results every test_epoch (-1 means no print).')
+        parser.add_argument('--early_stop', type=int, default=10, help='The number of epochs when dev results drop continuously.')
+        parser.add_argument('--lr', type=float, default=1e-3, help='Learning rate.')
+        parser.add_argument('--l2', type=float, default=0, help='Weight decay in optimizer.')
+        parser.add_argument('--intent_l2', type=float, default=1e-6, help='Parsed and ignored, like the reference (BaseRunner.py:160).')
+        parser.add_argument('--batch_size', type=int, default=256, help='Batch size during training.')
+        parser.add_argument('--eval_batch_size', type=int, default=100, help='Batch size during testing.')
+        parser.add_argument('--optimizer', type=str, default='Adam', help='optimizer: SGD, Adam, Adagrad, Adadelta')
+        parser.add_argument('--num_workers', type=int, default=4, help='Number of processors when prepare batches in DataLoader')
+        parser.add_argument('--pin_memory', type=int, default=0, help='pin_memory in DataLoader')
+        parser.add_argument('--topk', type=str, default='1,3,5', help='The number of items recommended to each user.')
+        parser.add_argument('--metrics', type=str, default='NDCG,HR', help='metrics: NDCG, HR')
+        parser.add_argument('--main_metric', type=str, default='NDCG@1', help='main metric')
+        parser.add_argument('--test_ensemble', type=int, default=1)
+        parser.add_argument('--decay_lr', type=float, default=0)
+        parser.add_argument('--decay_step', type=int, default=1)
+        return parser
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def evaluate_method(prediction_scores, ranking_lists, pos_nums, topk, metrics, session_len, show_num=False):
+        """helpers/BaseRunner.py:56-131.  Returns the same 25-key dict on the same inputs:
+        per-behaviour HR@k / NDCG@k with binary relevance over the label-sorted prefix, and the overall
+        ``NDCG@k`` with LINEAR gains; predictions are padded with 0 and labels with -2 (-> 0) up to
+        ``max(max(session_len), max(topk))`` (a padded slot therefore outranks a negative score)."""
+        count = min(len(session_len), len(prediction_scores))
+        session_len = np.asarray(session_len)[:count]
+        pos_nums = {k: np.asarray(v)[:count] for k, v in pos_nums.items()}
+        width = int(max(int(session_len.max()), max(topk)))
+        preds = np.zeros((count, width), dtype=np.float64)
+        labels = np.full((count, width), -2, dtype=np.int64)
+        for i in range(count):
+            n = min(int(session_len[i]), len(prediction_scores[i]))
+            preds[i, :n] = np.asarray(prediction_scores[i])[:n]
+            n2 = min(int(session_len[i]), len(ranking_lists[i]))
+            labels[i, :n2] = np.asarray(ranking_lists[i])[:n2]
+        rows = np.arange(count).reshape(-1, 1)
+        by_label = np.argsort(labels, axis=1)[:, ::-1]
+        labels, preds = labels[rows, by_label], preds[rows, by_label]
+        labels[labels < 0] = 0
+        rank_pos = preds.argsort(axis=1)                      # ascending: best prediction is the last column
+        discounts = 1.0 / np.log2(np.arange(width) + 2.0)
+        evaluations = dict()
+        total = np.sum(np.array(list(pos_nums.values())), axis=0).reshape(-1, 1)
+        for btype, pos_num in pos_nums.items():
+            behavior = btype.split('_')[1].split('num')[0]
+            all_pos = total if 'click' in btype else pos_num.reshape(-1, 1)
+            hits = rank_pos < all_pos
+            keep = np.flatnonzero(all_pos[:, 0] > 0)
+            hits, all_pos_k = hits[keep], all_pos[keep]
+            if show_num:
+                logging.info('# %s session: %d' % (behavior, len(keep)))
+            for k in topk:
+                kk = min(k, width)
+                for metric in metrics:
+                    key = '{}_{}@{}'.format(behavior, metric, k)
+                    if metric == 'HR':
+                        evaluations[key] = (hits[:, -kk:].sum(axis=1) > 0).mean()
+                    elif metric == 'NDCG':
+                        if k == 1:
+                            continue                          # NDCG@1 == HR@1
+                        dcg = (hits[:, -kk:] * discounts[:kk][::-1]).sum(axis=1)
+                        idcg = ((np.arange(kk).reshape(1, -1) < all_pos_k) * discounts[:kk]).sum(axis=1)
+                        evaluations[key] = (dcg / idcg).mean()
+                    else:
+                        raise ValueError('Undefined evaluation metric: {}.'.format(metric))
+        best_first = np.argsort(preds, axis=1)[:, ::-1]
+        gains = labels[rows, best_first]
+        ideal = np.sort(labels, axis=1)[:, ::-1]
+        for k in topk:
+            dcg = (gains[:, :k] * discounts[:k]).sum(axis=1)
+            idcg = (ideal[:, :k] * discounts[:k]).sum(axis=1)
+            evaluations['NDCG@%d' % k] = (dcg / idcg).mean()
+        return evaluations
+
+    @staticmethod
+    def evaluate_intents(true_intents, predict_intents, topk=[1, 5, 10, 30]):
+        """helpers/BaseRunner.py:133-150."""
+        true_intents, predict_intents = np.asarray(true_intents), np.asarray(predict_intents)
+        evaluations = dict()
+        true_labels = np.argmax(true_intents, axis=1).reshape(-1, 1)
+        asc = np.argsort(predict_intents, axis=1)
+        desc = asc[:, ::-1]
+        rows = np.arange(len(predict_intents)).reshape(-1, 1)
+        true_sort = true_intents[rows, desc]
+        true_perfect = np.sort(true_intents, axis=1)[:, ::-1]
+        discounts = 1 / np.log2(np.arange(40) + 2.0)
+        for k in topk:
+            dcg = (true_sort[:, :k] * discounts[:k]).sum(axis=1)
+            idcg = (true_perfect[:, :k] * discounts[:k]).sum(axis=1)
+            evaluations['Int-NDCG@%d' % k] = (dcg / idcg).mean()
+            evaluations['Int-HR@%d' % k] = ((asc == true_labels)[:, -k:].sum(axis=-1) > 0).mean()
+        return evaluations
+
+    # ------------------------------------------------------------------------------------------
+    def __init__(self, args, use_engine=True):
+        self.epoch = args.epoch
+        self.test_epoch = args.test_epoch
+        self.early_stop = args.early_stop
+        self.learning_rate = args.lr
+        self.batch_size = args.batch_size
+        self.eval_batch_size = args.eval_batch_size
+        self.l2 = args.l2
+        self.intent_l2 = args.l2           # sic: BaseRunner.py:160
+        self.optimizer_name = args.optimizer
+        self.topk = [int(x) for x in args.topk.split(',')]
+        self.metrics = [m.strip().upper() for m in args.metrics.split(',')]
+        self.main_metric = args.main_metric
+        self.test_ensemble = args.test_ensemble
+        self.decay_lr = args.decay_lr
+        self.decay_step = args.decay_step
+        self.stop_tol = 1e-4
+        self.use_engine = use_engine and self.optimizer_name == 'Adam'
+        self.args = args
+        self.engine = None
+        self.time = None
+
+    def _check_time(self, start=False):
+        if self.time is None or start:
+            self.time = [time()] * 2
+            return self.time[0]
+        tmp = self.time[1]
+        self.time[1] = time()
+        return self.time[1] - tmp
+
+    def _build_optimizer(self, model):
+        """helpers/BaseRunner.py:182-188."""
+        logging.info('Optimizer: ' + self.optimizer_name)
+        opt_cls = getattr(torch.optim, self.optimizer_name)
+        optimizer = opt_cls(model.customize_parameters({'intent_l2': self.intent_l2, 'ens_l2': self.l2}),
+                            lr=self.learning_rate, weight_decay=self.l2)
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.decay_step, gamma=self.decay_lr)
+        return optimizer, scheduler
+
+    def eval_termination(self, criterion):
+        return len(criterion) - criterion.index(max(criterion)) > self.early_stop
+
+    # ---- one epoch over an iterable of batch dicts (helpers/BaseRunner.py:268-291) ------------------
+    def fit(self, model, batches, criterion, loss_name=None):
+        model.train()
+        losses = []
+        if self.use_engine:
+            if self.engine is None:
+                self.engine = IntELEngine(model, loss_name or type(criterion).__name__, self.args, lr=self.learning_rate, l2=self.l2)
+            for batch in batches:
+                loss, _, _ = self.engine.train_step(batch)
+                losses.append(loss.detach())
+        else:
+            if model.optimizer is None:
+                model.optimizer, model.scheduler = self._build_optimizer(model)
+            for batch in batches:
+                model.optimizer.zero_grad()
+                out = model(batch)
+                loss, _, _ = criterion(out, batch)
+                loss.backward()
+                model.optimizer.step()
+                losses.append(loss.detach())
+        vals = torch.stack([l.double().reshape(()) for l in losses]).cpu().numpy()
+        return float(np.mean(vals))
+
+    # ---- predict / evaluate (helpers/BaseRunner.py:293-355) -----------------------------------------
+    @torch.no_grad()
+    def predict(self, model, batches, criterion):
+        model.eval()
+        preds, ranks, losses, true_int, pred_int, slens = [], [], [], [], [], []
+        for batch in batches:
+            out = model(batch)
+            loss, _, _ = criterion(out, batch)
+            losses.append(float(loss))
+            preds.extend(out['ens_score'].cpu().numpy())
+            ranks.extend(batch['ranking'].cpu().numpy())
+            slens.extend(batch['session_len'].cpu().numpy().tolist())
+            true_int.extend(batch['intents'].cpu().numpy())
+            pred_int.extend(out['intents'].cpu().numpy())
+        return preds, float(np.mean(losses)), ranks, true_int, pred_int, slens
+
+    def evaluate(self, model, batches, topk, metrics, criterion, pos_nums=None, topk_intent=[1, 5, 10, 30]):
+        preds, loss, ranks, true_int, pred_int, slens = self.predict(model, batches, criterion)
+        res = dict()
+        if self.test_ensemble:
+            if pos_nums is None:          # derive the per-behaviour positive counts from the labels
+                R = [np.asarray(r)[:n] for r, n in zip(ranks, slens)]
+                pos_nums = {'c_paynum_i': np.array([(r == 3).sum() for r in R]),
+                            'c_favnum_i': np.array([(r == 2).sum() for r in R]),
+                            'c_clicknum_i': np.array([(r == 1).sum() for r in R])}
+            res.update(self.evaluate_method(preds, ranks, pos_nums, topk, metrics, np.asarray(slens)))
+        if len(true_int):
+            res.update(self.evaluate_intents(true_int, pred_int, topk=[k for k in topk_intent if k <= len(true_int[0])]))
+        gc.collect()
+        return loss, res
+
+    def train(self, model, data, criterion, loss_name=None):
+        """helpers/BaseRunner.py:190-266.  ``data`` = {'train': callable -> iterable of batches per epoch,
+        'dev': list of batches, 'test': list of batches}."""
+        main_results, dev_results = [], []
+        self._check_time(start=True)
+        for epoch in range(self.epoch):
+            self._check_time()
+            loss = self.fit(model, data['train'](epoch), criterion, loss_name)
+            if np.isnan(loss):
+                raise ValueError('Loss is nan!')
+            train_t = self._check_time()
+            dev_loss, dev_res = self.evaluate(model, data['dev'], self.topk[:1], self.metrics, criterion, topk_intent=[3, 5])
+            dev_results.append(dev_res)
+            main_results.append(dev_res[self.main_metric])
+            msg = 'Epoch {:<5} loss={:<.4f} [{:<3.1f} s]\tdev loss={:<.4f}, ({})'.format(epoch + 1, loss, train_t, dev_loss, format_metric(dev_res))
+            if len(main_results) == 1 or max(main_results[:-1]) < main_results[-1] - self.stop_tol:
+                if model.model_path:
+                    model.save_model()
+                msg += ' *'
+            logging.info(msg)
+            if self.early_stop > 0 and self.eval_termination(main_results):
+                logging.info('Early stop at %d based on dev result.' % (epoch + 1))
+                break
+        best = main_results.index(max(main_results))
+        logging.info(os.linesep + 'Best Iter(dev)={:>5}\t dev=({}) [{:<.1f} s] '.format(best + 1, format_metric(dev_results[best]), self.time[1] - self.time[0]))
+        if model.model_path and os.path.exists(model.model_path):
+            model.load_model()
+        return main_results
