@@ -379,8 +379,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRowsArgs a) {
 // issue loads of tile t+2S; the only wait for loads sits before the stores are issued, so stores
 // drain under the next tile's MFMAs (vmcnt counts loads and stores in order).
 // ------------------------------------------------------------------------------------------
-template <int RT>
-__global__ __launch_bounds__(512, 2) void gemm_rows_w8_kernel(GemmRowsArgs a) {
+template <int RT, bool LN>
+__global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
   constexpr int RG = 4 / RT;            // row groups
   constexpr int CT = 8 / RG;            // column tiles per chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_w8_kernel(GemmRowsArgs a) {
   const int col = (nc + ct) * 16 + 4 * (lane >> 4);
   const bool colok = active && col + 3 < a.N;
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!ep.gamma && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+  if (!LN && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
 
   load_tile(t);
   store_tile(smem);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_w8_kernel(GemmRowsArgs a) {
     const int m0 = t * GR_BM;
     if (a.dbg & 1) {
       if (acc[0][0] == 12345.678f) a.C[0] = 1.f;
-    } else if (!ep.gamma) {
+    } else if (!LN) {
       if (a.vec_ep && colok) {
         f32x4 aux[RT];
 #pragma unroll
@@ -561,16 +561,16 @@ __global__ __launch_bounds__(512, 2) void gemm_rows_w8_kernel(GemmRowsArgs a) {
   }
 }
 
-template <int RT>
+template <int RT, bool LN>
 static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
   const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
   int gx = ntiles < 512 ? ntiles : 512;
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
-  allow_lds(gemm_rows_w8_kernel<RT>, smem);
+  allow_lds((gemm_rows_w8_kernel<RT, LN>), smem);
   LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
-           gemm_rows_w8_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
+           (gemm_rows_w8_kernel<RT, LN>), dim3(gx, nchunks), dim3(512), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -597,9 +597,14 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   const bool vecA = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   INTEL_CHECK_ARG(!(ep.gamma && (ep.mask || ep.accumulate)), "gemm_rows: LayerNorm epilogue cannot be combined with mask/accumulate");
   if (rup(K, 16) <= GR_KC && vecA && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
-    if (N > 64) return launch_w8<4>(a, st);
-    if (N > 32) return launch_w8<2>(a, st);
-    return launch_w8<1>(a, st);
+    if (ep.gamma) {
+      if (N > 64) return launch_w8<4, true>(a, st);
+      if (N > 32) return launch_w8<2, true>(a, st);
+      return launch_w8<1, true>(a, st);
+    }
+    if (N > 64) return launch_w8<4, false>(a, st);
+    if (N > 32) return launch_w8<2, false>(a, st);
+    return launch_w8<1, false>(a, st);
   }
   size_t smem = (size_t)(GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_kernel, smem);

@@ -48,10 +48,17 @@ struct EncBlockBufs {
   float *QKV, *A, *LSE, *C, *XH1, *RSTD1, *F1, *Eout, *XH2, *RSTD2;
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T, *bQKV;
 };
+// the LAST BERT4Rec block only feeds row len-1 of its output forward (GeneralSeq.py:103-105): it is run
+// "pruned" -- K/V for all rows, everything else for one row per session
+struct EncLastBufs {
+  float *KV, *XLAST, *QLAST, *PL, *OL, *CL, *XH1, *RSTD1, *F1, *XH2, *RSTD2;
+  float *pWkvT, *pWqT;
+};
 struct EncBufs {
   int T, dm, d_tab, pbase, predin_off;
   float* E0;
   EncBlockBufs blk[INTEL_ENC_MAX_BLOCKS];
+  EncLastBufs last;
   GruBufs gru;
 };
 
@@ -65,6 +72,7 @@ struct Layout {
   // backward temporaries
   float *dXa, *dXb, *dZ, *dF1, *dA, *dQKV, *DSUM, *SLABS;
   float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN, *dVB1, *dVB2, *dVB3, *ONEHOT;
+  float* dLB[5];            // [B, dmax] temporaries of the pruned last encoder block
   size_t total;
 };
 
@@ -150,6 +158,8 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
         k.pW2T = ar.f(packed_floats(dm, dm));
         k.bQKV = ar.f(3 * dm);
       }
+      n.last.pWkvT = ar.f(packed_floats(2 * rup(dm, 16), dm));
+      n.last.pWqT = ar.f(packed_floats(dm, dm));
     } else {
       gru_layout_packed(n.gru, dm, D.gru_hidden, ar.base, ar.off);
     }
@@ -194,7 +204,15 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     n.E0 = ar.f(md);
     if (md > maxMD) maxMD = md;
     if (D.encoder == INTEL_ENC_BERT4REC) {
-      for (int l = 0; l < D.enc_layers; ++l) {
+      {
+        EncLastBufs& q = n.last;
+        const size_t bd = (size_t)B * n.dm;
+        q.KV = ar.f(2 * md);
+        q.XLAST = ar.f(bd); q.QLAST = ar.f(bd); q.OL = ar.f(bd); q.CL = ar.f(bd); q.XH1 = ar.f(bd); q.F1 = ar.f(bd); q.XH2 = ar.f(bd);
+        q.RSTD1 = ar.f(B); q.RSTD2 = ar.f(B);
+        q.PL = ar.f((size_t)B * D.enc_heads * n.T);
+      }
+      for (int l = 0; l + 1 < D.enc_layers; ++l) {
         EncBlockBufs& k = n.blk[l];
         k.QKV = ar.f(3 * md);
         k.A = ar.f(md);
@@ -234,6 +252,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   y.dVB1 = ar.f((size_t)B * vmax);
   y.dVB2 = ar.f((size_t)B * vmax);
   y.dVB3 = ar.f((size_t)B * vmax);
+  for (int i = 0; i < 5; ++i) y.dLB[i] = ar.f((size_t)B * vmax);
   {
     const int Tm = H > Hi ? H : Hi;
     const int Rm = I > Tm ? I : Tm;
@@ -384,6 +403,12 @@ void pack_all(Run& r) {
         RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W1)), dm, dm, dm, 1, k.pW1T, 0, r.st));
         RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W2)), dm, dm, dm, 1, k.pW2T, 0, r.st));
       }
+      {   // last block, pruned: dX = dKV @ [Wk;Wv] and dXlast = dQ @ Wq
+        const int l = D.enc_layers - 1;
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_WK)), dm, dm, dm, 1, n.last.pWkvT, 0, r.st, 0, 2 * nt));
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_WV)), dm, dm, dm, 1, n.last.pWkvT, 0, r.st, nt, 2 * nt));
+        RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_WQ)), dm, dm, dm, 1, n.last.pWqT, 0, r.st));
+      }
     } else {
       RUN(gru_pack(n.gru, r.P(enc_slot(e, INTEL_ENC_GRU_WIH)), r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
                    r.P(enc_slot(e, INTEL_ENC_GRU_OUT)), dm, D.gru_hidden, r.st));
@@ -469,7 +494,7 @@ void bert_fwd(Run& r, int e) {
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
   RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
   const float* X = n.E0;
-  for (int l = 0; l < D.enc_layers; ++l) {
+  for (int l = 0; l + 1 < D.enc_layers; ++l) {
     EncBlockBufs& k = n.blk[l];
     {   // fused q/k/v projection (bias=True in TransformerLayer, layers.py:70)
       GemmEpilogue eb;
@@ -503,7 +528,45 @@ void bert_fwd(Run& r, int e) {
     if (r.rc) return;
     X = k.Eout;
   }
-  RUN(launch_select_last(X, dm, len, B, T, r.y.PREDIN, r.y.Pin, n.predin_off, r.st));
+  {   // ---- last block, pruned to the one output row that is used (his_vector = seq[b, len-1])
+    const int l = D.enc_layers - 1;
+    EncBlockBufs& k = n.blk[l];
+    EncLastBufs& q = n.last;
+    const size_t third = (size_t)rup(dm, 16) * rup(dm, 16);
+    GemmEpilogue ekv;
+    ekv.bias = k.bQKV + dm;
+    lin(r, X, dm, rows, dm, k.pWqkv + third, 2 * dm, q.KV, 2 * dm, ekv);            // [k | v] for every row
+    if (r.rc) return;
+    RUN(launch_select_last(X, dm, len, B, T, q.XLAST, dm, 0, r.st));
+    GemmEpilogue eq;
+    eq.bias = k.bQKV;
+    lin(r, q.XLAST, dm, B, dm, k.pWqkv, dm, q.QLAST, dm, eq);
+    if (r.rc) return;
+    RUN(launch_attn_lastq_fwd(q.KV, q.QLAST, len, B, T, dm, D.enc_heads, q.OL, q.PL, r.st));
+    RUN(launch_add_layernorm(q.OL, dm, q.XLAST, dm, B, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)),
+                             r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), q.CL, dm, q.XH1, dm, q.RSTD1, r.st));
+    GemmEpilogue e1;
+    e1.bias = r.P(enc_blk_slot(e, l, INTEL_ENC_B1));
+    e1.relu = 1;
+    lin(r, q.CL, dm, B, dm, k.pW1, dm, q.F1, dm, e1);
+    if (r.rc) return;
+    GemmEpilogue e2;
+    e2.bias = r.P(enc_blk_slot(e, l, INTEL_ENC_B2));
+    e2.res = q.CL; e2.ldres = dm;
+    float* vec = r.y.PREDIN + n.predin_off;
+    if (dm <= 128) {
+      e2.gamma = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)); e2.beta = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B));
+      e2.xhat = q.XH2; e2.ldxhat = dm; e2.rstd = q.RSTD2;
+      lin(r, q.F1, dm, B, dm, k.pW2, dm, vec, r.y.Pin, e2);
+    } else {
+      GemmEpilogue e2b;
+      e2b.bias = e2.bias;
+      lin(r, q.F1, dm, B, dm, k.pW2, dm, q.OL, dm, e2b);
+      if (r.rc) return;
+      RUN(launch_add_layernorm(q.OL, dm, q.CL, dm, B, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)),
+                               r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B)), vec, r.y.Pin, q.XH2, dm, q.RSTD2, r.st));
+    }
+  }
 }
 
 // returns dE0 (gradient w.r.t. the encoder input rows, pos-emb already handled)
@@ -514,8 +577,50 @@ float* bert_bwd(Run& r, int e) {
   const int B = y.B, T = n.T, dm = n.dm, rows = B * T;
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
   float *dX = y.dXa, *dXalt = y.dXb;
-  if (!r.ok(launch_select_last_bwd(y.dPREDIN, y.Pin, n.predin_off, dm, len, B, T, dX, r.st))) return nullptr;
-  for (int l = D.enc_layers - 1; l >= 0; --l) {
+  {   // ---- last block, pruned (see bert_fwd): gradient of one output row per session
+    const int l = D.enc_layers - 1;
+    EncBlockBufs& k = n.blk[l];
+    EncLastBufs& q = n.last;
+    const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
+    float *dZl = y.dLB[0], *dF1l = y.dLB[1], *dCl = y.dLB[2], *dSl = y.dLB[3], *dQl = y.dLB[4];
+    const float* dvec = y.dPREDIN + n.predin_off;
+    {
+      const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
+      int a = r.acc(sg);
+      r.acc(sb);
+      if (!r.ok(launch_layernorm_bwd(dvec, y.Pin, q.XH2, dm, q.RSTD2, B, dm, r.P(sg), dZl, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+        return nullptr;
+    }
+    wgrad(r, dZl, dm, q.F1, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
+    GemmEpilogue em;
+    em.mask = q.F1; em.ldmask = dm;
+    lin(r, dZl, dm, B, dm, k.pW2T, dm, dF1l, dm, em);
+    wgrad(r, dF1l, dm, q.CL, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
+    GemmEpilogue ec;
+    ec.res = dZl; ec.ldres = dm;
+    lin(r, dF1l, dm, B, dm, k.pW1T, dm, dCl, dm, ec);
+    if (r.rc) return nullptr;
+    {
+      const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
+      int a = r.acc(sg);
+      r.acc(sb);
+      if (!r.ok(launch_layernorm_bwd(dCl, dm, q.XH1, dm, q.RSTD1, B, dm, r.P(sg), dSl, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+        return nullptr;
+    }
+    // attention of the single query row: dS is both d(attention output) and the residual into Xlast
+    if (!r.ok(launch_attn_lastq_bwd(q.KV, q.QLAST, q.PL, dSl, len, B, T, dm, D.enc_heads, dQl, y.dQKV, r.st))) return nullptr;
+    wgrad(r, dQl, dm, q.XLAST, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_BQ));
+    GemmEpilogue exl;
+    exl.res = dSl; exl.ldres = dm;
+    lin(r, dQl, dm, B, dm, q.pWqT, dm, dZl, dm, exl);                       // dXlast = dQ Wq + dS
+    wgrad(r, y.dQKV, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_BK));
+    wgrad(r, y.dQKV + dm, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WV), enc_blk_slot(e, l, INTEL_ENC_BV));
+    GemmEpilogue e0;
+    lin(r, y.dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
+    if (r.rc) return nullptr;
+    if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st))) return nullptr;
+  }
+  for (int l = D.enc_layers - 2; l >= 0; --l) {
     EncBlockBufs& k = n.blk[l];
     const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
     // LN2: Eout = LN2(F2 + C)

@@ -22,6 +22,11 @@ int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, co
 int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int I, const int* idx, int M, float* dW,
                              float* db, hipStream_t st);
 int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, float* oh, hipStream_t st);
+int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
+                          float* P, hipStream_t st);
+int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const float* d_out, const int* len, int B, int T,
+                          int dm, int heads, float* dq, float* dkv, hipStream_t st);
+int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st);
 int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st);
 int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,

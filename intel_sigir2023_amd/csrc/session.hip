@@ -442,3 +442,157 @@ int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, f
   INTEL_CHECK_LAUNCH();
   return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------
+// Last BERT4Rec block, pruned: only row len-1 of the block's output is ever used
+// (his_vector = seq[b, len_b - 1], models/GeneralSeq.py:103-105), so the last block needs K/V for all
+// rows but Q, the attention output, both LayerNorms and the FFN for ONE row per session.  This kernel is
+// that row's attention: one wave per (session, head); scores over the valid keys j < len.
+//   kv: [B*T, 2*dm] = [k | v] rows;  q: [B, dm];  out: [B, dm];  P: [B*heads, T] (saved for backward)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const float* __restrict__ kv, const float* __restrict__ q,
+                                                             const int* __restrict__ len, int B, int T, int dm, int heads,
+                                                             float scale, float* __restrict__ out, float* __restrict__ P) {
+  __shared__ float s_att[4][XP_MAXL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= B * heads) return;
+  const int b = bh / heads, h = bh - b * heads;
+  const int dk = dm / heads;
+  const int n = min(max(len[b], 0), T);
+  const float* qh = q + (size_t)b * dm + h * dk;
+  const float* kb = kv + (size_t)b * T * 2 * dm + h * dk;
+  const float* vb = kb + dm;
+  float* att = s_att[wave];
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int j0 = 0; j0 < n; j0 += 4) {
+    const int j = j0 + grp;
+    float s = 0.f;
+    if (j < n) {
+      for (int c = sub * 4; c < dk; c += 64) {
+        const f32x4 kx = *reinterpret_cast<const f32x4*>(kb + (size_t)j * 2 * dm + c);
+        const f32x4 qx = *reinterpret_cast<const f32x4*>(qh + c);
+        s += kx[0] * qx[0] + kx[1] * qx[1] + kx[2] * qx[2] + kx[3] * qx[3];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (j < n && sub == 0) att[j] = s * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, att[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) sum += expf(att[j] - mx);
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  for (int j = lane; j < T; j += 64) {
+    const float w = j < n ? expf(att[j] - mx) * inv : 0.f;
+    att[j] = w;
+    P[(size_t)bh * T + j] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int c = lane; c < dk; c += 64) {
+    float acc = 0.f;
+    for (int j = 0; j < n; ++j) acc += att[j] * vb[(size_t)j * 2 * dm + c];
+    out[(size_t)b * dm + h * dk + c] = acc;
+  }
+}
+int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
+                          float* P, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(T <= XP_MAXL, "attn_lastq: history length %d > %d unsupported", T, XP_MAXL);
+  INTEL_CHECK_ARG(dm % heads == 0 && (dm / heads) % 4 == 0, "attn_lastq: head dim must be a multiple of 4");
+  const float scale = 1.0f / sqrtf((float)(dm / heads));
+  LAUNCH(attn_lastq_fwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, len, B, T, dm, heads, scale, out, P);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward: d_out [B, dm] -> dq [B, dm], dkv [B*T, 2*dm] (all T rows written; zero beyond len)
+__global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __restrict__ kv, const float* __restrict__ q,
+                                                             const float* __restrict__ P, const float* __restrict__ d_out,
+                                                             const int* __restrict__ len, int B, int T, int dm, int heads,
+                                                             float scale, float* __restrict__ dq, float* __restrict__ dkv) {
+  __shared__ float s_ds[4][XP_MAXL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.x * 4 + wave;
+  if (bh >= B * heads) return;
+  const int b = bh / heads, h = bh - b * heads;
+  const int dk = dm / heads;
+  const int n = min(max(len[b], 0), T);
+  const float* qh = q + (size_t)b * dm + h * dk;
+  const float* doh = d_out + (size_t)b * dm + h * dk;
+  const float* kb = kv + (size_t)b * T * 2 * dm + h * dk;
+  const float* vb = kb + dm;
+  const float* p = P + (size_t)bh * T;
+  float* ds = s_ds[wave];
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int j0 = 0; j0 < n; j0 += 4) {          // dP_j = <dO, V_j>
+    const int j = j0 + grp;
+    float s = 0.f;
+    if (j < n) {
+      for (int c = sub * 4; c < dk; c += 64) {
+        const f32x4 vx = *reinterpret_cast<const f32x4*>(vb + (size_t)j * 2 * dm + c);
+        const f32x4 gx = *reinterpret_cast<const f32x4*>(doh + c);
+        s += vx[0] * gx[0] + vx[1] * gx[1] + vx[2] * gx[2] + vx[3] * gx[3];
+      }
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (j < n && sub == 0) ds[j] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float dsum = 0.f;
+  for (int j = lane; j < n; j += 64) dsum += p[j] * ds[j];
+  dsum = wave_sum(dsum);
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < T; j += 64) ds[j] = j < n ? p[j] * (ds[j] - dsum) * scale : 0.f;
+  __builtin_amdgcn_wave_barrier();
+  float* dkb = dkv + (size_t)b * T * 2 * dm + h * dk;
+  for (int c = lane; c < dk; c += 64) {
+    const float qc = qh[c], gc = doh[c];
+    float acc = 0.f;
+    for (int j = 0; j < T; ++j) {
+      const float dsj = ds[j];
+      const float pj = j < n ? p[j] : 0.f;
+      if (j < n) acc += dsj * kb[(size_t)j * 2 * dm + c];
+      dkb[(size_t)j * 2 * dm + c] = dsj * qc;
+      dkb[(size_t)j * 2 * dm + dm + c] = pj * gc;
+    }
+    dq[(size_t)b * dm + h * dk + c] = acc;
+  }
+}
+int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const float* d_out, const int* len, int B, int T,
+                          int dm, int heads, float* dq, float* dkv, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(T <= XP_MAXL, "attn_lastq_bwd: history length %d > %d unsupported", T, XP_MAXL);
+  const float scale = 1.0f / sqrtf((float)(dm / heads));
+  LAUNCH(attn_lastq_bwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, P, d_out, len, B, T, dm, heads, scale, dq, dkv);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// dX[b*T + len_b - 1, :] += src[b, :]
+__global__ void add_at_last_kernel(const float* __restrict__ src, int lds, int dm, const int* __restrict__ len, int B, int T,
+                                   float* __restrict__ dX) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dm) return;
+  const int b = i / dm, c = i - b * dm;
+  int t = len[b] - 1;
+  t = t < 0 ? T + t : t;
+  t = min(max(t, 0), T - 1);
+  if (t < len[b]) dX[((size_t)b * T + t) * dm + c] += src[(size_t)b * lds + c];
+}
+int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st) {
+  if (B * dm <= 0) return 0;
+  LAUNCH(add_at_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, src, lds, dm, len, B, T, dX);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
