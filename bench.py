@@ -188,6 +188,15 @@ def main():
             ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
             roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': round(ach / (HBM_PEAK / 1e9), 5), 'traffic': None}
+        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
+            key = name.replace('(', '').replace(')', '').split('<')[0]
+            if key in pmc and a.workload == 'tmall' and B == 4096:
+                roof['traffic'] = pmc[key]['hbm_bytes_per_launch']
+                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950), bytes per launch'
+        except Exception:
+            pass
         roof.update({'kernel': name, 'launches_per_step': dom['launches'] / psteps, 'avg_launch_ms': round(avg_ms, 5),
                      'share_of_kernel_time': round(dom['ms'] / tot, 4),
                      'algorithmic_per_launch': (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches']})

@@ -623,10 +623,10 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 // Partials go to per-workgroup slabs and are summed in a fixed order (bitwise reproducible).
 // ------------------------------------------------------------------------------------------
 #define WG_RT 32          // rows per LDS tile
-#define WG_MAXS 1024      // max slabs (4 workgroups per CU)
+#define WG_MAXS 512       // max slabs: 2 resident workgroups per CU (72 KB LDS each)
 
 static inline int wgrad_num_slabs(int M) {
-  int s = cdiv(M, 4 * WG_RT);
+  int s = cdiv(M, 8 * WG_RT);
   return s < 1 ? 1 : (s > WG_MAXS ? WG_MAXS : s);
 }
 size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M) * ((size_t)N * K + N); }
@@ -636,87 +636,7 @@ struct WgradArgs {
   float* slabs; int S; int want_db;
 };
 
-// generic path (any alignment): stage -> sync -> MFMA, single LDS buffer
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.y * 128, k0 = blockIdx.z * 128;
-  const int nb = min(128, a.N - n0), kb = min(128, a.K - k0);
-  const int NTb = (nb + 15) >> 4, KTb = (kb + 15) >> 4;
-  const int ldy = ((NTb * 16 + 31) & ~31) + 16, ldx = ((KTb * 16 + 31) & ~31) + 16;
-  float* Ys = smem;                 // [WG_RT][ldy]
-  float* Xs = smem + WG_RT * ldy;   // [WG_RT][ldx]
-  const int wn = wave >> 1, wk = wave & 1;
-  const int ntw = (NTb + 1) >> 1, ktw = (KTb + 1) >> 1;     // tiles per wave along n / k (<= 4)
-  const int nt0 = wn * ntw, kt0 = wk * ktw;
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbacc = 0.f;
-  const int ntiles = (a.M + WG_RT - 1) / WG_RT;
-  for (int t = blockIdx.x; t < ntiles; t += a.S) {
-    const int m0 = t * WG_RT;
-    __syncthreads();
-    for (int i = tid; i < WG_RT * NTb * 16; i += 256) {
-      int r = i / (NTb * 16), c = i - r * (NTb * 16);
-      int row = m0 + r;
-      float v = 0.f;
-      if (row < a.M && c < nb) v = a.dY[(size_t)row * a.lddy + n0 + c];
-      Ys[r * ldy + c] = v;
-    }
-    for (int i = tid; i < WG_RT * KTb * 16; i += 256) {
-      int r = i / (KTb * 16), c = i - r * (KTb * 16);
-      int row = m0 + r;
-      float v = 0.f;
-      if (row < a.M && c < kb) v = a.X[(size_t)row * a.ldx + k0 + c];
-      Xs[r * ldx + c] = v;
-    }
-    __syncthreads();
-    if (a.want_db && blockIdx.z == 0 && tid < nb) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < WG_RT; ++r) s += Ys[r * ldy + tid];
-      dbacc += s;
-    }
-#pragma unroll 2
-    for (int ms = 0; ms < WG_RT / 4; ++ms) {
-      const int rr = ms * 4 + (lane >> 4);
-      float af[4], bf[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = (nt0 + i < NTb && i < ntw) ? Ys[rr * ldy + (nt0 + i) * 16 + (lane & 15)] : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = (kt0 + j < KTb && j < ktw) ? Xs[rr * ldx + (kt0 + j) * 16 + (lane & 15)] : 0.f;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if (nt0 + i < NTb && i < ntw) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kt0 + j < KTb && j < ktw) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
-        }
-      }
-    }
-  }
-  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (!(nt0 + i < NTb && i < ntw)) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (!(kt0 + j < KTb && j < ktw)) continue;
-      const int k = k0 + (kt0 + j) * 16 + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = n0 + (nt0 + i) * 16 + 4 * (lane >> 4) + r;
-        if (n < a.N && k < a.K) slab[(size_t)n * a.K + k] = acc[i][j][r];
-      }
-    }
-  }
-  if (a.want_db && blockIdx.z == 0 && tid < nb) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
-}
-
-// pipelined path (16-byte aligned operands): the next 32-row tile is prefetched global -> registers
+// the next 32-row tile is prefetched global -> registers (16-byte loads when the operands are aligned)
 // while the MFMAs of the current tile run from LDS; two LDS buffers, one barrier per tile.
 __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -729,6 +649,8 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
   const int wn = wave >> 1, wk = wave & 1;
   const int ntw = (NTb + 1) >> 1, ktw = (KTb + 1) >> 1;
   const int nt0 = wn * ntw, kt0 = wk * ktw;
+  const bool vecY = ((a.lddy & 3) == 0) && ((nb & 3) == 0) && ((n0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.dY) & 15) == 0);
+  const bool vecX = ((a.ldx & 3) == 0) && ((kb & 3) == 0) && ((k0 & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.X) & 15) == 0);
   const int cy = NTb * 4, cx = KTb * 4;                  // float4 per row
   const int njy = (WG_RT * cy + 255) >> 8, njx = (WG_RT * cx + 255) >> 8;   // float4 per thread (<= 4 each)
   f32x4 py[4], px[4];
@@ -749,14 +671,26 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
         const int i = tid + 256 * j;
         const int r = i / cy, c = (i - r * cy) * 4;
         const int row = m0 + r;
-        if (r < WG_RT && row < a.M && c < nb) py[j] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)row * a.lddy + n0 + c);
+        if (r < WG_RT && row < a.M && c < nb) {
+          if (vecY) py[j] = *reinterpret_cast<const f32x4*>(a.dY + (size_t)row * a.lddy + n0 + c);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) py[j][e] = (c + e < nb) ? a.dY[(size_t)row * a.lddy + n0 + c + e] : 0.f;
+          }
+        }
       }
       px[j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (j < njx) {
         const int i = tid + 256 * j;
         const int r = i / cx, c = (i - r * cx) * 4;
         const int row = m0 + r;
-        if (r < WG_RT && row < a.M && c < kb) px[j] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0 + c);
+        if (r < WG_RT && row < a.M && c < kb) {
+          if (vecX) px[j] = *reinterpret_cast<const f32x4*>(a.X + (size_t)row * a.ldx + k0 + c);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) px[j][e] = (c + e < kb) ? a.X[(size_t)row * a.ldx + k0 + c + e] : 0.f;
+          }
+        }
       }
     }
   };
@@ -931,13 +865,9 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   const int nbm = min(128, N), kbm = min(128, K);
   const int ldy = (rup(rup(nbm, 16), 32)) + 16, ldxs = (rup(rup(kbm, 16), 32)) + 16;
   size_t smem = (size_t)WG_RT * (ldy + ldxs) * sizeof(float);
-  const bool al = ((lddy & 3) == 0) && ((ldx & 3) == 0) && ((N & 3) == 0) && ((K & 3) == 0) &&
-                  (((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X)) & 15) == 0);
-  if (al) {
+  {
     allow_lds(wgrad_pipe_kernel, 2 * smem);
     LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), wgrad_pipe_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), 2 * smem, st, a);
-  } else {
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), wgrad_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), smem, st, a);
   }
   INTEL_CHECK_LAUNCH();
   size_t stride = (size_t)N * K + N;

@@ -272,7 +272,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   size_t rowsmax = (size_t)M;
   if ((size_t)B * H > rowsmax) rowsmax = (size_t)B * H;
   if ((size_t)B * Hi > rowsmax) rowsmax = (size_t)B * Hi;
-  size_t slab = 1024 * (maxNK + maxN);
+  size_t slab = 512 * (maxNK + maxN);
   size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;
   if (lnslab > slab) slab = lnslab;
   y.SLABS = ar.f(slab + 1024);
