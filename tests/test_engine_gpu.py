@@ -1,0 +1,157 @@
+"""GPU parity of the fast path (IntELEngine: flat buckets + fused Adam + on-device NDCG) and of the loss /
+NDCG kernels on larger random shapes, against the CPU oracle on identical inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import intel_oracle as O
+from tests.helpers import Fixture, build_model
+from tests.test_oracle_golden import check_adam_result
+
+pytestmark = pytest.mark.gpu
+
+
+def per_session_ndcg(ens, ranking, slen, k):
+    """NDCG@k of every session with the padding width evaluate_method uses for the WHOLE set
+    (max(max(session_len), k), helpers/BaseRunner.py:66): each session is evaluated together with a
+    full-length dummy list so that the width is fixed, then the dummy's share of the mean is removed."""
+    Lm = ens.shape[1]
+    dummy_e = np.linspace(1.0, 2.0, Lm, dtype=np.float32)[None, :]
+    dummy_r = np.zeros((1, Lm), dtype=np.int64)
+    dummy_r[0, 0] = 1
+    d = O.ndcg_at_k(dummy_e, dummy_r, np.array([Lm]), k)
+    out = []
+    for i in range(ens.shape[0]):
+        m = O.ndcg_at_k(np.concatenate([ens[i:i + 1], dummy_e]), np.concatenate([ranking[i:i + 1], dummy_r]),
+                        np.array([int(slen[i]), Lm]), k)
+        out.append(2 * m - d)
+    return np.array(out)
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('name', ['default', 'gru_bpr', 'noxatt'])
+def test_engine_two_steps_match_reference_adam(name):
+    """IntELEngine.train_step x2 == the reference's 2 torch.optim.Adam steps (fixture F7)."""
+    from intel_sigir2023_amd.engine import IntELEngine
+    fx = Fixture(name)
+    dev = _dev()
+    model, args = build_model(fx, dev)
+    model.train()
+    args.cal_diversity = 1
+    lr, l2 = [float(x) for x in fx['adam/lr_l2']]
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=lr, l2=l2)
+    batch = fx.batch(dev)
+    for step in range(2):
+        loss, ens, itl = eng.train_step(batch, noise=torch.from_numpy(fx['adam/noise%d' % step]).to(dev))
+        assert abs(float(loss) - float(fx['adam/losses'][step])) < 1e-5
+    rows = fx.group('adam_rows')
+    named = dict(model.named_parameters())
+    for pname, ref in fx.group('adam').items():
+        if pname in ('losses', 'lr_l2', 'noise0', 'noise1'):
+            continue
+        got = named[pname].detach().cpu()
+        if pname in rows:
+            got = got[torch.from_numpy(rows[pname])]
+        check_adam_result(fx, pname, got.numpy(), ref, lr)
+    # gradients were consumed and cleared by the fused Adam sweep
+    assert all(float(g.abs().max()) == 0.0 for g in eng.buckets())
+
+
+@pytest.mark.parametrize('workload,B', [('tiny', 64), ('tmall', 48), ('lifedata', 16)])
+def test_engine_step_matches_oracle_on_synthetic_workloads(workload, B):
+    """Full-size shapes (1M-item table for tmall): loss of one engine step vs the oracle, NDCG@3 on device vs
+    evaluate_method, and a size-independent property: the dense Adam sweep moves EVERY table row (weight decay)
+    while only touched rows carry gradient."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    over = dict(items=20000, users=2000) if workload != 'tiny' else None
+    torch.manual_seed(1)
+    args = synth.make_args(workload, dev, cal_diversity=1)
+    corpus, c = synth.make_corpus(workload, **(over or {}))
+    model = IntEL(args, corpus).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = synth.make_batch(workload, B, dev, seed=5, ragged=True, corpus_over=over)
+    ref_batch = synth.to_reference_layout(batch, c['I'])
+    cfg = O.Config(**{k: v for k, v in vars(args).items() if k != 'device'})
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+    # eval first (same parameters as the oracle's)
+    out, ndcg = eng.eval_step(batch, k=3)
+    with torch.no_grad():
+        ref = O.forward(sd, ref_batch, cfg)
+    for k in ('weights', 'ens_score', 'intents'):
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref[k].abs().max())), (k, err)
+    ref_nd = per_session_ndcg(ref['ens_score'].numpy(), ref_batch['ranking'].numpy(), ref_batch['session_len'].numpy(), 3)
+    np.testing.assert_allclose(ndcg.cpu().numpy(), ref_nd, atol=1e-4)
+    whole = O.ndcg_at_k(ref['ens_score'].numpy(), ref_batch['ranking'].numpy(), ref_batch['session_len'].numpy(), 3)
+    assert abs(float(ndcg.mean()) - whole) <= 1e-4
+    L = batch['i_id_s'].shape[1]
+    noise = torch.rand(B, L, L, device=dev)
+    p_before = model.iid_embeddings.weight.detach().clone()
+    loss, _, _ = eng.train_step(batch, noise=noise)
+    ref_loss, _, _ = O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
+    assert abs(float(loss) - float(ref_loss)) < 1e-5
+    moved = (model.iid_embeddings.weight.detach() != p_before).any(dim=1)
+    assert float(moved.float().mean()) > 0.999          # dense semantics: decay reaches untouched rows too
+
+
+@pytest.mark.parametrize('B,L,K', [(33, 50, 3), (7, 200, 8), (19, 100, 5)])
+def test_loss_kernels_match_oracle_random(B, L, K):
+    from intel_sigir2023_amd import loss as LS
+    import argparse
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * L + K)
+    ens = torch.randn(B, L, generator=g)
+    weights = torch.randn(B, L, K, generator=g)
+    scores = torch.rand(B, L, K, generator=g, dtype=torch.float64)
+    slen = torch.randint(3, L + 1, (B,), generator=g)
+    slen[0] = L
+    ranking = torch.zeros(B, L, dtype=torch.int64)
+    for b in range(B):
+        n = int(slen[b])
+        r = torch.zeros(n, dtype=torch.int64)
+        r[: min(n, 6)] = torch.tensor([3, 2, 2, 1, 1, 1])[: min(n, 6)]
+        ranking[b, :n] = r[torch.randperm(n, generator=g)]
+    noise = torch.rand(B, L, L, generator=g)
+    intents = torch.softmax(torch.randn(B, 30, generator=g, dtype=torch.float64), -1)
+    pred = torch.softmax(torch.randn(B, 30, generator=g), -1)
+    a = argparse.Namespace(cal_diversity=1, diversity_alpha=0.01, intent_weight=0.1, ensemble_weight=1.0, kl_temp=2.0, kl_weight=0.5)
+    cb = {'ranking': ranking, 'session_len': slen, 'scores': scores, 'intents': intents, 'bpr_noise': noise}
+    db = {k: v.to(dev) for k, v in cb.items()}
+    for cls, fn in ((LS.IntBPRloss, 'bpr'), (LS.IntListloss, 'pl')):
+        e_d, w_d, p_d = ens.to(dev).requires_grad_(True), weights.to(dev).requires_grad_(True), pred.to(dev).requires_grad_(True)
+        loss, el, il = cls(a)({'ens_score': e_d, 'weights': w_d, 'intents': p_d}, db)
+        loss.backward()
+        e_c, w_c, p_c = ens.clone().requires_grad_(True), weights.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+        cfg = O.Config(**vars(a))
+        out = {'ens_score': e_c, 'weights': w_c, 'intents': p_c}
+        ref, rel, ril = (O.int_bpr_loss(out, cb, cfg, noise) if fn == 'bpr' else O.int_list_loss(out, cb, cfg))
+        ref.backward()
+        assert abs(float(loss) - float(ref)) < 1e-5 and abs(float(el) - float(rel)) < 1e-5 and abs(float(il) - float(ril)) < 1e-5
+        for got, want, nm in ((e_d.grad, e_c.grad, 'd_ens'), (w_d.grad, w_c.grad, 'd_weights'), (p_d.grad, p_c.grad, 'd_intents')):
+            err = float((got.cpu() - want).abs().max())
+            assert err <= 1e-6 + 2e-4 * float(want.abs().max()), (fn, nm, err)
+
+
+def test_ndcg_kernel_matches_evaluate_method_on_ragged_lists():
+    from intel_sigir2023_amd import _lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    B, Lm = 257, 90
+    slen = torch.randint(1, Lm + 1, (B,), generator=g)
+    slen[0], slen[1] = 1, 2                      # shorter than k
+    ens = torch.randn(B, Lm, generator=g)         # negative scores: padded slots (0) outrank them
+    ranking = torch.randint(-1, 4, (B, Lm), generator=g)
+    ranking[:, 0] = 3                             # at least one positive inside every list
+    for k in (1, 3, 10):
+        out = torch.empty(B, dtype=torch.float32, device=dev)
+        e, r, s = ens.to(dev).contiguous(), ranking.to(torch.int32).to(dev).contiguous(), slen.to(torch.int32).to(dev)
+        L.check(L.lib().intel_ndcg(B, Lm, k, L.ptr(e), L.ptr(r), L.ptr(s), L.ptr(out), L.stream_ptr(dev)), 'intel_ndcg')
+        ref = per_session_ndcg(ens.numpy(), ranking.numpy(), slen.numpy(), k)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-6)
