@@ -23,15 +23,14 @@ def init_distributed(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        kw = {}
+            # INTEL_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that): used by the
+            # single-GPU test of the data-parallel path
+            backend = os.environ.get('INTEL_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if os.environ.get('INTEL_SINGLE_DEVICE'):
+            local_rank = 0
         if backend == 'nccl':
             torch.cuda.set_device(local_rank)
-            try:
-                kw['device_id'] = torch.device('cuda', local_rank)
-            except Exception:
-                kw = {}
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 

@@ -1,0 +1,70 @@
+"""Data-parallel engine on real kernels: two ranks (gloo, both on cuda:0 -- RCCL refuses two ranks per GPU and
+the test box has one) on the two halves of a global batch must reproduce the single-process step on the whole
+batch: same losses (mean of the shard losses) and same parameters after 2 steps."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests.helpers import Fixture, build_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), INTEL_DIST_BACKEND='gloo', INTEL_SINGLE_DEVICE='1')
+    from intel_sigir2023_amd import parallel
+    from intel_sigir2023_amd.engine import IntELEngine
+    if world > 1:
+        parallel.init_distributed()
+    dev = torch.device('cuda:0')
+    fx = Fixture('default')
+    model, args = build_model(fx, dev)
+    model.train()
+    args.cal_diversity = 1
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+    parallel.broadcast_(eng.param_buckets())
+    batch = fx.batch(dev)
+    local = parallel.shard_batch(batch, rank, world)
+    lo, hi = parallel.shard_range(batch['batch_size'], rank, world)
+    losses = []
+    for step in range(2):
+        noise = torch.from_numpy(fx['adam/noise%d' % step]).to(dev)[lo:hi].contiguous()
+        loss, _, _ = eng.train_step(local, noise=noise)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save({'sd': sd, 'losses': losses}, os.path.join(out_dir, 'w%d_r%d.pt' % (world, rank)))
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def test_two_rank_engine_equals_single_process():
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
+        mp.spawn(_run, args=(2, _free_port(), d), nprocs=2, join=True)
+        one = torch.load(os.path.join(d, 'w1_r0.pt'))
+        r0 = torch.load(os.path.join(d, 'w2_r0.pt'))
+        r1 = torch.load(os.path.join(d, 'w2_r1.pt'))
+    for s in range(2):
+        assert abs(0.5 * (r0['losses'][s] + r1['losses'][s]) - one['losses'][s]) < 2e-5
+    for k, v in one['sd'].items():
+        assert torch.equal(r0['sd'][k], r1['sd'][k]), 'replicas diverged: ' + k
+        if 'k_linear.bias' in k:
+            continue            # analytically-zero gradient: Adam direction is rounding noise
+        err = float((r0['sd'][k] - v).abs().max())
+        assert err < 5e-5, (k, err)
