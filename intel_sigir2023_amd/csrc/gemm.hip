@@ -400,41 +400,55 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
   const int c4n = Kp >> 2;                    // float4 per tile row
   const int tot4 = GR_BM * c4n;               // float4 per tile
   f32x4 pre[4];
+  // this thread's (up to) four 16-byte slots of an A tile, computed once.  Loads are UNCONDITIONAL
+  // (rows past M are clamped to the last row; their products are never stored) so that the compiler
+  // emits plain loads without zero-fill moves and waits; K-padding slots are zeroed in LDS once.
+  int trow[4], tcol[4], loff[4];
+  bool slot[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 512 * j;
+    const int r = i / c4n, c = (i - r * c4n) * 4;
+    slot[j] = i < tot4 && c < a.K;
+    trow[j] = r;
+    tcol[j] = c;
+    loff[j] = r * GR_LDA + c;
+    if (i < tot4 && c >= a.K) {          // k padding (K % 16 != 0): stays zero in both buffers
+      *reinterpret_cast<f32x4*>(smem + loff[j]) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(smem + GR_BM * GR_LDA + loff[j]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
   const int ntiles = (a.M + GR_BM - 1) / GR_BM;
   int t = blockIdx.x;
   if (t >= ntiles) return;
   auto load_tile = [&](int tt) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int i = tid + 512 * j;
-      if (i < tot4) {
-        const int r = i / c4n, c = (i - r * c4n) * 4;
-        const int row = tt * GR_BM + r;
-        pre[j] = (row < a.M && c < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (slot[j]) {
+        const int row = min(tt * GR_BM + trow[j], a.M - 1);
+        pre[j] = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + tcol[j]);
       }
     }
   };
   auto store_tile = [&](float* As) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid + 512 * j;
-      if (i < tot4) {
-        const int r = i / c4n, c = (i - r * c4n) * 4;
-        *reinterpret_cast<f32x4*>(As + r * GR_LDA + c) = pre[j];
-      }
-    }
+    for (int j = 0; j < 4; ++j)
+      if (slot[j]) *reinterpret_cast<f32x4*>(As + loff[j]) = pre[j];
   };
   // auxiliary epilogue operand (the plan never combines them): 1 relu mask, 2 residual, 3 accumulate
   const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
   const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
   const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
   const int col = (nc + ct) * 16 + 4 * (lane >> 4);
-  const bool colok = active && col + 3 < a.N;
+  const bool colok = active && col < a.N;
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (!LN && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
 
   load_tile(t);
   store_tile(smem);
+  // B fragments and the bias are loop invariants loaded once: retire those loads HERE so that no wait
+  // inside the loop (vmcnt is in-order and also counts the epilogue stores) has to cover them
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
   __syncthreads();
   if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);
   int buf = 0;
@@ -443,7 +457,7 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
     f32x4 acc[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (active && !(a.dbg & 2)) {
+    if (active) {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         if (g < KG) {
@@ -460,10 +474,8 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
     }
     if (t + (int)gridDim.x < ntiles) store_tile(smem + (buf ^ 1) * (GR_BM * GR_LDA));
     const int m0 = t * GR_BM;
-    if (a.dbg & 1) {
-      if (acc[0][0] == 12345.678f) a.C[0] = 1.f;
-    } else if (!LN) {
-      if (a.vec_ep && colok) {
+    if (!LN) {
+      if (colok) {       // host guarantees 16-byte aligned epilogue operands and N % 4 == 0
         f32x4 aux[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -485,23 +497,6 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
             x += aux[rt];
           }
           if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
-        }
-      } else if (active && col < a.N) {       // unaligned operands / ragged right edge: scalar
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
-          if (row >= a.M) continue;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int cc = col + r;
-            if (cc >= a.N) continue;
-            float x = acc[rt][r] + (ep.bias ? ep.bias[cc] : 0.f);
-            if (ep.relu) x = fmaxf(x, 0.f);
-            if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + cc] > 0.f) ? x : 0.f;
-            if (ep.res) x += ep.res[(size_t)row * ep.ldres + cc];
-            float* dst = a.C + (size_t)row * a.ldc + cc;
-            *dst = ep.accumulate ? (*dst + x) : x;
-          }
         }
       }
     } else {
@@ -596,7 +591,7 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   a.A = A; a.lda = lda; a.M = M; a.K = K; a.Bp = Bp; a.N = N; a.C = C; a.ldc = ldc; a.ep = ep;
   const bool vecA = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   INTEL_CHECK_ARG(!(ep.gamma && (ep.mask || ep.accumulate)), "gemm_rows: LayerNorm epilogue cannot be combined with mask/accumulate");
-  if (rup(K, 16) <= GR_KC && vecA && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
+  if (rup(K, 16) <= GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
     if (ep.gamma) {
       if (N > 64) return launch_w8<4, true>(a, st);
       if (N > 32) return launch_w8<2, true>(a, st);
@@ -626,7 +621,7 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 #define WG_MAXS 512       // max slabs: 2 resident workgroups per CU (72 KB LDS each)
 
 static inline int wgrad_num_slabs(int M) {
-  int s = cdiv(M, 8 * WG_RT);
+  int s = cdiv(M, WG_RT);      // one 32-row tile per workgroup until the chip is full
   return s < 1 ? 1 : (s > WG_MAXS ? WG_MAXS : s);
 }
 size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M) * ((size_t)N * K + N); }
