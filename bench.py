@@ -166,12 +166,14 @@ def main():
                               'peak_GBps': HBM_PEAK / 1e9, 'frac': round(bytes_train * res['value'] / world / HBM_PEAK, 6)}
     if not a.no_roofline:
         lib = _lib.lib()
+        lib.intel_set_concurrency(model._context(), 0)     # price kernels one at a time on one stream
         lib.intel_prof_enable(1)
         psteps = 3
         for i in range(psteps):
             one_step(i)
         prof_shapes = json.loads(lib.intel_prof_collect().decode())
         lib.intel_prof_enable(0)
+        lib.intel_set_concurrency(model._context(), 1)
         prof = {}                       # aggregate the shape-tagged GEMM records by kernel
         for k, v in prof_shapes.items():
             d = prof.setdefault(k.split('[')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})

@@ -136,6 +136,11 @@ void intel_abi_sizes(int* out4);
 IntelCtx* intel_create(const IntelDesc* desc);
 void intel_destroy(IntelCtx* ctx);
 
+/* The independent branches of a step (two towers, two sequence encoders) run on internal side streams that
+ * fork from / join into the caller's stream (event-ordered, graph-capturable).  on = 0 keeps everything on
+ * the caller's stream (bench.py does this while it prices single kernels).  Default: on. */
+void intel_set_concurrency(IntelCtx* ctx, int on);
+
 /* Bytes of workspace intel_forward/intel_backward need for a batch of this shape.  `train` != 0
  * also reserves the activation stash the backward pass reads. */
 size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train);

@@ -97,7 +97,7 @@ ENC_STRIDE = 6 + ENC_BLOCK_STRIDE * ENC_MAX_BLOCKS
 P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 
 EXPORTS = [
-    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_workspace_bytes',
+    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_bpr_loss', 'intel_list_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd',
@@ -118,6 +118,7 @@ def _declare(l):
     sig('intel_abi_sizes', None, [C.POINTER(C.c_int)])
     sig('intel_create', vp, [C.POINTER(IntelDesc)])
     sig('intel_destroy', None, [vp])
+    sig('intel_set_concurrency', None, [vp, i])
     sig('intel_workspace_bytes', sz, [vp, i, i, i, i, i])
     sig('intel_forward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, C.POINTER(IntelOut), i, vp])
     sig('intel_backward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, vp, vp, vp, C.POINTER(vp), vp])

@@ -6,6 +6,7 @@
 // Workspace layout (one caller-provided allocation, carved by `Layout`):
 //   [ packed weights | forward activations (stash) | backward temporaries | reduction slabs ]
 // Activations are fp32 row-major [rows, width]; "rows" are B*L candidate rows or B*T history rows.
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -62,17 +63,22 @@ struct EncBufs {
   GruBufs gru;
 };
 
+// backward temporaries; two sets so that two independent branches (item tower || score tower, encoder ||
+// item encoder) can run concurrently on two streams
+struct Temps {
+  float *dXa, *dXb, *dZ, *dF1, *dA, *dQKV, *DSUM, *SLABS, *dVB1, *dVB2, *dVB3, *ONEHOT, *dINT;
+  float* dLB[5];            // [B, dmax] temporaries of the pruned last encoder block
+};
+
 struct Layout {
   int B, L, H, Hi, M;
+  Temps tmp[2];
   TowerBufs tw[2];          // 0 = item tower, 1 = score tower
   EncBufs enc[2];           // 0 = "encoder" (session history), 1 = "item_encoder"
   int F, Pin;               // width of the fusion feature / pred_layer input
   float *FEAT, *WV, *WPAD, *FEATFULL, *PREDIN, *LOGITS, *INTENTS;
   float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
-  // backward temporaries
-  float *dXa, *dXb, *dZ, *dF1, *dA, *dQKV, *DSUM, *SLABS;
-  float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN, *dVB1, *dVB2, *dVB3, *ONEHOT;
-  float* dLB[5];            // [B, dmax] temporaries of the pruned last encoder block
+  float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN;
   size_t total;
 };
 
@@ -86,6 +92,11 @@ struct IntelCtx {
   int fB, fL, fH, fHi;
   const void* f_ws;
   unsigned char touched[INTEL_P_COUNT];
+  // side streams: independent branches of the step (the two towers, the two sequence encoders) run
+  // concurrently -- MFMA-bound GEMMs of one branch overlap the HBM-bound row kernels of another
+  hipStream_t side[3];
+  hipEvent_t ev_fork, ev_join[3];
+  int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
 };
 
 namespace {
@@ -231,13 +242,6 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     }
   }
   // ---- backward temporaries
-  y.dXa = ar.f(maxMD);
-  y.dXb = ar.f(maxMD);
-  y.dZ = ar.f(maxMD);
-  y.dF1 = ar.f(maxMD);
-  y.dA = ar.f(maxMD);
-  y.dQKV = ar.f(3 * maxMD);
-  y.DSUM = ar.f(maxLSE);
   y.dFEAT = ar.f((size_t)B * y.F);
   y.dWV = ar.f((size_t)B * K);
   y.dWPAD = ar.f((size_t)B * K);
@@ -249,15 +253,6 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   const int dmax = d_i > d_s ? (d_i > dm0 ? (d_i > dm1 ? d_i : dm1) : (dm0 > dm1 ? dm0 : dm1))
                              : (d_s > dm0 ? (d_s > dm1 ? d_s : dm1) : (dm0 > dm1 ? dm0 : dm1));
   const int vmax = dmax > I ? (dmax > D.q_size ? dmax : D.q_size) : (I > D.q_size ? I : D.q_size);
-  y.dVB1 = ar.f((size_t)B * vmax);
-  y.dVB2 = ar.f((size_t)B * vmax);
-  y.dVB3 = ar.f((size_t)B * vmax);
-  for (int i = 0; i < 5; ++i) y.dLB[i] = ar.f((size_t)B * vmax);
-  {
-    const int Tm = H > Hi ? H : Hi;
-    const int Rm = I > Tm ? I : Tm;
-    y.ONEHOT = ar.f((size_t)B * Tm * Rm);
-  }
   // slabs: the largest weight-gradient / LayerNorm / column-sum reduction
   size_t maxNK = (size_t)dmax * dmax;
   auto upd = [&](size_t v) { if (v > maxNK) maxNK = v; };
@@ -275,7 +270,25 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   size_t slab = 512 * (maxNK + maxN);
   size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;
   if (lnslab > slab) slab = lnslab;
-  y.SLABS = ar.f(slab + 1024);
+  const int Tm = H > Hi ? H : Hi;
+  const int Rm = I > Tm ? I : Tm;
+  for (int i = 0; i < 2; ++i) {
+    Temps& t = y.tmp[i];
+    t.dXa = ar.f(maxMD);
+    t.dXb = ar.f(maxMD);
+    t.dZ = ar.f(maxMD);
+    t.dF1 = ar.f(maxMD);
+    t.dA = ar.f(maxMD);
+    t.dQKV = ar.f(3 * maxMD);
+    t.DSUM = ar.f(maxLSE);
+    t.dVB1 = ar.f((size_t)B * vmax);
+    t.dVB2 = ar.f((size_t)B * vmax);
+    t.dVB3 = ar.f((size_t)B * vmax);
+    for (int j = 0; j < 5; ++j) t.dLB[j] = ar.f((size_t)B * vmax);
+    t.ONEHOT = ar.f((size_t)B * Tm * Rm);
+    t.dINT = ar.f((size_t)B * I);
+    t.SLABS = ar.f(slab + 1024);
+  }
   y.total = rup_sz(ar.off, 256) + 256;
 }
 
@@ -289,6 +302,7 @@ struct Run {
   const IntelBatch* bt;
   hipStream_t st;
   int rc;
+  Temps* T;
   const float* P(int slot) const { return static_cast<const float*>(params[slot]); }
   float* G(int slot) const { return static_cast<float*>(grads[slot]); }
   // 0 the first time a gradient slot is written in this backward, 1 afterwards (accumulate)
@@ -302,6 +316,45 @@ struct Run {
     return rc == 0;
   }
 };
+
+bool ensure_streams(IntelCtx* c) {
+  if (c->streams == 0) {
+    const char* e = getenv("INTEL_STREAMS");
+    if (e && e[0] == '0') { c->streams = -1; return false; }
+    bool ok = true;
+    for (int i = 0; i < 3; ++i) {
+      ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    c->streams = ok ? 1 : -1;
+  }
+  return c->streams == 1;
+}
+// side streams 0..n-1 wait for everything enqueued so far on the main stream
+void fork_streams(Run& r, int n) {
+  IntelCtx* c = r.ctx;
+  if (!ensure_streams(c)) return;
+  r.ok((int)hipEventRecord(c->ev_fork, r.st));
+  for (int i = 0; i < n; ++i) r.ok((int)hipStreamWaitEvent(c->side[i], c->ev_fork, 0));
+}
+// the main stream waits for side streams 0..n-1
+void join_streams(Run& r, int n) {
+  IntelCtx* c = r.ctx;
+  if (c->streams != 1) return;
+  for (int i = 0; i < n; ++i) {
+    r.ok((int)hipEventRecord(c->ev_join[i], c->side[i]));
+    r.ok((int)hipStreamWaitEvent(r.st, c->ev_join[i], 0));
+  }
+}
+// a Run on side stream i (or on the main stream when concurrency is off) with temporaries set t
+Run branch(Run& r, int side, int t) {
+  Run b = r;
+  if (r.ctx->streams == 1 && side >= 0) b.st = r.ctx->side[side];
+  b.T = &r.y.tmp[t];
+  b.rc = 0;
+  return b;
+}
 
 #define RUN(expr)             \
   do {                        \
@@ -328,7 +381,7 @@ void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, in
   if (!dW) return;
   int a = r.acc(w_slot);
   if (b_slot >= 0) { int ab = r.acc(b_slot); (void)ab; }
-  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, r.y.SLABS, r.st));
+  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, r.T->SLABS, r.st));
 }
 
 // ---- weight packing -------------------------------------------------------------------------
@@ -451,7 +504,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
   }
 }
 
-// dXout (in r.y.dXa) -> dX0 (returned pointer, one of dXa/dXb)
+// dXout (in r.T->dXa) -> dX0 (returned pointer, one of dXa/dXb)
 float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
@@ -462,24 +515,24 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
     {
       int a = r.acc(pb + T_LNG);
       r.acc(pb + T_LNB);
-      if (!r.ok(launch_layernorm_bwd(dX, d, b.XH, d, b.RSTD, M, d, r.P(pb + T_LNG), y.dZ, d, r.G(pb + T_LNG), r.G(pb + T_LNB), a,
-                                     y.SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dX, d, b.XH, d, b.RSTD, M, d, r.P(pb + T_LNG), r.T->dZ, d, r.G(pb + T_LNG), r.G(pb + T_LNB), a,
+                                     r.T->SLABS, r.st)))
         return nullptr;
     }
-    wgrad(r, y.dZ, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
+    wgrad(r, r.T->dZ, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
     GemmEpilogue em;
     em.mask = b.R1; em.ldmask = d;
-    lin(r, y.dZ, d, M, d, w.pW2T, d, y.dF1, d, em);                 // d(pre-relu) = (dZ W2) * [R1 > 0]
-    wgrad(r, y.dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1);
+    lin(r, r.T->dZ, d, M, d, w.pW2T, d, r.T->dF1, d, em);                 // d(pre-relu) = (dZ W2) * [R1 > 0]
+    wgrad(r, r.T->dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1);
     GemmEpilogue e0;
-    lin(r, y.dF1, d, M, d, w.pW1T, d, y.dA, d, e0);
+    lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
     if (r.rc) return nullptr;
-    if (!r.ok(launch_attn_bwd(b.QKV, b.A, y.dA, b.LSE, B, L, d, D.heads, nullptr, y.dQKV, y.DSUM, r.st))) return nullptr;
-    for (int j = 0; j < 3; ++j) wgrad(r, y.dQKV + j * d, 3 * d, Xin, d, M, d, d, pb + T_WQ + j, -1);
+    if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
+    for (int j = 0; j < 3; ++j) wgrad(r, r.T->dQKV + j * d, 3 * d, Xin, d, M, d, d, pb + T_WQ + j, -1);
     // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
     GemmEpilogue er;
-    er.res = y.dZ; er.ldres = d;
-    lin(r, y.dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
+    er.res = r.T->dZ; er.ldres = d;
+    lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
   }
@@ -576,19 +629,19 @@ float* bert_bwd(Run& r, int e) {
   EncBufs& n = y.enc[e];
   const int B = y.B, T = n.T, dm = n.dm, rows = B * T;
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
-  float *dX = y.dXa, *dXalt = y.dXb;
+  float *dX = r.T->dXa, *dXalt = r.T->dXb;
   {   // ---- last block, pruned (see bert_fwd): gradient of one output row per session
     const int l = D.enc_layers - 1;
     EncBlockBufs& k = n.blk[l];
     EncLastBufs& q = n.last;
     const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
-    float *dZl = y.dLB[0], *dF1l = y.dLB[1], *dCl = y.dLB[2], *dSl = y.dLB[3], *dQl = y.dLB[4];
+    float *dZl = r.T->dLB[0], *dF1l = r.T->dLB[1], *dCl = r.T->dLB[2], *dSl = r.T->dLB[3], *dQl = r.T->dLB[4];
     const float* dvec = y.dPREDIN + n.predin_off;
     {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dvec, y.Pin, q.XH2, dm, q.RSTD2, B, dm, r.P(sg), dZl, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dvec, y.Pin, q.XH2, dm, q.RSTD2, B, dm, r.P(sg), dZl, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
         return nullptr;
     }
     wgrad(r, dZl, dm, q.F1, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
@@ -604,19 +657,19 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dCl, dm, q.XH1, dm, q.RSTD1, B, dm, r.P(sg), dSl, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dCl, dm, q.XH1, dm, q.RSTD1, B, dm, r.P(sg), dSl, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
         return nullptr;
     }
     // attention of the single query row: dS is both d(attention output) and the residual into Xlast
-    if (!r.ok(launch_attn_lastq_bwd(q.KV, q.QLAST, q.PL, dSl, len, B, T, dm, D.enc_heads, dQl, y.dQKV, r.st))) return nullptr;
+    if (!r.ok(launch_attn_lastq_bwd(q.KV, q.QLAST, q.PL, dSl, len, B, T, dm, D.enc_heads, dQl, r.T->dQKV, r.st))) return nullptr;
     wgrad(r, dQl, dm, q.XLAST, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_BQ));
     GemmEpilogue exl;
     exl.res = dSl; exl.ldres = dm;
     lin(r, dQl, dm, B, dm, q.pWqT, dm, dZl, dm, exl);                       // dXlast = dQ Wq + dS
-    wgrad(r, y.dQKV, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_BK));
-    wgrad(r, y.dQKV + dm, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WV), enc_blk_slot(e, l, INTEL_ENC_BV));
+    wgrad(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_BK));
+    wgrad(r, r.T->dQKV + dm, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WV), enc_blk_slot(e, l, INTEL_ENC_BV));
     GemmEpilogue e0;
-    lin(r, y.dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
+    lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
     if (r.rc) return nullptr;
     if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st))) return nullptr;
   }
@@ -628,35 +681,35 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dX, dm, k.XH2, dm, k.RSTD2, rows, dm, r.P(sg), y.dZ, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dX, dm, k.XH2, dm, k.RSTD2, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
         return nullptr;
     }
-    wgrad(r, y.dZ, dm, k.F1, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
+    wgrad(r, r.T->dZ, dm, k.F1, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
     GemmEpilogue em;
     em.mask = k.F1; em.ldmask = dm;
-    lin(r, y.dZ, dm, rows, dm, k.pW2T, dm, y.dF1, dm, em);
-    wgrad(r, y.dF1, dm, k.C, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
+    lin(r, r.T->dZ, dm, rows, dm, k.pW2T, dm, r.T->dF1, dm, em);
+    wgrad(r, r.T->dF1, dm, k.C, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
     // dC = dF1 W1 + dZ (residual into LN2)
     GemmEpilogue ec;
-    ec.res = y.dZ; ec.ldres = dm;
-    lin(r, y.dF1, dm, rows, dm, k.pW1T, dm, y.dA, dm, ec);
+    ec.res = r.T->dZ; ec.ldres = dm;
+    lin(r, r.T->dF1, dm, rows, dm, k.pW1T, dm, r.T->dA, dm, ec);
     if (r.rc) return nullptr;
     // LN1: C = LN1(A + Xin): dS = LN1bwd(dC)  -> dA_attn = dS, residual dXin += dS
     {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(y.dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), y.dZ, dm, r.G(sg), r.G(sb), a, y.SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(r.T->dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
         return nullptr;
     }
-    if (!r.ok(launch_attn_bwd(k.QKV, k.A, y.dZ, k.LSE, B, T, dm, D.enc_heads, len, y.dQKV, y.DSUM, r.st))) return nullptr;
+    if (!r.ok(launch_attn_bwd(k.QKV, k.A, r.T->dZ, k.LSE, B, T, dm, D.enc_heads, len, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
     for (int j = 0; j < 3; ++j)
-      wgrad(r, y.dQKV + j * dm, 3 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j),
+      wgrad(r, r.T->dQKV + j * dm, 3 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j),
             enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j));
     {
       GemmEpilogue er;
-      er.res = y.dZ; er.ldres = dm;
-      lin(r, y.dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);   // dm % 16 == 0 (check_desc)
+      er.res = r.T->dZ; er.ldres = dm;
+      lin(r, r.T->dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);   // dm % 16 == 0 (check_desc)
     }
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
@@ -664,10 +717,10 @@ float* bert_bwd(Run& r, int e) {
   // position embedding gradient: dpos[p,:] = sum over rows at position p = onehot^T dE (MFMA wgrad)
   if (r.G(enc_slot(e, INTEL_ENC_POS))) {
     const int ps = enc_slot(e, INTEL_ENC_POS);
-    if (!r.ok(launch_make_onehot(nullptr, len, T, rows, T, y.ONEHOT, r.st))) return nullptr;
+    if (!r.ok(launch_make_onehot(nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;
     if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
     r.acc(ps);
-    if (!r.ok(launch_wgrad(y.ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, y.SLABS, r.st))) return nullptr;
+    if (!r.ok(launch_wgrad(r.T->ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, r.T->SLABS, r.st))) return nullptr;
   }
   return dX;
 }
@@ -680,8 +733,10 @@ void forward_impl(Run& r, const IntelOut* out) {
   const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
   pack_all(r);
   if (r.rc) return;
-  // ===== predict_intent (IntEL.py:126-155)
-  for (int e = 0; e < 2; ++e) {
+  // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
+  // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
+  fork_streams(r, 3);
+  auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = B * n.T, dm = n.dm;
     GemmEpilogue eb;
@@ -704,8 +759,28 @@ void forward_impl(Run& r, const IntelOut* out) {
       RUN(gru_fwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_BIH)),
                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st));
     }
-    if (r.rc) return;
+  };
+  TowerBufs& ti = y.tw[0];
+  TowerBufs& ts = y.tw[1];
+  {
+    Run b1 = branch(r, 0, 1), b2 = branch(r, 1, 0), b3 = branch(r, 2, 1);
+    encoder_branch(r, 0);
+    encoder_branch(b1, 1);
+    // item tower
+    if (b2.ok(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
+        (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st))))
+      tower_fwd(b2, ti);
+    // score tower
+    {
+      GemmEpilogue es;
+      es.bias = r.P(INTEL_P_SCORE_B);
+      lin(b3, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
+      if (!b3.rc) tower_fwd(b3, ts);
+    }
+    r.ok(b1.rc); r.ok(b2.rc); r.ok(b3.rc);
   }
+  join_streams(r, 3);
+  if (r.rc) return;
   RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
   {
@@ -715,21 +790,7 @@ void forward_impl(Run& r, const IntelOut* out) {
     if (r.rc) return;
     RUN(launch_softmax_rows(y.LOGITS, B, I, y.INTENTS, r.st));
   }
-  // ===== predict_ensemble (IntEL.py:158-217)
-  TowerBufs& ti = y.tw[0];
-  TowerBufs& ts = y.tw[1];
-  RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, r.st));
-  if (D.d_im > 0) RUN(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, r.st));
-  tower_fwd(r, ti);
-  if (r.rc) return;
-  {
-    GemmEpilogue es;
-    es.bias = r.P(INTEL_P_SCORE_B);
-    lin(r, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
-    if (r.rc) return;
-  }
-  tower_fwd(r, ts);
-  if (r.rc) return;
+  // ===== predict_ensemble, after the towers (IntEL.py:199-217)
   const int off_u = ti.d + ts.d, off_int = off_u + D.d_u;
   const float scale = 1.0f / sqrtf((float)D.q_size);
   GemmEpilogue e0;
@@ -806,7 +867,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
     if (r.rc) return;
     if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
-      RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, y.SLABS, r.st));
+      RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, r.T->SLABS, r.st));
     }
     lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
     lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
@@ -823,41 +884,43 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   if (r.G(INTEL_P_UID_EMB))
     RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
   // h_intent = relu(intent_embeddings(intent)): dpre -> dVB1 [B, d_int]
-  RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
-  wgrad(r, y.dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-  lin(r, y.dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
+  RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, r.T->dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
+  wgrad(r, r.T->dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+  lin(r, r.T->dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
   if (r.rc) return;
 
-  // ===== towers: cross attention + tied self-attention layers
-  for (int t = 0; t < 2; ++t) {
+  // ===== towers: cross attention + tied self-attention layers; the two towers are independent and run
+  // concurrently (main stream / side stream 0, temporaries set 0 / 1); each leaves its contribution to
+  // d(intent) in its own buffer
+  auto tower_branch = [&](Run& r, int t) {
     TowerBufs& w = y.tw[t];
     const int d = w.d;
     const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
-    float* dX = y.dXa;
+    float* dX = r.T->dXa;
     if (D.cross_attention) {
       const int xb = w.xbase;
       // pooled = xbar Wv^T
       wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1);
-      lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, y.dVB1, d, e0);          // dxbar
+      lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, r.T->dVB1, d, e0);          // dxbar
       if (r.rc) return;
-      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, y.dVB1, d, scale, dX, y.dVB2, r.st));   // dX, dQK
+      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dX, r.T->dVB2, r.st));   // dX, dQK
       // QK = QV Wk  (QK[b][j] = sum_i QV[b][i] Wk[i][j])
-      wgrad(r, w.QV, d, y.dVB2, d, B, d, d, xb + 1, -1);
-      lin(r, y.dVB2, d, B, d, w.pXk, d, y.dVB3, d, e0);                            // dQV
-      wgrad(r, y.dVB3, d, y.INTENTS, I, B, d, I, xb + 0, -1);
-      lin(r, y.dVB3, d, B, d, w.pXqT, I, y.dINTENT, I, eacc);
+      wgrad(r, w.QV, d, r.T->dVB2, d, B, d, d, xb + 1, -1);
+      lin(r, r.T->dVB2, d, B, d, w.pXk, d, r.T->dVB3, d, e0);                            // dQV
+      wgrad(r, r.T->dVB3, d, y.INTENTS, I, B, d, I, xb + 0, -1);
+      lin(r, r.T->dVB3, d, B, d, w.pXqT, I, r.T->dINT, I, e0);
     } else {
       const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
-      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dX, y.dVB1, r.st));    // dX, dMV
-      wgrad(r, y.dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
+      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dX, r.T->dVB1, r.st));    // dX, dMV
+      wgrad(r, r.T->dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
       GemmEpilogue em;
       em.mask = w.MH; em.ldmask = D.q_size;
-      lin(r, y.dVB1, d, B, d, w.pM2T, D.q_size, y.dVB2, D.q_size, em);            // d(pre-relu hidden)
-      wgrad(r, y.dVB2, D.q_size, y.INTENTS, I, B, D.q_size, I, mb + 0, mb + 1);
-      lin(r, y.dVB2, D.q_size, B, D.q_size, w.pM0T, I, y.dINTENT, I, eacc);
+      lin(r, r.T->dVB1, d, B, d, w.pM2T, D.q_size, r.T->dVB2, D.q_size, em);            // d(pre-relu hidden)
+      wgrad(r, r.T->dVB2, D.q_size, y.INTENTS, I, B, D.q_size, I, mb + 0, mb + 1);
+      lin(r, r.T->dVB2, D.q_size, B, D.q_size, w.pM0T, I, r.T->dINT, I, e0);
     }
     if (r.rc) return;
-    float* dX0 = tower_bwd(r, w, dX, y.dXb);
+    float* dX0 = tower_bwd(r, w, dX, r.T->dXb);
     if (r.rc || !dX0) return;
     if (t == 0) {
       if (r.G(INTEL_P_IID_EMB))
@@ -867,10 +930,20 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     } else {
       wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
     }
-    if (r.rc) return;
+  };
+  fork_streams(r, 1);
+  {
+    Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
+    tower_branch(b0, 0);
+    tower_branch(b1, 1);
+    r.ok(b0.rc); r.ok(b1.rc);
   }
+  join_streams(r, 1);
+  if (r.rc) return;
 
   // ===== predict_intent backward
+  RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
+  RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
   if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
   RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
   wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
@@ -880,7 +953,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
   if (r.G(INTEL_P_UID_EMB))
     RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
-  for (int e = 0; e < 2; ++e) {
+  // the two sequence encoders are independent: concurrent branches again.  The gradients of the SHARED
+  // intent_embeddings weight are taken after the join, on the main stream, in a fixed order.
+  float* dEs[2] = {nullptr, nullptr};
+  auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = B * n.T, dm = n.dm;
     float* dE = nullptr;
@@ -892,29 +968,44 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       gg.dWih = r.G(enc_slot(e, INTEL_ENC_GRU_WIH)); gg.dWhh = r.G(enc_slot(e, INTEL_ENC_GRU_WHH));
       gg.dbih = r.G(enc_slot(e, INTEL_ENC_GRU_BIH)); gg.dbhh = r.G(enc_slot(e, INTEL_ENC_GRU_BHH));
       gg.dWout = r.G(enc_slot(e, INTEL_ENC_GRU_OUT));
-      dE = y.dXa;
+      dE = r.T->dXa;
       r.ok(gru_bwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
-                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, y.dXb, y.SLABS, r.st));
+                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, r.T->dXb, r.T->SLABS, r.st));
     }
     if (r.rc || !dE) return;
+    dEs[e] = dE;
     // input rows: [table row | intent_embeddings(intent rows)]
     if (e == 0) {
       if (r.G(INTEL_P_CTX_EMB))
         RUN(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
-      wgrad(r, dE + D.d_c, dm, bt.his_intents, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
     } else {
       if (r.G(INTEL_P_IID_EMB))
         RUN(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
-      if (bt.his_item_idx) {
-        if (r.G(INTEL_P_INTENT_W)) {   // dW[c][j] = sum_m dE[m][c] onehot[m][j]: the dense wgrad on a materialised one-hot
-          RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows, I, y.ONEHOT, r.st));
-          wgrad(r, dE + D.d_id, dm, y.ONEHOT, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-        }
-      } else {
-        wgrad(r, dE + D.d_id, dm, bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-      }
     }
-    if (r.rc) return;
+  };
+  fork_streams(r, 1);
+  {
+    Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
+    encoder_branch(b0, 0);
+    encoder_branch(b1, 1);
+    r.ok(b0.rc); r.ok(b1.rc);
+  }
+  join_streams(r, 1);
+  if (r.rc || !dEs[0] || !dEs[1]) return;
+  {
+    const EncBufs& n0 = y.enc[0];
+    const EncBufs& n1 = y.enc[1];
+    wgrad(r, dEs[0] + D.d_c, n0.dm, bt.his_intents, I, B * n0.T, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+    const int rows1 = B * n1.T;
+    if (bt.his_item_idx) {
+      if (r.G(INTEL_P_INTENT_W)) {   // dW[c][j] = sum_m dE[m][c] onehot[m][j]: the dense wgrad on a materialised one-hot
+        RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows1, I, y.tmp[1].ONEHOT, r.st));
+        r.T = &y.tmp[0];
+        wgrad(r, dEs[1] + D.d_id, n1.dm, y.tmp[1].ONEHOT, I, rows1, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+      }
+    } else {
+      wgrad(r, dEs[1] + D.d_id, n1.dm, bt.his_item_int, I, rows1, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+    }
   }
 }
 
@@ -953,10 +1044,33 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->d = *desc;
   c->have_layout = false;
   c->fwd_done = false;
+  c->streams = 0;
   return c;
 }
 
-extern "C" void intel_destroy(IntelCtx* ctx) { delete ctx; }
+extern "C" void intel_destroy(IntelCtx* ctx) {
+  if (!ctx) return;
+  if (ctx->streams == 1 || ctx->streams == 2) {
+    for (int i = 0; i < 3; ++i) {
+      (void)hipStreamDestroy(ctx->side[i]);
+      (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    (void)hipEventDestroy(ctx->ev_fork);
+  }
+  delete ctx;
+}
+
+// on = 0: run every branch on the caller's stream (used while profiling single kernels); on = 1: default
+extern "C" void intel_set_concurrency(IntelCtx* ctx, int on) {
+  if (!ctx) return;
+  if (!on) {
+    if (ctx->streams == 1) ctx->streams = 2;          // keep the streams, just do not use them
+    else if (ctx->streams == 0) ctx->streams = -1;
+  } else {
+    if (ctx->streams == 2) ctx->streams = 1;
+    else if (ctx->streams == -1) ctx->streams = 0;
+  }
+}
 
 extern "C" size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train) {
   (void)train;
@@ -989,7 +1103,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
     return INTEL_E_WORKSPACE;
   }
   ctx->have_layout = true;
-  Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0};
+  Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0]};
   forward_impl(r, out);
   ctx->fwd_done = (r.rc == 0) && train;
   ctx->fB = batch->B; ctx->fL = batch->L; ctx->fH = batch->H; ctx->fHi = batch->Hi;
@@ -1010,7 +1124,7 @@ extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const In
   }
   if (workspace_bytes < ctx->lay.total) return INTEL_E_WORKSPACE;
   INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
-  Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0};
+  Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0]};
   backward_impl(r, d_weights, d_ens_score, d_intents);
   return r.rc;
 }
