@@ -155,3 +155,45 @@ def test_ndcg_kernel_matches_evaluate_method_on_ragged_lists():
         L.check(L.lib().intel_ndcg(B, Lm, k, L.ptr(e), L.ptr(r), L.ptr(s), L.ptr(out), L.stream_ptr(dev)), 'intel_ndcg')
         ref = per_session_ndcg(ens.numpy(), ranking.numpy(), slen.numpy(), k)
         np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-6)
+
+
+def test_reference_layout_batches_from_the_input_pipeline_run_end_to_end():
+    """config[0]-style plumbing on the GPU: CSV/JSON mini dataset -> SeqReader -> Dataset -> collate_batch
+    (the reference's own batch layout: int64 ids, float64 scores, dense one-hot history) -> IntEL.forward +
+    IntListloss on the HIP path, batch=2, against the oracle on the same batch."""
+    import argparse
+    import json
+    import os
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd.data import Dataset, SeqReader
+    from intel_sigir2023_amd.model import IntEL
+    from tests.helpers import GOLDEN
+    dev = _dev()
+    z = np.load(os.path.join(GOLDEN, 'data_feed.npz'))
+    cfg = json.loads(str(z['cfg']))
+    cfg['datapath'] = GOLDEN
+    args = argparse.Namespace(**cfg)
+    args.device = dev
+    corpus = SeqReader(args)
+    torch.manual_seed(0)
+    model = IntEL(args, corpus).to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    np.random.seed(7)
+    ds = Dataset(model, corpus, 'train')
+    args.cal_diversity = 1
+    crit = LS.IntListloss(args)
+    ocfg = O.Config(**{k: v for k, v in vars(args).items() if k not in ('device', 'datapath', 'dataset', 'sep', 'intent_note', 'max_session_len')})
+    for start in (0, 2, 4):
+        batch = ds.collate_batch([ds[i] for i in range(start, start + 2)])      # batch = 2
+        gbatch = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()}
+        model.train()
+        out = model(gbatch)
+        loss, el, il = crit(out, gbatch)
+        loss.backward()
+        with torch.no_grad():
+            ref = O.forward(sd, batch, ocfg)
+            rl, _, _ = O.int_list_loss(ref, batch, ocfg)
+        for k in ('weights', 'ens_score', 'intents'):
+            assert float((out[k].detach().cpu() - ref[k]).abs().max()) <= 3e-5 * max(1.0, float(ref[k].abs().max())), k
+        assert abs(float(loss) - float(rl)) < 1e-5
+        model.zero_grad()
