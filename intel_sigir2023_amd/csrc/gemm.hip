@@ -556,6 +556,156 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// gemm_rows for K > 128 (the data gradients through the fused q/k/v weights: K = 3d), same 8-wave
+// persistent structure; the K extent is swept in 128-wide chunks: one (row tile, k chunk) per
+// iteration, accumulators carried across the chunks of a tile, B fragments of the chunk re-read from
+// L2 at the top of the iteration (they cannot stay resident: 3 x 32 VGPRs), epilogue after the last
+// chunk.  No LayerNorm epilogue (never needed with K > 128).
+// ------------------------------------------------------------------------------------------
+template <int RT>
+__global__ __launch_bounds__(512, 4) void gemm_rows_w8k_kernel(GemmRowsArgs a) {
+  constexpr int RG = 4 / RT;
+  constexpr int CT = 8 / RG;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave / RG, rg = wave % RG;
+  const int Kp = (a.K + 15) & ~15, KG = Kp >> 4;
+  const int nch = (KG + 7) >> 3;                      // 128-wide k chunks
+  const int NT = (a.N + 15) >> 4;
+  const int nc = blockIdx.y * CT;
+  const int ntc = min(CT, NT - nc);
+  const bool active = ct < ntc;
+  const GemmEpilogue& ep = a.ep;
+  f32x4 pre[4];
+  int trow[4], tcol[4], loff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = tid + 512 * j;          // 64 rows x 32 float4 = 2048 slots
+    trow[j] = i >> 5;
+    tcol[j] = (i & 31) * 4;
+    loff[j] = trow[j] * GR_LDA + tcol[j];
+  }
+  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
+  const int niter = ntiles * nch;
+  // iteration it = (tile, chunk); this workgroup owns tiles blockIdx.x, +gridDim.x, ...
+  auto load_iter = [&](int tt, int c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = min(tt * GR_BM + trow[j], a.M - 1);
+      const int col = c * GR_KC + tcol[j];
+      pre[j] = (col < a.K) ? *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_iter = [&](float* As) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(As + loff[j]) = pre[j];
+  };
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
+  const bool colok = active && col < a.N;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+  (void)niter;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int c = 0;
+  load_iter(t, 0);
+  store_iter(smem);
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // retire bias / first tile loads before the loop
+  __syncthreads();
+  {   // prefetch the second iteration
+    int tn = t, cn = 1;
+    if (cn == nch) { cn = 0; tn += gridDim.x; }
+    if (tn < ntiles) load_iter(tn, cn);
+  }
+  int buf = 0;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  while (t < ntiles) {
+    float* As = smem + buf * (GR_BM * GR_LDA);
+    const int kg0 = c * 8, kgn = min(8, KG - kg0);
+    if (active) {
+      f32x4 bfr[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g)
+        if (g < kgn) bfr[g] = reinterpret_cast<const f32x4*>(a.Bp)[((size_t)(nc + ct) * KG + kg0 + g) * 64 + lane];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g < kgn) {
+          f32x4 af[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            af[rt] = *reinterpret_cast<const f32x4*>(As + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDA + g * 16 + 4 * (lane >> 4));
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(bfr[g][s], af[rt][s], acc[rt]);
+        }
+      }
+    }
+    // next iteration's coordinates
+    int tn = t, cn = c + 1;
+    if (cn == nch) { cn = 0; tn += gridDim.x; }
+    if (tn < ntiles) store_iter(smem + (buf ^ 1) * (GR_BM * GR_LDA));
+    if (c == nch - 1) {          // tile finished: epilogue (all loads before the stores)
+      const int m0 = t * GR_BM;
+      if (colok) {
+        f32x4 aux[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          f32x4 x = acc[rt] + bias;
+          if (ep.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
+          } else {
+            x += aux[rt];
+          }
+          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+          acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    __syncthreads();
+    {   // prefetch the iteration after next
+      int t2 = tn, c2 = cn + 1;
+      if (c2 == nch) { c2 = 0; t2 += gridDim.x; }
+      if (tn < ntiles && t2 < ntiles) load_iter(t2, c2);
+    }
+    t = tn;
+    c = cn;
+    buf ^= 1;
+  }
+}
+
+template <int RT>
+static int launch_w8k(const GemmRowsArgs& a, hipStream_t st) {
+  constexpr int CT = 8 / (4 / RT);
+  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
+  int gx = ntiles < 512 ? ntiles : 512;
+  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
+  allow_lds(gemm_rows_w8k_kernel<RT>, smem);
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+           gemm_rows_w8k_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int RT, bool LN>
 static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
@@ -600,6 +750,12 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 64) return launch_w8<4, false>(a, st);
     if (N > 32) return launch_w8<2, false>(a, st);
     return launch_w8<1, false>(a, st);
+  }
+  if (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && !((ep.mask || ep.res) && ep.accumulate) &&
+      !(ep.mask && ep.res)) {
+    if (N > 64) return launch_w8k<4>(a, st);
+    if (N > 32) return launch_w8k<2>(a, st);
+    return launch_w8k<1>(a, st);
   }
   size_t smem = (size_t)(GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_kernel, smem);
