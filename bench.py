@@ -19,7 +19,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
-MFMA_KERNELS = ('gemm_rows_kernel', 'wgrad_kernel', 'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel')
+MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel', 'attn_fwd_kernel',
+                'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel')
 
 
 def algorithmic_bytes_per_session(flags, corpus, shape, train, e=4):
@@ -176,13 +177,13 @@ def main():
         lib.intel_set_concurrency(model._context(), 1)
         prof = {}                       # aggregate the shape-tagged GEMM records by kernel
         for k, v in prof_shapes.items():
-            d = prof.setdefault(k.split('[')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            d = prof.setdefault(k.split('[')[0].strip('()').split('<')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
             for f in d:
                 d[f] += v[f]
         tot = sum(v['ms'] for v in prof.values())
         name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
         avg_ms = dom['ms'] / dom['launches']
-        if name.split('<')[0] in MFMA_KERNELS:
+        if name in MFMA_KERNELS:
             ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
                     'frac': round(ach / (F32_MFMA_PEAK / 1e12), 5), 'traffic': None}
@@ -193,7 +194,7 @@ def main():
         # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
-            key = name.replace('(', '').replace(')', '').split('<')[0]
+            key = name
             if key in pmc and a.workload == 'tmall' and B == 4096:
                 roof['traffic'] = pmc[key]['hbm_bytes_per_launch']
                 roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950), bytes per launch'

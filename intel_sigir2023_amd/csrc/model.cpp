@@ -303,6 +303,7 @@ struct Run {
   hipStream_t st;
   int rc;
   Temps* T;
+  int train;     // 0: inference forward -- the pure-stash outputs (x-hat, rstd) are not written
   const float* P(int slot) const { return static_cast<const float*>(params[slot]); }
   float* G(int slot) const { return static_cast<float*>(grads[slot]); }
   // 0 the first time a gradient slot is written in this backward, 1 afterwards (accumulate)
@@ -489,7 +490,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
     e2.bias = r.P(pb + T_B2);
     e2.res = X; e2.ldres = d;
     e2.gamma = r.P(pb + T_LNG); e2.beta = r.P(pb + T_LNB);
-    e2.xhat = b.XH; e2.ldxhat = d; e2.rstd = b.RSTD;
+    if (r.train) { e2.xhat = b.XH; e2.ldxhat = d; e2.rstd = b.RSTD; }
     if (d <= 128) {
       lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2);
     } else {
@@ -497,7 +498,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
       e2b.bias = e2.bias;
       lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2b);
       if (r.rc) return;
-      RUN(launch_add_layernorm(b.Xout, d, X, d, M, d, e2.gamma, e2.beta, b.Xout, d, b.XH, d, b.RSTD, r.st));
+      RUN(launch_add_layernorm(b.Xout, d, X, d, M, d, e2.gamma, e2.beta, b.Xout, d, r.train ? b.XH : nullptr, d, r.train ? b.RSTD : nullptr, r.st));
     }
     if (r.rc) return;
     X = b.Xout;
@@ -557,7 +558,7 @@ void bert_fwd(Run& r, int e) {
     }
     RUN(launch_attn_fwd(k.QKV, B, T, dm, D.enc_heads, len, k.A, k.LSE, r.st));
     RUN(launch_add_layernorm(k.A, dm, X, dm, rows, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)),
-                             r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), k.C, dm, k.XH1, dm, k.RSTD1, r.st));
+                             r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), k.C, dm, r.train ? k.XH1 : nullptr, dm, r.train ? k.RSTD1 : nullptr, r.st));
     GemmEpilogue e1;
     e1.bias = r.P(enc_blk_slot(e, l, INTEL_ENC_B1));
     e1.relu = 1;
@@ -568,7 +569,7 @@ void bert_fwd(Run& r, int e) {
     e2.res = k.C; e2.ldres = dm;
     if (dm <= 128) {
       e2.gamma = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)); e2.beta = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B));
-      e2.xhat = k.XH2; e2.ldxhat = dm; e2.rstd = k.RSTD2;
+      if (r.train) { e2.xhat = k.XH2; e2.ldxhat = dm; e2.rstd = k.RSTD2; }
       lin(r, k.F1, dm, rows, dm, k.pW2, dm, k.Eout, dm, e2);
     } else {
       GemmEpilogue e2b;
@@ -1103,7 +1104,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
     return INTEL_E_WORKSPACE;
   }
   ctx->have_layout = true;
-  Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0]};
+  Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], train};
   forward_impl(r, out);
   ctx->fwd_done = (r.rc == 0) && train;
   ctx->fB = batch->B; ctx->fL = batch->L; ctx->fH = batch->H; ctx->fHi = batch->Hi;
@@ -1124,7 +1125,7 @@ extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const In
   }
   if (workspace_bytes < ctx->lay.total) return INTEL_E_WORKSPACE;
   INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
-  Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0]};
+  Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], 1};
   backward_impl(r, d_weights, d_ens_score, d_intents);
   return r.rc;
 }
