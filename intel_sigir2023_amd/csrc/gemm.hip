@@ -706,6 +706,202 @@ static int launch_w8k(const GemmRowsArgs& a, hipStream_t st) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// gemm_rows_w8g: the w8 kernel with the A tile loaded DIRECT-TO-LDS (global_load_lds_dwordx4, LDS-DMA):
+// no prefetch registers, no ds_write pass, and -- what matters -- no compiler-placed vmcnt wait between
+// the loads and the MFMAs: the DMA of tile t+2 is issued right after the barrier that retires tile t
+// and is waited for by ONE explicit vmcnt(0) after the MFMAs of tile t+1.
+// An LDS-DMA writes wave-base + lane*16 linearly, so the tile rows are unpadded (K*4 bytes) and bank
+// conflicts are avoided by an XOR swizzle of the 16-byte chunk index with (row & 15), applied to the
+// per-lane SOURCE address when loading and to the chunk index when reading fragments (cdna guide,
+// rule 21: swizzle both sides or neither).  K in {64, 128}.
+// ------------------------------------------------------------------------------------------
+template <int RT, bool LN>
+__global__ __launch_bounds__(512, 4) void gemm_rows_w8g_kernel(GemmRowsArgs a) {
+  constexpr int RG = 4 / RT;
+  constexpr int CT = 8 / RG;
+  constexpr int BUF = GR_BM * GR_LDA;           // floats per buffer (also holds the padded LayerNorm tile)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave / RG, rg = wave % RG;
+  const int KG = a.K >> 4;                      // 4 or 8
+  const int cpr = a.K >> 2;                     // 16-byte chunks per row: 16 or 32
+  const int ipw = cpr >> 3;                     // DMA instructions per wave per tile: 2 or 4
+  const int NT = (a.N + 15) >> 4;
+  const int nc = blockIdx.y * CT;
+  const int ntc = min(CT, NT - nc);
+  const bool active = ct < ntc;
+  const GemmEpilogue& ep = a.ep;
+  f32x4 bfr[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    bfr[g] = (g < KG && active) ? reinterpret_cast<const f32x4*>(a.Bp)[((size_t)(nc + ct) * KG + g) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
+  // DMA slots of this lane: instruction q = wave*ipw + j covers linear chunks [q*64, q*64+64)
+  int drow[4], dcol[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int lin = (wave * ipw + j) * 64 + lane;
+    const int R = lin / cpr, pch = lin - R * cpr;
+    drow[j] = R;
+    dcol[j] = (pch ^ (R & 15)) * 4;             // source column of the chunk that lands at physical chunk pch
+  }
+  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  auto dma_tile = [&](int tt, float* As) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < ipw && !(a.dbg & 4)) {
+        const int row = min(tt * GR_BM + drow[j], a.M - 1);
+        __builtin_amdgcn_global_load_lds(a.A + (size_t)row * a.lda + dcol[j], As + (wave * ipw + j) * 256, 16, 0, 0);
+      }
+    }
+  };
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
+  const bool colok = active && col < a.N;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!LN && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+  // fragment read offsets (floats) of this lane inside a buffer, without the k-group term
+  int frow[RT], fswz[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int r = (rg * RT + rt) * 16 + (lane & 15);
+    frow[rt] = r * a.K;
+    fswz[rt] = r & 15;
+  }
+  const int jl = lane >> 4;
+
+  dma_tile(t, smem);
+  if (t + (int)gridDim.x < ntiles) dma_tile(t + gridDim.x, smem + BUF);
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): B fragments, bias and both first tiles
+  __syncthreads();
+  int buf = 0;
+  for (; t < ntiles; t += gridDim.x) {
+    float* As = smem + buf * BUF;
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (active && !(a.dbg & 2)) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (g < KG) {
+          f32x4 af[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            af[rt] = *reinterpret_cast<const f32x4*>(As + frow[rt] + (((g * 4 + jl) ^ fswz[rt]) << 2));
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(bfr[g][s], af[rt][s], acc[rt]);
+        }
+      }
+    }
+    // the DMA into the OTHER buffer (tile t+S, issued one iteration ago) and the previous tile's stores
+    // have had a whole MFMA phase to finish: retire them before this tile's stores are issued
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    const int m0 = t * GR_BM;
+    if (a.dbg & 1) {
+      if (acc[0][0] == 12345.678f) a.C[0] = 1.f;       // ablation: keep the accumulators live, no stores
+    } else if (!LN) {
+      if (colok) {
+        f32x4 aux[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          f32x4 x = acc[rt] + bias;
+          if (ep.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
+          } else {
+            x += aux[rt];
+          }
+          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+        }
+      }
+    } else {
+      __syncthreads();                 // all waves are done reading this A buffer
+      float* Es = As;
+      if (active) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          *reinterpret_cast<f32x4*>(Es + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDE + ct * 16 + 4 * (lane >> 4)) = acc[rt];
+      }
+      const int ncols = a.N;
+      const bool ok0 = lane < ncols, ok1 = lane + 64 < ncols;
+      float res0[8], res1[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = m0 + wave * 8 + rr;
+        const bool rok = row < a.M && ep.res != nullptr;
+        res0[rr] = (rok && ok0) ? ep.res[(size_t)row * ep.ldres + lane] : 0.f;
+        res1[rr] = (rok && ok1) ? ep.res[(size_t)row * ep.ldres + lane + 64] : 0.f;
+      }
+      const float bias0 = (ep.bias && ok0) ? ep.bias[lane] : 0.f, bias1 = (ep.bias && ok1) ? ep.bias[lane + 64] : 0.f;
+      const float g0 = ok0 ? ep.gamma[lane] : 0.f, g1 = ok1 ? ep.gamma[lane + 64] : 0.f;
+      const float be0 = ok0 ? ep.beta[lane] : 0.f, be1 = ok1 ? ep.beta[lane + 64] : 0.f;
+      __syncthreads();
+      const float inv_n = 1.f / (float)a.N;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr;
+        const int row = m0 + r;
+        float v0 = 0.f, v1 = 0.f;
+        if (ok0) { v0 = Es[r * GR_LDE + lane] + bias0; if (ep.relu) v0 = fmaxf(v0, 0.f); v0 += res0[rr]; }
+        if (ok1) { v1 = Es[r * GR_LDE + lane + 64] + bias1; if (ep.relu) v1 = fmaxf(v1, 0.f); v1 += res1[rr]; }
+        const float mean = wave_sum(v0 + v1) * inv_n;
+        const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
+        const float rs = 1.f / sqrtf(var + 1e-5f);
+        if (row < a.M) {
+          if (ep.rstd && lane == 0) ep.rstd[row] = rs;
+          if (ok0) {
+            const float xh = d0 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
+            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+          }
+          if (ok1) {
+            const float xh = d1 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
+            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+          }
+        }
+      }
+    }
+    __syncthreads();                   // every wave is done with this buffer (fragments / LayerNorm tile)
+    if (t + 2 * (int)gridDim.x < ntiles) dma_tile(t + 2 * gridDim.x, As);
+    buf ^= 1;
+  }
+}
+
+template <int RT, bool LN>
+static int launch_w8g(const GemmRowsArgs& a, hipStream_t st) {
+  constexpr int CT = 8 / (4 / RT);
+  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
+  int gx = ntiles < 512 ? ntiles : 512;
+  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
+  allow_lds((gemm_rows_w8g_kernel<RT, LN>), smem);
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+           (gemm_rows_w8g_kernel<RT, LN>), dim3(gx, nchunks), dim3(512), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int RT, bool LN>
 static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
@@ -742,6 +938,18 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   const bool vecA = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   INTEL_CHECK_ARG(!(ep.gamma && (ep.mask || ep.accumulate)), "gemm_rows: LayerNorm epilogue cannot be combined with mask/accumulate");
   if (rup(K, 16) <= GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
+    static int use_glds = -1;
+    if (use_glds < 0) { const char* e = getenv("INTEL_GLDS"); use_glds = (e && e[0] == '0') ? 0 : 1; }
+    if (use_glds && (K == 128 || K == 64)) {       // direct-to-LDS variant
+      if (ep.gamma) {
+        if (N > 64) return launch_w8g<4, true>(a, st);
+        if (N > 32) return launch_w8g<2, true>(a, st);
+        return launch_w8g<1, true>(a, st);
+      }
+      if (N > 64) return launch_w8g<4, false>(a, st);
+      if (N > 32) return launch_w8g<2, false>(a, st);
+      return launch_w8g<1, false>(a, st);
+    }
     if (ep.gamma) {
       if (N > 64) return launch_w8<4, true>(a, st);
       if (N > 32) return launch_w8<2, true>(a, st);
