@@ -18,7 +18,8 @@
 //   keys, sweeps queries); neither needs a cross-wave reduction or atomics.
 #include "kernels.h"
 
-#define AT_KB 64   // keys (or queries) staged per LDS block
+#define AT_QB 64   // rows (queries, or keys in the dK/dV kernel) owned by a workgroup: 4 waves x 16
+#define AT_KB 32   // rows staged in LDS per iteration: 2 x 32 x (dk+4) floats = 33 KB at dk = 128 -> 4 workgroups / CU
 
 template <int DKT>
 struct AttnSmem {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int q = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
   f32x4 qf[DKT];
   load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < T, dk, lane);
   f32x4 oT[DKT];
@@ -88,9 +89,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
     stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
     __syncthreads();
-    f32x4 st[4];
+    f32x4 st[AT_KB / 16];
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
       st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kb + kt * 16 < nkeys) {
 #pragma unroll
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < AT_KB / 16; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kb + kt * 16 + 4 * (lane >> 4) + r;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+    for (int kt = 0; kt < AT_KB / 16; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = expf(st[kt][r] - m_new);   // exp(-inf) = 0 for masked keys
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < DKT; ++i) oT[i] *= corr;
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
       if (kb + kt * 16 < nkeys) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int q = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
   const bool qok = q < T;
   f32x4 qf[DKT], dof[DKT];
   load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, qok, dk, lane);
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
     __syncthreads();
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
       if (kb + kt * 16 >= nkeys) continue;
       f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f}, dpT = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int key = blockIdx.y * AT_KB + wave * 16 + (lane & 15);
+  const int key = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
   const bool kok = key < T;
   f32x4 kf[DKT], vf[DKT];
   load_row_frags<DKT>(kf, base + (size_t)key * ldg + d + h * dk, kok, dk, lane);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool key_live = key < nkeys;          // masked keys get exactly zero gradient
-  const bool wave_live = (blockIdx.y * AT_KB + wave * 16) < nkeys;
+  const bool wave_live = (blockIdx.y * AT_QB + wave * 16) < nkeys;
 
   for (int qb = 0; qb < T; qb += AT_KB) {
     __syncthreads();
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     __syncthreads();
     if (!wave_live) continue;
 #pragma unroll
-    for (int qt = 0; qt < 4; ++qt) {
+    for (int qt = 0; qt < AT_KB / 16; ++qt) {
       if (qb + qt * 16 >= T) continue;
       f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -354,7 +355,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   if (rc) return rc;
   const int dk = d / heads, dkt = cdiv(dk, 16);
   const float scale = 1.0f / sqrtf((float)dk);
-  dim3 grid(B * heads, cdiv(T, AT_KB));
+  dim3 grid(B * heads, cdiv(T, AT_QB));
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_fwd_kernel<DKT>, smem);
@@ -371,7 +372,7 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   if (rc) return rc;
   const int dk = d / heads, dkt = cdiv(dk, 16);
   const float scale = 1.0f / sqrtf((float)dk);
-  dim3 grid(B * heads, cdiv(T, AT_KB));
+  dim3 grid(B * heads, cdiv(T, AT_QB));
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_bwd_dq_kernel<DKT>, smem);
