@@ -84,3 +84,75 @@ def test_standin_intents_recipe_is_deterministic_and_normalised():
     assert a == b and len(a) > 20
     for v in a.values():
         assert len(v) == 3 * 7 and abs(sum(v) - 1.0) < 1e-9
+
+
+TOY = '/root/reference/IntEL/data/Tmall_toy'
+
+
+@pytest.mark.skipif(not os.path.isdir(TOY), reason='toy Tmall sample only exists in the build container')
+def test_toy_tmall_sample_matches_reference_pipeline_and_runs_batch2(tmp_path):
+    """BASELINE.json configs[0] plumbing: the bundled toy Tmall sample (+ the deterministic stand-in for its
+    missing intents_multi.json) through OUR reader/Dataset vs the REFERENCE's, then batch=2 through the oracle."""
+    import shutil
+    import subprocess
+    import sys
+    from intel_sigir2023_amd.data import Dataset, SeqReader, standin_intents
+    from intel_sigir2023_amd.model import IntEL
+    from oracle import intel_oracle as O
+    root = tmp_path / 'Tmall_toy'
+    root.mkdir()
+    for f in ('train.csv', 'dev.csv', 'test.csv', 'item_metadata.json', 'user_metadata.json'):
+        os.symlink(os.path.join(TOY, f), root / f)
+    json.dump(standin_intents(str(root)), open(root / 'intents_multi.json', 'w'))
+    cfg = dict(datapath=str(tmp_path), dataset='Tmall_toy', sep='\t', intent_note='_multi', max_session_len=100, model_num=3,
+               history_max=20, model_path='', buffer=1, encoder='BERT4Rec', context_emb_size=16, i_emb_size=16, u_emb_size=32,
+               s_emb_size=32, im_emb_size=16, intent_emb_size=16, cross_attn_qsize=32, num_heads=1, dropout=0, num_layers=1,
+               cross_attention=1, intent_weight=0.1, ensemble_weight=1, kl_temp=2, kl_weight=0.5, cal_diversity=1,
+               diversity_alpha=0.01)
+    args = argparse.Namespace(**cfg)
+    args.device = torch.device('cpu')
+    corpus = SeqReader(args)
+    assert corpus.max_iid == 266340 and len(corpus.zero_int) == 1071 and corpus.contextfnum == [931]      # SURVEY §8
+    torch.manual_seed(0)
+    model = IntEL(args, corpus)
+    np.random.seed(11)
+    ds = Dataset(model, corpus, 'train')
+    mine = [ds[i] for i in range(6)]
+    # the reference on the same files / same numpy seed (separate process: it needs its own import shims)
+    code = r'''
+import sys, json, argparse
+sys.dont_write_bytecode = True
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from make_golden import install_shims
+install_shims()
+import numpy as np, torch
+from helpers.SeqReader import SeqReader
+from models.IntEL.IntEL import IntEL
+cfg = json.loads(%r)
+args = argparse.Namespace(**cfg); args.device = torch.device('cpu')
+corpus = SeqReader(args)
+torch.manual_seed(0)
+model = IntEL(args, corpus)
+np.random.seed(11)
+ds = IntEL.Dataset(model, corpus, 'train')
+out = {}
+for i in range(6):
+    fd = ds[i]
+    for k, v in fd.items():
+        out['%%d/%%s' %% (i, k)] = np.asarray(v)
+np.savez(%r, **out)
+print('ref-ok')
+''' % (os.path.join(os.path.dirname(GOLDEN), 'golden'), os.path.dirname(os.path.dirname(GOLDEN)), json.dumps(cfg), str(tmp_path / 'ref.npz'))
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert 'ref-ok' in r.stdout, r.stderr[-3000:]
+    ref = np.load(tmp_path / 'ref.npz')
+    for i, fd in enumerate(mine):
+        for k, v in fd.items():
+            np.testing.assert_array_equal(np.asarray(v), ref['%d/%s' % (i, k)], err_msg='%d/%s' % (i, k))
+    # batch = 2 through the oracle (the CPU-runnable configuration of the reference)
+    batch = ds.collate_batch(mine[:2])
+    ocfg = O.Config(**{k: v for k, v in cfg.items() if k not in ('datapath', 'dataset', 'sep', 'intent_note', 'max_session_len')})
+    with torch.no_grad():
+        out = O.forward(model.state_dict(), batch, ocfg)
+        loss, _, _ = O.int_list_loss(out, batch, ocfg)
+    assert out['ens_score'].shape[0] == 2 and bool(torch.isfinite(loss))
