@@ -1215,6 +1215,37 @@ int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int c
   return 0;
 }
 
+// dW and db of one wgrad in a single launch: outputs [0, N*K) -> dW (row stride lddw), [N*K, N*K+N) -> db
+__global__ __launch_bounds__(256) void slab_reduce_wb_kernel(const float* __restrict__ slabs, size_t stride, int S, int N, int K,
+                                                             float* __restrict__ dW, int lddw, float* __restrict__ db, int accumulate) {
+  __shared__ float red[16][17];
+  const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+  const int n = N * K + N;
+  const int i = blockIdx.x * 16 + o;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int s = q;
+    for (; s + 48 < S; s += 64) {
+      s0 += slabs[(size_t)s * stride + i];
+      s1 += slabs[(size_t)(s + 16) * stride + i];
+      s2 += slabs[(size_t)(s + 32) * stride + i];
+      s3 += slabs[(size_t)(s + 48) * stride + i];
+    }
+    for (; s < S; s += 16) s0 += slabs[(size_t)s * stride + i];
+  }
+  red[q][o] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && i < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += red[k][o];
+    float* dst;
+    if (i < N * K) { const int r = i / K, c = i - r * K; dst = dW + (size_t)r * lddw + c; }
+    else dst = db + (i - N * K);
+    *dst = accumulate ? (*dst + v) : v;
+  }
+}
+
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
                  float* db, int accumulate, float* slabs, hipStream_t st) {
   if (N <= 0 || K <= 0) return 0;
@@ -1230,6 +1261,11 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   }
   INTEL_CHECK_LAUNCH();
   size_t stride = (size_t)N * K + N;
+  if (db && (size_t)N * K < 4096) {     // small weight: one launch reduces dW and db together
+    LAUNCH_W(0.0, 4.0 * (double)a.S * (N * K + N), slab_reduce_wb_kernel, dim3(cdiv(N * K + N, 16)), dim3(256), 0, st, slabs, stride, a.S, N, K, dW, lddw, db, accumulate);
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   int rc = launch_slab_reduce(slabs, stride, a.S, N, K, dW, lddw, accumulate, st);
   if (rc) return rc;
   if (db) rc = launch_slab_reduce(slabs + (size_t)N * K, stride, a.S, 1, N, db, N, accumulate, st);

@@ -268,7 +268,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   if ((size_t)B * H > rowsmax) rowsmax = (size_t)B * H;
   if ((size_t)B * Hi > rowsmax) rowsmax = (size_t)B * Hi;
   size_t slab = 512 * (maxNK + maxN);
-  size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;
+  size_t lnslab = (size_t)cdiv((int)rowsmax, 64) * 2 * maxN;      // >= the LayerNorm-backward slab count
   if (lnslab > slab) slab = lnslab;
   const int Tm = H > Hi ? H : Hi;
   const int Rm = I > Tm ? I : Tm;

@@ -268,6 +268,31 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     slab[N + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
   }
 }
+// out1[c] (+)= sum_s slabs[s][c], out2[c] (+)= sum_s slabs[s][N + c]: LayerNorm dgamma / dbeta in one launch
+__global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float* __restrict__ slabs, int S, int N,
+                                                               float* __restrict__ out1, float* __restrict__ out2, int accumulate) {
+  __shared__ float red[64][5];
+  const int o = threadIdx.x & 3, q = threadIdx.x >> 2;
+  const int i = blockIdx.x * 4 + o;          // 0 .. 2N-1
+  float s0 = 0.f, s1 = 0.f;
+  if (i < 2 * N) {
+    int s = q;
+    for (; s + 64 < S; s += 128) {
+      s0 += slabs[(size_t)s * 2 * N + i];
+      s1 += slabs[(size_t)(s + 64) * 2 * N + i];
+    }
+    for (; s < S; s += 64) s0 += slabs[(size_t)s * 2 * N + i];
+  }
+  red[q][o] = s0 + s1;
+  __syncthreads();
+  if (q == 0 && i < 2 * N) {
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) acc += red[k][o];
+    float* dst = i < N ? out1 + i : out2 + (i - N);
+    *dst = accumulate ? (*dst + acc) : acc;
+  }
+}
+
 int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
                          const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
                          float* slabs, hipStream_t st) {
@@ -276,9 +301,9 @@ int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh,
   const int nb = ln_bwd_blocks(M);
   LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
   INTEL_CHECK_LAUNCH();
-  int rc = launch_slab_reduce(slabs, (size_t)2 * N, nb, 1, N, dgamma, N, accumulate, st);
-  if (rc) return rc;
-  return launch_slab_reduce(slabs + N, (size_t)2 * N, nb, 1, N, dbeta, N, accumulate, st);
+  LAUNCH_W(0.0, 8.0 * (double)nb * N, slab_reduce_pair_kernel, dim3(cdiv(2 * N, 4)), dim3(256), 0, st, slabs, nb, N, dgamma, dbeta, accumulate);
+  INTEL_CHECK_LAUNCH();
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------
