@@ -31,6 +31,13 @@ WORKLOADS = {
                               encoder='BERT4Rec', history_max=200),
                    corpus=dict(items=10000000, users=100000, classes=357, ctx=931, I=32),
                    batch=dict(L=200, H=200)),
+    # the bundled toy Tmall sample's shape (BASELINE.json configs[0]; SURVEY.md §8: 266 341 items, 5 147 users,
+    # 357 classes, 931 contexts, I = 3 behaviours x 357 classes = 1071, lists up to 90) with the reference's default flags
+    'toyshape': dict(flags=dict(model_num=3, context_emb_size=16, i_emb_size=16, u_emb_size=32, s_emb_size=32,
+                                im_emb_size=16, intent_emb_size=16, cross_attn_qsize=32, num_heads=1, num_layers=1,
+                                encoder='BERT4Rec', history_max=20),
+                     corpus=dict(items=266341, users=5147, classes=357, ctx=931, I=1071),
+                     batch=dict(L=90, H=20)),
     # tiny shape for smoke tests
     'tiny': dict(flags=dict(model_num=3, context_emb_size=16, i_emb_size=16, u_emb_size=32, s_emb_size=32,
                             im_emb_size=16, intent_emb_size=16, cross_attn_qsize=32, num_heads=1, num_layers=1,
