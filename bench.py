@@ -95,6 +95,7 @@ def main():
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--cpu_budget', type=float, default=20.0)
     ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
+    ap.add_argument('--encoder', type=str, default='', help='override the sequence encoder: BERT4Rec | GRU4Rec')
     a = ap.parse_args()
 
     import torch
@@ -110,7 +111,10 @@ def main():
     torch.cuda.set_device(dev)
     _lib.lib()
     w = synth.WORKLOADS[a.workload]
-    args_ns = synth.make_args(a.workload, dev, cal_diversity=a.cal_diversity)
+    over = dict(cal_diversity=a.cal_diversity)
+    if a.encoder:
+        over['encoder'] = a.encoder
+    args_ns = synth.make_args(a.workload, dev, **over)
     corpus, cinfo = synth.make_corpus(a.workload)
     torch.manual_seed(0)
     model = IntEL(args_ns, corpus).to(dev)
@@ -148,6 +152,17 @@ def main():
     ev_el = parallel.allreduce_max_float(time.perf_counter() - t1, dev)
     ndcg3 = float(nd.float().nan_to_num(0).mean())
 
+    # ---- per-kernel profile: EVERY rank runs the same extra steps (they contain the gradient all-reduce)
+    prof_shapes, psteps = None, 3
+    if not a.no_roofline:
+        lib = _lib.lib()
+        lib.intel_set_concurrency(model._context(), 0)     # price kernels one at a time on one stream
+        lib.intel_prof_enable(1)
+        for i in range(psteps):
+            one_step(i)
+        prof_shapes = json.loads(lib.intel_prof_collect().decode())
+        lib.intel_prof_enable(0)
+        lib.intel_set_concurrency(model._context(), 1)
     if rank != 0:
         return
     res = {
@@ -156,7 +171,7 @@ def main():
         'warmup': a.warmup, 'ms_per_step': round(1e3 * el / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, d=64, fp32, %s loss, cal_diversity=%d, %s item ids'
-                               % (a.workload, cinfo['items'], Lmax, w['flags']['model_num'], cinfo['I'], w['batch']['H'], a.loss,
+                               % (a.workload + ('/' + a.encoder if a.encoder else ''), cinfo['items'], Lmax, w['flags']['model_num'], cinfo['I'], w['batch']['H'], a.loss,
                                   a.cal_diversity, 'zipf' if a.zipf else 'uniform'),
                    'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world},
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
@@ -165,16 +180,7 @@ def main():
     bytes_train = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], True)
     res['gather_roofline'] = {'bytes_per_session': bytes_train, 'achieved_GBps': round(bytes_train * res['value'] / world / 1e9, 3),
                               'peak_GBps': HBM_PEAK / 1e9, 'frac': round(bytes_train * res['value'] / world / HBM_PEAK, 6)}
-    if not a.no_roofline:
-        lib = _lib.lib()
-        lib.intel_set_concurrency(model._context(), 0)     # price kernels one at a time on one stream
-        lib.intel_prof_enable(1)
-        psteps = 3
-        for i in range(psteps):
-            one_step(i)
-        prof_shapes = json.loads(lib.intel_prof_collect().decode())
-        lib.intel_prof_enable(0)
-        lib.intel_set_concurrency(model._context(), 1)
+    if prof_shapes is not None:
         prof = {}                       # aggregate the shape-tagged GEMM records by kernel
         for k, v in prof_shapes.items():
             d = prof.setdefault(k.split('[')[0].strip('()').split('<')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})

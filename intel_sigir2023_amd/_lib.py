@@ -24,8 +24,12 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise IntelHipError('libintel_hip.so is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
-                                '(or python intel_sigir2023_amd/build.py); there is no CPU fallback')
+            try:        # a fresh checkout: compile in-tree once (hipcc cross-compiles without a GPU)
+                from . import build as _build
+                _build.build_library()
+            except Exception as e:
+                raise IntelHipError('libintel_hip.so is missing and could not be built (%s): run `python -c "import '
+                                    '__graft_entry__ as g; g.build()"`; there is no CPU fallback' % e)
         try:
             _lib = C.CDLL(LIB_PATH)
         except OSError as e:
