@@ -157,6 +157,14 @@ int intel_backward(IntelCtx* ctx, const void* const* params, const IntelBatch* b
                    size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
                    const float* d_intents, void* const* grads, void* stream);
 
+/* The same backward in two halves for data-parallel overlap: phase 1 computes everything the item-id table
+ * gradient (the one large all-reduce) depends on, phase 2 the rest (score-tower layers, session-history
+ * encoder); the caller starts the all-reduce of grads[INTEL_P_IID_EMB] between the two calls.  phase 0 = both.
+ * Same arguments and preconditions as intel_backward; phase 1 must precede phase 2. */
+int intel_backward_phase(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                         size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                         const float* d_intents, void* const* grads, int phase, void* stream);
+
 /* ---- losses ------------------------------------------------------------------------------- */
 /* BPRloss.forward (loss/BPRloss.py:37-56) incl. bpr_loss (:20-34) and diversity (:12-18).
  *   noise [B,L,L] replaces torch.rand_like (BPRloss.py:26); scores_f64 may be NULL (then scores_f32

@@ -79,6 +79,8 @@ struct Layout {
   float *FEAT, *WV, *WPAD, *FEATFULL, *PREDIN, *LOGITS, *INTENTS;
   float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
   float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN;
+  float *dXS;       // gradient w.r.t. the score tower output, parked between the two backward phases
+  float *ONEHOT2;   // one-hot of the item-history intent indices (used on the main stream after a join)
   size_t total;
 };
 
@@ -250,6 +252,8 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   y.dINTENT = ar.f((size_t)B * I);
   y.dLOGITS = ar.f((size_t)B * I);
   y.dPREDIN = ar.f((size_t)B * y.Pin);
+  y.dXS = ar.f((size_t)M * d_s);
+  y.ONEHOT2 = ar.f((size_t)B * Hi * I);
   const int dmax = d_i > d_s ? (d_i > dm0 ? (d_i > dm1 ? d_i : dm1) : (dm0 > dm1 ? dm0 : dm1))
                              : (d_s > dm0 ? (d_s > dm1 ? d_s : dm1) : (dm0 > dm1 ? dm0 : dm1));
   const int vmax = dmax > I ? (dmax > D.q_size ? dmax : D.q_size) : (I > D.q_size ? I : D.q_size);
@@ -845,7 +849,9 @@ void forward_impl(Run& r, const IntelOut* out) {
 }
 
 // ---- backward -----------------------------------------------------------------------------------
-void backward_impl(Run& r, const float* d_weights, const float* d_ens, const float* d_intents) {
+// phase 0 = whole backward; phase 1 = everything the item-id table gradient depends on (so that its
+// data-parallel all-reduce can start) ; phase 2 = the rest (score tower layers, session-history encoder)
+void backward_impl(Run& r, const float* d_weights, const float* d_ens, const float* d_intents, int phase) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const IntelBatch& bt = *r.bt;
@@ -857,71 +863,75 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   GemmEpilogue e0;
   GemmEpilogue eacc;
   eacc.accumulate = 1;
-  memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
-  // embedding tables accumulate with atomics into caller-zeroed buffers
-  r.ctx->touched[INTEL_P_IID_EMB] = r.ctx->touched[INTEL_P_ITEM_EMB] = 1;
-  r.ctx->touched[INTEL_P_UID_EMB] = r.ctx->touched[INTEL_P_CTX_EMB] = 1;
+  if (phase != 2) {
+    memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
+    // embedding tables accumulate with atomics into caller-zeroed buffers
+    r.ctx->touched[INTEL_P_IID_EMB] = r.ctx->touched[INTEL_P_ITEM_EMB] = 1;
+    r.ctx->touched[INTEL_P_UID_EMB] = r.ctx->touched[INTEL_P_CTX_EMB] = 1;
 
-  // ===== fusion weights + aggregation (IntEL.py:212-215)
-  if (D.cross_attention) {
-    RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 0, y.dWV, y.dWPAD, nullptr, r.st));
-    wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
-    if (r.rc) return;
-    if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
-      RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, r.T->SLABS, r.st));
+    // ===== fusion weights + aggregation (IntEL.py:212-215)
+    if (D.cross_attention) {
+      RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 0, y.dWV, y.dWPAD, nullptr, r.st));
+      wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+      if (r.rc) return;
+      if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
+        RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, r.T->SLABS, r.st));
+      }
+      lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
+      lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
+    } else {
+      RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 1, nullptr, nullptr, y.dWT, r.st));
+      wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+      lin(r, y.dWT, K, M, K, y.pWeT, y.F, y.dFEATFULL, y.F, e0);
+      if (r.rc) return;
+      // per-session parts of the feature: h_u, h_intent are broadcast over the list
+      RUN(launch_session_colsum(y.dFEATFULL, y.F, off_u, npad, B, L, y.dFEAT, y.F, off_u, 0, r.st));
     }
-    lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
-    lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
-  } else {
-    RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 1, nullptr, nullptr, y.dWT, r.st));
-    wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
-    lin(r, y.dWT, K, M, K, y.pWeT, y.F, y.dFEATFULL, y.F, e0);
     if (r.rc) return;
-    // per-session parts of the feature: h_u, h_intent are broadcast over the list
-    RUN(launch_session_colsum(y.dFEATFULL, y.F, off_u, npad, B, L, y.dFEAT, y.F, off_u, 0, r.st));
+    // h_u = relu(uid_emb[u])
+    if (r.G(INTEL_P_UID_EMB))
+      RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
+    // h_intent = relu(intent_embeddings(intent)): dpre -> dVB1 [B, d_int]
+    RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, r.T->dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
+    wgrad(r, r.T->dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+    lin(r, r.T->dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
+    if (r.rc) return;
   }
-  if (r.rc) return;
-  // h_u = relu(uid_emb[u])
-  if (r.G(INTEL_P_UID_EMB))
-    RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
-  // h_intent = relu(intent_embeddings(intent)): dpre -> dVB1 [B, d_int]
-  RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, r.T->dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
-  wgrad(r, r.T->dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-  lin(r, r.T->dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
-  if (r.rc) return;
 
-  // ===== towers: cross attention + tied self-attention layers; the two towers are independent and run
-  // concurrently (main stream / side stream 0, temporaries set 0 / 1); each leaves its contribution to
-  // d(intent) in its own buffer
-  auto tower_branch = [&](Run& r, int t) {
+  // ===== cross attention backward of one tower (cheap: B-row GEMMs + one pass over [B,L,d]); leaves the
+  // gradient w.r.t. the tower output in dXout and this tower's contribution to d(intent) in dint
+  auto xatt_bwd = [&](Run& r, int t, float* dXout, float* dint) {
     TowerBufs& w = y.tw[t];
     const int d = w.d;
     const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
-    float* dX = r.T->dXa;
     if (D.cross_attention) {
       const int xb = w.xbase;
       // pooled = xbar Wv^T
       wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1);
       lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, r.T->dVB1, d, e0);          // dxbar
       if (r.rc) return;
-      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dX, r.T->dVB2, r.st));   // dX, dQK
+      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout, r.T->dVB2, r.st));   // dX, dQK
       // QK = QV Wk  (QK[b][j] = sum_i QV[b][i] Wk[i][j])
       wgrad(r, w.QV, d, r.T->dVB2, d, B, d, d, xb + 1, -1);
       lin(r, r.T->dVB2, d, B, d, w.pXk, d, r.T->dVB3, d, e0);                            // dQV
       wgrad(r, r.T->dVB3, d, y.INTENTS, I, B, d, I, xb + 0, -1);
-      lin(r, r.T->dVB3, d, B, d, w.pXqT, I, r.T->dINT, I, e0);
+      lin(r, r.T->dVB3, d, B, d, w.pXqT, I, dint, I, e0);
     } else {
       const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
-      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dX, r.T->dVB1, r.st));    // dX, dMV
+      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dXout, r.T->dVB1, r.st));    // dX, dMV
       wgrad(r, r.T->dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
       GemmEpilogue em;
       em.mask = w.MH; em.ldmask = D.q_size;
       lin(r, r.T->dVB1, d, B, d, w.pM2T, D.q_size, r.T->dVB2, D.q_size, em);            // d(pre-relu hidden)
       wgrad(r, r.T->dVB2, D.q_size, y.INTENTS, I, B, D.q_size, I, mb + 0, mb + 1);
-      lin(r, r.T->dVB2, D.q_size, B, D.q_size, w.pM0T, I, r.T->dINT, I, e0);
+      lin(r, r.T->dVB2, D.q_size, B, D.q_size, w.pM0T, I, dint, I, e0);
     }
-    if (r.rc) return;
-    float* dX0 = tower_bwd(r, w, dX, r.T->dXb);
+  };
+  // ===== tied self-attention layers of one tower + its input gradients
+  auto tower_layers_bwd = [&](Run& r, int t, float* dXout) {
+    TowerBufs& w = y.tw[t];
+    const int d = w.d;
+    float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa);
     if (r.rc || !dX0) return;
     if (t == 0) {
       if (r.G(INTEL_P_IID_EMB))
@@ -932,32 +942,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
     }
   };
-  fork_streams(r, 1);
-  {
-    Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
-    tower_branch(b0, 0);
-    tower_branch(b1, 1);
-    r.ok(b0.rc); r.ok(b1.rc);
-  }
-  join_streams(r, 1);
-  if (r.rc) return;
-
-  // ===== predict_intent backward
-  RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
-  RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
-  if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
-  RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
-  wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
-  lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
-  if (r.rc) return;
-  if (r.G(INTEL_P_CTX_EMB))
-    RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
-  if (r.G(INTEL_P_UID_EMB))
-    RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
-  // the two sequence encoders are independent: concurrent branches again.  The gradients of the SHARED
-  // intent_embeddings weight are taken after the join, on the main stream, in a fixed order.
-  float* dEs[2] = {nullptr, nullptr};
-  auto encoder_branch = [&](Run& r, int e) {
+  // ===== one sequence encoder: returns dE (gradient w.r.t. its input rows), scatters the table part
+  auto encoder_branch = [&](Run& r, int e) -> float* {
     EncBufs& n = y.enc[e];
     const int rows = B * n.T, dm = n.dm;
     float* dE = nullptr;
@@ -973,40 +959,86 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       r.ok(gru_bwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
                    r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, r.T->dXb, r.T->SLABS, r.st));
     }
-    if (r.rc || !dE) return;
-    dEs[e] = dE;
-    // input rows: [table row | intent_embeddings(intent rows)]
+    if (r.rc || !dE) return nullptr;
     if (e == 0) {
       if (r.G(INTEL_P_CTX_EMB))
-        RUN(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     } else {
       if (r.G(INTEL_P_IID_EMB))
-        RUN(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
     }
+    return dE;
   };
-  fork_streams(r, 1);
-  {
-    Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
-    encoder_branch(b0, 0);
-    encoder_branch(b1, 1);
-    r.ok(b0.rc); r.ok(b1.rc);
-  }
-  join_streams(r, 1);
-  if (r.rc || !dEs[0] || !dEs[1]) return;
-  {
-    const EncBufs& n0 = y.enc[0];
-    const EncBufs& n1 = y.enc[1];
-    wgrad(r, dEs[0] + D.d_c, n0.dm, bt.his_intents, I, B * n0.T, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-    const int rows1 = B * n1.T;
-    if (bt.his_item_idx) {
+  // gradient of the SHARED intent_embeddings weight from one encoder's input rows (main stream, fixed order)
+  auto intent_wgrad = [&](Run& r, int e, float* dE) {
+    const EncBufs& n = y.enc[e];
+    const int rows = B * n.T;
+    if (e == 0) {
+      wgrad(r, dE + D.d_c, n.dm, bt.his_intents, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+    } else if (bt.his_item_idx) {
       if (r.G(INTEL_P_INTENT_W)) {   // dW[c][j] = sum_m dE[m][c] onehot[m][j]: the dense wgrad on a materialised one-hot
-        RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows1, I, y.tmp[1].ONEHOT, r.st));
-        r.T = &y.tmp[0];
-        wgrad(r, dEs[1] + D.d_id, n1.dm, y.tmp[1].ONEHOT, I, rows1, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+        RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows, I, y.ONEHOT2, r.st));
+        wgrad(r, dE + D.d_id, n.dm, y.ONEHOT2, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
       }
     } else {
-      wgrad(r, dEs[1] + D.d_id, n1.dm, bt.his_item_int, I, rows1, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+      wgrad(r, dE + D.d_id, n.dm, bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
     }
+  };
+
+  if (phase != 2) {
+    // cross-attention backward of both towers first: d(intent) is then complete and the intent path can
+    // start while the (heavy) tower layers are still running
+    r.T = &y.tmp[0];
+    xatt_bwd(r, 0, y.tmp[0].dXa, y.tmp[0].dINT);
+    if (r.rc) return;
+    xatt_bwd(r, 1, y.dXS, y.tmp[1].dINT);
+    if (r.rc) return;
+    RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
+    RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
+    if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
+    RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
+    wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+    lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+    if (r.rc) return;
+    if (r.G(INTEL_P_CTX_EMB))
+      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+    if (r.G(INTEL_P_UID_EMB))
+      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
+    // phase 1 branches: item tower layers (main, set 0) || item-history encoder (side 0, set 1): after the
+    // join the item-id table gradient is complete
+    float* dE1 = nullptr;
+    fork_streams(r, 1);
+    {
+      Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
+      tower_layers_bwd(b0, 0, y.tmp[0].dXa);
+      dE1 = encoder_branch(b1, 1);
+      r.ok(b0.rc); r.ok(b1.rc);
+    }
+    join_streams(r, 1);
+    if (r.rc || !dE1) return;
+    r.T = &y.tmp[0];
+    intent_wgrad(r, 1, dE1);
+    if (r.rc) return;
+  }
+  if (phase != 1) {
+    // phase 2 branches: score tower layers (main, set 0) || session-history encoder (side 0, set 1)
+    float* dE0 = nullptr;
+    fork_streams(r, 1);
+    {
+      Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
+      // the score tower's output gradient was parked in dXS by phase 1; tower_bwd ping-pongs dXS <-> dXb
+      {
+        TowerBufs& w = y.tw[1];
+        float* dX0 = tower_bwd(b0, w, y.dXS, y.tmp[0].dXb);
+        if (!b0.rc && dX0) wgrad(b0, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
+      }
+      dE0 = encoder_branch(b1, 0);
+      r.ok(b0.rc); r.ok(b1.rc);
+    }
+    join_streams(r, 1);
+    if (r.rc || !dE0) return;
+    r.T = &y.tmp[0];
+    intent_wgrad(r, 0, dE0);
   }
 }
 
@@ -1112,10 +1144,11 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   return r.rc;
 }
 
-extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
-                              size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
-                              const float* d_intents, void* const* grads, void* stream) {
+static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                          size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                          const float* d_intents, void* const* grads, void* stream, int phase) {
   INTEL_CHECK_ARG(ctx && params && grads && workspace, "intel_backward: null argument");
+  INTEL_CHECK_ARG(phase >= 0 && phase <= 2, "intel_backward: phase must be 0, 1 or 2");
   int rc = check_batch(ctx, batch);
   if (rc) return rc;
   if (!ctx->fwd_done || ctx->fB != batch->B || ctx->fL != batch->L || ctx->fH != batch->H || ctx->fHi != batch->Hi ||
@@ -1126,6 +1159,18 @@ extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const In
   if (workspace_bytes < ctx->lay.total) return INTEL_E_WORKSPACE;
   INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
   Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], 1};
-  backward_impl(r, d_weights, d_ens_score, d_intents);
+  backward_impl(r, d_weights, d_ens_score, d_intents, phase);
   return r.rc;
+}
+
+extern "C" int intel_backward(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                              size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                              const float* d_intents, void* const* grads, void* stream) {
+  return backward_entry(ctx, params, batch, workspace, workspace_bytes, d_weights, d_ens_score, d_intents, grads, stream, 0);
+}
+
+extern "C" int intel_backward_phase(IntelCtx* ctx, const void* const* params, const IntelBatch* batch, void* workspace,
+                                    size_t workspace_bytes, const float* d_weights, const float* d_ens_score,
+                                    const float* d_intents, void* const* grads, int phase, void* stream) {
+  return backward_entry(ctx, params, batch, workspace, workspace_bytes, d_weights, d_ens_score, d_intents, grads, stream, phase);
 }

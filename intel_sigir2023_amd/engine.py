@@ -32,6 +32,7 @@ class IntELEngine(object):
         self.cal_diversity, self.alpha = int(g('cal_diversity', 0)), float(g('diversity_alpha', 0.01))
         self.lr, self.l2, self.betas, self.eps = float(lr), float(l2), betas, float(eps)
         self.step_count = 0
+        self.force_phases = False          # tests: run the two-phase backward without a process group
         self.device = next(model.parameters()).device
         L.require_gpu(next(model.parameters()))
         self._flatten()
@@ -40,9 +41,14 @@ class IntELEngine(object):
     # ---- flat parameter / gradient / moment buckets -------------------------------------------------
     def _flatten(self):
         items = self.model.slot_items()
-        groups = {'decay': [], 'nodecay': []}
+        # three flat buckets: the item-id table (its all-reduce is the big one and is overlapped with the second
+        # half of the backward pass), every other decayed parameter, the biases (weight_decay 0)
+        groups = {'iid': [], 'decay': [], 'nodecay': []}
         for s, name, p in items:
-            groups['nodecay' if 'bias' in name else 'decay'].append((s, name, p))
+            if name == 'iid_embeddings.weight':
+                groups['iid'].append((s, name, p))
+            else:
+                groups['nodecay' if 'bias' in name else 'decay'].append((s, name, p))
         self.flat, self.gflat, self.m, self.v = {}, {}, {}, {}
         self.grad_by_slot = {}
         for gname, lst in groups.items():
@@ -64,10 +70,10 @@ class IntELEngine(object):
             self.v[gname] = torch.zeros_like(flat)
 
     def buckets(self):
-        return [self.gflat['decay'], self.gflat['nodecay']]
+        return [self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']]
 
     def param_buckets(self):
-        return [self.flat['decay'], self.flat['nodecay']]
+        return [self.flat['iid'], self.flat['decay'], self.flat['nodecay']]
 
     def _buf(self, name, shape, dtype):
         t = self._bufs.get(name)
@@ -123,11 +129,20 @@ class IntELEngine(object):
             L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label.contiguous()), self.kl_weight, self.kl_temp,
                                           self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws), nb, st),
                     'intel_intent_loss')
-        model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
-        parallel.allreduce_sum_(self.buckets())
+        if world > 1 or self.force_phases:
+            # phase 1 completes the item-id table gradient; its all-reduce (the large one) then runs on the
+            # communication stream underneath phase 2 (score-tower layers, session-history encoder)
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
+            work = parallel.allreduce_sum_async(self.gflat['iid'])
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
+            parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
+            if work is not None:
+                work.wait()
+        else:
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
         self.step_count += 1
         b1, b2 = self.betas
-        for gname, wd in (('decay', self.l2), ('nodecay', 0.0)):
+        for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
             n = self.flat[gname].numel()
             if n:
                 L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),

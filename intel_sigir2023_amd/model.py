@@ -373,7 +373,7 @@ class IntEL(nn.Module):
                                   L.stream_ptr(dev)), 'intel_forward')
         return weights, ens, intents
 
-    def run_backward(self, batch, keep, param_tensors, d_weights, d_ens, d_intents, grad_tensors=None):
+    def run_backward(self, batch, keep, param_tensors, d_weights, d_ens, d_intents, grad_tensors=None, phase=0):
         """d(out) -> d(param).  grad_tensors: optional {slot: tensor} of persistent buffers (embedding
         tables must arrive zeroed); otherwise fresh ones are allocated."""
         items = self.slot_items()
@@ -391,8 +391,8 @@ class IntEL(nn.Module):
                 grad_tensors[s] = torch.zeros_like(t) if s in table_slots else torch.empty_like(t)
         parr = self._param_array({s: t.contiguous() for (s, _, _), t in zip(items, param_tensors)})
         garr = self._param_array(grad_tensors)
-        L.check(lib.intel_backward(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(d_weights), L.ptr(d_ens),
-                                   L.ptr(d_intents), garr, L.stream_ptr(dev)), 'intel_backward')
+        L.check(lib.intel_backward_phase(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(d_weights), L.ptr(d_ens),
+                                         L.ptr(d_intents), garr, int(phase), L.stream_ptr(dev)), 'intel_backward')
         return grad_tensors
 
 

@@ -74,6 +74,15 @@ def allreduce_sum_(tensors):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def allreduce_sum_async(t):
+    """Start an in-place sum over ranks and return the work handle (None for a single process).  The collective
+    is ordered after everything already enqueued on the current stream; ``handle.wait()`` orders the current
+    stream after the collective."""
+    if world_size() == 1:
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
 def broadcast_(tensors, src=0):
     if world_size() == 1:
         return

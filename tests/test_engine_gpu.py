@@ -34,6 +34,30 @@ def _dev():
 
 
 @pytest.mark.parametrize('name', ['default', 'gru_bpr', 'noxatt'])
+def test_two_phase_backward_equals_whole_backward(name):
+    """intel_backward_phase(1) + (2) (the data-parallel overlap path) == intel_backward, bit for bit apart from the
+    atomically accumulated embedding rows."""
+    from intel_sigir2023_amd.engine import IntELEngine
+    fx = Fixture(name)
+    dev = _dev()
+    res = []
+    for phased in (False, True):
+        model, args = build_model(fx, dev)
+        model.train()
+        args.cal_diversity = 1
+        eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+        eng.force_phases = phased
+        loss, _, _ = eng.train_step(fx.batch(dev), noise=torch.from_numpy(fx['adam/noise0']).to(dev))
+        res.append((float(loss), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    assert res[0][0] == res[1][0]
+    for k, v in res[0][1].items():
+        if 'embeddings.weight' in k and ('iid' in k or 'uid' in k or 'context' in k or 'item_' in k):
+            assert float((v - res[1][1][k]).abs().max()) < 1e-6, k       # atomics: summation order may differ
+        else:
+            assert torch.equal(v, res[1][1][k]), k
+
+
+@pytest.mark.parametrize('name', ['default', 'gru_bpr', 'noxatt'])
 def test_engine_two_steps_match_reference_adam(name):
     """IntELEngine.train_step x2 == the reference's 2 torch.optim.Adam steps (fixture F7)."""
     from intel_sigir2023_amd.engine import IntELEngine
