@@ -56,13 +56,8 @@ int launch_gather_rows(const float* table, int d, const int* idx, int M, float* 
 // dst[b*T+t, col0:col0+d] = src[b, :]  broadcast of a per-session vector
 int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st);
 // grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics
-// table_rows > 0 enables the LDS-staged path for small destination tables
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
-                            const float* relu_out, int ldr, int rcol0, hipStream_t st, int table_rows = 0);
-// out[row*rs + c*cs] += src[m, col0+c] with row = idx[m] (or the BERT4Rec position of row m when idx is
-// null and len/T are given, or 0 when both are null); the whole [R, d] table is staged in LDS.
-int launch_scatter_add_small(const float* src, int lds, int col0, int d, const int* idx, const int* len, int T, int M, int R,
-                             float* out, int rs, int cs, const float* relu_out, int ldr, int rcol0, hipStream_t st);
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st);
 // y = LN(x + r) rows
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
                          const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st);
@@ -78,6 +73,3 @@ int launch_softmax_rows_bwd(const float* y, const float* dy, int M, int N, float
 // generic elementwise: y = a (+ b)
 int launch_add2(const float* a, const float* b, long long n, float* y, hipStream_t st);
 int launch_fill(float* p, long long n, float v, hipStream_t st);
-// column sums: out[N] (+)= sum_m x[m][n]  (small M*N; single pass with atomics-free two-level)
-int launch_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate, float* slabs, hipStream_t st);
-size_t colsum_slab_floats(int M, int N);

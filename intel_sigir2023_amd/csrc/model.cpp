@@ -927,20 +927,16 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       lin(r, r.T->dVB2, D.q_size, B, D.q_size, w.pM0T, I, dint, I, e0);
     }
   };
-  // ===== tied self-attention layers of one tower + its input gradients
-  auto tower_layers_bwd = [&](Run& r, int t, float* dXout) {
-    TowerBufs& w = y.tw[t];
+  // ===== tied self-attention layers of the item tower + its embedding-table gradients
+  auto item_tower_bwd = [&](Run& r, float* dXout) {
+    TowerBufs& w = y.tw[0];
     const int d = w.d;
     float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa);
     if (r.rc || !dX0) return;
-    if (t == 0) {
-      if (r.G(INTEL_P_IID_EMB))
-        RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
-      if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
-        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
-    } else {
-      wgrad(r, dX0, d, bt.scores, K, M, d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
-    }
+    if (r.G(INTEL_P_IID_EMB))
+      RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+    if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
+      RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
   };
   // ===== one sequence encoder: returns dE (gradient w.r.t. its input rows), scatters the table part
   auto encoder_branch = [&](Run& r, int e) -> float* {
@@ -1010,7 +1006,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     fork_streams(r, 1);
     {
       Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
-      tower_layers_bwd(b0, 0, y.tmp[0].dXa);
+      item_tower_bwd(b0, y.tmp[0].dXa);
       dE1 = encoder_branch(b1, 1);
       r.ok(b0.rc); r.ok(b1.rc);
     }

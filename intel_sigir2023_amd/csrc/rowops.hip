@@ -85,68 +85,10 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int lds, 
   if (relu_out && !(relu_out[(size_t)m * ldr + rcol0 + c] > 0.f)) v = 0.f;
   if (v != 0.f) atomicAdd(grad_table + (size_t)row * d + c, v);
 }
-// Small destination tables (item classes, positions, the [d_int, I] intent weight): thousands of
-// rows hit the same few destination rows, so global atomics serialise on them (measured 1.6 ms for
-// a 64x30 table).  Each workgroup instead accumulates its slice of rows in an LDS image of the whole
-// table (ds_add_f32) and flushes it with one global atomic per touched element.
-struct SmallScatterArgs {
-  const float* src; int lds, col0, d;
-  const int* idx;        // row index per source row, or null
-  const int* len; int T; // when idx == null && len != null: position index (t < len[b] ? t : 0)
-  int M, R;              // source rows, table rows
-  float* out; int rs, cs; // out[row*rs + c*cs]
-  const float* relu_out; int ldr, rcol0;
-  int rows_per_block;
-};
-__global__ __launch_bounds__(256) void scatter_add_small_kernel(SmallScatterArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];
-  const int n = a.R * a.d;
-  for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.f;
-  __syncthreads();
-  const int r0 = blockIdx.x * a.rows_per_block;
-  const int r1 = min(a.M, r0 + a.rows_per_block);
-  const int cnt = (r1 - r0) * a.d;
-  for (int i = threadIdx.x; i < cnt; i += 256) {
-    const int m = r0 + i / a.d, c = i % a.d;
-    int row = 0;
-    if (a.idx) row = a.idx[m];
-    else if (a.len) { const int b = m / a.T, t = m - b * a.T; row = t < a.len[b] ? t : 0; }
-    if (row < 0 || row >= a.R) continue;
-    float v = a.src[(size_t)m * a.lds + a.col0 + c];
-    if (a.relu_out && !(a.relu_out[(size_t)m * a.ldr + a.rcol0 + c] > 0.f)) v = 0.f;
-    if (v != 0.f) atomicAdd(&tab[row * a.d + c], v);
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = tab[i];
-    if (v != 0.f) atomicAdd(a.out + (size_t)(i / a.d) * a.rs + (size_t)(i % a.d) * a.cs, v);
-  }
-}
-#define SMALL_SCATTER_MAX_FLOATS 24576   // 96 KB LDS image
-int launch_scatter_add_small(const float* src, int lds, int col0, int d, const int* idx, const int* len, int T, int M, int R,
-                             float* out, int rs, int cs, const float* relu_out, int ldr, int rcol0, hipStream_t st) {
-  if (M <= 0 || d <= 0) return 0;
-  INTEL_CHECK_ARG((size_t)R * d <= SMALL_SCATTER_MAX_FLOATS, "scatter_add_small: table %d x %d too large", R, d);
-  SmallScatterArgs a;
-  a.src = src; a.lds = lds; a.col0 = col0; a.d = d; a.idx = idx; a.len = len; a.T = T; a.M = M; a.R = R; a.out = out;
-  a.rs = rs; a.cs = cs; a.relu_out = relu_out; a.ldr = ldr; a.rcol0 = rcol0;
-  int blocks = cdiv(M, 256);
-  if (blocks > 128) blocks = 128;     // every workgroup flushes the whole table: keep the flush count low
-  a.rows_per_block = cdiv(M, blocks);
-  blocks = cdiv(M, a.rows_per_block);
-  size_t smem = (size_t)R * d * sizeof(float);
-  allow_lds(scatter_add_small_kernel, smem);
-  LAUNCH_W(0.0, 4.0 * (double)M * d, scatter_add_small_kernel, dim3(blocks), dim3(256), smem, st, a);
-  INTEL_CHECK_LAUNCH();
-  return 0;
-}
-
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
-                            const float* relu_out, int ldr, int rcol0, hipStream_t st, int table_rows) {
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st) {
   long long n = (long long)M * d;
   if (n <= 0) return 0;
-  if (table_rows > 0 && (size_t)table_rows * d <= SMALL_SCATTER_MAX_FLOATS && M >= 8 * table_rows)
-    return launch_scatter_add_small(src, lds, col0, d, idx, nullptr, 0, M, table_rows, grad_table, d, 1, relu_out, ldr, rcol0, st);
   LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, col0, d, idx, M,
                      grad_table, relu_out, ldr, rcol0);
   INTEL_CHECK_LAUNCH();
@@ -374,24 +316,4 @@ int launch_fill(float* p, long long n, float v, hipStream_t st) {
   LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
   INTEL_CHECK_LAUNCH();
   return 0;
-}
-
-// column sums of a [M,N] matrix -> out[N]; per-block partials then deterministic reduce
-#define CS_ROWS 256
-size_t colsum_slab_floats(int M, int N) { return (size_t)cdiv(M, CS_ROWS) * N; }
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ldx, int M, int N, float* __restrict__ slabs) {
-  const int r0 = blockIdx.x * CS_ROWS;
-  const int r1 = min(M, r0 + CS_ROWS);
-  for (int c = threadIdx.x; c < N; c += 256) {
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ldx + c];
-    slabs[(size_t)blockIdx.x * N + c] = s;
-  }
-}
-int launch_colsum(const float* x, int ldx, int M, int N, float* out, int accumulate, float* slabs, hipStream_t st) {
-  if (N <= 0) return 0;
-  const int nb = cdiv(M, CS_ROWS);
-  LAUNCH(colsum_kernel, dim3(nb), dim3(256), 0, st, x, ldx, M, N, slabs);
-  INTEL_CHECK_LAUNCH();
-  return launch_slab_reduce(slabs, (size_t)N, nb, 1, N, out, N, accumulate, st);
 }

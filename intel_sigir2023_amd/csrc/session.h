@@ -16,11 +16,8 @@ int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d
 int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int L, float* out, int ldo, int ocol0,
                           int accumulate, hipStream_t st);
 int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st);
-int launch_add_pos_bwd(const float* dE, int dm, const int* len, int B, int T, float* dpos, hipStream_t st);
 int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
                          int col0, hipStream_t st);
-int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int I, const int* idx, int M, float* dW,
-                             float* db, hipStream_t st);
 int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, float* oh, hipStream_t st);
 int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
                           float* P, hipStream_t st);
@@ -28,7 +25,6 @@ int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const
                           int dm, int heads, float* dq, float* dkv, hipStream_t st);
 int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st);
 int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st);
-int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,
                      const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st);
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,

@@ -290,28 +290,6 @@ int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, in
   INTEL_CHECK_LAUNCH();
   return 0;
 }
-// dpos[p,:] += sum over (b,t) with position p of dE[b*T+t,:]  (atomics; tiny table)
-__global__ void add_pos_bwd_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ len, int B, int T,
-                                   float* __restrict__ dpos) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * T * dm) return;
-  const int c = (int)(i % dm);
-  const long long m = i / dm;
-  const int b = (int)(m / T), t = (int)(m - (long long)b * T);
-  const int p = t < len[b] ? t : 0;
-  const float v = dE[i];
-  if (v != 0.f) atomicAdd(dpos + (size_t)p * dm + c, v);
-}
-int launch_add_pos_bwd(const float* dE, int dm, const int* len, int B, int T, float* dpos, hipStream_t st) {
-  long long n = (long long)B * T * dm;
-  if (n <= 0) return 0;
-  if ((size_t)T * dm <= 24576)   // positions 0..T-1 only: stage the table in LDS
-    return launch_scatter_add_small(dE, dm, 0, dm, nullptr, len, T, B * T, T, dpos, dm, 1, nullptr, 0, 0, st);
-  LAUNCH(add_pos_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, dm, len, B, T, dpos);
-  INTEL_CHECK_LAUNCH();
-  return 0;
-}
-
 // one-hot intent rows of the item history (IntEL.py:142 with his_item_int one-hot):
 // E[m, col0:col0+d_int] = Wint[:, idx[m]] + bint   (idx < 0: bias only)
 __global__ void onehot_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int d_int, int I,
@@ -333,33 +311,6 @@ int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, co
   INTEL_CHECK_LAUNCH();
   return 0;
 }
-// dW[c, idx[m]] += dE[m, col0+c];  db[c] += dE[m, col0+c]   (atomics; [d_int, I] is tiny)
-__global__ void onehot_linear_bwd_kernel(const float* __restrict__ dE, int lde, int col0, int d_int, int I,
-                                         const int* __restrict__ idx, int M, float* __restrict__ dW, float* __restrict__ db) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)M * d_int) return;
-  const int c = (int)(i % d_int);
-  const int m = (int)(i / d_int);
-  const float v = dE[(size_t)m * lde + col0 + c];
-  if (v == 0.f) return;
-  const int j = idx[m];
-  if (j >= 0) atomicAdd(dW + (size_t)c * I + j, v);
-  atomicAdd(db + c, v);
-}
-int launch_onehot_linear_bwd(const float* dE, int lde, int col0, int d_int, int I, const int* idx, int M, float* dW,
-                             float* db, hipStream_t st) {
-  long long n = (long long)M * d_int;
-  if (n <= 0) return 0;
-  if ((size_t)I * d_int <= 24576) {
-    int rc = launch_scatter_add_small(dE, lde, col0, d_int, idx, nullptr, 0, M, I, dW, 1, I, nullptr, 0, 0, st);   // dW[c*I + j]
-    if (rc) return rc;
-    return launch_scatter_add_small(dE, lde, col0, d_int, nullptr, nullptr, 0, M, 1, db, 0, 1, nullptr, 0, 0, st);  // db[c]
-  }
-  LAUNCH(onehot_linear_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dE, lde, col0, d_int, I, idx, M, dW, db);
-  INTEL_CHECK_LAUNCH();
-  return 0;
-}
-
 // oh[m, :] = one_hot(row index of m) over R columns: idx[m] when idx != null, else the BERT4Rec
 // position of row m (t < len[b] ? t : 0).  The small-table gradients (position embeddings, the
 // one-hot intent rows) are then plain dY^T X products on the MFMA wgrad kernel: deterministic and
@@ -400,27 +351,6 @@ int launch_select_last(const float* E, int dm, const int* len, int B, int T, flo
   INTEL_CHECK_LAUNCH();
   return 0;
 }
-// dE = 0 except dE[b*T + len_b - 1, :] = dvec[b, col0:col0+dm]
-__global__ void select_last_bwd_kernel(const float* __restrict__ dvec, int ldv, int col0, int dm, const int* __restrict__ len,
-                                       int B, int T, float* __restrict__ dE) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)B * T * dm) return;
-  const int c = (int)(i % dm);
-  const long long m = i / dm;
-  const int b = (int)(m / T), t = (int)(m - (long long)b * T);
-  int tl = len[b] - 1;
-  tl = tl < 0 ? T + tl : tl;
-  tl = min(max(tl, 0), T - 1);
-  dE[i] = (t == tl && tl < len[b]) ? dvec[(size_t)b * ldv + col0 + c] : 0.f;
-}
-int launch_select_last_bwd(const float* dvec, int ldv, int col0, int dm, const int* len, int B, int T, float* dE, hipStream_t st) {
-  long long n = (long long)B * T * dm;
-  if (n <= 0) return 0;
-  LAUNCH(select_last_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dvec, ldv, col0, dm, len, B, T, dE);
-  INTEL_CHECK_LAUNCH();
-  return 0;
-}
-
 // copy a column block: dst[m, dcol0 + c] = src[m, scol0 + c] (optionally * (mask>0))
 __global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int scol0, int d, long long M, float* __restrict__ dst,
                                  int ldd, int dcol0, const float* __restrict__ relu_out, int ldr, int rcol0, int accumulate) {
