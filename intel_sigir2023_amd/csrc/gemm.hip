@@ -11,6 +11,8 @@
 // The k index inside a 16-wide k group is permuted (lane group j holds k = 4j..4j+3) identically
 // in A fragments and in the packed B, which is what lets both sides use 16-byte loads.
 #include <stdlib.h>
+#include <new>
+#include <vector>
 
 #include "kernels.h"
 
@@ -1246,9 +1248,189 @@ __global__ __launch_bounds__(256) void slab_reduce_wb_kernel(const float* __rest
   }
 }
 
+// ---- deferred reductions: job queue + one batched kernel per dependency round ----------------
+#define RED_MAX_JOBS 64
+struct RedJob {
+  const float* slabs; float* out; unsigned long long stride;
+  int S, n, cols, ldo;
+  int accumulate, mode, blk0, round;
+};
+struct RedJobs { int n; int pad; RedJob j[RED_MAX_JOBS]; };      // 3.6 KB of kernel arguments
+
+// mode 0: 16 output lanes x float4, 16 slab lanes; mode 1: the same, scalar; mode 2: 4 outputs x 64 slab lanes
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(RedJobs jobs) {
+  __shared__ float red[16 * 65];
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].blk0) ++ji;
+  const float* __restrict__ slabs = jobs.j[ji].slabs;
+  float* __restrict__ out = jobs.j[ji].out;
+  const size_t stride = jobs.j[ji].stride;
+  const int S = jobs.j[ji].S, n = jobs.j[ji].n, cols = jobs.j[ji].cols, ldo = jobs.j[ji].ldo;
+  const int accumulate = jobs.j[ji].accumulate, mode = jobs.j[ji].mode;
+  const int blk = blockIdx.x - jobs.j[ji].blk0;
+  if (mode == 0) {
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int i0 = (blk * 16 + o) * 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (i0 < n) {
+      int s = q;
+      for (; s + 48 < S; s += 64) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride + i0);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 16) * stride + i0);
+        const f32x4 a2 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 32) * stride + i0);
+        const f32x4 a3 = *reinterpret_cast<const f32x4*>(slabs + (size_t)(s + 48) * stride + i0);
+        s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      }
+      for (; s < S; s += 16) s0 += *reinterpret_cast<const f32x4*>(slabs + (size_t)s * stride + i0);
+    }
+    const f32x4 t = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[q * 65 + o * 4 + v] = t[v];
+    __syncthreads();
+    if (q < 4) {                       // 64 outputs of this workgroup, one per thread
+      const int i = blk * 64 + o * 4 + q;
+      if (i < n) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k * 65 + o * 4 + q];
+        const int r = i / cols, c = i - r * cols;
+        float* dst = out + (size_t)r * ldo + c;
+        *dst = accumulate ? (*dst + acc) : acc;
+      }
+    }
+  } else if (mode == 1) {
+    const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int i = blk * 16 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int s = q;
+      for (; s + 48 < S; s += 64) {
+        s0 += slabs[(size_t)s * stride + i];
+        s1 += slabs[(size_t)(s + 16) * stride + i];
+        s2 += slabs[(size_t)(s + 32) * stride + i];
+        s3 += slabs[(size_t)(s + 48) * stride + i];
+      }
+      for (; s < S; s += 16) s0 += slabs[(size_t)s * stride + i];
+    }
+    red[q * 17 + o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < n) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc += red[k * 17 + o];
+      const int r = i / cols, c = i - r * cols;
+      float* dst = out + (size_t)r * ldo + c;
+      *dst = accumulate ? (*dst + acc) : acc;
+    }
+  } else {
+    const int o = threadIdx.x & 3, q = threadIdx.x >> 2;
+    const int i = blk * 4 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+      int s = q;
+      for (; s + 192 < S; s += 256) {
+        s0 += slabs[(size_t)s * stride + i];
+        s1 += slabs[(size_t)(s + 64) * stride + i];
+        s2 += slabs[(size_t)(s + 128) * stride + i];
+        s3 += slabs[(size_t)(s + 192) * stride + i];
+      }
+      for (; s < S; s += 64) s0 += slabs[(size_t)s * stride + i];
+    }
+    red[q * 5 + o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && i < n) {
+      float acc = 0.f;
+      for (int k = 0; k < 64; ++k) acc += red[k * 5 + o];
+      const int r = i / cols, c = i - r * cols;
+      float* dst = out + (size_t)r * ldo + c;
+      *dst = accumulate ? (*dst + acc) : acc;
+    }
+  }
+}
+
+struct ReduceQueue {
+  std::vector<RedJob> jobs;
+  float* arena = nullptr;
+  size_t cap = 0, used = 0;
+  int max_round = -1;
+};
+ReduceQueue* redq_create() { return new (std::nothrow) ReduceQueue(); }
+void redq_destroy(ReduceQueue* q) { delete q; }
+void redq_reset(ReduceQueue* q, float* arena, size_t arena_floats) {
+  q->jobs.clear();
+  q->arena = arena; q->cap = arena_floats; q->used = 0; q->max_round = -1;
+}
+float* redq_alloc(ReduceQueue* q, size_t floats) {
+  const size_t need = (floats + 63) & ~(size_t)63;
+  if (!q->arena || q->used + need > q->cap) return nullptr;
+  float* p = q->arena + q->used;
+  q->used += need;
+  return p;
+}
+void redq_push(ReduceQueue* q, const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
+               int accumulate) {
+  if (!out || rows <= 0 || cols <= 0) return;
+  RedJob j;
+  j.slabs = slabs; j.out = out; j.stride = stride; j.S = S; j.n = rows * cols; j.cols = cols; j.ldo = ldo;
+  j.accumulate = accumulate; j.blk0 = 0;
+  const bool vec = ((stride & 3) == 0) && ((j.n & 3) == 0) && ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0) && j.n >= 1024;
+  j.mode = vec ? 0 : ((j.n < 1024 && S > 32) ? 2 : 1);
+  // destinations that overlap an earlier job must be reduced after it
+  const float* lo = out;
+  const float* hi = out + (size_t)(rows - 1) * ldo + cols;
+  int round = 0;
+  for (const RedJob& e : q->jobs) {
+    const float* elo = e.out;
+    const float* ehi = e.out + (size_t)(e.n / e.cols - 1) * e.ldo + e.cols;
+    if (lo < ehi && elo < hi && e.round + 1 > round) round = e.round + 1;
+  }
+  j.round = round;
+  if (round > q->max_round) q->max_round = round;
+  q->jobs.push_back(j);
+}
+int redq_flush(ReduceQueue* q, hipStream_t st) {
+  for (int rnd = 0; rnd <= q->max_round; ++rnd) {
+    RedJobs jb;
+    jb.n = 0; jb.pad = 0;
+    int blocks = 0;
+    double bytes = 0.0;
+    auto fire = [&]() -> int {
+      if (jb.n == 0) return 0;
+      LAUNCH_W(0.0, bytes, slab_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, jb);
+      INTEL_CHECK_LAUNCH();
+      jb.n = 0; blocks = 0; bytes = 0.0;
+      return 0;
+    };
+    for (const RedJob& e : q->jobs) {
+      if (e.round != rnd) continue;
+      if (jb.n == RED_MAX_JOBS) {
+        int rc = fire();
+        if (rc) return rc;
+      }
+      RedJob j = e;
+      j.blk0 = blocks;
+      blocks += cdiv(j.n, j.mode == 0 ? 64 : (j.mode == 1 ? 16 : 4));
+      bytes += 4.0 * (double)j.S * j.n;
+      jb.j[jb.n++] = j;
+    }
+    int rc = fire();
+    if (rc) return rc;
+  }
+  q->jobs.clear();
+  q->used = 0; q->max_round = -1;
+  return 0;
+}
+
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st) {
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q) {
   if (N <= 0 || K <= 0) return 0;
+  if (q) {
+    slabs = redq_alloc(q, wgrad_slab_floats(M, N, K));
+    if (!slabs) {
+      intel_set_error("wgrad: reduction arena exhausted");
+      return -2;   // INTEL_E_WORKSPACE
+    }
+  }
   WgradArgs a;
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.slabs = slabs;
   a.S = wgrad_num_slabs(M); a.want_db = db != nullptr;
@@ -1261,6 +1443,11 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   }
   INTEL_CHECK_LAUNCH();
   size_t stride = (size_t)N * K + N;
+  if (q) {
+    redq_push(q, slabs, stride, a.S, N, K, dW, lddw, accumulate);
+    if (db) redq_push(q, slabs + (size_t)N * K, stride, a.S, 1, N, db, N, accumulate);
+    return 0;
+  }
   if (db && (size_t)N * K < 4096) {     // small weight: one launch reduces dW and db together
     LAUNCH_W(0.0, 4.0 * (double)a.S * (N * K + N), slab_reduce_wb_kernel, dim3(cdiv(N * K + N, 16)), dim3(256), 0, st, slabs, stride, a.S, N, K, dW, lddw, db, accumulate);
     INTEL_CHECK_LAUNCH();

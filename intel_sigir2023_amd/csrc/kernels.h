@@ -38,8 +38,29 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 // dW[N,K] (+)= dY[M,N]^T X[M,K];  db[N] (+)= colsum(dY) when db != null.  `slabs` needs
 // wgrad_slab_floats(M,N,K) floats.
 size_t wgrad_slab_floats(int M, int N, int K);
+
+// Deferred slab reductions.  A backward pass produces ~50 small [N,K] weight gradients, each as a few
+// hundred per-workgroup partial slabs.  Reducing each one right after its producer costs two tiny
+// launches per gradient; with a queue the producers only record a job (their slabs live in an arena
+// until the flush) and one batched launch per dependency round sums everything in a fixed order.
+// Jobs whose destinations overlap (tied layer weights, the shared intent embedding) land in
+// successive rounds in push order, so the result does not depend on scheduling.
+struct ReduceQueue;
+ReduceQueue* redq_create();
+void redq_destroy(ReduceQueue* q);
+// drop queued jobs and hand the queue a fresh arena
+void redq_reset(ReduceQueue* q, float* arena, size_t arena_floats);
+// carve `floats` from the arena (256-byte aligned); nullptr when the arena is exhausted
+float* redq_alloc(ReduceQueue* q, size_t floats);
+// out[r*ldo + c] (+)= sum_s slabs[s*stride + r*cols + c]
+void redq_push(ReduceQueue* q, const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
+               int accumulate);
+int redq_flush(ReduceQueue* q, hipStream_t st);
+
+// with q == nullptr the reduction is launched immediately and `slabs` is used; with a queue the
+// partials go to the queue's arena and dW / db are valid only after redq_flush
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st);
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
 
 // ---- attention (attn.hip) -------------------------------------------------------------------
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
@@ -65,7 +86,7 @@ int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M
 size_t ln_bwd_slab_floats(int M, int N);
 int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
                          const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
-                         float* slabs, hipStream_t st);
+                         float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
 // softmax over rows of length N (in place allowed)
 int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st);
 // dx = y * (dy - sum(dy*y))

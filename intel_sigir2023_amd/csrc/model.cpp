@@ -81,6 +81,8 @@ struct Layout {
   float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN;
   float *dXS;       // gradient w.r.t. the score tower output, parked between the two backward phases
   float *ONEHOT2;   // one-hot of the item-history intent indices (used on the main stream after a join)
+  float *ARENA;     // slabs of the deferred reductions (ReduceQueue)
+  size_t arena_floats;
   size_t total;
 };
 
@@ -99,6 +101,8 @@ struct IntelCtx {
   hipStream_t side[3];
   hipEvent_t ev_fork, ev_join[3];
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
+  // weight-gradient / LayerNorm partial sums of a backward phase, reduced together when the phase ends
+  ReduceQueue* rq;
 };
 
 namespace {
@@ -293,6 +297,26 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     t.dINT = ar.f((size_t)B * I);
     t.SLABS = ar.f(slab + 1024);
   }
+  // arena of the deferred reductions: every weight gradient of one backward keeps its slabs until the flush
+  {
+    auto Wf = [&](size_t rows, size_t N, size_t Kk) { return rup_sz(wgrad_slab_floats((int)rows, (int)N, (int)Kk), 64); };
+    auto Lf = [&](size_t rows, size_t N) { return 2 * rup_sz(ln_bwd_slab_floats((int)rows, (int)N), 64); };
+    const size_t mx = (size_t)(dmax > I ? dmax : I), qs = (size_t)D.q_size;
+    size_t a = 0;
+    a += (size_t)D.layers * (5 * Wf(M, d_i, d_i) + Lf(M, d_i));
+    a += (size_t)D.layers * (5 * Wf(M, d_s, d_s) + Lf(M, d_s));
+    if (D.encoder == INTEL_ENC_BERT4REC) {
+      a += (size_t)D.enc_layers * (6 * Wf((size_t)B * H, dm0, dm0) + Lf((size_t)B * H, dm0)) + Lf((size_t)B * H, dm0) + Wf((size_t)B * H, H, dm0);
+      a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
+    }
+    a += 2 * Wf(D.cross_attention ? B : M, K, y.F);                       // fusion weights (+ pad rows)
+    a += Wf(B, D.d_int, I) + Wf(B, I, y.Pin) + Wf(M, d_s, K);             // intent embedding, predictor, score embedding
+    a += Wf((size_t)B * H, D.d_int, I) + Wf((size_t)B * Hi, D.d_int, I);  // shared intent embedding from the histories
+    a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
+    a += 2 * (Wf(B, mx, qs) + Wf(B, qs, mx));                             // gate MLPs (cross_attention = 0)
+    y.arena_floats = a + 4096;
+    y.ARENA = ar.f(y.arena_floats);
+  }
   y.total = rup_sz(ar.off, 256) + 256;
 }
 
@@ -386,7 +410,7 @@ void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, in
   if (!dW) return;
   int a = r.acc(w_slot);
   if (b_slot >= 0) { int ab = r.acc(b_slot); (void)ab; }
-  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, r.T->SLABS, r.st));
+  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
 }
 
 // ---- weight packing -------------------------------------------------------------------------
@@ -521,7 +545,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
       int a = r.acc(pb + T_LNG);
       r.acc(pb + T_LNB);
       if (!r.ok(launch_layernorm_bwd(dX, d, b.XH, d, b.RSTD, M, d, r.P(pb + T_LNG), r.T->dZ, d, r.G(pb + T_LNG), r.G(pb + T_LNB), a,
-                                     r.T->SLABS, r.st)))
+                                     nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
     wgrad(r, r.T->dZ, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
@@ -646,7 +670,7 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dvec, y.Pin, q.XH2, dm, q.RSTD2, B, dm, r.P(sg), dZl, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dvec, y.Pin, q.XH2, dm, q.RSTD2, B, dm, r.P(sg), dZl, dm, r.G(sg), r.G(sb), a, nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
     wgrad(r, dZl, dm, q.F1, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
@@ -662,7 +686,7 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dCl, dm, q.XH1, dm, q.RSTD1, B, dm, r.P(sg), dSl, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dCl, dm, q.XH1, dm, q.RSTD1, B, dm, r.P(sg), dSl, dm, r.G(sg), r.G(sb), a, nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
     // attention of the single query row: dS is both d(attention output) and the residual into Xlast
@@ -686,7 +710,7 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN2G), sb = enc_blk_slot(e, l, INTEL_ENC_LN2B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(dX, dm, k.XH2, dm, k.RSTD2, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(dX, dm, k.XH2, dm, k.RSTD2, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
     wgrad(r, r.T->dZ, dm, k.F1, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
@@ -704,7 +728,7 @@ float* bert_bwd(Run& r, int e) {
       const int sg = enc_blk_slot(e, l, INTEL_ENC_LN1G), sb = enc_blk_slot(e, l, INTEL_ENC_LN1B);
       int a = r.acc(sg);
       r.acc(sb);
-      if (!r.ok(launch_layernorm_bwd(r.T->dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, r.T->SLABS, r.st)))
+      if (!r.ok(launch_layernorm_bwd(r.T->dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
     if (!r.ok(launch_attn_bwd(k.QKV, k.A, r.T->dZ, k.LSE, B, T, dm, D.enc_heads, len, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
@@ -725,7 +749,7 @@ float* bert_bwd(Run& r, int e) {
     if (!r.ok(launch_make_onehot(nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;
     if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
     r.acc(ps);
-    if (!r.ok(launch_wgrad(r.T->ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, r.T->SLABS, r.st))) return nullptr;
+    if (!r.ok(launch_wgrad(r.T->ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, nullptr, r.st, r.ctx->rq))) return nullptr;
   }
   return dX;
 }
@@ -863,6 +887,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   GemmEpilogue e0;
   GemmEpilogue eacc;
   eacc.accumulate = 1;
+  redq_reset(r.ctx->rq, y.ARENA, y.arena_floats);
   if (phase != 2) {
     memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
     // embedding tables accumulate with atomics into caller-zeroed buffers
@@ -875,7 +900,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
       if (r.rc) return;
       if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
-        RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, r.T->SLABS, r.st));
+        RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, nullptr, r.st, r.ctx->rq));
       }
       lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
       lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
@@ -1015,6 +1040,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.T = &y.tmp[0];
     intent_wgrad(r, 1, dE1);
     if (r.rc) return;
+    RUN(redq_flush(r.ctx->rq, r.st));
   }
   if (phase != 1) {
     // phase 2 branches: score tower layers (main, set 0) || session-history encoder (side 0, set 1)
@@ -1035,6 +1061,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     if (r.rc || !dE0) return;
     r.T = &y.tmp[0];
     intent_wgrad(r, 0, dE0);
+    if (r.rc) return;
+    RUN(redq_flush(r.ctx->rq, r.st));
   }
 }
 
@@ -1074,6 +1102,11 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->have_layout = false;
   c->fwd_done = false;
   c->streams = 0;
+  c->rq = redq_create();
+  if (!c->rq) {
+    delete c;
+    return nullptr;
+  }
   return c;
 }
 
@@ -1086,6 +1119,7 @@ extern "C" void intel_destroy(IntelCtx* ctx) {
     }
     (void)hipEventDestroy(ctx->ev_fork);
   }
+  redq_destroy(ctx->rq);
   delete ctx;
 }
 

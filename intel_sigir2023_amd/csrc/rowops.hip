@@ -237,12 +237,24 @@ __global__ __launch_bounds__(256) void slab_reduce_pair_kernel(const float* __re
 
 int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
                          const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
-                         float* slabs, hipStream_t st) {
+                         float* slabs, hipStream_t st, ReduceQueue* q) {
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm_bwd: N=%d unsupported", N);
   const int nb = ln_bwd_blocks(M);
+  if (q) {
+    slabs = redq_alloc(q, ln_bwd_slab_floats(M, N));
+    if (!slabs) {
+      intel_set_error("layernorm_bwd: reduction arena exhausted");
+      return -2;   // INTEL_E_WORKSPACE
+    }
+  }
   LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
   INTEL_CHECK_LAUNCH();
+  if (q) {
+    redq_push(q, slabs, (size_t)2 * N, nb, 1, N, dgamma, N, accumulate);
+    redq_push(q, slabs + N, (size_t)2 * N, nb, 1, N, dbeta, N, accumulate);
+    return 0;
+  }
   LAUNCH_W(0.0, 8.0 * (double)nb * N, slab_reduce_pair_kernel, dim3(cdiv(2 * N, 4)), dim3(256), 0, st, slabs, nb, N, dgamma, dbeta, accumulate);
   INTEL_CHECK_LAUNCH();
   return 0;
