@@ -221,8 +221,10 @@ int intel_op_linear_wgrad(const float* dy, const float* x, int M, int N, int K, 
  * (modules/layers.py:50-60); key_len NULL = all T rows are keys. */
 int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,
                        float* lse, void* stream);
+/* workspace: intel_op_attention_bwd_workspace_bytes(B, T, d, heads) bytes of device memory. */
+size_t intel_op_attention_bwd_workspace_bytes(int B, int T, int d, int heads);
 int intel_op_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, int B,
-                           int T, int d, int heads, const int* key_len, float* d_qkv, float* dsum_ws,
+                           int T, int d, int heads, const int* key_len, float* d_qkv, float* workspace,
                            void* stream);
 /* y = LayerNorm(x + r) (r may be NULL), eps 1e-5; xhat/rstd optional stash. */
 int intel_op_add_layernorm(const float* x, const float* r, int M, int N, const float* gamma, const float* beta,

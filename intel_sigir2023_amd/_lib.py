@@ -104,7 +104,7 @@ EXPORTS = [
     'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_list_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
-    'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd',
+    'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
     'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect',
 ]
 
@@ -138,6 +138,7 @@ def _declare(l):
     sig('intel_op_linear_wgrad', i, [vp, vp, i, i, i, vp, vp, vp, sz, vp])
     sig('intel_op_attention', i, [vp, i, i, i, i, vp, vp, vp, vp])
     sig('intel_op_attention_bwd', i, [vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp])
+    sig('intel_op_attention_bwd_workspace_bytes', sz, [i, i, i, i])
     sig('intel_op_add_layernorm', i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp])
     sig('intel_op_workspace_bytes', sz, [i, i, i])
     sig('intel_prof_enable', None, [i])

@@ -67,10 +67,15 @@ extern "C" int intel_op_attention(const float* qkv, int B, int T, int d, int hea
   return launch_attn_fwd(qkv, B, T, d, heads, key_len, out, lse, (hipStream_t)stream);
 }
 
+extern "C" size_t intel_op_attention_bwd_workspace_bytes(int B, int T, int d, int heads) {
+  if (B <= 0 || T <= 0 || d <= 0 || heads <= 0) return 0;
+  return attn_bwd_scratch_floats(B, T, d, heads) * sizeof(float);
+}
+
 extern "C" int intel_op_attention_bwd(const float* qkv, const float* out, const float* d_out, const float* lse, int B,
-                                      int T, int d, int heads, const int* key_len, float* d_qkv, float* dsum_ws,
+                                      int T, int d, int heads, const int* key_len, float* d_qkv, float* workspace,
                                       void* stream) {
-  return launch_attn_bwd(qkv, out, d_out, lse, B, T, d, heads, key_len, d_qkv, dsum_ws, (hipStream_t)stream);
+  return launch_attn_bwd(qkv, out, d_out, lse, B, T, d, heads, key_len, d_qkv, workspace, (hipStream_t)stream);
 }
 
 extern "C" int intel_op_add_layernorm(const float* x, const float* r, int M, int N, const float* gamma,

@@ -66,9 +66,10 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                     hipStream_t st);
-// dsum: scratch [B*heads*T]
+// scratch: attn_bwd_scratch_floats(B, T, d, heads) floats (row sums of dO*O; dS tiles of the whole-sequence path)
+size_t attn_bwd_scratch_floats(int B, int T, int d, int heads);
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                    int heads, const int* key_len, float* dqkv, float* dsum, hipStream_t st);
+                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st);
 
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu

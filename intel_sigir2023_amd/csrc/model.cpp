@@ -214,7 +214,8 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   y.LOGITS = ar.f((size_t)B * I);
   y.INTENTS = ar.f((size_t)B * I);
   size_t maxMD = (size_t)M * (d_i > d_s ? d_i : d_s);
-  size_t maxLSE = (size_t)B * D.heads * L;
+  size_t maxLSE = attn_bwd_scratch_floats(B, L, d_i, D.heads);      // attention-backward scratch of the largest user
+  if (attn_bwd_scratch_floats(B, L, d_s, D.heads) > maxLSE) maxLSE = attn_bwd_scratch_floats(B, L, d_s, D.heads);
   for (int e = 0; e < 2; ++e) {
     EncBufs& n = y.enc[e];
     const size_t rows = (size_t)B * n.T, md = rows * n.dm;
@@ -242,7 +243,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
         k.XH2 = ar.f(md);
         k.RSTD2 = ar.f(rows);
       }
-      if ((size_t)B * D.enc_heads * n.T > maxLSE) maxLSE = (size_t)B * D.enc_heads * n.T;
+      if (attn_bwd_scratch_floats(B, n.T, n.dm, D.enc_heads) > maxLSE) maxLSE = attn_bwd_scratch_floats(B, n.T, n.dm, D.enc_heads);
     } else {
       gru_layout_act(n.gru, B, n.T, n.dm, D.gru_hidden, ar.base, ar.off);
     }

@@ -53,7 +53,8 @@ def attention(qkv, B, T, d, heads, key_len=None):
 
 def attention_bwd(qkv, out, dout, lse, B, T, d, heads, key_len=None):
     dqkv = torch.empty_like(qkv)
-    dsum = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)
+    nbytes = L.lib().intel_op_attention_bwd_workspace_bytes(B, T, d, heads)
+    dsum = torch.empty(max(1, nbytes // 4), dtype=torch.float32, device=qkv.device)
     L.check(L.lib().intel_op_attention_bwd(L.ptr(qkv), L.ptr(out), L.ptr(dout), L.ptr(lse), B, T, d, heads,
                                            L.ptr(key_len), L.ptr(dqkv), L.ptr(dsum), L.stream_ptr(qkv.device)),
             'intel_op_attention_bwd')

@@ -60,7 +60,11 @@ def _attn_ref(qkv, B, T, d, heads, key_len):
 
 @pytest.mark.parametrize('B,T,d,heads,masked', [(3, 50, 128, 1, False), (2, 50, 64, 2, False), (4, 20, 128, 2, True),
                                                 (2, 200, 128, 2, False), (2, 200, 128, 2, True), (3, 37, 32, 2, True),
-                                                (2, 70, 32, 1, False), (2, 100, 96, 2, True), (3, 9, 16, 2, False)])
+                                                (2, 70, 32, 1, False), (2, 100, 96, 2, True), (3, 9, 16, 2, False),
+                                                # whole-sequence kernels (T <= 64, head dim 64 / 128): every tile count, ragged pair counts
+                                                (5, 20, 128, 2, True), (3, 16, 64, 1, False), (7, 10, 128, 1, True), (3, 33, 128, 1, True),
+                                                (2, 48, 128, 2, True), (5, 64, 64, 1, True), (3, 50, 256, 2, False), (2, 20, 64, 1, False),
+                                                (9, 50, 128, 1, True), (6, 1, 64, 1, False)])
 def test_attention_fwd_bwd(B, T, d, heads, masked):
     from intel_sigir2023_amd import ops
     dev = _dev()
