@@ -1,0 +1,571 @@
+// Whole-sequence attention for T <= 64 and head dim 64 / 128 (the IntEL towers at list length 50, the
+// BERT4Rec blocks at history length 20): restates modules/layers.py:50-60 like attn.hip, for the shapes where
+// everything a (session, head) pair needs fits in LDS at once.
+//
+//   * wave = one 16-row tile of one pair; PW = 4 / ceil(T/16) pairs share a workgroup ("item" = those PW pairs);
+//   * persistent workgroups loop over items; the operand rows of item i+1 are copied global -> LDS by the DMA
+//     path (global_load_lds_dwordx4) while item i is computed: two LDS stages, no staging registers.  A DMA
+//     instruction writes 1 KB linearly, so rows are unpadded and the 16-byte chunk index is XOR-swizzled with
+//     (row & 15) on the per-lane source address and again when fragments are read.  Rows >= T are never
+//     copied: the stages are zeroed once and T is the same for every item, so padding rows stay zero;
+//   * rows are staged PERMUTED inside each 16-row tile (row 4a+b -> slot 4b+a): accumulator row 4j+r then is
+//     key (query) 4r+j, so k-step s of the following product covers rows 4s..4s+3 and the k-steps that hold
+//     only padding are dropped AT COMPILE TIME (template LS = live k-steps of the last tile; a runtime branch
+//     around accumulating MFMAs makes the compiler shuttle every accumulator between AGPRs and VGPRs);
+//   * "transposed" operands (V^T, dO^T, Q^T, K^T) are read as one b128 along the head dim: lane p takes dims
+//     4p..4p+3 of its row and feeds FOUR MFMAs whose output row p means dim 4p+t -- the output rows of the
+//     four tiles interleave and the epilogue stores float4s;
+//   * softmax in base 2 (v_exp_f32 on fma(s, c, -m c), c = log2(e)/sqrt(dk)): 6 VALU instructions per logit;
+//     at one or two waves per SIMD every VALU instruction is time the MFMA pipe idles.
+//   * backward = dK/dV kernel that also writes dS[q][key] (S and dP are computed once: 5 tile products instead
+//     of 7) + a dQ = dS K kernel; delta = rowsum(dO * O) = rowsum(P * dP) is reduced across the four key-tile
+//     waves through LDS, so O is not read at all.
+#include <stdio.h>
+#include <stdlib.h>
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int perm16(int r) { return (r & ~15) | ((r & 3) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float gsum16(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+template <int DKT, int NT>
+struct SeqP {
+  static constexpr int DK = DKT * 16;
+  static constexpr int PW = 4 / NT;                   // pairs per item
+  static constexpr int TP = NT * 16;                  // padded rows per pair
+  static constexpr int ROWS = PW * TP;
+  static constexpr int CPR = DKT * 4;                 // 16-byte chunks per row
+  static constexpr int BUF = ROWS * DK;               // floats per matrix per stage
+  static constexpr int IPW = ROWS * CPR / 256;        // DMA instructions per wave per matrix per stage
+};
+
+// per-lane constants of the DMA instructions of this wave: source row in the pair, source column, pair slot
+template <int DKT, int NT, bool PERM>
+struct DmaSlots {
+  int rho[SeqP<DKT, NT>::IPW], col[SeqP<DKT, NT>::IPW], slot[SeqP<DKT, NT>::IPW];
+  unsigned live;        // bit j: instruction j holds at least one row < T (wave-uniform)
+  __device__ __forceinline__ void init(int wave, int lane, int T) {
+    using C = SeqP<DKT, NT>;
+    live = 0;
+#pragma unroll
+    for (int j = 0; j < C::IPW; ++j) {
+      const int lin = (wave * C::IPW + j) * 64 + lane;
+      const int R = lin / C::CPR, pch = lin - R * C::CPR;
+      const int sl = R / C::TP, r = R - sl * C::TP;
+      const int rr = PERM ? perm16(r) : r;
+      slot[j] = sl;
+      col[j] = (pch ^ (R & 15)) * 4;
+      if (__ballot(rr < T) != 0ull) live |= 1u << j;
+      rho[j] = min(rr, T - 1);          // lanes of a live instruction that sit on a padding row copy row T-1 (finite, unused)
+    }
+  }
+};
+
+// fragment of one row ("row on the lane" operand form): element s of group g = x[row][g*16 + 4*(lane>>4) + s]
+template <int DKT>
+__device__ __forceinline__ void load_row_frags(f32x4 (&f)[DKT], const float* __restrict__ rowp, bool rowok, int dk, int lane) {
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) {
+    const int col = g * 16 + 4 * (lane >> 4);
+    f[g] = (rowok && col < dk) ? *reinterpret_cast<const f32x4*>(rowp + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+__device__ __forceinline__ void split_pair(int bh, int heads, int& b, int& h) {
+  b = bh;
+  h = 0;
+  if (heads > 1) {
+    b = bh / heads;
+    h = bh - b * heads;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int DKT, int NT, int LS>
+__global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restrict__ qkv, int BH, int T, int d, int heads,
+                                                           const int* __restrict__ key_len, float c2, float scale,
+                                                           float* __restrict__ out, float* __restrict__ lse) {
+  using C = SeqP<DKT, NT>;
+  constexpr int DK = C::DK, DQ = DKT / 4, NSTEPS = (NT - 1) * 4 + LS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [stage][K | V][ROWS][DK]
+  const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ldg = 3 * d;
+  const int nitems = (BH + C::PW - 1) / C::PW;
+  const int slot = wave / NT, tile = wave - slot * NT;
+  const bool wlive = slot < C::PW;
+  for (int i = tid; i < C::BUF; i += 256) reinterpret_cast<f32x4*>(smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // 4 BUF floats
+  DmaSlots<DKT, NT, true> ds;
+  ds.init(wave, lane, T);
+  auto dma_item = [&](int it, float* stage) {
+#pragma unroll
+    for (int jj = 0; jj < C::IPW; ++jj) {
+      if (!((ds.live >> jj) & 1u)) continue;
+      int b, h;
+      split_pair(min(it * C::PW + ds.slot[jj], BH - 1), heads, b, h);
+      // (pointers in plain locals: the builtin's argument check mishandles template-dependent expressions)
+      const float* srck = qkv + ((size_t)b * T + ds.rho[jj]) * ldg + d + h * DK + ds.col[jj];
+      const float* srcv = srck + d;
+      float* dstk = stage + (wave * C::IPW + jj) * 256;
+      float* dstv = dstk + C::BUF;
+      __builtin_amdgcn_global_load_lds(srck, dstk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(srcv, dstv, 16, 0, 0);
+    }
+  };
+  auto load_q = [&](int it, f32x4 (&qf)[DKT]) {
+    int b, h;
+    split_pair(min(it * C::PW + slot, BH - 1), heads, b, h);
+    const float* rowp = qkv + ((size_t)b * T + min(tile * 16 + p, T - 1)) * ldg + h * DK + 4 * j;
+#pragma unroll
+    for (int g = 0; g < DKT; ++g) qf[g] = *reinterpret_cast<const f32x4*>(rowp + g * 16);
+  };
+  int it = blockIdx.x;
+  const int G = gridDim.x;
+  __syncthreads();
+  dma_item(it, smem);
+  if (it + G < nitems) dma_item(it + G, smem + 2 * C::BUF);
+  f32x4 qf[DKT], qn[DKT];
+  load_q(it, qf);
+  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+  __syncthreads();
+  int cur = 0;
+  for (; it < nitems; it += G) {
+    const float* Kp = smem + cur * 2 * C::BUF + slot * C::TP * DK;
+    const float* Vp = Kp + C::BUF;
+    if (it + G < nitems) load_q(it + G, qn);
+    const int bh = it * C::PW + slot;
+    const bool live = wlive && bh < BH;
+    int b, h;
+    split_pair(live ? bh : 0, heads, b, h);
+    const int q = tile * 16 + p;
+    const bool qok = live && q < T;
+    const int nkeys = key_len ? min(key_len[b], T) : T;
+    f32x4 st[NT];
+    f32x4 oT[DKT];
+    float ps = 0.f, mref = 0.f;
+    if (wlive) {
+      // S^T tiles; operand fragments are fetched one k-group ahead of the MFMAs that consume them
+      f32x4 kf[2][NT];
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt) {
+        st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kf[0][kt] = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + p) * DK + ((j ^ p) << 2));
+      }
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        if (g + 1 < DKT) {
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt)
+            kf[(g + 1) & 1][kt] = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + p) * DK + ((((g + 1) * 4 + j) ^ p) << 2));
+        }
+        __builtin_amdgcn_sched_barrier(0);      // the prefetch stays above the MFMAs it overlaps
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt) st[kt] = mfma16(kf[g & 1][kt][s], qf[g][s], st[kt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // first V fragment rides under the softmax
+      f32x4 vv[2][DQ];
+      auto load_v = [&](int step, f32x4 (&dst)[DQ]) {
+        const int row = (step >> 2) * 16 + 4 * j + (step & 3);
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) dst[dq] = *reinterpret_cast<const f32x4*>(Vp + row * DK + (((dq * 16 + p) ^ (row & 15)) << 2));
+      };
+      load_v(0, vv[0]);
+      // accumulator row 4j+r of tile kt is key kt*16 + 4r + j: valid iff j < nkeys - (kt*16 + 4r)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = j < nkeys - (kt * 16 + 4 * r) ? st[kt][r] : -INFINITY;
+          st[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = gmax16(mx);
+      mref = mx == -INFINITY ? 0.f : mx;
+      const float moff = -mref * c2;
+#pragma unroll
+      for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c2, moff));
+          st[kt][r] = e;
+          ps += e;
+        }
+      ps = gsum16(ps);
+#pragma unroll
+      for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int step = 0; step < NSTEPS; ++step) {
+        if (step + 1 < NSTEPS) load_v(step + 1, vv[(step + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = mfma16(vv[step & 1][dq][t], st[step >> 2][step & 3], oT[dq * 4 + t]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the copy into the other stage (issued one item ago) and the next query fragments had this whole compute
+    // phase to land
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    if (qok) {
+      const float inv = ps > 0.f ? 1.f / ps : 0.f;
+      float* orow = out + ((size_t)b * T + q) * d + h * DK;
+#pragma unroll
+      for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 o = f32x4{oT[dq * 4 + 0][r], oT[dq * 4 + 1][r], oT[dq * 4 + 2][r], oT[dq * 4 + 3][r]} * inv;
+          *reinterpret_cast<f32x4*>(orow + dq * 64 + 16 * j + 4 * r) = o;
+        }
+      // natural-log lse, as the backward kernels and the general path use it
+      if (lane < 16) lse[(size_t)bh * T + q] = ps > 0.f ? mref * scale + __logf(ps) : INFINITY;
+    }
+    __syncthreads();
+    if (it + 2 * G < nitems) dma_item(it + 2 * G, smem + cur * 2 * C::BUF);
+    cur ^= 1;
+#pragma unroll
+    for (int g = 0; g < DKT; ++g) qf[g] = qn[g];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward (register-staged, one item per workgroup)
+// ------------------------------------------------------------------------------------------
+template <int DKT, int NT>
+struct SeqCfg {
+  static constexpr int LD = DKT * 16 + 4;
+  static constexpr int DK = DKT * 16;
+  static constexpr int PW = 4 / NT;          // pairs per workgroup
+  static constexpr int TP = NT * 16;         // padded rows per pair
+  static constexpr int ROWS = PW * TP;
+  static constexpr int C4 = DKT * 4;         // float4 per row
+  static constexpr int ITERS = ROWS * C4 / 256;
+};
+
+// address of float4 #i of the staged block: LDS row rl (pair slot, row in pair), source row, validity
+template <int DKT, int NT, bool PERM>
+__device__ __forceinline__ bool seq_src(int i, int bh0, int BH, int T, int heads, int& rl, int& c4, size_t& grow, int& hcol) {
+  using C = SeqCfg<DKT, NT>;
+  rl = i / C::C4;
+  c4 = i - rl * C::C4;
+  const int sl = rl / C::TP, r = rl - sl * C::TP;
+  const int rho = PERM ? perm16(r) : r;
+  const int bh = bh0 + sl;
+  int b = bh, h = 0;
+  if (heads > 1) { b = bh / heads; h = bh - b * heads; }
+  grow = (size_t)b * T + rho;
+  hcol = h * C::DK + c4 * 4;
+  return bh < BH && rho < T;
+}
+
+// stage the same rows of two matrices (all loads in flight before the first LDS store)
+template <int DKT, int NT, bool PERM, bool TWO>
+__device__ __forceinline__ void stage_seq2(float* dst0, const float* __restrict__ src0, int ld0, int coff0, float* dst1,
+                                           const float* __restrict__ src1, int ld1, int coff1, int bh0, int BH, int T,
+                                           int heads, int tid) {
+  using C = SeqCfg<DKT, NT>;
+  f32x4 v0[C::ITERS], v1[C::ITERS];
+#pragma unroll
+  for (int it = 0; it < C::ITERS; ++it) {
+    int rl, c4, hcol;
+    size_t grow;
+    const bool ok = seq_src<DKT, NT, PERM>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol);
+    // unconditional loads from a clamped (always valid) address + select: keeps the staging registers scalarised
+    const size_t gr = ok ? grow : 0;
+    const int hc = ok ? hcol : 0;
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 t0 = *reinterpret_cast<const f32x4*>(src0 + gr * ld0 + coff0 + hc);
+    v0[it] = ok ? t0 : zero;
+    if (TWO) {
+      const f32x4 t1 = *reinterpret_cast<const f32x4*>(src1 + gr * ld1 + coff1 + hc);
+      v1[it] = ok ? t1 : zero;
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < C::ITERS; ++it) {
+    const int i = tid + it * 256;
+    const int rl = i / C::C4, c4 = i - rl * C::C4;
+    *reinterpret_cast<f32x4*>(dst0 + rl * C::LD + c4 * 4) = v0[it];
+    if (TWO) *reinterpret_cast<f32x4*>(dst1 + rl * C::LD + c4 * 4) = v1[it];
+  }
+}
+
+// dK, dV of a 16-key tile + the dS tile column for the dQ kernel.  dS layout: [BH][TP][TP], row = query.
+template <int DKT, int NT, int LS>
+__global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse,
+                                                              int BH, int T, int d, int heads, const int* __restrict__ key_len,
+                                                              float c2, float scale, float* __restrict__ dqkv, float* __restrict__ dS) {
+  using C = SeqCfg<DKT, NT>;
+  constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP, NSTEPS = (NT - 1) * 4 + LS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Os = smem + C::ROWS * LD;
+  float* Ls = smem + 2 * C::ROWS * LD;
+  float* Ds = Ls + C::ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 4, p = lane & 15;
+  const int bh0 = blockIdx.x * C::PW, ldg = 3 * d;
+  const int slot = wave / NT, tile = wave - slot * NT, bh = bh0 + slot;
+  const bool live = slot < C::PW && bh < BH;
+  int b = live ? bh : 0, h = 0;
+  if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
+  const int key = tile * 16 + p;
+  const bool kok = live && key < T;
+  f32x4 kf[DKT], vf[DKT];
+  load_row_frags<DKT>(kf, qkv + ((size_t)b * T + key) * ldg + d + h * DK, kok, DK, lane);
+  load_row_frags<DKT>(vf, qkv + ((size_t)b * T + key) * ldg + 2 * d + h * DK, kok, DK, lane);
+  {
+    // stage Q and dO (permuted rows); delta[row] = sum_d dO * O rides along: the C4 lanes of a row are adjacent
+    f32x4 vq[C::ITERS], vo[C::ITERS];
+    float dot[C::ITERS];
+#pragma unroll
+    for (int it = 0; it < C::ITERS; ++it) {
+      int rl, c4, hcol;
+      size_t grow;
+      const bool ok = seq_src<DKT, NT, true>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol);
+      const size_t gr = ok ? grow : 0;
+      const int hc = ok ? hcol : 0;
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 tq = *reinterpret_cast<const f32x4*>(qkv + gr * ldg + hc);
+      const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(out + gr * d + hc);
+      vq[it] = ok ? tq : zero;
+      vo[it] = ok ? to : zero;
+      dot[it] = ok ? (to[0] * w[0] + to[1] * w[1] + to[2] * w[2] + to[3] * w[3]) : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < C::ITERS; ++it) {
+      const int i = tid + it * 256;
+      const int rl = i / C::C4, c4 = i - rl * C::C4;
+      *reinterpret_cast<f32x4*>(Qs + rl * LD + c4 * 4) = vq[it];
+      *reinterpret_cast<f32x4*>(Os + rl * LD + c4 * 4) = vo[it];
+      float s = dot[it];
+#pragma unroll
+      for (int m = 1; m < C::C4; m <<= 1) s += __shfl_xor(s, m);
+      if (c4 == 0) Ds[rl] = s;
+    }
+    if (tid < C::ROWS) {
+      const int sl = tid / TP, r = tid - sl * TP, rho = perm16(r), bb = bh0 + sl;
+      Ls[tid] = (bb < BH && rho < T) ? -1.44269504088896340736f * lse[(size_t)bb * T + rho] : -INFINITY;   // -lse in base 2
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const bool key_live = key < nkeys;             // masked keys get exactly zero gradient
+  const float* Qp = Qs + slot * TP * LD;
+  const float* Op = Os + slot * TP * LD;
+  const float* Lp = Ls + slot * TP;
+  const float* Dp = Ds + slot * TP;
+  float* dSp = dS + (size_t)bh * TP * TP;
+  f32x4 dkT[DKT], dvT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) {
+    dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        const int off = (qt * 16 + p) * LD + g * 16 + 4 * j;
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(Qp + off);
+        const f32x4 oa = *reinterpret_cast<const f32x4*>(Op + off);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sa = mfma16(qa[s], kf[g][s], sa);     // S[query slot][key]
+          dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
+        }
+      }
+      f32x4 pr, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = qt * 16 + 4 * j + r;     // staged slot of accumulator row 4j+r; its query is 4r+j
+        const int qg = qt * 16 + 4 * r + j;
+        const float pv = key_live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, Lp[rl])) : 0.f;
+        pr[r] = pv;
+        ds[r] = pv * (dp[r] - Dp[rl]) * scale;
+        if (qg < T && key < T) dSp[(size_t)qg * TP + key] = ds[r];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (qt * 4 + s >= NSTEPS) continue;     // queries 4s..4s+3 of the tile are padding (compile-time)
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          const int off = (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p;
+          const f32x4 ov = *reinterpret_cast<const f32x4*>(Op + off);
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qp + off);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
+            dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
+          }
+        }
+      }
+    }
+  }
+  if (kok) {
+    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK;
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = dq * 64 + 16 * j + 4 * r;
+        *reinterpret_cast<f32x4*>(drow + d + col) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
+        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
+      }
+  }
+}
+
+// dQ[q][dim] = sum_key dS[q][key] K[key][dim]  (dS already carries 1/sqrt(dk))
+template <int DKT, int NT>
+__global__ __launch_bounds__(256, 3) void attn_seq_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dS,
+                                                             int BH, int T, int d, int heads, const int* __restrict__ key_len,
+                                                             float* __restrict__ dqkv) {
+  using C = SeqCfg<DKT, NT>;
+  constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 4, p = lane & 15;
+  const int bh0 = blockIdx.x * C::PW, ldg = 3 * d;
+  const int slot = wave / NT, tile = wave - slot * NT, bh = bh0 + slot;
+  const bool live = slot < C::PW && bh < BH;
+  int b = live ? bh : 0, h = 0;
+  if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
+  const int q = tile * 16 + p;
+  const bool qok = live && q < T;
+  const int nkeys = live ? (key_len ? min(key_len[b], T) : T) : 0;
+  f32x4 dsT[NT];
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+    dsT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (qok && kt * 16 < nkeys) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dS + ((size_t)bh * TP + q) * TP + kt * 16 + 4 * j);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dsT[kt][s] = (kt * 16 + 4 * j + s < nkeys) ? v[s] : 0.f;
+    }
+  }
+  stage_seq2<DKT, NT, false, false>(Ks, qkv, ldg, d, nullptr, nullptr, 0, 0, bh0, BH, T, heads, tid);
+  __syncthreads();
+  if (!live) return;
+  const float* Kp = Ks + slot * TP * LD;
+  f32x4 dqT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int dq = 0; dq < DQ; ++dq) {
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dqT[dq * 4 + t] = mfma16(kv[t], dsT[kt][s], dqT[dq * 4 + t]);
+      }
+    __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads of later tiles from being hoisted (register pressure)
+  }
+  if (qok) {
+    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * DK;
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) =
+            f32x4{dqT[dq * 4 + 0][r], dqT[dq * 4 + 1][r], dqT[dq * 4 + 2][r], dqT[dq * 4 + 3][r]};
+  }
+}
+
+}  // namespace
+
+#define SEQ_DISPATCH3(DKT_RT, NT_RT, LS_RT, ...)                                        \
+  do {                                                                                  \
+    auto with_ls = [&](auto dkt_c, auto nt_c) {                                         \
+      constexpr int DKT = decltype(dkt_c)::value;                                       \
+      constexpr int NT = decltype(nt_c)::value;                                         \
+      switch (LS_RT) {                                                                  \
+        case 1: { constexpr int LS = 1; __VA_ARGS__; } break;                           \
+        case 2: { constexpr int LS = 2; __VA_ARGS__; } break;                           \
+        case 3: { constexpr int LS = 3; __VA_ARGS__; } break;                           \
+        default: { constexpr int LS = 4; __VA_ARGS__; } break;                          \
+      }                                                                                 \
+    };                                                                                  \
+    auto with_nt = [&](auto dkt_c) {                                                    \
+      switch (NT_RT) {                                                                  \
+        case 1: with_ls(dkt_c, std::integral_constant<int, 1>()); break;                \
+        case 2: with_ls(dkt_c, std::integral_constant<int, 2>()); break;                \
+        case 3: with_ls(dkt_c, std::integral_constant<int, 3>()); break;                \
+        default: with_ls(dkt_c, std::integral_constant<int, 4>()); break;               \
+      }                                                                                 \
+    };                                                                                  \
+    if ((DKT_RT) == 4) with_nt(std::integral_constant<int, 4>());                       \
+    else with_nt(std::integral_constant<int, 8>());                                     \
+  } while (0)
+
+bool attn_seq_supported(int T, int dk) {
+  static const int off = [] { const char* e = getenv("INTEL_ATTN_SEQ"); return (e && e[0] == '0') ? 1 : 0; }();
+  return !off && T >= 1 && T <= 64 && (dk == 64 || dk == 128);
+}
+
+int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
+                        hipStream_t st) {
+  const int dk = d / heads, dkt = dk / 16, BH = B * heads;
+  const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
+  const float scale = 1.0f / sqrtf((float)dk);
+  SEQ_DISPATCH3(dkt, nt, ls, {
+    using C = SeqP<DKT, NT>;
+    const size_t smem = (size_t)4 * C::BUF * sizeof(float);
+    const int per_cu = (int)((size_t)160 * 1024 / smem);
+    const int grid = min(cdiv(BH, C::PW), num_cus() * (per_cu < 1 ? 1 : per_cu));
+    allow_lds((attn_seq_fwd_kernel<DKT, NT, LS>), smem);
+    LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, out, lse);
+  });
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+size_t attn_seq_bwd_scratch_floats(int B, int T, int heads) {
+  const size_t tp = (size_t)cdiv(T, 16) * 16;
+  return (size_t)B * heads * tp * tp;
+}
+
+// scratch: attn_seq_bwd_scratch_floats(B, T, heads) floats (the dS tiles)
+int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st) {
+  const int dk = d / heads, dkt = dk / 16, BH = B * heads;
+  const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
+  const float scale = 1.0f / sqrtf((float)dk);
+  SEQ_DISPATCH3(dkt, nt, ls, {
+    using C = SeqCfg<DKT, NT>;
+    const size_t smem = (size_t)(2 * C::ROWS * C::LD + 2 * C::ROWS) * sizeof(float);
+    allow_lds((attn_seq_bwd_kv_kernel<DKT, NT, LS>), smem);
+    LAUNCH_S(BH, T, dk, 8.0 * B * T * (double)T * d, 28.0 * B * T * (double)d, (attn_seq_bwd_kv_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv, dS);
+  });
+  INTEL_CHECK_LAUNCH();
+  SEQ_DISPATCH3(dkt, nt, 4, {
+    using C = SeqCfg<DKT, NT>;
+    const size_t smem = (size_t)C::ROWS * C::LD * sizeof(float);
+    (void)LS;
+    allow_lds((attn_seq_bwd_q_kernel<DKT, NT>), smem);
+    LAUNCH_S(BH, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d, (attn_seq_bwd_q_kernel<DKT, NT>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, dS, BH, T, d, heads, key_len, dqkv);
+  });
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

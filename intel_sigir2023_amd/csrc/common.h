@@ -49,6 +49,17 @@ static inline void allow_lds(F* kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// compute units of the current device (256 on MI355X); sizes the grids of the persistent kernels
+static inline int num_cus() {
+  static const int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+    return v;
+  }();
+  return n;
+}
+
 // ---- error reporting (host) ----------------------------------------------------------------
 void intel_set_error(const char* fmt, ...);
 #define INTEL_CHECK_ARG(cond, ...)        \

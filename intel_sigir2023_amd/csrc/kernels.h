@@ -66,6 +66,13 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                     hipStream_t st);
+// whole-sequence kernels (attn_seq.hip): T <= 64, head dim 64 / 128
+bool attn_seq_supported(int T, int dk);
+int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
+                        hipStream_t st);
+size_t attn_seq_bwd_scratch_floats(int B, int T, int heads);
+int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st);
 // scratch: attn_bwd_scratch_floats(B, T, d, heads) floats (row sums of dO*O; dS tiles of the whole-sequence path)
 size_t attn_bwd_scratch_floats(int B, int T, int d, int heads);
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
