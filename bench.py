@@ -19,8 +19,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
-MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel', 'attn_fwd_kernel',
-                'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel')
+MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
+                'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_kv_kernel',
+                'attn_seq_bwd_q_kernel')
 
 
 def algorithmic_bytes_per_session(flags, corpus, shape, train, e=4):
@@ -216,6 +217,9 @@ def main():
         if a.shapes:
             res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f TF/s' % (v['ms'] / psteps, v['launches'] // psteps, v['flops'] / v['ms'] / 1e9)
                                   for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01 and v['flops'] > 0}
+        if a.shapes:
+            res['kernel_table'] = {k: '%d launches/step, %.4f ms/step, avg %.1f us' % (v['launches'] // psteps, v['ms'] / psteps, 1e3 * v['ms'] / max(1, v['launches']))
+                                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)
