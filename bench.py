@@ -24,6 +24,37 @@ MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel
                 'attn_seq_bwd_q_kernel')
 
 
+def feed_throughput(w, cinfo, B, dev, reps=20):
+    """sessions/s of intel_feed_collate (columnar corpus in HBM -> one padded batch) on a synthetic corpus
+    of the workload's shape; the kernel is HBM-bound, so the achieved GB/s over the bytes it writes and reads is reported."""
+    import numpy as np
+    import torch
+    from intel_sigir2023_amd import feed
+    K, I = w['flags']['model_num'], cinfo['I']
+    Lb, H = w['batch']['L'], w['batch']['H']
+    n_sess = max(4 * B, 16384)
+    st = feed.ColumnarStore.synthetic(n_sess, Lb, K, I, H, min(cinfo['items'], 1 << 20), min(cinfo['users'], 1 << 16), cinfo['classes'],
+                                      cinfo['ctx']).to(dev)
+    rs = np.random.RandomState(1)
+    idx = [torch.from_numpy(rs.randint(0, n_sess, B).astype(np.int32)).to(dev) for _ in range(4)]
+    shape = st.max_shape()
+
+    def one(i):
+        return st.collate(idx[i % 4], shuffle='device', seed=i, shape=shape)
+    for i in range(3):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(reps):
+        one(i)
+    torch.cuda.synchronize()
+    el = (time.time() - t0) / reps
+    out_bytes = B * (4 * 3 * Lb + 4 * Lb * K + 4 * I + 4 * H + 4 * H * I + 8 * H + 24)
+    in_bytes = B * (Lb * (8 + 8 * K) * 2 + 4 * I + H * (8 + 4 * I) + 64)
+    return {'sessions_per_s': round(B / el, 1), 'ms_per_batch': round(el * 1e3, 4), 'achieved_GBps': round((out_bytes + in_bytes) / el / 1e9, 1),
+            'peak_GBps': HBM_PEAK / 1e9, 'store_MB': round(st.nbytes() / 1e6, 1), 'shuffle': 'device (counter-based RNG)'}
+
+
 def algorithmic_bytes_per_session(flags, corpus, shape, train, e=4):
     """bytes a session's forward (and training extras) must move, fp32 (e=4)."""
     L, H, Hi = shape['L'], shape['H'], shape['H']
@@ -94,6 +125,7 @@ def main():
     ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_roofline', action='store_true')
+    ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
     ap.add_argument('--cpu_budget', type=float, default=20.0)
     ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
     ap.add_argument('--encoder', type=str, default='', help='override the sequence encoder: BERT4Rec | GRU4Rec')
@@ -178,6 +210,8 @@ def main():
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
     }
+    if rank == 0 and not a.no_feed:
+        res['feed'] = feed_throughput(w, cinfo, B, dev)
     bytes_train = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], True)
     res['gather_roofline'] = {'bytes_per_session': bytes_train, 'achieved_GBps': round(bytes_train * res['value'] / world / 1e9, 3),
                               'peak_GBps': HBM_PEAK / 1e9, 'frac': round(bytes_train * res['value'] / world / HBM_PEAK, 6)}

@@ -200,6 +200,69 @@ int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float l
 int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
                float* ndcg, void* stream);
 
+/* ---- input feed ------------------------------------------------------------------------------ */
+/* Device-side batch assembly: the work of the reference's per-sample Dataset._get_feed_dict chain
+ * (models/BaseModel.py:158-197, models/GeneralSeq.py:35-54, models/IntEL/IntEL.py:220-239) and of
+ * collate_batch (models/BaseModel.py:121-142), done by one kernel over a columnar corpus that stays in HBM.
+ * The store is the corpus of helpers/BaseReader.py + helpers/SeqReader.py flattened to arrays (CSR for the
+ * ragged parts); intel_sigir2023_amd/feed.py builds it.  All pointers are device pointers. */
+typedef struct IntelFeedStore {
+  int n_sessions, n_users, n_scores, intent_num, max_his, n_intent_rows;
+  /* per session [n_sessions] */
+  const int* u_id;            /* u_id_c */
+  const int* context_mh;      /* combined context feature index (BaseModel.py:163-165) */
+  const int* n_pay;           /* c_paynum_i, c_favnum_i, c_clicknum_i, c_trueneg_i: label counts in list order */
+  const int* n_fav;
+  const int* n_click;
+  const int* n_trueneg;
+  const int* position;        /* number of earlier sessions of the user (SeqReader.py:43) */
+  const int* item_position;   /* number of earlier positive items of the user (SeqReader.py:44) */
+  const int* intent_row;      /* row of intent_rows holding the session's intent label (0 = the zero row) */
+  const long long* list_off;  /* [n_sessions + 1] offsets into the per-candidate arrays (lists already cut at max_session_len) */
+  /* per candidate */
+  const int* item_id;         /* i_id_s */
+  const int* item_class;      /* i_class_c of the item */
+  const double* scores;       /* [n_candidates, n_scores] raw base-ranker scores (min-max normalised per list on the fly) */
+  /* intents */
+  const float* intent_rows;   /* [n_intent_rows, intent_num]; row 0 is all zeros */
+  /* per user, chronological (CSR over u_id) */
+  const long long* uhis_off;  /* [n_users + 1] */
+  const int* uhis_context_mh; /* context index of each historical session */
+  const int* uhis_intent_row; /* its intent row */
+  const long long* uitem_off; /* [n_users + 1] */
+  const int* uitem_id;        /* positive items in order */
+  const int* uitem_intent_idx;/* int(behaviour * I / K + class) of each (IntEL.py:226) */
+} IntelFeedStore;
+
+/* Caller-allocated outputs in the layout of IntelBatch (+ the labels the losses read).  L / H / Hi must be at
+ * least the batch maxima of session_len / history_len / history_item_len (feed.py computes them on the host). */
+typedef struct IntelFeedOut {
+  int B, L, H, Hi;
+  int* i_id_s;           /* [B, L]    pad 0 */
+  int* i_class_c;        /* [B, L]    pad 0 */
+  float* scores;         /* [B, L, K] pad 0 */
+  int* ranking;          /* [B, L]    3/2/1/0 labels, -1 beyond the labelled prefix, pad 0 (as pad_sequence does) */
+  int* session_len;      /* [B] */
+  int* u_id_c;           /* [B] */
+  int* context_mh;       /* [B] */
+  float* intents;        /* [B, I] */
+  int* his_context_mh;   /* [B, H]    pad 0 */
+  float* his_intents;    /* [B, H, I] pad 0 */
+  int* history_len;      /* [B]       1 when the user has no history (one all-zero entry, GeneralSeq.py:49-51) */
+  int* his_item_id;      /* [B, Hi]   pad 0 */
+  int* his_item_idx;     /* [B, Hi]   intent index of the one-hot row, -1 = all-zero row / pad */
+  int* history_item_len; /* [B] */
+} IntelFeedOut;
+
+/* shuffle = 0: candidates keep their stored order; 1: per-list permutation from a counter-based RNG keyed by
+ * (seed, session index) -- GeneralShuffleModel's per-access shuffle (BaseModel.py:194-196) without the host;
+ * 2: perm[b*L + i] gives the stored position that lands at slot i (the reference's np.random.choice draw made
+ * on the host, for bit-exact parity).  sess_idx: [B] session indices into the store. */
+/* sizeof(IntelFeedStore), sizeof(IntelFeedOut): lets a binding verify its mirror of the two structs. */
+void intel_feed_abi_sizes(int* out2);
+int intel_feed_collate(const IntelFeedStore* store, const int* sess_idx, int shuffle, const int* perm,
+                       unsigned long long seed, const IntelFeedOut* out, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 /* Per-kernel HIP-event timing on the launch stream (used by bench.py for the `roofline` block; the
  * reference only has wall-clock _check_time, helpers/BaseRunner.py:174-180).  intel_prof_collect()

@@ -42,6 +42,10 @@ def lib():
         mine = [C.sizeof(IntelDesc), C.sizeof(IntelBatch), C.sizeof(IntelOut), P_COUNT]
         if list(sizes) != mine:
             raise IntelHipError('struct layout mismatch between _lib.py and intel_hip.h: %s vs %s' % (list(sizes), mine))
+        fs = (C.c_int * 2)()
+        _lib.intel_feed_abi_sizes(fs)
+        if list(fs) != [C.sizeof(IntelFeedStore), C.sizeof(IntelFeedOut)]:
+            raise IntelHipError('feed struct layout mismatch between _lib.py and intel_hip.h')
     return _lib
 
 
@@ -82,6 +86,19 @@ class IntelBatch(C.Structure):
         'his_intents', 'history_len', 'his_item_id', 'his_item_idx', 'his_item_int', 'history_item_len')]
 
 
+class IntelFeedStore(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('n_sessions', 'n_users', 'n_scores', 'intent_num', 'max_his', 'n_intent_rows')] + \
+               [(n, C.c_void_p) for n in ('u_id', 'context_mh', 'n_pay', 'n_fav', 'n_click', 'n_trueneg', 'position', 'item_position',
+                                          'intent_row', 'list_off', 'item_id', 'item_class', 'scores', 'intent_rows', 'uhis_off',
+                                          'uhis_context_mh', 'uhis_intent_row', 'uitem_off', 'uitem_id', 'uitem_intent_idx')]
+
+
+class IntelFeedOut(C.Structure):
+    _fields_ = [('B', C.c_int), ('L', C.c_int), ('H', C.c_int), ('Hi', C.c_int)] + \
+               [(n, C.c_void_p) for n in ('i_id_s', 'i_class_c', 'scores', 'ranking', 'session_len', 'u_id_c', 'context_mh', 'intents',
+                                          'his_context_mh', 'his_intents', 'history_len', 'his_item_id', 'his_item_idx', 'history_item_len')]
+
+
 class IntelOut(C.Structure):
     _fields_ = [('weights', C.c_void_p), ('ens_score', C.c_void_p), ('intents', C.c_void_p)]
 
@@ -105,7 +122,7 @@ EXPORTS = [
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_list_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
-    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect',
+    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_feed_collate', 'intel_feed_abi_sizes',
 ]
 
 
@@ -141,5 +158,7 @@ def _declare(l):
     sig('intel_op_attention_bwd_workspace_bytes', sz, [i, i, i, i])
     sig('intel_op_add_layernorm', i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp])
     sig('intel_op_workspace_bytes', sz, [i, i, i])
+    sig('intel_feed_abi_sizes', None, [C.POINTER(C.c_int)])
+    sig('intel_feed_collate', i, [C.POINTER(IntelFeedStore), vp, i, vp, C.c_ulonglong, C.POINTER(IntelFeedOut), vp])
     sig('intel_prof_enable', None, [i])
     sig('intel_prof_collect', C.c_char_p, [])

@@ -2,8 +2,9 @@
 ``python -m intel_sigir2023_amd.main --model_name IntEL --loss_name IntBPRloss --workload tmall ...``
 
 Classes are resolved by name like the reference (main.py:127-130); flags come from the same
-``parse_*_args`` hooks.  Data: synthetic workloads (synth.py) -- the CSV/JSON reader is outside the hot
-path.  Needs an MI355X; there is no CPU path.
+``parse_*_args`` hooks.  Data: synthetic workloads (synth.py) by default; ``--dataset NAME --datapath DIR``
+reads the reference's CSV / JSON corpus (data.SeqReader), flattens it into HBM (feed.ColumnarStore) and assembles
+every batch on the device.  Needs an MI355X; there is no CPU path.
 """
 import argparse
 import logging
@@ -13,6 +14,8 @@ import numpy as np
 import torch
 
 from . import loss as loss_mod
+from . import data as data_mod
+from . import feed
 from . import synth
 from .model import IntEL
 from .runner import BaseRunner
@@ -30,6 +33,11 @@ def parse_global_args(parser):
     parser.add_argument('--workload', type=str, default='tiny', help='synthetic workload: ' + ', '.join(synth.WORKLOADS))
     parser.add_argument('--train_batches', type=int, default=8, help='synthetic batches per epoch')
     parser.add_argument('--use_engine', type=int, default=1)
+    parser.add_argument('--dataset', type=str, default='', help='corpus directory name under --datapath (empty: synthetic workload)')
+    parser.add_argument('--datapath', type=str, default='../data/')
+    parser.add_argument('--sep', type=str, default='\t')
+    parser.add_argument('--intent_note', type=str, default='')
+    parser.add_argument('--max_session_len', type=int, default=40)
     return parser
 
 
@@ -61,14 +69,26 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit('intel_sigir2023_amd needs an MI355X (no CPU path)')
     args.device = torch.device('cuda', int(args.gpu or 0))
-    corpus, cinfo = synth.make_corpus(args.workload)
+    if args.dataset:
+        corpus = data_mod.SeqReader(args)
+    else:
+        corpus, _ = synth.make_corpus(args.workload)
     model = MODELS[init_args.model_name](args, corpus).to(args.device)
     logging.info('#params: %d' % model.count_variables())
     criterion = LOSSES[init_args.loss_name](args)
     runner = RUNNERS[init_args.runner_name](args, use_engine=bool(args.use_engine))
-    dev = [synth.make_batch(args.workload, args.eval_batch_size, args.device, seed=10_000 + i, ragged=True) for i in range(2)]
-    data = {'train': lambda ep: [synth.make_batch(args.workload, args.batch_size, args.device, seed=ep * 1000 + i, ragged=True)
-                                 for i in range(args.train_batches)], 'dev': dev, 'test': dev}
+    if args.dataset:
+        stores = {p: feed.ColumnarStore(corpus, p, model.model_num, model.intent_num, model.max_his).to(args.device)
+                  for p in ('train', 'dev', 'test')}
+        logging.info('columnar corpus in HBM: %s' % ', '.join('%s %d sessions / %.1f MB' % (p, s.n_sessions, s.nbytes() / 1e6)
+                                                               for p, s in stores.items()))
+        fixed = lambda p: list(feed.epoch_batches(stores[p], args.eval_batch_size, seed=args.random_seed + 1, shuffle_sessions=False))
+        data = {'train': lambda ep: feed.epoch_batches(stores['train'], args.batch_size, epoch=ep, seed=args.random_seed),
+                'dev': fixed('dev'), 'test': fixed('test')}
+    else:
+        dev = [synth.make_batch(args.workload, args.eval_batch_size, args.device, seed=10_000 + i, ragged=True) for i in range(2)]
+        data = {'train': lambda ep: [synth.make_batch(args.workload, args.batch_size, args.device, seed=ep * 1000 + i, ragged=True)
+                                     for i in range(args.train_batches)], 'dev': dev, 'test': dev}
     if args.train > 0:
         runner.train(model, data, criterion, init_args.loss_name)
     loss, res = runner.evaluate(model, data['test'], runner.topk, runner.metrics, criterion)
