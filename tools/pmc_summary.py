@@ -19,7 +19,7 @@ def agg(path, counter):
     for r in csv.DictReader(open(path)):
         if r['Counter_Name'] != counter:
             continue
-        name = r['Kernel_Name'].split('(')[0].replace('void ', '').strip()
+        name = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').strip()
         name = re.sub(r'<.*>', '', name)
         d[name][0] += 1
         d[name][1] += float(r['Counter_Value'])
