@@ -180,6 +180,12 @@ int intel_list_loss(int B, int L, int K, const float* ens_score, const int* rank
                     const double* scores_f64, const float* scores_f32, const float* weights,
                     int cal_diversity, double alpha, float grad_scale, float* loss, float* d_ens,
                     float* d_weights, void* workspace, size_t workspace_bytes, void* stream);
+/* MSEloss.forward (loss/MSEloss.py:22-30) incl. diversity (:14-20): per-list mean of (ens - max(label, 0))^2
+ * over the valid slots; same conventions as the two losses above. */
+int intel_mse_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                   const double* scores_f64, const float* scores_f32, const float* weights,
+                   int cal_diversity, double alpha, float grad_scale, float* loss, float* d_ens,
+                   float* d_weights, void* workspace, size_t workspace_bytes, void* stream);
 /* BaseIntloss.get_intloss (loss/BaseIntloss.py:57-67): out3 = {intent_loss, ce, kl} (fp64);
  * d_pred (optional) = grad_scale * d(intent_loss)/d(pred). */
 int intel_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,

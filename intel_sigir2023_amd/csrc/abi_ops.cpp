@@ -111,6 +111,15 @@ extern "C" int intel_list_loss(int B, int L, int K, const float* ens_score, cons
                           grad_scale, loss, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+extern "C" int intel_mse_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                              const double* scores_f64, const float* scores_f32, const float* weights,
+                              int cal_diversity, double alpha, float grad_scale, float* loss, float* d_ens,
+                              float* d_weights, void* workspace, size_t workspace_bytes, void* stream) {
+  INTEL_CHECK_ARG(B > 0 && L > 0 && K > 0 && ens_score && ranking && session_len && loss && workspace, "mse loss: bad argument");
+  return launch_mse_loss(B, L, K, ens_score, ranking, session_len, scores_f64, scores_f32, weights, cal_diversity, alpha,
+                         grad_scale, loss, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 extern "C" int intel_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
                                  float grad_scale, double* out3, float* d_pred, void* workspace, size_t workspace_bytes,
                                  void* stream) {

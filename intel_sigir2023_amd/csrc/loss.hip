@@ -267,6 +267,56 @@ __global__ __launch_bounds__(256) void list_loss_kernel(LossArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// MSE (loss/MSEloss.py:12-30): one wave per session.  lossb = mean over the valid slots of (ens - max(label,0))^2;
+// divb = mean over the valid slots of sum_k w_k (s_k - ens)^2 in float64 (the base scores are float64 there).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_loss_kernel(LossArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int L = a.L, K = a.K;
+  const int n = min(a.slen[b], L);
+  const float c = a.grad_scale / ((float)a.B * (float)n);
+  float acc = 0.f;
+  double dacc = 0.0;
+  for (int i = lane; i < L; i += 64) {
+    const size_t o = (size_t)b * L + i;
+    float g = 0.f;
+    if (i < n) {
+      const float e = a.ens[o];
+      const float df = e - (float)max(a.ranking[o], 0);
+      acc += df * df;
+      g = 2.f * c * df;
+      if (a.cal_div) {
+        double gz = 0.0;
+        for (int k = 0; k < K; ++k) {
+          const double dl = score_at(a, o * K + k) - (double)e;
+          const double w = (double)a.weights[o * K + k];
+          dacc += w * dl * dl;
+          gz += w * dl;
+          if (a.d_weights) a.d_weights[o * K + k] = (float)(-a.alpha * (double)c * dl * dl);
+        }
+        g += (float)(a.alpha * (double)c * 2.0 * gz);          // d/de of -alpha * w (s - e)^2 = +2 alpha w (s - e)
+      } else if (a.d_weights) {
+        for (int k = 0; k < K; ++k) a.d_weights[o * K + k] = 0.f;
+      }
+    } else if (a.d_weights) {
+      for (int k = 0; k < K; ++k) a.d_weights[o * K + k] = 0.f;
+    }
+    if (a.d_ens) a.d_ens[o] = g;
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    acc += __shfl_xor(acc, m);
+    dacc += __shfl_xor(dacc, m);
+  }
+  if (lane == 0) {
+    a.lossb[b] = acc / (float)n;
+    a.divb[b] = dacc / (double)n;
+  }
+}
+
 // loss = mean_b lossb;  total = float(double(loss) + (-mean_b divb) * alpha)  (in-place += keeps fp32)
 __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ lossb, const double* __restrict__ divb, int B,
                                                             int cal_div, double alpha, float* __restrict__ loss) {
@@ -319,6 +369,23 @@ int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, c
   a.d_weights = d_weights; a.lossb = nullptr; a.divb = nullptr;
   INTEL_CHECK_ARG(noise && select, "bpr loss: noise and select buffers are required");
   return run_pair_loss(true, a, loss, ws, ws_bytes, st);
+}
+int launch_mse_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
+                    const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
+                    float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st) {
+  LossArgs a;
+  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.sc64 = sc64; a.sc32 = sc32;
+  a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = nullptr; a.d_ens = d_ens;
+  a.d_weights = d_weights;
+  INTEL_CHECK_ARG(ws_bytes >= loss_ws_bytes(B), "loss: workspace too small");
+  INTEL_CHECK_ARG(!cal_div || (weights && (sc64 || sc32)), "mse loss: diversity needs the fusion weights and the base scores");
+  a.divb = reinterpret_cast<double*>(ws);
+  a.lossb = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + rup_sz((size_t)B * sizeof(double), 16));
+  LAUNCH(mse_loss_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, a);
+  INTEL_CHECK_LAUNCH();
+  LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a.lossb, a.divb, B, cal_div, alpha, loss);
+  INTEL_CHECK_LAUNCH();
+  return 0;
 }
 int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
                      const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,

@@ -40,6 +40,9 @@ int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, c
 int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
                      const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                      float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_mse_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
+                    const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
+                    float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st);
 int launch_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
                        float grad_scale, double* out3, float* d_pred, void* ws, size_t ws_bytes, hipStream_t st);
 // optim.hip

@@ -21,9 +21,9 @@ class IntELEngine(object):
     def __init__(self, model, loss_name='IntBPRloss', args=None, lr=1e-3, l2=0.0, betas=(0.9, 0.999), eps=1e-8):
         self.model = model
         self.loss_name = loss_name
-        if loss_name not in ('IntBPRloss', 'IntListloss', 'BPRloss', 'Listloss'):
+        if loss_name not in ('IntBPRloss', 'IntListloss', 'IntMSEloss', 'BPRloss', 'Listloss', 'MSEloss'):
             raise ValueError('unsupported loss ' + loss_name)
-        self.kind = 'bpr' if 'BPR' in loss_name else 'list'
+        self.kind = 'bpr' if 'BPR' in loss_name else ('mse' if 'MSE' in loss_name else 'list')
         self.with_intent = loss_name.startswith('Int')
         g = lambda k, d: getattr(args, k, d) if args is not None else d
         self.intent_weight = float(g('intent_weight', 0.1))
@@ -116,6 +116,10 @@ class IntELEngine(object):
             L.check(lib.intel_bpr_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(noise), L.ptr(sc64),
                                        L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
                                        L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss')
+        elif self.kind == 'mse':
+            L.check(lib.intel_mse_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(sc64), L.ptr(sc32),
+                                       L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e), L.ptr(d_ens),
+                                       L.ptr(d_w), L.ptr(ws), nb, st), 'intel_mse_loss')
         else:
             L.check(lib.intel_list_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(sc64), L.ptr(sc32),
                                         L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e), L.ptr(d_ens),

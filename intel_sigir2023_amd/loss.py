@@ -50,6 +50,10 @@ class _PairLossFn(torch.autograd.Function):
                                        L.ptr(loss), L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb,
                                        L.stream_ptr(dev)), 'intel_bpr_loss')
             ctx.select = select
+        elif kind == 'mse':
+            L.check(lib.intel_mse_loss(B, Lmax, K, L.ptr(ens_c), L.ptr(ranking), L.ptr(session_len), L.ptr(sc64),
+                                       L.ptr(sc32), L.ptr(w_c), int(cal_div), float(alpha), 1.0, L.ptr(loss),
+                                       L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, L.stream_ptr(dev)), 'intel_mse_loss')
         else:
             L.check(lib.intel_list_loss(B, Lmax, K, L.ptr(ens_c), L.ptr(ranking), L.ptr(session_len), L.ptr(sc64),
                                         L.ptr(sc32), L.ptr(w_c), int(cal_div), float(alpha), 1.0, L.ptr(loss),
@@ -152,6 +156,24 @@ class Listloss(BaseIntloss):
     def forward(self, out_dict, in_batch):
         loss = self._pair('list', out_dict, in_batch)
         return loss, loss, loss
+
+
+class MSEloss(BaseIntloss):
+    """loss/MSEloss.py:7-30."""
+
+    def forward(self, out_dict, in_batch):
+        loss = self._pair('mse', out_dict, in_batch)
+        return loss, loss, loss
+
+
+class IntMSEloss(MSEloss):
+    """loss/IntMSEloss.py:11-21."""
+
+    def forward(self, out_dict, in_batch):
+        intent_loss, _, _ = self.get_intloss(out_dict, in_batch)
+        ensemble_loss = self._pair('mse', out_dict, in_batch)
+        loss = ensemble_loss * self.ensemble_weight + intent_loss * self.intent_weight
+        return loss, ensemble_loss, intent_loss
 
 
 class IntBPRloss(BPRloss):

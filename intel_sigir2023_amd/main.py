@@ -21,7 +21,7 @@ from .model import IntEL
 from .runner import BaseRunner
 
 MODELS = {'IntEL': IntEL}
-LOSSES = {n: getattr(loss_mod, n) for n in ('BPRloss', 'Listloss', 'IntBPRloss', 'IntListloss')}
+LOSSES = {n: getattr(loss_mod, n) for n in ('BPRloss', 'Listloss', 'MSEloss', 'IntBPRloss', 'IntListloss', 'IntMSEloss')}
 RUNNERS = {'BaseRunner': BaseRunner}
 
 

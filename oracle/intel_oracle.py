@@ -270,6 +270,28 @@ def list_loss(ens, ranking, session_len, scores=None, weights=None, cal_diversit
     return loss
 
 
+def mse_loss(ens, ranking, session_len, scores=None, weights=None, cal_diversity=0, alpha=0.01):
+    """loss/MSEloss.py:22-30 (+ diversity :14-20): per-list mean squared error against the clamped labels."""
+    L = ens.shape[1]
+    valid = torch.arange(L, device=ens.device)[None, :] < session_len[:, None]
+    r = ranking.clamp(min=0)
+    n = valid.sum(-1)
+    loss = ((((ens - r) ** 2) * valid).sum(-1) / n).mean()
+    if cal_diversity:
+        d = weights * ((scores - ens.unsqueeze(2)) ** 2)                  # float64 through the float64 base scores
+        div = -((d * valid.unsqueeze(2)).sum(-1).sum(-1) / n).mean()
+        loss = (loss.double() + div * alpha).float()                      # in-place += keeps float32 (MSEloss.py:29)
+    return loss
+
+
+def int_mse_loss(out, batch, cfg):
+    """loss/IntMSEloss.py:16-21."""
+    il, _, _ = intent_loss(out['intents'], batch['intents'], cfg.kl_weight, cfg.kl_temp)
+    el = mse_loss(out['ens_score'], batch['ranking'], batch['session_len'], batch['scores'], out['weights'],
+                  cfg.cal_diversity, cfg.diversity_alpha)
+    return el * cfg.ensemble_weight + il * cfg.intent_weight, el, il
+
+
 def intent_loss(pred, label, kl_weight=0.5, kl_temp=2.0):
     """loss/BaseIntloss.py:30-67.  ``label`` float64; CE uses the float64 label, KL the float32
     cast; per-class weights are all ones."""
