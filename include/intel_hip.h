@@ -143,6 +143,12 @@ void intel_set_concurrency(IntelCtx* ctx, int on);
 
 /* Bytes of workspace intel_forward/intel_backward need for a batch of this shape.  `train` != 0
  * also reserves the activation stash the backward pass reads. */
+/* nn.Dropout(--dropout) of the two tower layers (models/IntEL/IntEL.py:63,187,196) for the following
+ * intel_forward(train=1) calls: p = 0 (default) disables it; evaluation never drops.  keep_flags (optional, device):
+ * 0/1 floats -- item-tower layers [layers][B*L][d_i] then score-tower layers [layers][B*L][d_s] -- replace the
+ * built-in counter-based generator (parity tests pass the reference's own draw).  Call it BEFORE
+ * intel_workspace_bytes: the training workspace grows by one mask per tower layer. */
+int intel_set_dropout(IntelCtx* ctx, float p, unsigned long long seed, const float* keep_flags);
 size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train);
 
 /* IntEL.forward (IntEL.py:117-124) = predict_intent (:126-155) + predict_ensemble (:158-217). */

@@ -118,7 +118,7 @@ ENC_STRIDE = 6 + ENC_BLOCK_STRIDE * ENC_MAX_BLOCKS
 P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 
 EXPORTS = [
-    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_workspace_bytes',
+    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_dropout', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
@@ -140,6 +140,7 @@ def _declare(l):
     sig('intel_create', vp, [C.POINTER(IntelDesc)])
     sig('intel_destroy', None, [vp])
     sig('intel_set_concurrency', None, [vp, i])
+    sig('intel_set_dropout', i, [vp, f, C.c_ulonglong, vp])
     sig('intel_workspace_bytes', sz, [vp, i, i, i, i, i])
     sig('intel_forward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, C.POINTER(IntelOut), i, vp])
     sig('intel_backward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, vp, vp, vp, C.POINTER(vp), vp])

@@ -89,7 +89,11 @@ int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const in
                             const float* relu_out, int ldr, int rcol0, hipStream_t st);
 // y = LN(x + r) rows
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
-                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st);
+                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st,
+                         const float* xscale = nullptr);   // xscale: optional elementwise factor on x (dropout mask)
+// dropout keep mask scaled by 1/(1-p); ext = optional 0/1 keep flags, else a counter-based generator
+int launch_dropout_mask(float* mask, long long n, float p, unsigned long long seed, unsigned stream_id, const float* ext, hipStream_t st);
+int launch_mul2(const float* a, const float* b, long long n, float* y, hipStream_t st);
 // dz = LN backward; dgamma/dbeta (+)= column sums (via slabs: needs ln_bwd_slab_floats(M,N))
 size_t ln_bwd_slab_floats(int M, int N);
 int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,

@@ -34,7 +34,7 @@ struct Arena {
 // tower parameter offsets relative to INTEL_P_I_WQ / INTEL_P_S_WQ
 enum { T_WQ = 0, T_WK, T_WV, T_W1, T_B1, T_W2, T_B2, T_LNG, T_LNB };
 
-struct TowerLayerBufs { float *QKV, *A, *LSE, *R1, *XH, *RSTD, *Xout; };
+struct TowerLayerBufs { float *QKV, *A, *LSE, *R1, *XH, *RSTD, *Xout, *DM; };   // DM: dropout mask / (1-p), only with dropout
 struct TowerBufs {
   int d, pbase, xbase, feat_off;
   float* X0;
@@ -103,6 +103,11 @@ struct IntelCtx {
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
   // weight-gradient / LayerNorm partial sums of a backward phase, reduced together when the phase ends
   ReduceQueue* rq;
+  // nn.Dropout of the tower layers (IntEL.py:187,196) for the next training forward: p = 0 disables
+  float drop_p;
+  unsigned long long drop_seed;
+  const float* drop_ext;       // optional 0/1 keep flags, item-tower layers then score-tower layers
+  bool fwd_dropout;            // the stashed forward ran with dropout
 };
 
 namespace {
@@ -110,7 +115,7 @@ namespace {
 inline int enc_slot(int e, int off) { return INTEL_P_ENC0 + e * INTEL_ENC_STRIDE + off; }
 inline int enc_blk_slot(int e, int l, int off) { return enc_slot(e, INTEL_ENC_BLOCK0 + l * INTEL_ENC_BLOCK_STRIDE + off); }
 
-void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, Layout& y) {
+void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, Layout& y, bool dropout = false) {
   Arena ar{base, 0};
   y.B = B; y.L = L; y.H = H; y.Hi = Hi; y.M = B * L;
   const int M = y.M;
@@ -195,6 +200,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
       b.XH = ar.f(md);
       b.RSTD = ar.f(M);
       b.Xout = ar.f(md);
+      b.DM = dropout ? ar.f(md) : nullptr;
     }
     if (D.cross_attention) {
       w.QV = ar.f((size_t)B * w.d);
@@ -520,7 +526,18 @@ void tower_fwd(Run& r, TowerBufs& w) {
     e2.res = X; e2.ldres = d;
     e2.gamma = r.P(pb + T_LNG); e2.beta = r.P(pb + T_LNB);
     if (r.train) { e2.xhat = b.XH; e2.ldxhat = d; e2.rstd = b.RSTD; }
-    if (d <= 128) {
+    if (r.train && r.ctx->drop_p > 0.f) {
+      // h = LayerNorm(dropout(W2 relu(.) + b2) + residual): mask, plain-bias GEMM, then the masked add + LayerNorm
+      const int tower = &w == &r.y.tw[0] ? 0 : 1;
+      const float* ext = nullptr;
+      if (r.ctx->drop_ext) ext = r.ctx->drop_ext + (tower == 0 ? (size_t)l * M * r.y.tw[0].d : (size_t)D.layers * M * r.y.tw[0].d + (size_t)l * M * r.y.tw[1].d);
+      RUN(launch_dropout_mask(b.DM, (long long)M * d, r.ctx->drop_p, r.ctx->drop_seed, (unsigned)(tower * MAX_TOWER_LAYERS + l), ext, r.st));
+      GemmEpilogue e2b;
+      e2b.bias = e2.bias;
+      lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2b);
+      if (r.rc) return;
+      RUN(launch_add_layernorm(b.Xout, d, X, d, M, d, e2.gamma, e2.beta, b.Xout, d, b.XH, d, b.RSTD, r.st, b.DM));
+    } else if (d <= 128) {
       lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2);
     } else {
       GemmEpilogue e2b;
@@ -549,10 +566,15 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
                                      nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
-    wgrad(r, r.T->dZ, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
+    const float* dZd = r.T->dZ;            // gradient behind the dropout: dZ * mask (the residual branch keeps dZ)
+    if (r.ctx->fwd_dropout) {
+      if (!r.ok(launch_mul2(r.T->dZ, b.DM, (long long)M * d, r.T->dA, r.st))) return nullptr;
+      dZd = r.T->dA;
+    }
+    wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
     GemmEpilogue em;
     em.mask = b.R1; em.ldmask = d;
-    lin(r, r.T->dZ, d, M, d, w.pW2T, d, r.T->dF1, d, em);                 // d(pre-relu) = (dZ W2) * [R1 > 0]
+    lin(r, dZd, d, M, d, w.pW2T, d, r.T->dF1, d, em);                     // d(pre-relu) = (dZ W2) * [R1 > 0]
     wgrad(r, r.T->dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1);
     GemmEpilogue e0;
     lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
@@ -1103,6 +1125,10 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->have_layout = false;
   c->fwd_done = false;
   c->streams = 0;
+  c->drop_p = 0.f;
+  c->drop_seed = 0;
+  c->drop_ext = nullptr;
+  c->fwd_dropout = false;
   c->rq = redq_create();
   if (!c->rq) {
     delete c;
@@ -1136,11 +1162,19 @@ extern "C" void intel_set_concurrency(IntelCtx* ctx, int on) {
   }
 }
 
+extern "C" int intel_set_dropout(IntelCtx* ctx, float p, unsigned long long seed, const float* keep_flags) {
+  INTEL_CHECK_ARG(ctx, "intel_set_dropout: null context");
+  INTEL_CHECK_ARG(p >= 0.f && p < 1.f, "intel_set_dropout: p=%g outside [0, 1)", (double)p);
+  ctx->drop_p = p;
+  ctx->drop_seed = seed;
+  ctx->drop_ext = keep_flags;
+  return 0;
+}
+
 extern "C" size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train) {
-  (void)train;
   if (!ctx || B <= 0 || L <= 0 || H <= 0 || Hi <= 0) return 0;
   Layout y;
-  make_layout(ctx->d, B, L, H, Hi, nullptr, y);
+  make_layout(ctx->d, B, L, H, Hi, nullptr, y, train && ctx->drop_p > 0.f);
   return y.total;
 }
 
@@ -1161,7 +1195,9 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   if (rc) return rc;
   INTEL_CHECK_ARG(out->weights && out->ens_score && out->intents, "intel_forward: null output");
   INTEL_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 255) == 0, "workspace must be 256-byte aligned");
-  make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay);
+  const bool dropout = train && ctx->drop_p > 0.f;
+  make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay, dropout);
+  ctx->fwd_dropout = dropout;
   if (workspace_bytes < ctx->lay.total) {
     intel_set_error("intel_forward: workspace %zu < %zu bytes", workspace_bytes, ctx->lay.total);
     return INTEL_E_WORKSPACE;

@@ -102,7 +102,8 @@ int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const in
 __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r,
                                                             int ldr, int M, int N, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ y, int ldy,
-                                                            float* __restrict__ xhat, int ldxh, float* __restrict__ rstd) {
+                                                            float* __restrict__ xhat, int ldxh, float* __restrict__ rstd,
+                                                            const float* __restrict__ xscale) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     float t = 0.f;
     if (c < N) {
       t = x[(size_t)row * ldx + c];
+      if (xscale) t *= xscale[(size_t)row * ldx + c];          // dropout keep mask / (1 - p), same layout as x
       if (r) t += r[(size_t)row * ldr + c];
     }
     v[i] = t;
@@ -141,11 +143,12 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
   }
 }
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
-                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st) {
+                         const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st,
+                         const float* xscale) {
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm: N=%d > %d unsupported", N, 64 * LN_MAXPL);
   LAUNCH(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, ldx, r, ldr, M, N, gamma, beta, y, ldy, xhat,
-                     ldxh, rstd);
+                     ldxh, rstd, xscale);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -326,6 +329,50 @@ int launch_fill(float* p, long long n, float v, hipStream_t st) {
   long long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   LAUNCH(fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, v);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// nn.Dropout (IntEL.py:63,187,196): mask[i] = keep_i / (1 - p).  keep comes from `ext` (0/1 floats, parity tests
+// feed the reference's own draw) or from a counter-based generator keyed by (seed, stream, i).
+// ------------------------------------------------------------------------------------------
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, float p, unsigned long long seed, unsigned stream_id,
+                                    const float* __restrict__ ext) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float scale = 1.f / (1.f - p);
+  float keep;
+  if (ext) {
+    keep = ext[i];
+  } else {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)stream_id * 0x100000000ull + (unsigned long long)i + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);      // 24 uniform bits in [0, 1)
+    keep = u >= p ? 1.f : 0.f;
+  }
+  mask[i] = keep * scale;
+}
+int launch_dropout_mask(float* mask, long long n, float p, unsigned long long seed, unsigned stream_id, const float* ext, hipStream_t st) {
+  if (n <= 0) return 0;
+  LAUNCH(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mask, n, p, seed, stream_id, ext);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+__global__ void mul2_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ y) {
+  const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    const f32x4 u = *reinterpret_cast<const f32x4*>(a + i), v = *reinterpret_cast<const f32x4*>(b + i);
+    *reinterpret_cast<f32x4*>(y + i) = u * v;
+  } else {
+    for (long long k = i; k < n; ++k) y[k] = a[k] * b[k];
+  }
+}
+int launch_mul2(const float* a, const float* b, long long n, float* y, hipStream_t st) {
+  if (n <= 0) return 0;
+  LAUNCH(mul2_kernel, dim3((unsigned)((n / 4 + 256) / 256)), dim3(256), 0, st, a, b, n, y);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -341,8 +341,6 @@ class IntEL(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data):
-        if self.training and self.dropout > 0:
-            raise NotImplementedError('dropout > 0 is not implemented in the HIP path (BPR / P-L scripts use --dropout 0)')
         batch, keep = self.prepare_batch(data)
         items = self.slot_items()
         params = [p for _, _, p in items]
@@ -361,6 +359,12 @@ class IntEL(nn.Module):
             L.require_gpu(t)
         lib = L.lib()
         ctx = self._context()
+        # nn.Dropout of the tower layers (IntEL.py:63,187,196): training only; a fresh seed per forward from torch's CPU
+        # generator (reproducible under torch.manual_seed); tests may pin the keep flags through self._dropout_keep
+        p_drop = float(self.dropout) if train else 0.0
+        keep_flags = getattr(self, '_dropout_keep', None) if p_drop > 0 else None
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_drop > 0 and keep_flags is None) else 0
+        L.check(lib.intel_set_dropout(ctx, p_drop, C.c_ulonglong(seed), L.ptr(keep_flags)), 'intel_set_dropout')
         nb = lib.intel_workspace_bytes(ctx, batch.B, batch.L, batch.H, batch.Hi, int(train))
         ws = self._workspace(nb, dev)
         K, I = self.model_num, self.intent_num

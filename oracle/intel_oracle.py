@@ -80,14 +80,17 @@ def mha(x, sd, prefix, heads, key_mask=None):
     return o.transpose(1, 2).reshape(B, T, D)
 
 
-def tied_tower(h, sd, attn, w1, w2, ln, heads, layers):
+def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0):
     """models/IntEL/IntEL.py:182-188 / 191-197: the SAME weights are applied ``layers`` times,
-    attention is unmasked (padded rows act as keys and queries)."""
-    for _ in range(layers):
+    attention is unmasked (padded rows act as keys and queries).  keep: per-layer 0/1 tensors of the
+    training-mode nn.Dropout(p) applied before the residual add (:187, :196); None = evaluation."""
+    for l in range(layers):
         res = h
         h = mha(h, sd, attn, heads)
         h = _lin(h, sd, w1)
         h = _lin(torch.relu(h), sd, w2)
+        if keep is not None:
+            h = h * keep[l] / (1.0 - p)
         h = F.layer_norm(h + res, (h.shape[-1],), sd[ln + '.weight'], sd[ln + '.bias'], 1e-5)
     return h
 
@@ -169,7 +172,7 @@ def predict_intent(sd, data, cfg):
     return torch.softmax(logits, dim=-1)
 
 
-def predict_ensemble(sd, data, intent, cfg):
+def predict_ensemble(sd, data, intent, cfg, dropout_keep=None):
     """models/IntEL/IntEL.py:158-217."""
     scores = data['scores'].float()
     B, L, K = scores.shape
@@ -177,9 +180,11 @@ def predict_ensemble(sd, data, intent, cfg):
     h_i = torch.cat([sd['iid_embeddings.weight'][data['i_id_s']],
                      sd['item_embeddings.weight'][data['i_class_c']]], dim=-1)
     h_u = torch.relu(sd['uid_embeddings.weight'][data['u_id_c']])[:, None, :].expand(B, L, -1)
-    h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers)
+    ki, ks = (dropout_keep if dropout_keep is not None else (None, None))
+    pd = float(getattr(cfg, 'dropout', 0.0))
+    h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers, ki, pd)
     h_s = _lin(scores, sd, 'score_embeddings')
-    h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers)
+    h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers, ks, pd)
     if cfg.cross_attention:
         scale = 1.0 / math.sqrt(cfg.cross_attn_qsize)
         item_x = single_query_pool(intent, h_i, valid, sd, 'intent_item_attention', scale)
@@ -197,10 +202,11 @@ def predict_ensemble(sd, data, intent, cfg):
     return weights, ens
 
 
-def forward(sd, data, cfg):
-    """models/IntEL/IntEL.py:117-124."""
+def forward(sd, data, cfg, dropout_keep=None):
+    """models/IntEL/IntEL.py:117-124.  dropout_keep = (item-tower keep masks, score-tower keep masks), one 0/1
+    tensor per layer, reproduces a training-mode forward with that nn.Dropout draw."""
     intent = predict_intent(sd, data, cfg)
-    weights, ens = predict_ensemble(sd, data, intent, cfg)
+    weights, ens = predict_ensemble(sd, data, intent, cfg, dropout_keep)
     return {'weights': weights, 'ens_score': ens, 'intents': intent}
 
 
