@@ -1118,6 +1118,135 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
   if (a.want_db && blockIdx.z == 0 && tid < nb) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_dma_kernel<NTW,KTW>: the same slab product for the shapes that matter (M % 32 == 0, N and K multiples of
+// 32, 16-byte aligned operands) with nothing conditional in the inner loop -- a branch around an accumulating MFMA
+// makes the compiler bounce every accumulator between AGPRs and VGPRs.
+//   * the 32-row dY / X tiles are copied global -> LDS by the DMA path, two stages, one vmcnt(0) + one barrier
+//     per tile; rows are unpadded (a DMA instruction writes 1 KB linearly);
+//   * wave (wn, wk) owns NTW x KTW 16x16 tiles; the operand values of ALL its tiles come from ONE LDS read per
+//     operand per k-step: lane p reads the NTW consecutive dY columns NTW*p .. NTW*p+NTW-1 of its row and feeds them
+//     to the NTW tiles, so row p of tile i is output row NTW*p + i (same for X / columns): the tiles interleave and
+//     the epilogue stores KTW consecutive floats;
+//   * 128-wide rows read with b128 are conflict-free as they are; 64- and 32-wide rows swap their halves on odd
+//     rows (applied to the DMA source column and to the reads) so that the two rows a lane group touches use
+//     disjoint banks.
+// ------------------------------------------------------------------------------------------
+template <int W>
+struct WgVec;
+template <>
+struct WgVec<4> { using T = f32x4; };
+template <>
+struct WgVec<2> { using T = float __attribute__((ext_vector_type(2))); };
+template <>
+struct WgVec<1> { using T = float; };
+template <int W>
+__device__ __forceinline__ float wg_elem(const typename WgVec<W>::T& v, int i) { return v[i]; }
+template <>
+__device__ __forceinline__ float wg_elem<1>(const float& v, int) { return v; }
+
+template <int NTW, int KTW>
+__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
+  constexpr int NB = 32 * NTW, KB = 32 * KTW;
+  constexpr int YIW = WG_RT * NB / 4 / 64 / 4, XIW = WG_RT * KB / 4 / 64 / 4;      // DMA instructions per wave per tile
+  constexpr int BUF = WG_RT * (NB + KB);
+  constexpr int SWY = NB == 128 ? 0 : NB / 2, SWX = KB == 128 ? 0 : KB / 2;        // odd rows: halves swapped
+  using VY = typename WgVec<NTW>::T;
+  using VX = typename WgVec<KTW>::T;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
+  const int ntiles = a.M / WG_RT, S = gridDim.x;
+  size_t yoff[YIW], xoff[XIW];
+#pragma unroll
+  for (int j = 0; j < YIW; ++j) {
+    const int lin = (wave * YIW + j) * 64 + lane;
+    const int row = lin / (NB / 4), c = (lin - row * (NB / 4)) * 4;
+    yoff[j] = (size_t)row * a.lddy + n0 + (c ^ ((row & 1) * SWY));
+  }
+#pragma unroll
+  for (int j = 0; j < XIW; ++j) {
+    const int lin = (wave * XIW + j) * 64 + lane;
+    const int row = lin / (KB / 4), c = (lin - row * (KB / 4)) * 4;
+    xoff[j] = (size_t)row * a.ldx + k0 + (c ^ ((row & 1) * SWX));
+  }
+  auto dma_tile = [&](int tt, float* stage) {
+    const float* yb = a.dY + (size_t)tt * WG_RT * a.lddy;
+    const float* xb = a.X + (size_t)tt * WG_RT * a.ldx;
+#pragma unroll
+    for (int j = 0; j < YIW; ++j) {
+      const float* src = yb + yoff[j];
+      float* dst = stage + (wave * YIW + j) * 256;
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < XIW; ++j) {
+      const float* src = xb + xoff[j];
+      float* dst = stage + WG_RT * NB + (wave * XIW + j) * 256;
+      __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+    }
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) dma_tile(t, smem);
+  if (t + S < ntiles) dma_tile(t + S, smem + BUF);
+  f32x4 acc[NTW][KTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbacc = 0.f;
+  const bool do_db = a.want_db && blockIdx.z == 0 && tid < NB;
+  // read offsets of this lane inside a stage: row 4*ms + g, NTW (KTW) consecutive columns
+  const int ycol = (wn * 16 * NTW + NTW * p) ^ ((g & 1) * SWY), xcol = (wk * 16 * KTW + KTW * p) ^ ((g & 1) * SWX);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  int buf = 0;
+  for (; t < ntiles; t += S) {
+    const float* Ys = smem + buf * BUF;
+    const float* Xs = Ys + WG_RT * NB;
+    if (do_db) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WG_RT; ++r) s += Ys[r * NB + (tid ^ ((r & 1) * SWY))];
+      dbacc += s;
+    }
+#pragma unroll
+    for (int ms = 0; ms < WG_RT / 4; ++ms) {
+      const int row = ms * 4 + g;
+      const VY av = *reinterpret_cast<const VY*>(Ys + row * NB + ycol);
+      const VX bv = *reinterpret_cast<const VX*>(Xs + row * KB + xcol);
+#pragma unroll
+      for (int i = 0; i < NTW; ++i)
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = mfma16(wg_elem<NTW>(av, i), wg_elem<KTW>(bv, j), acc[i][j]);
+    }
+    // the copy of tile t+S into the other stage was issued one tile ago
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (t + 2 * S < ntiles) dma_tile(t + 2 * S, smem + buf * BUF);
+    buf ^= 1;
+  }
+  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wn * 16 * NTW + NTW * (4 * g + r) + i;
+      float* dst = slab + (size_t)n * a.K + k0 + wk * 16 * KTW + KTW * p;
+      if (KTW == 4) {
+        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][KTW > 1 ? 1 : 0][r], acc[i][KTW > 2 ? 2 : 0][r], acc[i][KTW > 3 ? 3 : 0][r]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) dst[j] = acc[i][j][r];
+      }
+    }
+  if (do_db) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
+}
+
 // out[i] (+)= sum_s slabs[s][i]; i < n.  16 slab lanes x 16 output groups per workgroup; each lane
 // sums its strided slabs with 4 independent accumulators, then a fixed-order LDS tree: reproducible.
 template <int VEC>
@@ -1434,6 +1563,29 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   WgradArgs a;
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.slabs = slabs;
   a.S = wgrad_num_slabs(M); a.want_db = db != nullptr;
+  {
+    // fast path: exact 32-row tiles, widths in 32-float steps, 16-byte aligned operands
+    static const int use_dma = [] { const char* e = getenv("INTEL_WGRAD_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool aligned = ((lddy & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
+    if (use_dma && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
+      const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
+      const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
+      const size_t smem = (size_t)2 * WG_RT * 32 * (ntw + ktw) * sizeof(float);
+#define WG_CASE(A_, B_)                                                                                              \
+  if (ntw == A_ && ktw == B_) {                                                                                      \
+    allow_lds((wgrad_dma_kernel<A_, B_>), smem);                                                                     \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_dma_kernel<A_, B_>), grid, \
+             dim3(256), smem, st, a);                                                                                \
+  }
+      WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1) WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
+#undef WG_CASE
+      INTEL_CHECK_LAUNCH();
+      goto reduce;
+    }
+  }
+  {
   const int nbm = min(128, N), kbm = min(128, K);
   const int ldy = (rup(rup(nbm, 16), 32)) + 16, ldxs = (rup(rup(kbm, 16), 32)) + 16;
   size_t smem = (size_t)WG_RT * (ldy + ldxs) * sizeof(float);
@@ -1442,6 +1594,8 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
     LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), wgrad_pipe_kernel, dim3(a.S, cdiv(N, 128), cdiv(K, 128)), dim3(256), 2 * smem, st, a);
   }
   INTEL_CHECK_LAUNCH();
+  }
+reduce:
   size_t stride = (size_t)N * K + N;
   if (q) {
     redq_push(q, slabs, stride, a.S, N, K, dW, lddw, accumulate);
