@@ -62,6 +62,14 @@ int redq_flush(ReduceQueue* q, hipStream_t st);
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
                  float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
 
+// ---- tiny input width (smallk.hip): K <= 32, N <= 128, raw (unpacked) weights W[N, K] ---------------------
+bool smallk_supported(int N, int K);
+int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
+                         int relu, hipStream_t st);
+int smallk_wgrad_slabs(int M);
+int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,
+                        int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
+
 // ---- attention (attn.hip) -------------------------------------------------------------------
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,

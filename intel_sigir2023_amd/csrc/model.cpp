@@ -417,6 +417,10 @@ void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, in
   if (!dW) return;
   int a = r.acc(w_slot);
   if (b_slot >= 0) { int ab = r.acc(b_slot); (void)ab; }
+  if (smallk_supported(N, K) && K <= 32 && M >= 4096 && (K % 16 != 0)) {     // tiny input width: VALU kernel (smallk.hip)
+    RUN(launch_wgrad_smallk(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
+    return;
+  }
   RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
 }
 
@@ -795,7 +799,10 @@ void forward_impl(Run& r, const IntelOut* out) {
     eb.bias = r.P(INTEL_P_INTENT_B);
     if (e == 0) {
       RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st));
-      lin(r, bt.his_intents, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
+      if (smallk_supported(D.d_int, I))
+        RUN(launch_linear_smallk(bt.his_intents, I, rows, I, r.P(INTEL_P_INTENT_W), eb.bias, D.d_int, n.E0 + D.d_c, dm, 0, r.st));
+      else
+        lin(r, bt.his_intents, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
     } else {
       RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
       if (bt.his_item_idx)
@@ -826,7 +833,10 @@ void forward_impl(Run& r, const IntelOut* out) {
     {
       GemmEpilogue es;
       es.bias = r.P(INTEL_P_SCORE_B);
-      lin(b3, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
+      if (smallk_supported(D.d_s, K))
+        b3.ok(launch_linear_smallk(bt.scores, K, M, K, r.P(INTEL_P_SCORE_W), es.bias, D.d_s, ts.X0, D.d_s, 0, b3.st));
+      else
+        lin(b3, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
       if (!b3.rc) tower_fwd(b3, ts);
     }
     r.ok(b1.rc); r.ok(b2.rc); r.ok(b3.rc);
