@@ -269,8 +269,22 @@ class IntEL(nn.Module):
 
     def slot_items(self):
         """[(slot, name, parameter)] for every parameter the kernels read."""
-        named = dict(self.named_parameters())
-        return [(s, n, named[n]) for s, n in sorted(self._slot_names.items())]
+        # resolved by attribute path each call (parameters may be re-assigned, e.g. by .to() or the engine's flat
+        # buckets) but without walking the whole module tree: named_parameters() costs ~0.2 ms per call
+        out = []
+        for s, n in self._slot_order():
+            obj = self
+            for part in n.split('.'):
+                obj = obj._modules[part] if part in obj._modules else obj._parameters[part]
+            out.append((s, n, obj))
+        return out
+
+    def _slot_order(self):
+        so = getattr(self, '_slot_order_cache', None)
+        if so is None:
+            so = sorted(self._slot_names.items())
+            self._slot_order_cache = so
+        return so
 
     def _param_array(self, tensors_by_slot):
         arr = (C.c_void_p * L.P_COUNT)()
