@@ -559,6 +559,231 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_rows_b3: the same product on the bf16 matrix pipe at fp32 accuracy.  Every fp32 operand value is split
+// into three bf16 planes x = hi + mid + lo (24 significant bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi
+// - mid); the two subtractions are exact) and a product is the sum of the six plane products whose weight is
+// >= 2^-16: hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid, each exact in the fp32 accumulator.  Measured on
+// random data the result is closer to the exact dot product than the fp32 fmaf chain (3e-8 vs 1e-7 relative to
+// sum |terms|).  v_mfma_f32_16x16x32_bf16 does 16x16x32 in 16 cycles, v_mfma_f32_16x16x4_f32 16x16x4 in 32: six
+// plane products cost 96 cycles per 32-deep block against 256 -- the GEMM leaves the MFMA roof for the HBM roof.
+//   * the A tile (64 rows x K) is split ONCE by the 512 threads on its way global -> registers -> LDS (three
+//     bf16 planes, 288-byte rows: b128 fragment reads are conflict-free), not by every consuming wave;
+//   * the weight fragments come from the same fp32 packed buffer as the fp32 kernels and are split once per
+//     workgroup into registers (3 planes x K/32 blocks x 4 VGPRs);
+//   * operand order and accumulator layout equal the fp32 kernels': the epilogues are shared verbatim.
+// K in {64, 128} (template KBN = K / 32).  One LDS buffer, the next tile is prefetched into registers under the MFMAs.
+// ------------------------------------------------------------------------------------------
+#define B3_LDP 144          // bf16 elements per LDS row: 128 + 16
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void b3_split4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hh = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[i] = hh;
+    m[i] = mm;
+    l[i] = (__bf16)r2;
+  }
+}
+__device__ __forceinline__ bf16x8 b3_cat(const bf16x4& a, const bf16x4& b) {
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+template <int RT, bool LN, int KBN>
+__global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
+  constexpr int RG = 4 / RT;
+  constexpr int CT = 8 / RG;
+  constexpr int KW = KBN * 32;                  // K
+  constexpr int C4N = KW / 4;                   // float4 per tile row
+  constexpr int NJ = GR_BM * C4N / 512;         // float4 per thread per tile: 4 (K = 128) or 2 (K = 64)
+  constexpr int PLANE = GR_BM * B3_LDP;         // bf16 elements per plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave / RG, rg = wave % RG;
+  const int KG = KW >> 4;
+  const int NT = (a.N + 15) >> 4;
+  const int nc = blockIdx.y * CT;
+  const int ntc = min(CT, NT - nc);
+  const bool active = ct < ntc;
+  const GemmEpilogue& ep = a.ep;
+  // weight fragments: lane (n = lane & 15, j = lane >> 4) needs k = kb*32 + 8j .. +7 of column n; in the fp32
+  // packed buffer those are two float4 of k-group g = 2 kb + (j >> 1), lanes (2 (j & 1)) * 16 + n and + 16
+  bf16x8 bh[KBN], bm[KBN], bl[KBN];
+  {
+    const int n = lane & 15, j = lane >> 4;
+    const int ls = (2 * (j & 1)) * 16 + n;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+      const int g = 2 * kb + (j >> 1);
+      f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f}, w1 = w0;
+      if (active) {
+        const f32x4* P4 = reinterpret_cast<const f32x4*>(a.Bp) + ((size_t)(nc + ct) * KG + g) * 64;
+        w0 = P4[ls];
+        w1 = P4[ls + 16];
+      }
+      bf16x4 h0, m0, l0, h1, m1, l1;
+      b3_split4(w0, h0, m0, l0);
+      b3_split4(w1, h1, m1, l1);
+      bh[kb] = b3_cat(h0, h1);
+      bm[kb] = b3_cat(m0, m1);
+      bl[kb] = b3_cat(l0, l1);
+    }
+  }
+  f32x4 pre[NJ];
+  int trow[NJ], tcol[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int i = tid + 512 * jj;
+    trow[jj] = i / C4N;
+    tcol[jj] = (i - trow[jj] * C4N) * 4;
+  }
+  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  auto load_tile = [&](int tt) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int row = min(tt * GR_BM + trow[jj], a.M - 1);
+      pre[jj] = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + tcol[jj]);
+    }
+  };
+  auto store_tile = [&]() {            // split into the three planes on the way into LDS
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      bf16x4 h, m, l;
+      b3_split4(pre[jj], h, m, l);
+      const int off = trow[jj] * B3_LDP + tcol[jj];
+      *reinterpret_cast<bf16x4*>(planes + off) = h;
+      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+    }
+  };
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
+  const bool colok = active && col < a.N;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (!LN && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+  load_tile(t);
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // weight fragments, bias and the first tile
+  float* As = smem;                        // the LayerNorm epilogue stages its tile over the planes
+  for (; t < ntiles; t += gridDim.x) {
+    store_tile();
+    __syncthreads();
+    if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);     // in flight during the MFMAs and the epilogue
+    f32x4 acc[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      const __bf16* frag = planes + ((rg * RT) * 16 + (lane & 15)) * B3_LDP + 8 * (lane >> 4);
+#pragma unroll
+      for (int kb = 0; kb < KBN; ++kb) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const __bf16* fp = frag + rt * 16 * B3_LDP + kb * 32;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+          f32x4 c = acc[rt];
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[kb], am, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kb], al, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[kb], ah, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kb], am, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[kb], ah, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kb], ah, c, 0, 0, 0);
+          acc[rt] = c;
+        }
+      }
+    }
+    const int m0 = t * GR_BM;
+    if (!LN) {
+      if (colok) {       // host guarantees 16-byte aligned epilogue operands and N % 4 == 0
+        f32x4 aux[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+          f32x4 x = acc[rt] + bias;
+          if (ep.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          }
+          if (mode == 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
+          } else {
+            x += aux[rt];
+          }
+          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+        }
+      }
+    } else {
+      // LayerNorm epilogue (one chunk covers all N <= 128 columns): accumulators -> LDS tile ->
+      // one wave per 8 rows; every residual row is loaded before the first store
+      __syncthreads();                 // all waves are done reading this A buffer
+      float* Es = As;
+      if (active) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          *reinterpret_cast<f32x4*>(Es + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDE + ct * 16 + 4 * (lane >> 4)) = acc[rt];
+      }
+      const int ncols = a.N;
+      const bool ok0 = lane < ncols, ok1 = lane + 64 < ncols;
+      float res0[8], res1[8];
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int row = m0 + wave * 8 + rr;
+        const bool rok = row < a.M && ep.res != nullptr;
+        res0[rr] = (rok && ok0) ? ep.res[(size_t)row * ep.ldres + lane] : 0.f;
+        res1[rr] = (rok && ok1) ? ep.res[(size_t)row * ep.ldres + lane + 64] : 0.f;
+      }
+      const float bias0 = (ep.bias && ok0) ? ep.bias[lane] : 0.f, bias1 = (ep.bias && ok1) ? ep.bias[lane + 64] : 0.f;
+      const float g0 = ok0 ? ep.gamma[lane] : 0.f, g1 = ok1 ? ep.gamma[lane + 64] : 0.f;
+      const float be0 = ok0 ? ep.beta[lane] : 0.f, be1 = ok1 ? ep.beta[lane + 64] : 0.f;
+      __syncthreads();
+      const float inv_n = 1.f / (float)a.N;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) {
+        const int r = wave * 8 + rr;
+        const int row = m0 + r;
+        float v0 = 0.f, v1 = 0.f;
+        if (ok0) { v0 = Es[r * GR_LDE + lane] + bias0; if (ep.relu) v0 = fmaxf(v0, 0.f); v0 += res0[rr]; }
+        if (ok1) { v1 = Es[r * GR_LDE + lane + 64] + bias1; if (ep.relu) v1 = fmaxf(v1, 0.f); v1 += res1[rr]; }
+        const float mean = wave_sum(v0 + v1) * inv_n;
+        const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
+        const float rs = 1.f / sqrtf(var + 1e-5f);
+        if (row < a.M) {
+          if (ep.rstd && lane == 0) ep.rstd[row] = rs;
+          if (ok0) {
+            const float xh = d0 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
+            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+          }
+          if (ok1) {
+            const float xh = d1 * rs;
+            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
+            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+          }
+        }
+      }
+    }
+    __syncthreads();                   // every wave is done with the planes (fragments / LayerNorm tile)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_rows for K > 128 (the data gradients through the fused q/k/v weights: K = 3d), same 8-wave
 // persistent structure; the K extent is swept in 128-wide chunks: one (row tile, k chunk) per
 // iteration, accumulators carried across the chunks of a tile, B fragments of the chunk re-read from
@@ -905,6 +1130,26 @@ static int launch_w8g(const GemmRowsArgs& a, hipStream_t st) {
 }
 
 template <int RT, bool LN>
+static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
+  constexpr int CT = 8 / (4 / RT);
+  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
+  int gx = ntiles < 512 ? ntiles : 512;
+  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);      // >= the LayerNorm staging tile (64 x 132 floats)
+  if (a.K == 128) {
+    allow_lds((gemm_rows_b3_kernel<RT, LN, 4>), smem);
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+             (gemm_rows_b3_kernel<RT, LN, 4>), dim3(gx, nchunks), dim3(512), smem, st, a);
+  } else {
+    allow_lds((gemm_rows_b3_kernel<RT, LN, 2>), smem);
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+             (gemm_rows_b3_kernel<RT, LN, 2>), dim3(gx, nchunks), dim3(512), smem, st, a);
+  }
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int RT, bool LN>
 static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
   const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
@@ -942,6 +1187,18 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   if (rup(K, 16) <= GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("INTEL_GLDS"); use_glds = (e && e[0] == '0') ? 0 : 1; }
+    static int use_b3 = -1;
+    if (use_b3 < 0) { const char* e = getenv("INTEL_GEMM_B3"); use_b3 = (e && e[0] == '0') ? 0 : 1; }
+    if (use_b3 && (K == 128 || K == 64)) {         // bf16 matrix pipe, three-plane split (fp32 accuracy)
+      if (ep.gamma) {
+        if (N > 64) return launch_b3<4, true>(a, st);
+        if (N > 32) return launch_b3<2, true>(a, st);
+        return launch_b3<1, true>(a, st);
+      }
+      if (N > 64) return launch_b3<4, false>(a, st);
+      if (N > 32) return launch_b3<2, false>(a, st);
+      return launch_b3<1, false>(a, st);
+    }
     if (use_glds && (K == 128 || K == 64)) {       // direct-to-LDS variant
       if (ep.gamma) {
         if (N > 64) return launch_w8g<4, true>(a, st);
