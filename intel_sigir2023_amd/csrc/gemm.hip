@@ -783,6 +783,189 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
   }
 }
 
+// K > 128 on the bf16 pipe (the data gradients through the fused q/k/v weights, K = 3d or 2d): the K extent is
+// swept in 128-wide chunks, one (row tile, chunk) per iteration with the accumulators carried across the chunks of a
+// tile.  The weight fragments cannot stay in registers (3 planes x K/32 blocks), so they come pre-split from a
+// bf16 image made once per step by pack_b3_kernel: 12 x 16 bytes per lane per chunk from L2, no VALU work.
+// K is padded to a multiple of 128 with zero planes on both sides, so the chunk loop has no conditional MFMAs.
+// image layout: uint4 index ((nt * KBT + kb) * 3 + plane) * 64 + lane, KBT = 4 * ceil(K / 128).
+__global__ void pack_b3_kernel(const float* __restrict__ Pf, int KG, int KBT, uint4* __restrict__ Pb) {
+  const int nt = blockIdx.x / KBT, kb = blockIdx.x - nt * KBT;
+  const int lane = threadIdx.x, n = lane & 15, j = lane >> 4;
+  const int g = 2 * kb + (j >> 1);
+  f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f}, w1 = w0;
+  if (g < KG) {
+    const f32x4* P4 = reinterpret_cast<const f32x4*>(Pf) + ((size_t)nt * KG + g) * 64;
+    const int ls = (2 * (j & 1)) * 16 + n;
+    w0 = P4[ls];
+    w1 = P4[ls + 16];
+  }
+  bf16x4 h0, m0, l0, h1, m1, l1;
+  b3_split4(w0, h0, m0, l0);
+  b3_split4(w1, h1, m1, l1);
+  const bf16x8 H = b3_cat(h0, h1), Mi = b3_cat(m0, m1), Lo = b3_cat(l0, l1);
+  uint4* dst = Pb + ((size_t)(nt * KBT + kb) * 3) * 64 + lane;
+  dst[0] = __builtin_bit_cast(uint4, H);
+  dst[64] = __builtin_bit_cast(uint4, Mi);
+  dst[128] = __builtin_bit_cast(uint4, Lo);
+}
+size_t packed_b3_bytes(int Kd, int Nd) { return (size_t)(rup(Nd, 16) / 16) * (4 * cdiv(Kd, 128)) * 3 * 64 * 16; }
+int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st) {
+  const int NT = rup(Nd, 16) / 16, KG = rup(Kd, 16) / 16, KBT = 4 * cdiv(Kd, 128);
+  LAUNCH(pack_b3_kernel, dim3(NT * KBT), dim3(64), 0, st, Pf32, KG, KBT, reinterpret_cast<uint4*>(Pb3));
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int RT>
+__global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
+  constexpr int RG = 4 / RT;
+  constexpr int CT = 8 / RG;
+  constexpr int NJ = GR_BM * 32 / 512;          // float4 per thread per (tile, chunk): 4
+  constexpr int PLANE = GR_BM * B3_LDP;
+  constexpr bool LN = false;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ct = wave / RG, rg = wave % RG;
+  const int nch = (a.K + 127) >> 7, KBT = 4 * nch;
+  const int NT = (a.N + 15) >> 4;
+  const int nc = blockIdx.y * CT;
+  const int ntc = min(CT, NT - nc);
+  const bool active = ct < ntc;
+  const GemmEpilogue& ep = a.ep;
+  const uint4* Bimg = reinterpret_cast<const uint4*>(ep.b3) + ((size_t)(nc + (active ? ct : 0)) * KBT * 3) * 64 + lane;
+  f32x4 pre[NJ];
+  int trow[NJ], tcol[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int i = tid + 512 * jj;
+    trow[jj] = i >> 5;
+    tcol[jj] = (i & 31) * 4;
+  }
+  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
+  auto load_iter = [&](int tt, int c) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int row = min(tt * GR_BM + trow[jj], a.M - 1);
+      const int col = c * 128 + tcol[jj];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + min(col, a.K - 4));
+      pre[jj] = col < a.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_iter = [&]() {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      bf16x4 h, m, l;
+      b3_split4(pre[jj], h, m, l);
+      const int off = trow[jj] * B3_LDP + tcol[jj];
+      *reinterpret_cast<bf16x4*>(planes + off) = h;
+      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+    }
+  };
+  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
+  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
+  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
+  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
+  const bool colok = active && col < a.N;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int c = 0;
+  load_iter(t, 0);
+  f32x4 acc[RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  while (t < ntiles) {
+    // weight fragments of this chunk: in flight while the A chunk is split and stored
+    uint4 bw[4][3];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)(c * 4 + kb) * 3 + pl) * 64];
+    store_iter();
+    __syncthreads();
+    {   // prefetch the next (tile, chunk)
+      int tn = t, cn = c + 1;
+      if (cn == nch) { cn = 0; tn += gridDim.x; }
+      if (tn < ntiles) load_iter(tn, cn);
+    }
+    {
+      const __bf16* frag = planes + ((rg * RT) * 16 + (lane & 15)) * B3_LDP + 8 * (lane >> 4);
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[kb][0]), bm = __builtin_bit_cast(bf16x8, bw[kb][1]), bl = __builtin_bit_cast(bf16x8, bw[kb][2]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const __bf16* fp = frag + rt * 16 * B3_LDP + kb * 32;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+          f32x4 cc = acc[rt];
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, am, cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, am, cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm, ah, cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, cc, 0, 0, 0);
+          acc[rt] = cc;
+        }
+      }
+    }
+    if (c == nch - 1) {
+      const int m0 = t * GR_BM;
+      {
+        if (colok) {       // host guarantees 16-byte aligned epilogue operands and N % 4 == 0
+          f32x4 aux[RT];
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+            aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
+            f32x4 x = acc[rt] + bias;
+            if (ep.relu) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+            }
+            if (mode == 1) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
+            } else {
+              x += aux[rt];
+            }
+            if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (++c == nch) { c = 0; t += gridDim.x; }
+  }
+  (void)LN;
+}
+
+template <int RT>
+static int launch_b3k(const GemmRowsArgs& a, hipStream_t st) {
+  constexpr int CT = 8 / (4 / RT);
+  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
+  int gx = ntiles < 512 ? ntiles : 512;
+  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);
+  allow_lds(gemm_rows_b3k_kernel<RT>, smem);
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+           gemm_rows_b3k_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // gemm_rows for K > 128 (the data gradients through the fused q/k/v weights: K = 3d), same 8-wave
 // persistent structure; the K extent is swept in 128-wide chunks: one (row tile, k chunk) per
@@ -1220,6 +1403,13 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   }
   if (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && !((ep.mask || ep.res) && ep.accumulate) &&
       !(ep.mask && ep.res)) {
+    static int use_b3k = -1;
+    if (use_b3k < 0) { const char* e = getenv("INTEL_GEMM_B3"); use_b3k = (e && e[0] == '0') ? 0 : 1; }
+    if (use_b3k && ep.b3 && (K & 3) == 0) {      // pre-split weight image available: bf16 pipe
+      if (N > 64) return launch_b3k<4>(a, st);
+      if (N > 32) return launch_b3k<2>(a, st);
+      return launch_b3k<1>(a, st);
+    }
     if (N > 64) return launch_w8k<4>(a, st);
     if (N > 32) return launch_w8k<2>(a, st);
     return launch_w8k<1>(a, st);

@@ -31,7 +31,11 @@ struct GemmEpilogue {
   int ldxhat = 0;
   float* rstd = nullptr;          // [M]
   int accumulate = 0;             // C += value instead of C = value
+  const void* b3 = nullptr;       // optional pre-split bf16 image of B (launch_pack_b3): used when K > 128
 };
+// bf16 three-plane image of a packed fp32 B (any launch_pack_b result) for the K > 128 GEMM on the bf16 pipe
+size_t packed_b3_bytes(int Kd, int Nd);
+int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st);
 // C[M,N] = epilogue(A[M,K] @ B) with B packed by launch_pack_b (k extent K, n extent N).
 int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc,
                      const GemmEpilogue& ep, hipStream_t st);

@@ -41,6 +41,7 @@ struct TowerBufs {
   TowerLayerBufs layer[MAX_TOWER_LAYERS];
   float *QV, *QK, *XBAR, *ATTW;
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T;
+  float* b3WqkvT;           // bf16 three-plane image of pWqkvT (K = 3d > 128: GEMM on the bf16 pipe)
   float *pXq, *pXqT, *pXk, *pXkT, *pXv, *pXvT;
   // --cross_attention 0
   float *MH, *MV, *pM0, *pM2, *pM2T, *pM0T;
@@ -48,12 +49,14 @@ struct TowerBufs {
 struct EncBlockBufs {
   float *QKV, *A, *LSE, *C, *XH1, *RSTD1, *F1, *Eout, *XH2, *RSTD2;
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T, *bQKV;
+  float* b3WqkvT;
 };
 // the LAST BERT4Rec block only feeds row len-1 of its output forward (GeneralSeq.py:103-105): it is run
 // "pruned" -- K/V for all rows, everything else for one row per session
 struct EncLastBufs {
   float *KV, *XLAST, *QLAST, *PL, *OL, *CL, *XH1, *RSTD1, *F1, *XH2, *RSTD2;
   float *pWkvT, *pWqT;
+  float* b3WkvT;
 };
 struct EncBufs {
   int T, dm, d_tab, pbase, predin_off;
@@ -136,6 +139,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     w.pW1 = ar.f(packed_floats(d, d));
     w.pW2 = ar.f(packed_floats(d, d));
     w.pWqkvT = ar.f(packed_floats(3 * rup(d, 16), d));
+    w.b3WqkvT = ar.f(packed_b3_bytes(3 * rup(d, 16), d) / 4);
     w.pW1T = ar.f(packed_floats(d, d));
     w.pW2T = ar.f(packed_floats(d, d));
     if (D.cross_attention) {
@@ -176,11 +180,13 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
         k.pW1 = ar.f(packed_floats(dm, dm));
         k.pW2 = ar.f(packed_floats(dm, dm));
         k.pWqkvT = ar.f(packed_floats(3 * rup(dm, 16), dm));
+        k.b3WqkvT = ar.f(packed_b3_bytes(3 * rup(dm, 16), dm) / 4);
         k.pW1T = ar.f(packed_floats(dm, dm));
         k.pW2T = ar.f(packed_floats(dm, dm));
         k.bQKV = ar.f(3 * dm);
       }
       n.last.pWkvT = ar.f(packed_floats(2 * rup(dm, 16), dm));
+      n.last.b3WkvT = ar.f(packed_b3_bytes(2 * rup(dm, 16), dm) / 4);
       n.last.pWqT = ar.f(packed_floats(dm, dm));
     } else {
       gru_layout_packed(n.gru, dm, D.gru_hidden, ar.base, ar.off);
@@ -456,7 +462,28 @@ void pack_tower(Run& r, TowerBufs& w) {
   }
 }
 
+void pack_fp32(Run& r);
+
 void pack_all(Run& r) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  pack_fp32(r);
+  if (r.rc) return;
+  // bf16 three-plane images of the K > 128 weights (data gradients through the fused q/k/v weights)
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
+  }
+  if (D.encoder == INTEL_ENC_BERT4REC) {
+    for (int e = 0; e < 2; ++e) {
+      EncBufs& n = y.enc[e];
+      for (int l = 0; l + 1 < D.enc_layers; ++l) RUN(launch_pack_b3(n.blk[l].pWqkvT, 3 * rup(n.dm, 16), n.dm, n.blk[l].b3WqkvT, r.st));
+      RUN(launch_pack_b3(n.last.pWkvT, 2 * rup(n.dm, 16), n.dm, n.last.b3WkvT, r.st));
+    }
+  }
+}
+
+void pack_fp32(Run& r) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const int I = D.intent_num, K = D.model_num;
@@ -588,6 +615,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
     // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
     GemmEpilogue er;
     er.res = r.T->dZ; er.ldres = d;
+    er.b3 = w.b3WqkvT;
     lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
@@ -725,6 +753,7 @@ float* bert_bwd(Run& r, int e) {
     wgrad(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_BK));
     wgrad(r, r.T->dQKV + dm, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WV), enc_blk_slot(e, l, INTEL_ENC_BV));
     GemmEpilogue e0;
+    e0.b3 = q.b3WkvT;
     lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
     if (r.rc) return nullptr;
     if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st))) return nullptr;
@@ -765,6 +794,7 @@ float* bert_bwd(Run& r, int e) {
     {
       GemmEpilogue er;
       er.res = r.T->dZ; er.ldres = dm;
+      er.b3 = k.b3WqkvT;
       lin(r, r.T->dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);   // dm % 16 == 0 (check_desc)
     }
     if (r.rc) return nullptr;
