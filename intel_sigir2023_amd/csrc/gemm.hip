@@ -1694,6 +1694,162 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
   if (do_db) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_b3_kernel<NTW,KTW>: the slab product on the bf16 matrix pipe with the three-plane split of gemm_rows_b3
+// (fp32 accuracy).  The reduction runs over ROWS, so one v_mfma_f32_16x16x32_bf16 consumes a whole 32-row tile and
+// both operands are needed "k-contiguous": 8 consecutive rows of one column per lane.  The tile is therefore
+// staged TRANSPOSED: a thread loads a 4-row x 4-column block (four 16-byte loads), splits its 16 values and writes,
+// per column, the four rows as one 8-byte store into planesT[plane][column][row] (40-element = 80-byte column
+// pitch, see WB_LDT).  Single LDS stage (61 KB at 128+128 columns -> two workgroups per
+// CU), the next tile is prefetched into registers under the MFMAs.  db = column sums of dY is accumulated by the
+// staging threads in registers (a thread always owns the same four columns).
+// ------------------------------------------------------------------------------------------
+#define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
+                           // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
+template <int NTW, int KTW>
+__global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
+  constexpr int NB = 32 * NTW, KB = 32 * KTW;
+  constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
+  constexpr int YPT = (YBL + 255) / 256, XPT = (XBL + 255) / 256;  // blocks per thread (1 at 128 columns)
+  constexpr int PLANE = (NB + KB) * WB_LDT;                        // bf16 elements per plane
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
+  const int ntiles = a.M / WG_RT, S = gridDim.x;
+  // staging blocks of this thread: block b -> rows 4*(b % 8) .., columns 4*(b / 8) ..  (row block fastest: the stores of
+  // eight adjacent lanes fill one column's 64 bytes)
+  f32x4 py[YPT][4], px[XPT][4];
+  float dbacc[YPT][4];
+#pragma unroll
+  for (int u = 0; u < YPT; ++u)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+  auto load_tile = [&](int tt) {
+    const size_t m0 = (size_t)tt * WG_RT;
+#pragma unroll
+    for (int u = 0; u < YPT; ++u) {
+      const int b = min(tid + 256 * u, YBL - 1), rb = b & 7, cb = b >> 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) py[u][r] = *reinterpret_cast<const f32x4*>(a.dY + (m0 + 4 * rb + r) * a.lddy + n0 + 4 * cb);
+    }
+#pragma unroll
+    for (int u = 0; u < XPT; ++u) {
+      const int b = min(tid + 256 * u, XBL - 1), rb = b & 7, cb = b >> 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) px[u][r] = *reinterpret_cast<const f32x4*>(a.X + (m0 + 4 * rb + r) * a.ldx + k0 + 4 * cb);
+    }
+  };
+  auto store_block = [&](const f32x4 (&v)[4], int colbase, int rb, int cb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 colv = f32x4{v[0][c], v[1][c], v[2][c], v[3][c]};       // four consecutive rows of one column
+      bf16x4 h, m, l;
+      b3_split4(colv, h, m, l);
+      const int off = (colbase + 4 * cb + c) * WB_LDT + 4 * rb;
+      *reinterpret_cast<bf16x4*>(planes + off) = h;
+      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int u = 0; u < YPT; ++u) {
+      const int b = tid + 256 * u;
+      if (b < YBL) {
+        const int rb = b & 7, cb = b >> 3;
+        store_block(py[u], 0, rb, cb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dbacc[u][c] += (py[u][0][c] + py[u][1][c]) + (py[u][2][c] + py[u][3][c]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < XPT; ++u) {
+      const int b = tid + 256 * u;
+      if (b < XBL) {
+        const int rb = b & 7, cb = b >> 3;
+        store_block(px[u], NB, rb, cb);
+      }
+    }
+  };
+  f32x4 acc[NTW][KTW];
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = blockIdx.x;
+  if (t < ntiles) load_tile(t);
+  // fragment addresses: column (wn*16*NTW + i*16 + p) of dY, (NB + wk*16*KTW + j*16 + p) of X, rows 8g .. 8g+7
+  const __bf16* fy = planes + (wn * 16 * NTW + p) * WB_LDT + 8 * g;
+  const __bf16* fx = planes + (NB + wk * 16 * KTW + p) * WB_LDT + 8 * g;
+  for (; t < ntiles; t += S) {
+    store_tile();
+    __syncthreads();
+    if (t + S < ntiles) load_tile(t + S);
+    bf16x8 xh[KTW], xm[KTW], xl[KTW];
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const __bf16* q = fx + j * 16 * WB_LDT;
+      xh[j] = *reinterpret_cast<const bf16x8*>(q);
+      xm[j] = *reinterpret_cast<const bf16x8*>(q + PLANE);
+      xl[j] = *reinterpret_cast<const bf16x8*>(q + 2 * PLANE);
+    }
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) {
+      const __bf16* q = fy + i * 16 * WB_LDT;
+      const bf16x8 yh = *reinterpret_cast<const bf16x8*>(q);
+      const bf16x8 ym = *reinterpret_cast<const bf16x8*>(q + PLANE);
+      const bf16x8 yl = *reinterpret_cast<const bf16x8*>(q + 2 * PLANE);
+#pragma unroll
+      for (int j = 0; j < KTW; ++j) {
+        f32x4 c = acc[i][j];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ym, xm[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xl[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yl, xh[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xm[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ym, xh[j], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[j], c, 0, 0, 0);
+        acc[i][j] = c;
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
+#pragma unroll
+  for (int i = 0; i < NTW; ++i)
+#pragma unroll
+    for (int j = 0; j < KTW; ++j) {
+      const int k = k0 + wk * 16 * KTW + j * 16 + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 16 * NTW + i * 16 + 4 * g + r;
+        slab[(size_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+  if (a.want_db && blockIdx.z == 0) {
+    // column sums: the 8 row-blocks of a column block live in threads cb, cb + NB/4, ... ; reduce through LDS
+    float* red = smem;                          // [8][NB] after the last barrier of the loop
+#pragma unroll
+    for (int u = 0; u < YPT; ++u) {
+      const int b = tid + 256 * u;
+      if (b < YBL) {
+        const int rb = b & 7, cb = b >> 3;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[rb * NB + 4 * cb + c] = dbacc[u][c];
+      }
+    }
+    __syncthreads();
+    if (tid < NB) {
+      float sdb = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) sdb += red[rb * NB + tid];
+      slab[(size_t)a.N * a.K + n0 + tid] = sdb;
+    }
+  }
+}
+
 // out[i] (+)= sum_s slabs[s][i]; i < n.  16 slab lanes x 16 output groups per workgroup; each lane
 // sums its strided slabs with 4 independent accumulators, then a fixed-order LDS tree: reproducible.
 template <int VEC>
@@ -2016,6 +2172,23 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
     const bool aligned = ((lddy & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
+    static const int use_wb3 = [] { const char* e = getenv("INTEL_WGRAD_B3"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (use_wb3 && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
+      const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
+      const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
+      size_t smem = (size_t)3 * 32 * (ntw + ktw) * WB_LDT * sizeof(__bf16);
+      if (smem < (size_t)8 * 32 * ntw * sizeof(float)) smem = (size_t)8 * 32 * ntw * sizeof(float);
+#define WB_CASE(A_, B_)                                                                                             \
+  if (ntw == A_ && ktw == B_) {                                                                                     \
+    allow_lds((wgrad_b3_kernel<A_, B_>), smem);                                                                     \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_>), grid, \
+             dim3(256), smem, st, a);                                                                               \
+  }
+      WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
+#undef WB_CASE
+      INTEL_CHECK_LAUNCH();
+      goto reduce;
+    }
     if (use_dma && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
