@@ -32,11 +32,20 @@ class IntELEngine(object):
         self.cal_diversity, self.alpha = int(g('cal_diversity', 0)), float(g('diversity_alpha', 0.01))
         self.lr, self.l2, self.betas, self.eps = float(lr), float(l2), betas, float(eps)
         self.step_count = 0
-        self.force_phases = False          # tests: run the two-phase backward without a process group
+        self.force_phases = False          # kept for tests written against the earlier interface (no effect)
+        # two-phase backward + table all-reduce / Adam on a side stream (default); INTEL_OVERLAP_TABLE=0 runs the plain order
+        import os
+        self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
+        self._side = None
         self.device = next(model.parameters()).device
         L.require_gpu(next(model.parameters()))
         self._flatten()
         self._bufs = {}
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # ---- flat parameter / gradient / moment buckets -------------------------------------------------
     def _flatten(self):
@@ -133,25 +142,42 @@ class IntELEngine(object):
             L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label.contiguous()), self.kl_weight, self.kl_temp,
                                           self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws), nb, st),
                     'intel_intent_loss')
-        if world > 1 or self.force_phases:
-            # phase 1 completes the item-id table gradient; its all-reduce (the large one) then runs on the
-            # communication stream underneath phase 2 (score-tower layers, session-history encoder)
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
-            work = parallel.allreduce_sum_async(self.gflat['iid'])
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
-            parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
-            if work is not None:
-                work.wait()
-        else:
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
         self.step_count += 1
         b1, b2 = self.betas
-        for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
+
+        def adam(gname, wd, stream_ptr):
             n = self.flat[gname].numel()
             if n:
                 L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
                                             L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
-                                            1, st), 'intel_adam_step')
+                                            1, stream_ptr), 'intel_adam_step')
+        if self.overlap_table_update:
+            # phase 1 completes the item-id table gradient (the 256 MB bucket).  Its all-reduce (data parallel) and its
+            # dense Adam sweep -- HBM-bound, 28 B per parameter -- then run on a side stream underneath phase 2 (score-tower
+            # layers, session-history encoder: matrix work that touches neither the table nor its gradient)
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream()
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
+            work = parallel.allreduce_sum_async(self.gflat['iid']) if world > 1 else None
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                if work is not None:
+                    work.wait()
+                adam('iid', self.l2, L.stream_ptr(dev))
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
+            if world > 1:
+                parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
+            adam('decay', self.l2, st)
+            adam('nodecay', 0.0, st)
+            cur.wait_stream(side)
+        else:
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+            if world > 1:
+                parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
+            for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
+                adam(gname, wd, st)
         ens_loss = loss_e.reshape(()).clone()
         if self.with_intent:
             int_loss = out3[0].clone()
