@@ -886,7 +886,9 @@ void forward_impl(Run& r, const IntelOut* out) {
   const int off_u = ti.d + ts.d, off_int = off_u + D.d_u;
   const float scale = 1.0f / sqrtf((float)D.q_size);
   GemmEpilogue e0;
-  for (int t = 0; t < 2; ++t) {
+  // the two towers' intent-conditioned pooling chains (five small launches each) are independent: item tower on the
+  // main stream, score tower on a side stream
+  auto pool_tower = [&](Run& r, int t) {
     TowerBufs& w = y.tw[t];
     const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
     if (D.cross_attention) {
@@ -905,8 +907,16 @@ void forward_impl(Run& r, const IntelOut* out) {
       if (r.rc) return;
       RUN(launch_gate_fwd(Xf, w.d, w.MV, B, L, y.FEATFULL, y.F, w.feat_off, r.st));
     }
-    if (r.rc) return;
+  };
+  fork_streams(r, 1);
+  {
+    Run b1 = branch(r, 0, 1);
+    pool_tower(b1, 1);
+    pool_tower(r, 0);
+    r.ok(b1.rc);
   }
+  join_streams(r, 1);
+  if (r.rc) return;
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.FEAT, y.F, off_u, 1, r.st));     // relu(h_u)
   {
     GemmEpilogue eh;
@@ -1073,9 +1083,14 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     // cross-attention backward of both towers first: d(intent) is then complete and the intent path can
     // start while the (heavy) tower layers are still running
     r.T = &y.tmp[0];
-    xatt_bwd(r, 0, y.tmp[0].dXa, y.tmp[0].dINT);
-    if (r.rc) return;
-    xatt_bwd(r, 1, y.dXS, y.tmp[1].dINT);
+    fork_streams(r, 1);
+    {
+      Run b1 = branch(r, 0, 1);
+      xatt_bwd(b1, 1, y.dXS, y.tmp[1].dINT);
+      xatt_bwd(r, 0, y.tmp[0].dXa, y.tmp[0].dINT);
+      r.ok(b1.rc);
+    }
+    join_streams(r, 1);
     if (r.rc) return;
     RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
     RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
