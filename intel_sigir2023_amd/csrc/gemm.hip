@@ -1434,8 +1434,11 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 #define WG_MAXS 512       // max slabs: 2 resident workgroups per CU (72 KB LDS each)
 
 static inline int wgrad_num_slabs(int M) {
-  int s = cdiv(M, WG_RT);      // one 32-row tile per workgroup until the chip is full
-  return s < 1 ? 1 : (s > WG_MAXS ? WG_MAXS : s);
+  static const int maxs = [] { const char* e = getenv("INTEL_WGRAD_SLABS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > WG_MAXS ? WG_MAXS : v); }();
+  // default 256 = one workgroup per CU: with the products on the bf16 pipe the kernel is HBM-bound and the slab traffic
+  // (write here, read by the batched reduction) matters more than a second resident workgroup (measured: -1.5 % step time)
+  int s = cdiv(M, WG_RT);
+  return s < 1 ? 1 : (s > maxs ? maxs : s);
 }
 size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M) * ((size_t)N * K + N); }
 
