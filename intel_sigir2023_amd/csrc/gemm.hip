@@ -789,8 +789,44 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
 // bf16 image made once per step by pack_b3_kernel: 12 x 16 bytes per lane per chunk from L2, no VALU work.
 // K is padded to a multiple of 128 with zero planes on both sides, so the chunk loop has no conditional MFMAs.
 // image layout: uint4 index ((nt * KBT + kb) * 3 + plane) * 64 + lane, KBT = 4 * ceil(K / 128).
-__global__ void pack_b3_kernel(const float* __restrict__ Pf, int KG, int KBT, uint4* __restrict__ Pb) {
-  const int nt = blockIdx.x / KBT, kb = blockIdx.x - nt * KBT;
+// small contiguous vector copies (bias concatenation for the fused q/k/v projections), recorded and issued together
+#define VCOPY_MAX_JOBS 32
+struct VCopyJob { const float* src; float* dst; int n, pad; };
+struct VCopyJobs { int n; int pad; VCopyJob j[VCOPY_MAX_JOBS]; };
+__global__ void vec_copy_batch_kernel(VCopyJobs jobs) {
+  const VCopyJob jb = jobs.j[blockIdx.x];
+  for (int i = threadIdx.x; i < jb.n; i += blockDim.x) jb.dst[i] = jb.src[i];
+}
+static thread_local VCopyJobs g_vcopy;
+int vec_copy_flush(hipStream_t st) {
+  if (g_vcopy.n == 0) return 0;
+  LAUNCH(vec_copy_batch_kernel, dim3(g_vcopy.n), dim3(256), 0, st, g_vcopy);
+  g_vcopy.n = 0;
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+int launch_vec_copy(const float* src, float* dst, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (g_vcopy.n == VCOPY_MAX_JOBS) {
+    int rc = vec_copy_flush(st);
+    if (rc) return rc;
+  }
+  VCopyJob& jb = g_vcopy.j[g_vcopy.n++];
+  jb.src = src; jb.dst = dst; jb.n = n; jb.pad = 0;
+  return 0;
+}
+
+#define PACK3_MAX_JOBS 16
+struct Pack3Job { const float* Pf; uint4* Pb; int KG, KBT, blk0, pad; };
+struct Pack3Jobs { int n; int pad; Pack3Job j[PACK3_MAX_JOBS]; };
+__global__ void pack_b3_kernel(Pack3Jobs jobs) {
+  int ji = 0;
+  while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].blk0) ++ji;
+  const float* __restrict__ Pf = jobs.j[ji].Pf;
+  uint4* __restrict__ Pb = jobs.j[ji].Pb;
+  const int KG = jobs.j[ji].KG, KBT = jobs.j[ji].KBT;
+  const int blk = blockIdx.x - jobs.j[ji].blk0;
+  const int nt = blk / KBT, kb = blk - nt * KBT;
   const int lane = threadIdx.x, n = lane & 15, j = lane >> 4;
   const int g = 2 * kb + (j >> 1);
   f32x4 w0 = f32x4{0.f, 0.f, 0.f, 0.f}, w1 = w0;
@@ -810,10 +846,26 @@ __global__ void pack_b3_kernel(const float* __restrict__ Pf, int KG, int KBT, ui
   dst[128] = __builtin_bit_cast(uint4, Lo);
 }
 size_t packed_b3_bytes(int Kd, int Nd) { return (size_t)(rup(Nd, 16) / 16) * (4 * cdiv(Kd, 128)) * 3 * 64 * 16; }
+// conversions are recorded and issued together by pack_b3_flush (one launch per 16 weights)
+static thread_local Pack3Jobs g_pack3;
+static thread_local int g_pack3_blocks = 0;
+int pack_b3_flush(hipStream_t st) {
+  if (g_pack3.n == 0) return 0;
+  LAUNCH(pack_b3_kernel, dim3(g_pack3_blocks), dim3(64), 0, st, g_pack3);
+  g_pack3.n = 0;
+  g_pack3_blocks = 0;
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
 int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st) {
   const int NT = rup(Nd, 16) / 16, KG = rup(Kd, 16) / 16, KBT = 4 * cdiv(Kd, 128);
-  LAUNCH(pack_b3_kernel, dim3(NT * KBT), dim3(64), 0, st, Pf32, KG, KBT, reinterpret_cast<uint4*>(Pb3));
-  INTEL_CHECK_LAUNCH();
+  if (g_pack3.n == PACK3_MAX_JOBS) {
+    int rc = pack_b3_flush(st);
+    if (rc) return rc;
+  }
+  Pack3Job& jb = g_pack3.j[g_pack3.n++];
+  jb.Pf = Pf32; jb.Pb = reinterpret_cast<uint4*>(Pb3); jb.KG = KG; jb.KBT = KBT; jb.blk0 = g_pack3_blocks; jb.pad = 0;
+  g_pack3_blocks += NT * KBT;
   return 0;
 }
 

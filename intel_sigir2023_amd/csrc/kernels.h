@@ -35,7 +35,11 @@ struct GemmEpilogue {
 };
 // bf16 three-plane image of a packed fp32 B (any launch_pack_b result) for the K > 128 GEMM on the bf16 pipe
 size_t packed_b3_bytes(int Kd, int Nd);
-int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st);
+int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st);   // records; pack_b3_flush launches
+int pack_b3_flush(hipStream_t st);
+// dst[0:n] = src[0:n], recorded; vec_copy_flush launches all recorded copies as one kernel
+int launch_vec_copy(const float* src, float* dst, int n, hipStream_t st);
+int vec_copy_flush(hipStream_t st);
 // C[M,N] = epilogue(A[M,K] @ B) with B packed by launch_pack_b (k extent K, n extent N).
 int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc,
                      const GemmEpilogue& ep, hipStream_t st);

@@ -481,6 +481,8 @@ void pack_all(Run& r) {
       RUN(launch_pack_b3(n.last.pWkvT, 2 * rup(n.dm, 16), n.dm, n.last.b3WkvT, r.st));
     }
   }
+  RUN(pack_b3_flush(r.st));
+  RUN(vec_copy_flush(r.st));
 }
 
 void pack_fp32(Run& r) {
@@ -516,7 +518,7 @@ void pack_fp32(Run& r) {
           const float* W = r.P(enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j));
           RUN(launch_pack_b(W, dm, dm, dm, 0, k.pWqkv, j * nt, r.st));
           RUN(launch_pack_b(W, dm, dm, dm, 1, k.pWqkvT, 0, r.st, j * nt, 3 * nt));
-          RUN(launch_copy_cols(r.P(enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j)), dm, 0, dm, 1, k.bQKV, 3 * dm, j * dm, nullptr, 0, 0, 0, r.st));
+          RUN(launch_vec_copy(r.P(enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j)), k.bQKV + j * dm, dm, r.st));
         }
         RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W1)), dm, dm, dm, 0, k.pW1, 0, r.st));
         RUN(launch_pack_b(r.P(enc_blk_slot(e, l, INTEL_ENC_W2)), dm, dm, dm, 0, k.pW2, 0, r.st));
