@@ -192,11 +192,13 @@ def main():
     if not a.no_roofline:
         lib = _lib.lib()
         lib.intel_set_concurrency(model._context(), 0)     # price kernels one at a time on one stream
+        ov, eng.overlap_table_update = eng.overlap_table_update, False
         lib.intel_prof_enable(1)
         for i in range(psteps):
             one_step(i)
         prof_shapes = json.loads(lib.intel_prof_collect().decode())
         lib.intel_prof_enable(0)
+        eng.overlap_table_update = ov
         lib.intel_set_concurrency(model._context(), 1)
     if rank != 0:
         return

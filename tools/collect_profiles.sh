@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1 < /dev/null
 tail -2 $out/tests.log
 timeout 600 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
-INTEL_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_feed > $out/stats1s.log 2>&1 < /dev/null
+INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_feed > $out/stats1s.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_feed > $out/stats.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline --no_feed > $out/fetch.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline --no_feed > $out/write.log 2>&1 < /dev/null
