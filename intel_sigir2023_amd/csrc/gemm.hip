@@ -1485,14 +1485,17 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 #define WG_RT 32          // rows per LDS tile
 #define WG_MAXS 512       // max slabs: 2 resident workgroups per CU (72 KB LDS each)
 
-static inline int wgrad_num_slabs(int M) {
+static inline int wgrad_num_slabs(int M, int N = 128, int K = 128) {
   static const int maxs = [] { const char* e = getenv("INTEL_WGRAD_SLABS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > WG_MAXS ? WG_MAXS : v); }();
   // default 256 = one workgroup per CU: with the products on the bf16 pipe the kernel is HBM-bound and the slab traffic
-  // (write here, read by the batched reduction) matters more than a second resident workgroup (measured: -1.5 % step time)
+  // (write here, read by the batched reduction) matters more than a second resident workgroup (measured: -1.5 % step time).
+  // Narrow products (N + K <= 128: 30 KB of LDS, 16 KB slabs) are latency-bound instead: two workgroups per CU.
+  int cap = (N + K <= 128 && N % 32 == 0 && K % 32 == 0) ? 2 * maxs : maxs;
+  if (cap > WG_MAXS) cap = WG_MAXS;
   int s = cdiv(M, WG_RT);
-  return s < 1 ? 1 : (s > maxs ? maxs : s);
+  return s < 1 ? 1 : (s > cap ? cap : s);
 }
-size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M) * ((size_t)N * K + N); }
+size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M, N, K) * ((size_t)N * K + N); }
 
 struct WgradArgs {
   const float* dY; int lddy; const float* X; int ldx; int M, N, K;
@@ -2220,7 +2223,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   }
   WgradArgs a;
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.slabs = slabs;
-  a.S = wgrad_num_slabs(M); a.want_db = db != nullptr;
+  a.S = wgrad_num_slabs(M, N, K); a.want_db = db != nullptr;
   {
     // fast path: exact 32-row tiles, widths in 32-float steps, 16-byte aligned operands
     static const int use_dma = [] { const char* e = getenv("INTEL_WGRAD_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
