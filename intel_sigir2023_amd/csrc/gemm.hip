@@ -118,6 +118,16 @@ struct GemmRowsArgs {
   GemmEpilogue ep;
 };
 
+// bytes a launch must move: A, packed B, C, plus the epilogue operands (residual / relu mask / accumulate input,
+// LayerNorm x-hat stash)
+static double gemm_algorithmic_bytes(const GemmRowsArgs& a) {
+  double b = 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
+  if (a.ep.res || a.ep.mask || a.ep.accumulate) b += 4.0 * (double)a.M * a.N;
+  if (a.ep.xhat) b += 4.0 * (double)a.M * a.N + 4.0 * (double)a.M;
+  return b;
+}
+
+
 // Epilogues.  The MFMAs are issued with the WEIGHT fragment as the A operand and the activation
 // fragment as the B operand, so an accumulator register quad holds 4 CONSECUTIVE OUTPUT COLUMNS of
 // one row (row = lane&15 of the tile): every epilogue load/store is a 16-byte access.
@@ -1012,7 +1022,7 @@ static int launch_b3k(const GemmRowsArgs& a, hipStream_t st) {
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);
   allow_lds(gemm_rows_b3k_kernel<RT>, smem);
-  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
            gemm_rows_b3k_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -1162,7 +1172,7 @@ static int launch_w8k(const GemmRowsArgs& a, hipStream_t st) {
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_w8k_kernel<RT>, smem);
-  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
            gemm_rows_w8k_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -1358,7 +1368,7 @@ static int launch_w8g(const GemmRowsArgs& a, hipStream_t st) {
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
   allow_lds((gemm_rows_w8g_kernel<RT, LN>), smem);
-  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
            (gemm_rows_w8g_kernel<RT, LN>), dim3(gx, nchunks), dim3(512), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -1373,11 +1383,11 @@ static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);      // >= the LayerNorm staging tile (64 x 132 floats)
   if (a.K == 128) {
     allow_lds((gemm_rows_b3_kernel<RT, LN, 4>), smem);
-    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
              (gemm_rows_b3_kernel<RT, LN, 4>), dim3(gx, nchunks), dim3(512), smem, st, a);
   } else {
     allow_lds((gemm_rows_b3_kernel<RT, LN, 2>), smem);
-    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
              (gemm_rows_b3_kernel<RT, LN, 2>), dim3(gx, nchunks), dim3(512), smem, st, a);
   }
   INTEL_CHECK_LAUNCH();
@@ -1392,7 +1402,7 @@ static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
   allow_lds((gemm_rows_w8_kernel<RT, LN>), smem);
-  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N),
+  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
            (gemm_rows_w8_kernel<RT, LN>), dim3(gx, nchunks), dim3(512), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
