@@ -859,6 +859,12 @@ size_t packed_b3_bytes(int Kd, int Nd) { return (size_t)(rup(Nd, 16) / 16) * (4 
 // conversions are recorded and issued together by pack_b3_flush (one launch per 16 weights)
 static thread_local Pack3Jobs g_pack3;
 static thread_local int g_pack3_blocks = 0;
+// drop anything a failed earlier call left recorded
+void pack_jobs_reset() {
+  g_pack3.n = 0;
+  g_pack3_blocks = 0;
+  g_vcopy.n = 0;
+}
 int pack_b3_flush(hipStream_t st) {
   if (g_pack3.n == 0) return 0;
   LAUNCH(pack_b3_kernel, dim3(g_pack3_blocks), dim3(64), 0, st, g_pack3);

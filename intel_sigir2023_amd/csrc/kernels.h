@@ -40,6 +40,7 @@ int pack_b3_flush(hipStream_t st);
 // dst[0:n] = src[0:n], recorded; vec_copy_flush launches all recorded copies as one kernel
 int launch_vec_copy(const float* src, float* dst, int n, hipStream_t st);
 int vec_copy_flush(hipStream_t st);
+void pack_jobs_reset();
 // C[M,N] = epilogue(A[M,K] @ B) with B packed by launch_pack_b (k extent K, n extent N).
 int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int N, float* C, int ldc,
                      const GemmEpilogue& ep, hipStream_t st);

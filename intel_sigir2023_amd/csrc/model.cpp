@@ -467,6 +467,7 @@ void pack_fp32(Run& r);
 void pack_all(Run& r) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
+  pack_jobs_reset();
   pack_fp32(r);
   if (r.rc) return;
   // bf16 three-plane images of the K > 128 weights (data gradients through the fused q/k/v weights)
