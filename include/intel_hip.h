@@ -206,6 +206,14 @@ size_t intel_loss_workspace_bytes(int B, int L, int K);
 int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
 
+/* ---- data-parallel gradient exchange of a table's touched rows ------------------------------ */
+/* out[i,:] = table[idx[i],:] (zeros for idx[i] < 0); zero_rows != 0 also clears those table rows.  idx: a rank's
+ * unique touched rows, padded with -1.  No reference counterpart (the reference is single-GPU). */
+int intel_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, void* stream);
+/* table[idx[i],:] += rows[i,:] for idx[i] >= 0; idx must not repeat within one call (no atomics: called once per
+ * source rank, in rank order, so that every replica sums in the same order). */
+int intel_rows_add(float* table, int d, const int* idx, int n, const float* rows, void* stream);
+
 /* ---- evaluation --------------------------------------------------------------------------- */
 /* Overall NDCG@k of BaseRunner.evaluate_method (helpers/BaseRunner.py:117-126) for a padded batch:
  * ndcg[b] per session (linear gains, pads scored 0 / labelled 0, width = max(L, k)). */

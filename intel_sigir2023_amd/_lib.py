@@ -122,7 +122,7 @@ EXPORTS = [
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
-    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_feed_collate', 'intel_feed_abi_sizes',
+    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add',
 ]
 
 
@@ -160,6 +160,8 @@ def _declare(l):
     sig('intel_op_attention_bwd_workspace_bytes', sz, [i, i, i, i])
     sig('intel_op_add_layernorm', i, [vp, vp, i, i, vp, vp, vp, vp, vp, vp])
     sig('intel_op_workspace_bytes', sz, [i, i, i])
+    sig('intel_rows_take', i, [vp, i, vp, i, vp, i, vp])
+    sig('intel_rows_add', i, [vp, i, vp, i, vp, vp])
     sig('intel_feed_abi_sizes', None, [C.POINTER(C.c_int)])
     sig('intel_feed_collate', i, [C.POINTER(IntelFeedStore), vp, i, vp, C.c_ulonglong, C.POINTER(IntelFeedOut), vp])
     sig('intel_prof_enable', None, [i])

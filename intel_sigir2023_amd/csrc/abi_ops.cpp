@@ -78,6 +78,16 @@ extern "C" int intel_op_attention_bwd(const float* qkv, const float* out, const 
   return launch_attn_bwd(qkv, out, d_out, lse, B, T, d, heads, key_len, d_qkv, workspace, (hipStream_t)stream);
 }
 
+extern "C" int intel_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, void* stream) {
+  INTEL_CHECK_ARG(table && idx && out && d > 0 && n >= 0, "intel_rows_take: bad argument");
+  return launch_rows_take(table, d, idx, n, out, zero_rows, (hipStream_t)stream);
+}
+
+extern "C" int intel_rows_add(float* table, int d, const int* idx, int n, const float* rows, void* stream) {
+  INTEL_CHECK_ARG(table && idx && rows && d > 0 && n >= 0, "intel_rows_add: bad argument");
+  return launch_rows_add(table, d, idx, n, rows, (hipStream_t)stream);
+}
+
 extern "C" int intel_op_add_layernorm(const float* x, const float* r, int M, int N, const float* gamma,
                                       const float* beta, float* y, float* xhat, float* rstd, void* stream) {
   return launch_add_layernorm(x, N, r, N, M, N, gamma, beta, y, N, xhat, N, rstd, (hipStream_t)stream);

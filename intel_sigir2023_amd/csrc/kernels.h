@@ -116,6 +116,9 @@ size_t ln_bwd_slab_floats(int M, int N);
 int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh, const float* rstd, int M, int N,
                          const float* gamma, float* dz, int lddz, float* dgamma, float* dbeta, int accumulate,
                          float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
+// touched-row exchange of a gradient table (data parallel): see rowops.hip
+int launch_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, hipStream_t st);
+int launch_rows_add(float* table, int d, const int* idx, int n, const float* rows, hipStream_t st);
 // softmax over rows of length N (in place allowed)
 int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st);
 // dx = y * (dy - sum(dy*y))

@@ -376,3 +376,52 @@ int launch_mul2(const float* a, const float* b, long long n, float* y, hipStream
   INTEL_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Data-parallel exchange of a gradient table's touched rows: rows_take moves rows idx[i] of
+// the table into a dense buffer (and clears them in the table), rows_add adds a buffer of rows back.  Within one
+// call idx holds no repeats (a rank's compacted, unique row list; -1 = padding), so there are no atomics and the
+// sum over ranks is taken in rank order on every rank: replicas stay bit-identical.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rows_take_kernel(float* __restrict__ table, int d, const int* __restrict__ idx, int n,
+                                                        float* __restrict__ out, int zero_rows) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int r = idx[i];
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r >= 0) {
+      f32x4* src = reinterpret_cast<f32x4*>(table + (size_t)r * d + c);
+      v = *src;
+      if (zero_rows) *src = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)i * d + c) = v;
+  }
+}
+__global__ __launch_bounds__(256) void rows_add_kernel(float* __restrict__ table, int d, const int* __restrict__ idx, int n,
+                                                       const float* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int r = idx[i];
+  if (r < 0) return;
+  for (int c = lane * 4; c < d; c += 256) {
+    f32x4* dst = reinterpret_cast<f32x4*>(table + (size_t)r * d + c);
+    *dst = *dst + *reinterpret_cast<const f32x4*>(rows + (size_t)i * d + c);
+  }
+}
+int launch_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, hipStream_t st) {
+  if (n <= 0) return 0;
+  INTEL_CHECK_ARG(d % 4 == 0, "rows_take: row width %d must be a multiple of 4", d);
+  LAUNCH_W(0.0, 8.0 * (double)n * d, rows_take_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, table, d, idx, n, out, zero_rows);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+int launch_rows_add(float* table, int d, const int* idx, int n, const float* rows, hipStream_t st) {
+  if (n <= 0) return 0;
+  INTEL_CHECK_ARG(d % 4 == 0, "rows_add: row width %d must be a multiple of 4", d);
+  LAUNCH_W(0.0, 12.0 * (double)n * d, rows_add_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, table, d, idx, n, rows);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

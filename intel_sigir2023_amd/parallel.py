@@ -83,6 +83,16 @@ def allreduce_sum_async(t):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def allgather(t):
+    """[world, *t.shape] tensor holding every rank's ``t`` (same shape on all ranks)."""
+    w = world_size()
+    if w == 1:
+        return t.unsqueeze(0)
+    out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather(list(out.unbind(0)), t.contiguous())
+    return out
+
+
 def broadcast_(tensors, src=0):
     if world_size() == 1:
         return

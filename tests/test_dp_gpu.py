@@ -22,7 +22,8 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir):
+def _run(rank, world, port, out_dir, exchange='auto'):
+    os.environ['INTEL_DP_EXCHANGE'] = exchange
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), INTEL_DIST_BACKEND='gloo', INTEL_SINGLE_DEVICE='1')
     from intel_sigir2023_amd import parallel
@@ -52,11 +53,13 @@ def _run(rank, world, port, out_dir):
         torch.distributed.destroy_process_group()
 
 
-def test_two_rank_engine_equals_single_process():
+@pytest.mark.parametrize('exchange', ['dense', 'sparse'])
+def test_two_rank_engine_equals_single_process(exchange):
+    """exchange: dense all-reduce of the item-id table gradient, or the touched-rows all-gather."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
-        mp.spawn(_run, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_run, args=(2, _free_port(), d, exchange), nprocs=2, join=True)
         one = torch.load(os.path.join(d, 'w1_r0.pt'))
         r0 = torch.load(os.path.join(d, 'w2_r0.pt'))
         r1 = torch.load(os.path.join(d, 'w2_r1.pt'))
