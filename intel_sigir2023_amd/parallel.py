@@ -89,7 +89,10 @@ def allgather(t):
     if w == 1:
         return t.unsqueeze(0)
     out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather(list(out.unbind(0)), t.contiguous())
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(out, t.contiguous())      # RCCL: one collective into the stacked buffer
+    else:
+        dist.all_gather(list(out.unbind(0)), t.contiguous())
     return out
 
 
