@@ -210,7 +210,9 @@ def main():
         'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, d=64, fp32, %s loss, cal_diversity=%d, %s item ids'
                                % (a.workload + ('/' + a.encoder if a.encoder else ''), cinfo['items'], Lmax, w['flags']['model_num'], cinfo['I'], w['batch']['H'], a.loss,
                                   a.cal_diversity, 'zipf' if a.zipf else 'uniform'),
-                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world},
+                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world,
+                   'arithmetic': 'fp32 storage and accumulation; the large products run as three-plane bf16 splits (hi+mid+lo, six plane '
+                                 'products) on the bf16 MFMA pipe = fp32 accuracy, same parity thresholds as the fp32-MFMA kernels'},
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
     }
