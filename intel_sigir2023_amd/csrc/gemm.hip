@@ -2228,8 +2228,12 @@ int redq_flush(ReduceQueue* q, hipStream_t st) {
 }
 
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q) {
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q, const WgradSplit* split) {
   if (N <= 0 || K <= 0) return 0;
+  if (split) {
+    INTEL_CHECK_ARG(q && split->n >= 1 && split->n <= 4 && N % split->n == 0, "wgrad: a split product needs the reduce queue and N divisible by the number of parts");
+    db = split->db[0];
+  }
   if (q) {
     slabs = redq_alloc(q, wgrad_slab_floats(M, N, K));
     if (!slabs) {
@@ -2291,6 +2295,14 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   }
 reduce:
   size_t stride = (size_t)N * K + N;
+  if (q && split) {       // one product over the stacked columns, one reduction job per weight
+    const int Ns = N / split->n;
+    for (int p = 0; p < split->n; ++p) {
+      redq_push(q, slabs + (size_t)p * Ns * K, stride, a.S, Ns, K, split->dW[p], K, split->acc[p]);
+      if (split->db[p]) redq_push(q, slabs + (size_t)N * K + (size_t)p * Ns, stride, a.S, 1, Ns, split->db[p], Ns, split->acc[p]);
+    }
+    return 0;
+  }
   if (q) {
     redq_push(q, slabs, stride, a.S, N, K, dW, lddw, accumulate);
     if (db) redq_push(q, slabs + (size_t)N * K, stride, a.S, 1, N, db, N, accumulate);

@@ -68,8 +68,11 @@ int redq_flush(ReduceQueue* q, hipStream_t st);
 
 // with q == nullptr the reduction is launched immediately and `slabs` is used; with a queue the
 // partials go to the queue's arena and dW / db are valid only after redq_flush
+// split: the N columns of dY are the stacked outputs of several weights that share the input X (fused q/k/v): one
+// product, one reduction job per weight (dW[p] is [N/n, K]; db[p] all null or all set).  Needs the queue.
+struct WgradSplit { int n; float* dW[4]; float* db[4]; int acc[4]; };
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr, const WgradSplit* split = nullptr);
 
 // ---- tiny input width (smallk.hip): K <= 32, N <= 128, raw (unpacked) weights W[N, K] ---------------------
 bool smallk_supported(int N, int K);

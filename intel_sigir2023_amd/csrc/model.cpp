@@ -430,6 +430,33 @@ void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, in
   RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
 }
 
+// the weight gradients of n linears that share the input X and whose output gradients sit side by side in dY
+// (fused q/k/v): one product over the stacked columns
+void wgrad_split(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, int Nsub, int K, int n, const int* w_slots,
+                 const int* b_slots) {
+  WgradSplit sp;
+  sp.n = n;
+  bool any = false, all = true;
+  for (int p = 0; p < n; ++p) {
+    sp.dW[p] = r.G(w_slots[p]);
+    sp.db[p] = b_slots[p] >= 0 ? r.G(b_slots[p]) : nullptr;
+    any = any || sp.dW[p];
+    all = all && sp.dW[p];
+  }
+  bool bias_uniform = true;
+  for (int p = 1; p < n; ++p) bias_uniform = bias_uniform && ((sp.db[p] != nullptr) == (sp.db[0] != nullptr));
+  if (!any) return;
+  if (!all || !bias_uniform || smallk_supported(Nsub, K)) {      // mixed cases: one product per weight
+    for (int p = 0; p < n; ++p) wgrad(r, dY + p * Nsub, lddy, X, ldx, M, Nsub, K, w_slots[p], b_slots[p]);
+    return;
+  }
+  for (int p = 0; p < n; ++p) {
+    sp.acc[p] = r.acc(w_slots[p]);
+    if (b_slots[p] >= 0) r.acc(b_slots[p]);
+  }
+  RUN(launch_wgrad(dY, lddy, X, ldx, M, n * Nsub, K, nullptr, K, nullptr, 0, nullptr, r.st, r.ctx->rq, &sp));
+}
+
 // ---- weight packing -------------------------------------------------------------------------
 void pack_tower(Run& r, TowerBufs& w) {
   const int d = w.d, pb = w.pbase;
@@ -614,7 +641,10 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
     lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
     if (r.rc) return nullptr;
     if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
-    for (int j = 0; j < 3; ++j) wgrad(r, r.T->dQKV + j * d, 3 * d, Xin, d, M, d, d, pb + T_WQ + j, -1);
+    {
+      const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
+      wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs);
+    }
     // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
     GemmEpilogue er;
     er.res = r.T->dZ; er.ldres = d;
@@ -753,8 +783,11 @@ float* bert_bwd(Run& r, int e) {
     GemmEpilogue exl;
     exl.res = dSl; exl.ldres = dm;
     lin(r, dQl, dm, B, dm, q.pWqT, dm, dZl, dm, exl);                       // dXlast = dQ Wq + dS
-    wgrad(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_BK));
-    wgrad(r, r.T->dQKV + dm, 2 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WV), enc_blk_slot(e, l, INTEL_ENC_BV));
+    {
+      const int ws[2] = {enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
+      const int bs[2] = {enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
+      wgrad_split(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, 2, ws, bs);
+    }
     GemmEpilogue e0;
     e0.b3 = q.b3WkvT;
     lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
@@ -791,9 +824,11 @@ float* bert_bwd(Run& r, int e) {
         return nullptr;
     }
     if (!r.ok(launch_attn_bwd(k.QKV, k.A, r.T->dZ, k.LSE, B, T, dm, D.enc_heads, len, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
-    for (int j = 0; j < 3; ++j)
-      wgrad(r, r.T->dQKV + j * dm, 3 * dm, Xin, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ + 2 * j),
-            enc_blk_slot(e, l, INTEL_ENC_BQ + 2 * j));
+    {
+      const int ws[3] = {enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
+      const int bs[3] = {enc_blk_slot(e, l, INTEL_ENC_BQ), enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
+      wgrad_split(r, r.T->dQKV, 3 * dm, Xin, dm, rows, dm, dm, 3, ws, bs);
+    }
     {
       GemmEpilogue er;
       er.res = r.T->dZ; er.ldres = dm;
