@@ -63,12 +63,15 @@ class IntELEngine(object):
         lib = L.lib()
         table = self.model.iid_embeddings.weight.grad
         d = table.shape[1]
+        # unique touched rows at a static shape (torch.unique would synchronise the host to size its result, which
+        # stalls the enqueueing of the second backward phase): sort, keep the first of every run, -1 elsewhere
         ids = torch.cat([keep['i_id_s'].reshape(-1), keep['his_item_id'].reshape(-1)])
-        uniq = torch.unique(ids)
         cap = ids.numel()
-        idx = self._buf('xch_idx', (cap,), torch.int32)
-        idx.fill_(-1)
-        idx[:uniq.numel()] = uniq.to(torch.int32)
+        srt = ids.sort().values
+        prev = torch.empty_like(srt)
+        prev[0] = -1
+        prev[1:] = srt[:-1]
+        idx = torch.where(srt != prev, srt, torch.full_like(srt, -1)).to(torch.int32).contiguous()
         rows = self._buf('xch_rows', (cap, d), torch.float32)
         L.check(lib.intel_rows_take(L.ptr(table), d, L.ptr(idx), cap, L.ptr(rows), 1, stream_ptr), 'intel_rows_take')
         all_idx = parallel.allgather(idx)
