@@ -181,6 +181,13 @@ int intel_bpr_loss(int B, int L, int K, const float* ens_score, const int* ranki
                    const float* weights, int cal_diversity, double alpha, float grad_scale,
                    float* loss, int* select, float* d_ens, float* d_weights, void* workspace,
                    size_t workspace_bytes, void* stream);
+/* The same with the tie-breaking noise of BPRloss.py:26 drawn inside the kernel (counter-based generator keyed by
+ * seed and the element index) instead of read from a [B,L,L] tensor: the fused training step uses this form. */
+int intel_bpr_loss_seeded(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
+                          unsigned long long seed, const double* scores_f64, const float* scores_f32,
+                          const float* weights, int cal_diversity, double alpha, float grad_scale,
+                          float* loss, int* select, float* d_ens, float* d_weights, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* Listloss.forward (loss/Listloss.py:25-43) incl. list_loss (:12-15) and diversity (:17-23). */
 int intel_list_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
                     const double* scores_f64, const float* scores_f32, const float* weights,

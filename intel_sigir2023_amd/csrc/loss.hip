@@ -27,7 +27,8 @@ __device__ __forceinline__ T block_sum(T v, T* red /* [4] */) {
 struct LossArgs {
   int B, L, K;
   const float* ens; const int* ranking; const int* slen;
-  const float* noise;                       // BPR only
+  const float* noise;                       // BPR only; NULL -> counter-based generator keyed by (seed, b, i, j)
+  unsigned long long seed;
   const double* sc64; const float* sc32;    // base scores (either)
   const float* weights;
   int cal_div; double alpha; float grad_scale;
@@ -83,12 +84,23 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
         if (D > 0 && D < minD) minD = D;
       }
     }
-    const float* nrow = a.noise + ((size_t)b * L + i) * L;
+    const float* nrow = a.noise ? a.noise + ((size_t)b * L + i) * L : nullptr;
+    const unsigned long long ctr0 = ((unsigned long long)b * L + i) * L;
     float best = -1.f;
     int sel = 0;
     for (int j = 0; j < L; ++j) {
       const bool cand = vi && j < len && (ri - s_r[j]) == minD;
-      const float v = (cand ? 1.f : 0.f) + nrow[j] / 10.f;      // possible_mask + rand/10 (BPRloss.py:26-28)
+      float u;
+      if (nrow) {
+        u = nrow[j];
+      } else {            // 24 uniform bits from a splitmix64 hash of the element counter
+        unsigned long long z = a.seed + 0x9E3779B97F4A7C15ull * (ctr0 + j + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        u = (float)(z >> 40) * (1.0f / 16777216.0f);
+      }
+      const float v = (cand ? 1.f : 0.f) + u / 10.f;            // possible_mask + rand/10 (BPRloss.py:26-28)
       if (v > best) { best = v; sel = j; }
     }
     s_sel[i] = sel;
@@ -362,19 +374,20 @@ static int run_pair_loss(bool bpr, LossArgs& a, float* loss, void* ws, size_t ws
 int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const float* noise,
                     const double* sc64, const float* sc32, const float* weights, int cal_div, double alpha,
                     float grad_scale, float* loss, int* select, float* d_ens, float* d_weights, void* ws, size_t ws_bytes,
-                    hipStream_t st) {
+                    hipStream_t st, unsigned long long seed, int use_seed) {
   LossArgs a;
   a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = noise; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = select; a.d_ens = d_ens;
   a.d_weights = d_weights; a.lossb = nullptr; a.divb = nullptr;
-  INTEL_CHECK_ARG(noise && select, "bpr loss: noise and select buffers are required");
+  a.seed = seed;
+  INTEL_CHECK_ARG((noise || use_seed) && select, "bpr loss: a noise tensor (or a seed) and the select buffer are required");
   return run_pair_loss(true, a, loss, ws, ws_bytes, st);
 }
 int launch_mse_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
                     const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                     float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st) {
   LossArgs a;
-  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.sc64 = sc64; a.sc32 = sc32;
+  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = nullptr; a.d_ens = d_ens;
   a.d_weights = d_weights;
   INTEL_CHECK_ARG(ws_bytes >= loss_ws_bytes(B), "loss: workspace too small");
@@ -391,7 +404,7 @@ int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, 
                      const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                      float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st) {
   LossArgs a;
-  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.sc64 = sc64; a.sc32 = sc32;
+  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = nullptr; a.d_ens = d_ens;
   a.d_weights = d_weights; a.lossb = nullptr; a.divb = nullptr;
   return run_pair_loss(false, a, loss, ws, ws_bytes, st);

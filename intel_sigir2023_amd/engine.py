@@ -37,6 +37,7 @@ class IntELEngine(object):
         import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
         self._side = None
+        self._noise_tensor = os.environ.get('INTEL_BPR_NOISE', 'kernel') == 'tensor'     # A/B switch: draw the BPR noise with torch.rand
         self.device = next(model.parameters()).device
         L.require_gpu(next(model.parameters()))
         self._flatten()
@@ -157,12 +158,20 @@ class IntELEngine(object):
         sc32 = keep['scores']
         gs_e = self.ensemble_weight / world
         if self.kind == 'bpr':
-            if noise is None:
-                noise = torch.rand(B, Lmax, Lmax, dtype=torch.float32, device=dev)      # BPRloss.py:26
             select = self._buf('select', (B, Lmax), torch.int32)
-            L.check(lib.intel_bpr_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(noise), L.ptr(sc64),
-                                       L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
-                                       L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss')
+            if noise is None and self._noise_tensor:
+                noise = torch.rand(B, Lmax, Lmax, dtype=torch.float32, device=dev)      # BPRloss.py:26, as a tensor
+            if noise is None:
+                # the tie-breaking noise of BPRloss.py:26 is drawn inside the kernel (no [B,L,L] tensor); the seed comes from
+                # torch's CPU generator, so runs are reproducible under torch.manual_seed
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                L.check(lib.intel_bpr_loss_seeded(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), C.c_ulonglong(seed), L.ptr(sc64),
+                                                  L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
+                                                  L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss_seeded')
+            else:
+                L.check(lib.intel_bpr_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(noise), L.ptr(sc64),
+                                           L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
+                                           L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss')
         elif self.kind == 'mse':
             L.check(lib.intel_mse_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(sc64), L.ptr(sc32),
                                        L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e), L.ptr(d_ens),
