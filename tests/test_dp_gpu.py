@@ -53,21 +53,22 @@ def _run(rank, world, port, out_dir, exchange='auto'):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('exchange', ['dense', 'sparse'])
-def test_two_rank_engine_equals_single_process(exchange):
-    """exchange: dense all-reduce of the item-id table gradient, or the touched-rows all-gather."""
+@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse')])
+def test_n_rank_engine_equals_single_process(world, exchange):
+    """exchange: dense all-reduce of the item-id table gradient, or the touched-rows all-gather.
+    world 4 = one session per rank of the 4-session fixture batch."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
-        mp.spawn(_run, args=(2, _free_port(), d, exchange), nprocs=2, join=True)
+        mp.spawn(_run, args=(world, _free_port(), d, exchange), nprocs=world, join=True)
         one = torch.load(os.path.join(d, 'w1_r0.pt'))
-        r0 = torch.load(os.path.join(d, 'w2_r0.pt'))
-        r1 = torch.load(os.path.join(d, 'w2_r1.pt'))
+        ranks = [torch.load(os.path.join(d, 'w%d_r%d.pt' % (world, r))) for r in range(world)]
     for s in range(2):
-        assert abs(0.5 * (r0['losses'][s] + r1['losses'][s]) - one['losses'][s]) < 2e-5
+        assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
     for k, v in one['sd'].items():
-        assert torch.equal(r0['sd'][k], r1['sd'][k]), 'replicas diverged: ' + k
+        for r in ranks[1:]:
+            assert torch.equal(ranks[0]['sd'][k], r['sd'][k]), 'replicas diverged: ' + k
         if 'k_linear.bias' in k:
             continue            # analytically-zero gradient: Adam direction is rounding noise
-        err = float((r0['sd'][k] - v).abs().max())
+        err = float((ranks[0]['sd'][k] - v).abs().max())
         assert err < 5e-5, (k, err)
