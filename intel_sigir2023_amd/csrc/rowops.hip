@@ -1,5 +1,7 @@
 // Row-wise HBM-bound kernels: embedding row gather / scatter-add, LayerNorm fwd/bwd, row softmax,
 // small reductions.  One wave per row wherever a row reduction is needed (wave shuffles only).
+#include <cstdint>
+#include <initializer_list>
 #include "kernels.h"
 
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
@@ -142,11 +144,79 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     }
   }
 }
+// 16 lanes per row, 4 rows per wave, 16-byte accesses: N = 64*NV exactly, all pitches multiples of 4, 16-byte aligned bases
+static inline bool ln_v4_ok(int N, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+  if (N != 64 && N != 128 && N != 256) return false;
+  for (int l : lds)
+    if (l & 3) return false;
+  for (const void* q : ptrs)
+    if ((uintptr_t)q & 15) return false;
+  return true;
+}
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_v4_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ r,
+                                                               int ldr, int M, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y, int ldy,
+                                                               float* __restrict__ xhat, int ldxh, float* __restrict__ rstd,
+                                                               const float* __restrict__ xscale) {
+  constexpr int N = 64 * NV;
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 6) * 4 + (lane >> 4);
+  const bool valid = row < M;
+  const size_t rc = valid ? row : M - 1;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = sub * 4 + 64 * i;
+    f32x4 t = *reinterpret_cast<const f32x4*>(x + rc * ldx + c);
+    if (xscale) t *= *reinterpret_cast<const f32x4*>(xscale + rc * ldx + c);
+    if (r) t += *reinterpret_cast<const f32x4*>(r + rc * ldr + c);
+    v[i] = t;
+    s += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  const float mean = sum16(s) / (float)N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] -= mean;
+    q += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+  }
+  const float rs = 1.f / sqrtf(sum16(q) / (float)N + 1e-5f);
+  if (!valid) return;
+  if (rstd && sub == 0) rstd[row] = rs;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = sub * 4 + 64 * i;
+    const f32x4 xh = v[i] * rs;
+    if (xhat) *reinterpret_cast<f32x4*>(xhat + rc * ldxh + c) = xh;
+    *reinterpret_cast<f32x4*>(y + rc * ldy + c) =
+        xh * *reinterpret_cast<const f32x4*>(gamma + c) + *reinterpret_cast<const f32x4*>(beta + c);
+  }
+}
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
                          const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st,
                          const float* xscale) {
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(N <= 64 * LN_MAXPL, "layernorm: N=%d > %d unsupported", N, 64 * LN_MAXPL);
+  if (ln_v4_ok(N, {ldx, r ? ldr : 0, ldy, xhat ? ldxh : 0}, {x, r, y, xhat, gamma, beta, xscale})) {
+#define LN_V4(NV)                                                                                                       \
+  LAUNCH(add_layernorm_v4_kernel<NV>, dim3(cdiv(M, 16)), dim3(256), 0, st, x, ldx, r, ldr, M, gamma, beta, y, ldy, xhat, \
+         ldxh, rstd, xscale)
+    if (N == 64) LN_V4(1);
+    else if (N == 128) LN_V4(2);
+    else LN_V4(4);
+#undef LN_V4
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   LAUNCH(add_layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, st, x, ldx, r, ldr, M, N, gamma, beta, y, ldy, xhat,
                      ldxh, rstd, xscale);
   INTEL_CHECK_LAUNCH();
@@ -158,11 +228,12 @@ int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M
 // dgamma/dbeta: per-block column partials (each block owns LNB_ROWS rows) -> slabs -> reduce.
 // ------------------------------------------------------------------------------------------
 #define LNB_ROWS 64
-static inline int ln_bwd_blocks(int M) { return cdiv(M, LNB_ROWS); }
+#define LNB_SMALL_M 16384          // at most this many rows: 16 rows per block so that the launch still covers the chip
+static inline int ln_bwd_blocks(int M) { return M <= LNB_SMALL_M ? cdiv(M, 16) : cdiv(M, LNB_ROWS); }
 size_t ln_bwd_slab_floats(int M, int N) { return (size_t)ln_bwd_blocks(M) * 2 * N; }
 
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ xhat,
-                                                            int ldxh, const float* __restrict__ rstd, int M, int N,
+                                                            int ldxh, const float* __restrict__ rstd, int M, int N, int rows_per_block,
                                                             const float* __restrict__ gamma, float* __restrict__ dz, int lddz,
                                                             float* __restrict__ slabs) {
   __shared__ float sg[4][64 * LN_MAXPL];
@@ -171,8 +242,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   float ag[LN_MAXPL], ab[LN_MAXPL];
 #pragma unroll
   for (int i = 0; i < LN_MAXPL; ++i) ag[i] = ab[i] = 0.f;
-  const int r0 = blockIdx.x * LNB_ROWS;
-  for (int rr = wave; rr < LNB_ROWS; rr += 4) {
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int rr = wave; rr < rows_per_block; rr += 4) {
     const int row = r0 + rr;
     if (row >= M) break;
     float g[LN_MAXPL], xh[LN_MAXPL];
@@ -205,6 +276,76 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
   for (int i = 0; i < LN_MAXPL; ++i) {
     sg[wave][lane + 64 * i] = ag[i];
     sb[wave][lane + 64 * i] = ab[i];
+  }
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * 2 * N;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    slab[c] = (sg[0][c] + sg[1][c]) + (sg[2][c] + sg[3][c]);
+    slab[N + c] = (sb[0][c] + sb[1][c]) + (sb[2][c] + sb[3][c]);
+  }
+}
+// same row mapping as add_layernorm_v4_kernel; TR trips of 16 rows per block
+template <int NV, int TR>
+__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ xhat,
+                                                               int ldxh, const float* __restrict__ rstd, int M,
+                                                               const float* __restrict__ gamma, float* __restrict__ dz, int lddz,
+                                                               float* __restrict__ slabs) {
+  constexpr int N = 64 * NV;
+  __shared__ float sg[4][N];
+  __shared__ float sb[4][N];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sub = lane & 15, grp = lane >> 4;
+  f32x4 gm[NV], ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    gm[i] = *reinterpret_cast<const f32x4*>(gamma + sub * 4 + 64 * i);
+    ag[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int r0 = blockIdx.x * (16 * TR) + wave * 4 + grp;
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    const int row = r0 + 16 * t;
+    const bool valid = row < M;
+    const size_t rc = valid ? row : M - 1;
+    f32x4 g[NV], h[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = sub * 4 + 64 * i;
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + rc * lddy + c);
+      h[i] = *reinterpret_cast<const f32x4*>(xhat + rc * ldxh + c);
+      if (!valid) d = f32x4{0.f, 0.f, 0.f, 0.f};
+      ag[i] += d * h[i];
+      ab[i] += d;
+      g[i] = d * gm[i];
+      const f32x4 gh = g[i] * h[i];
+      s1 += (g[i][0] + g[i][1]) + (g[i][2] + g[i][3]);
+      s2 += (gh[0] + gh[1]) + (gh[2] + gh[3]);
+    }
+    const float m1 = sum16(s1) / (float)N, m2 = sum16(s2) / (float)N;
+    const float rs = rstd[rc];
+    if (valid) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        *reinterpret_cast<f32x4*>(dz + rc * lddz + sub * 4 + 64 * i) = rs * (g[i] - m1 - h[i] * m2);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = ag[i][e], b = ab[i][e];
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      b += __shfl_xor(b, 16);
+      b += __shfl_xor(b, 32);
+      ag[i][e] = a;
+      ab[i][e] = b;
+    }
+    if (grp == 0) {
+      *reinterpret_cast<f32x4*>(&sg[wave][sub * 4 + 64 * i]) = ag[i];
+      *reinterpret_cast<f32x4*>(&sb[wave][sub * 4 + 64 * i]) = ab[i];
+    }
   }
   __syncthreads();
   float* slab = slabs + (size_t)blockIdx.x * 2 * N;
@@ -251,7 +392,20 @@ int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh,
       return -2;   // INTEL_E_WORKSPACE
     }
   }
-  LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, gamma, dz, lddz, slabs);
+  const bool small = M <= LNB_SMALL_M;
+  if (ln_v4_ok(N, {lddy, ldxh, lddz}, {dy, xhat, dz, gamma})) {
+#define LNB_V4(NV)                                                                                                          \
+  do {                                                                                                                      \
+    if (small) LAUNCH((layernorm_bwd_v4_kernel<NV, 1>), dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, gamma, dz, lddz, slabs); \
+    else LAUNCH((layernorm_bwd_v4_kernel<NV, 4>), dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, gamma, dz, lddz, slabs);     \
+  } while (0)
+    if (N == 64) LNB_V4(1);
+    else if (N == 128) LNB_V4(2);
+    else LNB_V4(4);
+#undef LNB_V4
+  } else {
+    LAUNCH(layernorm_bwd_kernel, dim3(nb), dim3(256), 0, st, dy, lddy, xhat, ldxh, rstd, M, N, small ? 16 : LNB_ROWS, gamma, dz, lddz, slabs);
+  }
   INTEL_CHECK_LAUNCH();
   if (q) {
     redq_push(q, slabs, (size_t)2 * N, nb, 1, N, dgamma, N, accumulate);
