@@ -262,7 +262,8 @@ def main():
         res['kernel_rate'] = {k: ('%.1f TF/s' % (v['flops'] / v['ms'] / 1e9) if v['flops'] > 0 else '%.0f GB/s' % (v['bytes'] / v['ms'] / 1e6))
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16] if v['flops'] > 0 or v['bytes'] > 0}
         if a.shapes:
-            res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f TF/s' % (v['ms'] / psteps, v['launches'] // psteps, v['flops'] / v['ms'] / 1e9)
+            res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f us, %.1f TF/s, %.0f GB/s' % (v['ms'] / psteps, v['launches'] // psteps, 1e3 * v['ms'] / v['launches'],
+                                                                                                      v['flops'] / v['ms'] / 1e9, v['bytes'] / v['ms'] / 1e6)
                                   for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01 and v['flops'] > 0}
         if a.shapes:
             res['kernel_table'] = {k: '%d launches/step, %.4f ms/step, avg %.1f us' % (v['launches'] // psteps, v['ms'] / psteps, 1e3 * v['ms'] / max(1, v['launches']))

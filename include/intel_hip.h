@@ -141,14 +141,20 @@ void intel_destroy(IntelCtx* ctx);
  * the caller's stream (bench.py does this while it prices single kernels).  Default: on. */
 void intel_set_concurrency(IntelCtx* ctx, int on);
 
-/* Bytes of workspace intel_forward/intel_backward need for a batch of this shape.  `train` != 0
- * also reserves the activation stash the backward pass reads. */
 /* nn.Dropout(--dropout) of the two tower layers (models/IntEL/IntEL.py:63,187,196) for the following
  * intel_forward(train=1) calls: p = 0 (default) disables it; evaluation never drops.  keep_flags (optional, device):
  * 0/1 floats -- item-tower layers [layers][B*L][d_i] then score-tower layers [layers][B*L][d_s] -- replace the
  * built-in counter-based generator (parity tests pass the reference's own draw).  Call it BEFORE
  * intel_workspace_bytes: the training workspace grows by one mask per tower layer. */
 int intel_set_dropout(IntelCtx* ctx, float p, unsigned long long seed, const float* keep_flags);
+
+/* row_flags[item_num] (device, may be NULL = off): intel_backward sets row_flags[i] = 1 for every row i of the
+ * iid_embeddings.weight gradient it adds into (the nn.Embedding backward of IntEL.py:135,170).  The caller owns the
+ * array and keeps "flag == 0 => gradient row == 0" true; intel_adam_step_rows consumes and resets the flags. */
+int intel_set_iid_grad_row_flags(IntelCtx* ctx, unsigned char* row_flags);
+
+/* Bytes of workspace intel_forward/intel_backward need for a batch of this shape.  `train` != 0
+ * also reserves the activation stash the backward pass reads. */
 size_t intel_workspace_bytes(const IntelCtx* ctx, int B, int L, int H, int Hi, int train);
 
 /* IntEL.forward (IntEL.py:117-124) = predict_intent (:126-155) + predict_ensemble (:158-217). */
@@ -212,6 +218,14 @@ size_t intel_loss_workspace_bytes(int B, int L, int K);
  * (g += wd*p), bias-corrected moments, dense over all n elements.  zero_grad != 0 also clears g. */
 int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* The same update over a [rows, d] embedding table whose gradient g is zero outside the rows flagged in row_flags
+ * (one byte per row; see intel_set_iid_grad_row_flags): g is read, cleared and the flag reset only in flagged rows, every
+ * other row is updated with g = 0 -- bit-identical to intel_adam_step(..., zero_grad = 1) at 6 instead of 8 memory
+ * streams.  d in {16, 32, 64, 128, 256}. */
+int intel_adam_step_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags,
+                         float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         float grad_scale, void* stream);
 
 /* ---- data-parallel gradient exchange of a table's touched rows ------------------------------ */
 /* out[i,:] = table[idx[i],:] (zeros for idx[i] < 0); zero_rows != 0 also clears those table rows.  idx: a rank's

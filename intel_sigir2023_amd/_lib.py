@@ -118,9 +118,9 @@ ENC_STRIDE = 6 + ENC_BLOCK_STRIDE * ENC_MAX_BLOCKS
 P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 
 EXPORTS = [
-    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_dropout', 'intel_workspace_bytes',
+    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_dropout', 'intel_set_iid_grad_row_flags', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_bpr_loss_seeded', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
-    'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_ndcg', 'intel_op_linear',
+    'intel_loss_workspace_bytes', 'intel_adam_step', 'intel_adam_step_rows', 'intel_ndcg', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
     'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add',
 ]
@@ -141,6 +141,7 @@ def _declare(l):
     sig('intel_destroy', None, [vp])
     sig('intel_set_concurrency', None, [vp, i])
     sig('intel_set_dropout', i, [vp, f, C.c_ulonglong, vp])
+    sig('intel_set_iid_grad_row_flags', i, [vp, vp])
     sig('intel_workspace_bytes', sz, [vp, i, i, i, i, i])
     sig('intel_forward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, C.POINTER(IntelOut), i, vp])
     sig('intel_backward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, vp, vp, vp, C.POINTER(vp), vp])
@@ -152,6 +153,7 @@ def _declare(l):
     sig('intel_intent_loss', i, [i, i, vp, vp, d, d, f, vp, vp, vp, sz, vp])
     sig('intel_loss_workspace_bytes', sz, [i, i, i])
     sig('intel_adam_step', i, [vp, vp, vp, vp, ll, f, f, f, f, f, i, f, i, vp])
+    sig('intel_adam_step_rows', i, [vp, vp, vp, vp, ll, i, vp, f, f, f, f, f, i, f, vp])
     sig('intel_ndcg', i, [i, i, i, vp, vp, vp, vp, vp])
     sig('intel_op_linear', i, [vp, i, i, vp, i, vp, i, vp, vp, sz, vp])
     sig('intel_op_linear_dgrad', i, [vp, i, i, vp, i, vp, vp, sz, vp])

@@ -154,6 +154,13 @@ extern "C" int intel_adam_step(float* p, float* g, float* m, float* v, long long
   return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, (hipStream_t)stream);
 }
 
+extern "C" int intel_adam_step_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags,
+                                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    float grad_scale, void* stream) {
+  INTEL_CHECK_ARG(p && g && m && v && row_flags, "adam_rows: null tensor");
+  return launch_adam_rows(p, g, m, v, rows, d, row_flags, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
+}
+
 extern "C" int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
                           float* ndcg, void* stream) {
   INTEL_CHECK_ARG(ens_score && ranking && session_len && ndcg, "ndcg: null tensor");

@@ -584,6 +584,9 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
 // K in {64, 128} (template KBN = K / 32).  One LDS buffer, the next tile is prefetched into registers under the MFMAs.
 // ------------------------------------------------------------------------------------------
 #define B3_LDP 144          // bf16 elements per LDS row: 128 + 16
+#ifndef B3_ABLATE           // tools/b3_ablate.sh: 1 no C stores, 2 no MFMAs, 8 only the first A tile is loaded, 16 no split, 32 one LDS fragment address
+#define B3_ABLATE 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -667,7 +670,11 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       bf16x4 h, m, l;
-      b3_split4(pre[jj], h, m, l);
+      if (B3_ABLATE & 16) {
+        h = m = l = bf16x4{(__bf16)pre[jj][0], (__bf16)pre[jj][1], (__bf16)pre[jj][2], (__bf16)pre[jj][3]};
+      } else {
+        b3_split4(pre[jj], h, m, l);
+      }
       const int off = trow[jj] * B3_LDP + tcol[jj];
       *reinterpret_cast<bf16x4*>(planes + off) = h;
       *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
   for (; t < ntiles; t += gridDim.x) {
     store_tile();
     __syncthreads();
-    if (t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);     // in flight during the MFMAs and the epilogue
+    if (!(B3_ABLATE & 8) && t + (int)gridDim.x < ntiles) load_tile(t + gridDim.x);     // in flight during the MFMAs and the epilogue
     f32x4 acc[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -697,11 +704,15 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
       for (int kb = 0; kb < KBN; ++kb) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-          const __bf16* fp = frag + rt * 16 * B3_LDP + kb * 32;
+          const __bf16* fp = (B3_ABLATE & 32) ? frag : frag + rt * 16 * B3_LDP + kb * 32;
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
           f32x4 c = acc[rt];
+          if (B3_ABLATE & 2) {
+            acc[rt] = c + f32x4{(float)ah[0], (float)am[1], (float)al[2], 0.f};
+            continue;
+          }
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bm[kb], am, c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kb], al, c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[kb], ah, c, 0, 0, 0);
@@ -735,7 +746,7 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
           } else {
             x += aux[rt];
           }
-          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+          if (row < a.M && !((B3_ABLATE & 1) && x[0] != 12345.678f)) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
         }
       }
     } else {

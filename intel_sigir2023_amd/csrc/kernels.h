@@ -106,7 +106,7 @@ int launch_gather_rows(const float* table, int d, const int* idx, int M, float* 
 int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st);
 // grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
-                            const float* relu_out, int ldr, int rcol0, hipStream_t st);
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st, unsigned char* row_flags = nullptr);
 // y = LN(x + r) rows
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
                          const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st,

@@ -111,6 +111,7 @@ struct IntelCtx {
   unsigned long long drop_seed;
   const float* drop_ext;       // optional 0/1 keep flags, item-tower layers then score-tower layers
   bool fwd_dropout;            // the stashed forward ran with dropout
+  unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
 };
 
 namespace {
@@ -1070,7 +1071,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa);
     if (r.rc || !dX0) return;
     if (r.G(INTEL_P_IID_EMB))
-      RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+      RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
     if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
       RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
   };
@@ -1097,7 +1098,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     } else {
       if (r.G(INTEL_P_IID_EMB))
-        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st));
+        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
     }
     return dE;
   };
@@ -1222,6 +1223,7 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->drop_seed = 0;
   c->drop_ext = nullptr;
   c->fwd_dropout = false;
+  c->iid_row_flags = nullptr;
   c->rq = redq_create();
   if (!c->rq) {
     delete c;
@@ -1261,6 +1263,12 @@ extern "C" int intel_set_dropout(IntelCtx* ctx, float p, unsigned long long seed
   ctx->drop_p = p;
   ctx->drop_seed = seed;
   ctx->drop_ext = keep_flags;
+  return 0;
+}
+
+extern "C" int intel_set_iid_grad_row_flags(IntelCtx* ctx, unsigned char* row_flags) {
+  INTEL_CHECK_ARG(ctx, "intel_set_iid_grad_row_flags: null context");
+  ctx->iid_row_flags = row_flags;
   return 0;
 }
 

@@ -50,6 +50,61 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
   }
 }
 
+// The same update over a [rows, d] table whose gradient is all zero except in the rows flagged in row_flags (set by the
+// embedding scatter-add): the gradient row is read, cleared and its flag reset only where the flag is set, elsewhere g = 0
+// is used without touching memory -- identical arithmetic, 6 instead of 8 streams over an embedding table.
+// d / 4 lanes per row (d in {16, 32, 64, 128, 256}), rows strided over the grid.
+__global__ __launch_bounds__(256) void adam_rows_kernel(AdamArgs a, int d, unsigned char* __restrict__ row_flags) {
+  const int lpr = d >> 2;                                   // lanes per row
+  const long long rows = a.n / d;
+  const int sub = threadIdx.x % lpr;
+  const long long r0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+  const long long stride = (long long)gridDim.x * blockDim.x / lpr;
+  for (long long r = r0; r < rows; r += stride) {
+    const long long i = r * lpr + sub;
+    const bool hit = row_flags[r] != 0;
+    f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (hit) g = reinterpret_cast<f32x4*>(a.g)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = p[k], mk = m[k], vk = v[k];
+      adam_one(pk, g[k], mk, vk, a);
+      p[k] = pk; m[k] = mk; v[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(a.p)[i] = p;
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+    if (hit) {
+      reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sub == 0) row_flags[r] = 0;
+    }
+  }
+}
+
+int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags, float lr,
+                     float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t st) {
+  if (rows <= 0) return 0;
+  INTEL_CHECK_ARG(step >= 1, "adam: step must be >= 1");
+  INTEL_CHECK_ARG(d == 16 || d == 32 || d == 64 || d == 128 || d == 256, "adam_rows: row width %d unsupported", d);
+  INTEL_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                    reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adam: tensors must be 16-byte aligned");
+  AdamArgs a;
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = rows * d;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = 1;
+  long long blocks = ((a.n >> 2) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  LAUNCH_W(0.0, 24.0 * (double)a.n + (double)rows, adam_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, d, row_flags);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                 float wd, int step, float grad_scale, int zero_grad, hipStream_t st) {
   if (n <= 0) return 0;

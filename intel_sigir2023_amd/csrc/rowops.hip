@@ -77,22 +77,24 @@ int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst
 // ------------------------------------------------------------------------------------------
 __global__ void scatter_add_rows_kernel(const float* __restrict__ src, int lds, int col0, int d,
                                         const int* __restrict__ idx, int M, float* __restrict__ grad_table,
-                                        const float* __restrict__ relu_out, int ldr, int rcol0) {
+                                        const float* __restrict__ relu_out, int ldr, int rcol0,
+                                        unsigned char* __restrict__ row_flags) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * d) return;
   const int m = (int)(i / d), c = (int)(i - (long long)m * d);
   const int row = idx[m];
   if (row < 0) return;
+  if (row_flags && c == 0) row_flags[row] = 1;       // "this gradient row is not all zero" for launch_adam_rows
   float v = src[(size_t)m * lds + col0 + c];
   if (relu_out && !(relu_out[(size_t)m * ldr + rcol0 + c] > 0.f)) v = 0.f;
   if (v != 0.f) atomicAdd(grad_table + (size_t)row * d + c, v);
 }
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
-                            const float* relu_out, int ldr, int rcol0, hipStream_t st) {
+                            const float* relu_out, int ldr, int rcol0, hipStream_t st, unsigned char* row_flags) {
   long long n = (long long)M * d;
   if (n <= 0) return 0;
   LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, scatter_add_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, lds, col0, d, idx, M,
-                     grad_table, relu_out, ldr, rcol0);
+                     grad_table, relu_out, ldr, rcol0, row_flags);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -48,4 +48,6 @@ int launch_intent_loss(int B, int I, const float* pred, const double* label, dou
 // optim.hip
 int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                 float wd, int step, float grad_scale, int zero_grad, hipStream_t st);
+int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags, float lr,
+                     float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t st);
 int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const int* slen, float* out, hipStream_t st);

@@ -11,6 +11,8 @@ parity tests exercise), the engine keeps every parameter, gradient and Adam mome
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -42,6 +44,13 @@ class IntELEngine(object):
         L.require_gpu(next(model.parameters()))
         self._flatten()
         self._bufs = {}
+        # one byte per item-id gradient row: the backward marks the rows it adds into, the table's Adam sweep reads and
+        # clears the gradient only there (the other ~95 % of the rows have g = 0): 6 instead of 8 streams over the table
+        self._iid_flags = None
+        w = model.iid_embeddings.weight
+        if os.environ.get('INTEL_ADAM_ROWS', '1') != '0' and w.shape[1] in (16, 32, 64, 128, 256):
+            self._iid_flags = torch.zeros(w.shape[0], dtype=torch.uint8, device=self.device)
+            L.check(L.lib().intel_set_iid_grad_row_flags(model._context(), L.ptr(self._iid_flags)), 'intel_set_iid_grad_row_flags')
 
     # ---- data-parallel exchange of the item-id table gradient ------------------------------------------------------
     def _sparse_exchange(self, keep, world):
@@ -79,6 +88,8 @@ class IntELEngine(object):
         all_rows = parallel.allgather(rows)
         for r in range(all_idx.shape[0]):
             L.check(lib.intel_rows_add(L.ptr(table), d, L.ptr(all_idx[r]), cap, L.ptr(all_rows[r]), stream_ptr), 'intel_rows_add')
+        if self._iid_flags is not None:                   # rows of the other ranks (row 0 for the -1 padding: harmless)
+            self._iid_flags.index_fill_(0, all_idx.reshape(-1).clamp_min(0).long(), 1)
         self._bufs['xch_keep'] = (all_idx, all_rows)      # alive until the kernels have run
 
     def _side_stream(self):
@@ -192,9 +203,16 @@ class IntELEngine(object):
         self.step_count += 1
         b1, b2 = self.betas
 
-        def adam(gname, wd, stream_ptr):
+        def adam(gname, wd, stream_ptr, dense_reduced=False):
             n = self.flat[gname].numel()
-            if n:
+            if gname == 'iid' and self._iid_flags is not None and n:
+                if dense_reduced:       # the gradient was summed over ranks as a dense table: so are the row marks
+                    parallel.allreduce_max_(self._iid_flags)
+                rows, d = self.model.iid_embeddings.weight.shape
+                L.check(lib.intel_adam_step_rows(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
+                                                 L.ptr(self.v[gname]), rows, d, L.ptr(self._iid_flags), self.lr, b1, b2, self.eps,
+                                                 wd, self.step_count, 1.0, stream_ptr), 'intel_adam_step_rows')
+            elif n:
                 L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
                                             L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
                                             1, stream_ptr), 'intel_adam_step')
@@ -215,7 +233,7 @@ class IntELEngine(object):
                     work.wait()
                 if sparse:
                     self._exchange_touched_rows(keep, L.stream_ptr(dev))
-                adam('iid', self.l2, L.stream_ptr(dev))
+                adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=work is not None)
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
             if world > 1:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
@@ -227,7 +245,7 @@ class IntELEngine(object):
             if world > 1:
                 parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
             for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
-                adam(gname, wd, st)
+                adam(gname, wd, st, dense_reduced=world > 1)
         ens_loss = loss_e.reshape(()).clone()
         if self.with_intent:
             int_loss = out3[0].clone()

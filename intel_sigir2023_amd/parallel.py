@@ -74,6 +74,12 @@ def allreduce_sum_(tensors):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def allreduce_max_(t):
+    """In-place element-wise maximum over ranks (the OR of 0/1 byte flags)."""
+    if world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+
 def allreduce_sum_async(t):
     """Start an in-place sum over ranks and return the work handle (None for a single process).  The collective
     is ordered after everything already enqueued on the current stream; ``handle.wait()`` orders the current

@@ -340,3 +340,44 @@ def test_training_learns_a_planted_ranking_signal():
     after = float(eng.eval_step(held_out)[1].float().mean())
     assert before < 0.5, before
     assert after > 0.85 and after > before + 0.3, (before, after)
+
+
+@pytest.mark.parametrize('workload,B', [('tiny', 64), ('tmall', 48)])
+def test_flagged_row_adam_equals_dense_adam(workload, B, monkeypatch):
+    """The item-id table's Adam sweep that reads the gradient only in the rows the backward marked (intel_adam_step_rows)
+    == the dense sweep (intel_adam_step): parameters and both moments after three steps, untouched rows bit for bit,
+    touched rows up to the summation order of the embedding atomics; the gradient table and the marks are clean after
+    every step."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    over = dict(items=20000, users=2000) if workload != 'tiny' else None
+    res = []
+    for rows_mode in ('1', '0'):
+        monkeypatch.setenv('INTEL_ADAM_ROWS', rows_mode)
+        torch.manual_seed(3)
+        args = synth.make_args(workload, dev, cal_diversity=0)
+        corpus, c = synth.make_corpus(workload, **(over or {}))
+        model = IntEL(args, corpus).to(dev)
+        eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+        assert (eng._iid_flags is not None) == (rows_mode == '1')
+        touched = torch.zeros(model.iid_embeddings.weight.shape[0], dtype=torch.bool, device=dev)
+        for step in range(3):
+            batch = synth.make_batch(workload, B, dev, seed=20 + step, ragged=True, corpus_over=over)
+            L = batch['i_id_s'].shape[1]
+            noise = torch.rand(B, L, L, device=dev, generator=torch.Generator(device=dev).manual_seed(step))
+            eng.train_step(batch, noise=noise)
+            touched[batch['i_id_s'].reshape(-1).long().clamp_min(0)] = True
+            touched[batch['his_item_id'].reshape(-1).long().clamp_min(0)] = True
+            torch.cuda.synchronize()
+            assert float(eng.gflat['iid'].abs().max()) == 0.0
+            if eng._iid_flags is not None:
+                assert int(eng._iid_flags.max()) == 0
+        res.append((model.iid_embeddings.weight.detach().clone(), eng.m['iid'].clone(), eng.v['iid'].clone(), touched))
+    (p1, m1, v1, t1), (p0, m0, v0, t0) = res
+    assert torch.equal(t1, t0) and 0 < int(t1.sum()) < t1.numel()
+    d = p1.shape[1]
+    for a, b in ((p1, p0), (m1[:p1.numel()].view(-1, d), m0[:p0.numel()].view(-1, d)), (v1[:p1.numel()].view(-1, d), v0[:p0.numel()].view(-1, d))):
+        assert torch.equal(a[~t1], b[~t1])
+        assert float((a[t1] - b[t1]).abs().max()) < 1e-6
