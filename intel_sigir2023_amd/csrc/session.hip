@@ -3,7 +3,10 @@
 //   - fusion weights broadcast + weighted-sum score aggregation (IntEL.py:212-215)
 //   - the --cross_attention 0 elementwise gating (IntEL.py:206-209)
 // One wave (64 lanes) per session, four sessions per 256-thread workgroup, wave shuffles for every
-// per-list reduction; the candidate-list tile X[b] (L x d floats) is streamed twice from L1/L2.
+// per-list reduction; the candidate-list tile X[b] (L x d floats) stays in registers between the two passes
+// over it when it fits (d in {64, 128}), else it is streamed twice.
+#include <cstdint>
+#include <initializer_list>
 #include "kernels.h"
 #include "session.h"
 
@@ -68,12 +71,105 @@ __global__ __launch_bounds__(256) void xatt_pool_fwd_kernel(const float* __restr
   }
 }
 
+// Register-resident form for d = 64 * NV and L <= 4 * LP: the session's X rows are read from HBM ONCE (16 lanes per
+// row, 4 rows per pass, 16-byte loads) and stay in registers between the score pass and the weighted sum.
+template <int NV, int LP>
+__global__ __launch_bounds__(256) void xatt_pool_fwd_reg_kernel(const float* __restrict__ X, int L, const float* __restrict__ qk,
+                                                                const int* __restrict__ slen, float scale, int B,
+                                                                float* __restrict__ xbar, float* __restrict__ attw) {
+  constexpr int d = 64 * NV;
+  __shared__ float s_att[4][4 * LP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float* Xb = X + (size_t)b * L * d;
+  const int len = min(slen[b], L);
+  float* att = s_att[wave];
+  const int sub = lane & 15, grp = lane >> 4;
+  f32x4 qv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) qv[i] = *reinterpret_cast<const f32x4*>(qk + (size_t)b * d + sub * 4 + 64 * i);
+  f32x4 x[LP][NV];
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int l = 4 * p + grp;
+    const int lc = min(l, L - 1);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      x[p][i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)lc * d + sub * 4 + 64 * i);
+      const f32x4 t = x[p][i] * qv[i];
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (l < L && sub == 0) att[l] = s * scale;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float mx = -INFINITY;
+  for (int l = lane; l < L; l += 64) mx = fmaxf(mx, att[l]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int l = lane; l < len; l += 64) sum += expf(att[l] - mx);
+  sum = wave_sum(sum);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  for (int l = lane; l < L; l += 64) {
+    const float w = l < len ? expf(att[l] - mx) * inv : 0.f;
+    att[l] = w;
+    attw[(size_t)b * L + l] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  f32x4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int l = 4 * p + grp;
+    const float w = l < len ? att[l] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] += w * x[p][i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = acc[i][e];
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      acc[i][e] = a;
+    }
+    if (grp == 0) *reinterpret_cast<f32x4*>(xbar + (size_t)b * d + sub * 4 + 64 * i) = acc[i];
+  }
+}
+static inline bool xp_aligned(std::initializer_list<const void*> ptrs) {
+  for (const void* q : ptrs)
+    if ((uintptr_t)q & 15) return false;
+  return true;
+}
+#define XP_REG_DISPATCH(KERNEL, ...)                                                        \
+  do {                                                                                      \
+    if (d == 64) {                                                                          \
+      if (L <= 20) LAUNCH((KERNEL<1, 5>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__); \
+      else if (L <= 52) LAUNCH((KERNEL<1, 13>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__); \
+      else LAUNCH((KERNEL<1, 25>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__);        \
+    } else {                                                                                \
+      if (L <= 20) LAUNCH((KERNEL<2, 5>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__); \
+      else LAUNCH((KERNEL<2, 13>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__);        \
+    }                                                                                       \
+  } while (0)
+
 int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
                          float* xbar, float* attw, hipStream_t st) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool: list length %d > %d unsupported", L, XP_MAXL);
   INTEL_CHECK_ARG(d % 4 == 0, "xatt_pool: width %d must be a multiple of 4", d);
-  LAUNCH(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
+  if ((d == 64 || d == 128) && L <= (d == 64 ? 100 : 52) && xp_aligned({X, qk, xbar})) {
+    XP_REG_DISPATCH(xatt_pool_fwd_reg_kernel, X, L, qk, slen, scale, B, xbar, attw);
+  } else {
+    LAUNCH(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
+  }
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -130,11 +226,90 @@ __global__ __launch_bounds__(256) void xatt_pool_bwd_kernel(const float* __restr
   }
 }
 
+template <int NV, int LP>
+__global__ __launch_bounds__(256) void xatt_pool_bwd_reg_kernel(const float* __restrict__ X, int L, const float* __restrict__ qk,
+                                                                const float* __restrict__ attw, const float* __restrict__ dxbar,
+                                                                int ldxb, float scale, int B, float* __restrict__ dX,
+                                                                float* __restrict__ dqk) {
+  constexpr int d = 64 * NV;
+  __shared__ float s_g[4][4 * LP];
+  __shared__ float s_w[4][4 * LP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float* Xb = X + (size_t)b * L * d;
+  float* g = s_g[wave];
+  float* w = s_w[wave];
+  const int sub = lane & 15, grp = lane >> 4;
+  for (int l = lane; l < L; l += 64) w[l] = attw[(size_t)b * L + l];
+  f32x4 qv[NV], gv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    qv[i] = *reinterpret_cast<const f32x4*>(qk + (size_t)b * d + sub * 4 + 64 * i);
+    gv[i] = *reinterpret_cast<const f32x4*>(dxbar + (size_t)b * ldxb + sub * 4 + 64 * i);
+  }
+  f32x4 x[LP][NV];
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int l = 4 * p + grp;
+    const int lc = min(l, L - 1);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      x[p][i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)lc * d + sub * 4 + 64 * i);
+      const f32x4 t = x[p][i] * gv[i];
+      s += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (l < L && sub == 0) g[l] = s;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float wg = 0.f;
+  for (int l = lane; l < L; l += 64) wg += w[l] * g[l];
+  wg = wave_sum(wg);
+  __builtin_amdgcn_wave_barrier();
+  for (int l = lane; l < L; l += 64) g[l] = w[l] * (g[l] - wg) * scale;   // = datt_l * scale
+  __builtin_amdgcn_wave_barrier();
+  f32x4 acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int p = 0; p < LP; ++p) {
+    const int l = 4 * p + grp;
+    if (l < L) {
+      const float da = g[l], wl = w[l];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        *reinterpret_cast<f32x4*>(dX + ((size_t)b * L + l) * d + sub * 4 + 64 * i) = wl * gv[i] + da * qv[i];
+        acc[i] += da * x[p][i];
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = acc[i][e];
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      acc[i][e] = a;
+    }
+    if (grp == 0) *reinterpret_cast<f32x4*>(dqk + (size_t)b * d + sub * 4 + 64 * i) = acc[i];
+  }
+}
+
 int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, const float* attw, const float* dxbar,
                          int ldxb, float scale, float* dX, float* dqk, hipStream_t st) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool_bwd: list length %d > %d unsupported", L, XP_MAXL);
-  LAUNCH(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
+  if ((d == 64 || d == 128) && L <= (d == 64 ? 100 : 52) && (ldxb & 3) == 0 && xp_aligned({X, qk, dxbar, dX, dqk})) {
+    XP_REG_DISPATCH(xatt_pool_bwd_reg_kernel, X, L, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
+  } else {
+    LAUNCH(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
+  }
   INTEL_CHECK_LAUNCH();
   return 0;
 }
