@@ -85,7 +85,7 @@ def test_engine_two_steps_match_reference_adam(name):
     assert all(float(g.abs().max()) == 0.0 for g in eng.buckets())
 
 
-@pytest.mark.parametrize('workload,B', [('tiny', 64), ('tmall', 48), ('lifedata', 16), ('toyshape', 6)])
+@pytest.mark.parametrize('workload,B', [('tiny', 64), ('tmall', 48), ('tmall', 37), ('lifedata', 16), ('lifedata', 5), ('toyshape', 6)])
 def test_engine_step_matches_oracle_on_synthetic_workloads(workload, B):
     """Full-size shapes (1M-item table for tmall): loss of one engine step vs the oracle, NDCG@3 on device vs
     evaluate_method, and a size-independent property: the dense Adam sweep moves EVERY table row (weight decay)

@@ -89,7 +89,7 @@ def test_attention_fwd_bwd(B, T, d, heads, masked):
     _close(dqkv, qkv_r.grad, tol=5e-5, name='attn bwd')
 
 
-@pytest.mark.parametrize('M,N', [(10, 32), (130, 128), (77, 64), (5, 200)])
+@pytest.mark.parametrize('M,N', [(10, 32), (130, 128), (77, 64), (5, 200), (1, 256), (4099, 128), (16, 64)])
 def test_add_layernorm(M, N):
     from intel_sigir2023_amd import ops
     dev = _dev()
