@@ -17,9 +17,12 @@
 //     four tiles interleave and the epilogue stores float4s;
 //   * softmax in base 2 (v_exp_f32 on fma(s, c, -m c), c = log2(e)/sqrt(dk)): 6 VALU instructions per logit;
 //     at one or two waves per SIMD every VALU instruction is time the MFMA pipe idles.
-//   * backward = dK/dV kernel that also writes dS[q][key] (S and dP are computed once: 5 tile products instead
-//     of 7) + a dQ = dS K kernel; delta = rowsum(dO * O) = rowsum(P * dP) is reduced across the four key-tile
-//     waves through LDS, so O is not read at all.
+//   * backward = ONE kernel per item (attn_seq_bwd_fused_kernel): the dK/dV sweep with wave = 16 keys computes S and dP
+//     once and keeps its dS column block in registers; then the waves park K (from registers) and dS in the LDS space of
+//     the dead Q / dO stages and become 16-query tiles for dQ = dS K: 5 tile products instead of the 7 of a recompute
+//     scheme, no dS / K round trip through HBM.  delta = rowsum(dO * O) is folded into the staging of dO.
+//     (attn_seq_bwd_kv_kernel + attn_seq_bwd_q_kernel, the two-kernel form with dS in global memory, stay behind
+//     INTEL_ATTN_FUSED_BWD=0.)
 #include <stdio.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -256,6 +259,8 @@ struct SeqCfg {
   static constexpr int ROWS = PW * TP;
   static constexpr int C4 = DKT * 4;         // float4 per row
   static constexpr int ITERS = ROWS * C4 / 256;
+  static constexpr int TPD = TP + 8;         // pitch of the dS rows the fused backward parks in LDS
+  static constexpr int OSZ = ROWS * LD > PW * TP * TPD ? ROWS * LD : PW * TP * TPD;   // dO stage, later the dS tiles
 };
 
 // address of float4 #i of the staged block: LDS row rl (pair slot, row in pair), source row, validity
@@ -435,6 +440,182 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __
   }
 }
 
+// The whole backward of one item in ONE kernel: the dK/dV sweep above, then -- the staged Q / dO rows being dead -- every
+// wave parks its 16 K rows (still in registers) and its dS column block in their LDS space and turns into a 16-QUERY
+// tile for dQ = dS K.  Neither dS nor K makes a round trip through HBM (bwd_kv + bwd_q: 0.6 GB per Tmall-shape step).
+template <int DKT, int NT, int LS>
+__global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse,
+                                                              int BH, int T, int d, int heads, const int* __restrict__ key_len,
+                                                              float c2, float scale, float* __restrict__ dqkv) {
+  using C = SeqCfg<DKT, NT>;
+  constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP, NSTEPS = (NT - 1) * 4 + LS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Qs = smem;
+  float* Os = smem + C::ROWS * LD;
+  float* Ls = smem + C::ROWS * LD + C::OSZ;
+  float* Ds = Ls + C::ROWS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 4, p = lane & 15;
+  const int bh0 = blockIdx.x * C::PW, ldg = 3 * d;
+  const int slot = wave / NT, tile = wave - slot * NT, bh = bh0 + slot;
+  const bool live = slot < C::PW && bh < BH;
+  int b = live ? bh : 0, h = 0;
+  if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
+  const int key = tile * 16 + p;
+  const bool kok = live && key < T;
+  f32x4 kf[DKT], vf[DKT];
+  load_row_frags<DKT>(kf, qkv + ((size_t)b * T + key) * ldg + d + h * DK, kok, DK, lane);
+  load_row_frags<DKT>(vf, qkv + ((size_t)b * T + key) * ldg + 2 * d + h * DK, kok, DK, lane);
+  {
+    // stage Q and dO (permuted rows); delta[row] = sum_d dO * O rides along: the C4 lanes of a row are adjacent
+    f32x4 vq[C::ITERS], vo[C::ITERS];
+    float dot[C::ITERS];
+#pragma unroll
+    for (int it = 0; it < C::ITERS; ++it) {
+      int rl, c4, hcol;
+      size_t grow;
+      const bool ok = seq_src<DKT, NT, true>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol);
+      const size_t gr = ok ? grow : 0;
+      const int hc = ok ? hcol : 0;
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 tq = *reinterpret_cast<const f32x4*>(qkv + gr * ldg + hc);
+      const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(out + gr * d + hc);
+      vq[it] = ok ? tq : zero;
+      vo[it] = ok ? to : zero;
+      dot[it] = ok ? (to[0] * w[0] + to[1] * w[1] + to[2] * w[2] + to[3] * w[3]) : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < C::ITERS; ++it) {
+      const int i = tid + it * 256;
+      const int rl = i / C::C4, c4 = i - rl * C::C4;
+      *reinterpret_cast<f32x4*>(Qs + rl * LD + c4 * 4) = vq[it];
+      *reinterpret_cast<f32x4*>(Os + rl * LD + c4 * 4) = vo[it];
+      float s = dot[it];
+#pragma unroll
+      for (int m = 1; m < C::C4; m <<= 1) s += __shfl_xor(s, m);
+      if (c4 == 0) Ds[rl] = s;
+    }
+    if (tid < C::ROWS) {
+      const int sl = tid / TP, r = tid - sl * TP, rho = perm16(r), bb = bh0 + sl;
+      Ls[tid] = (bb < BH && rho < T) ? -1.44269504088896340736f * lse[(size_t)bb * T + rho] : -INFINITY;   // -lse in base 2
+    }
+  }
+  __syncthreads();
+  constexpr int TPD = C::TPD;                    // dS rows in LDS: b128 reads of 16 queries x 4 key groups are conflict-free
+  f32x4 dsk[NT];                                 // this wave's dS column block, query tile by query tile
+  if (live) {
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const bool key_live = key < nkeys;             // masked keys get exactly zero gradient
+  const float* Qp = Qs + slot * TP * LD;
+  const float* Op = Os + slot * TP * LD;
+  const float* Lp = Ls + slot * TP;
+  const float* Dp = Ds + slot * TP;
+  f32x4 dkT[DKT], dvT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) {
+    dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        const int off = (qt * 16 + p) * LD + g * 16 + 4 * j;
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(Qp + off);
+        const f32x4 oa = *reinterpret_cast<const f32x4*>(Op + off);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sa = mfma16(qa[s], kf[g][s], sa);     // S[query slot][key]
+          dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
+        }
+      }
+      f32x4 pr, ds;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = qt * 16 + 4 * j + r;     // staged slot of accumulator row 4j+r; its query is 4r+j
+        const float pv = key_live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, Lp[rl])) : 0.f;
+        pr[r] = pv;
+        ds[r] = pv * (dp[r] - Dp[rl]) * scale;
+      }
+      dsk[qt] = ds;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (qt * 4 + s >= NSTEPS) continue;     // queries 4s..4s+3 of the tile are padding (compile-time)
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          const int off = (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p;
+          const f32x4 ov = *reinterpret_cast<const f32x4*>(Op + off);
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qp + off);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
+            dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
+          }
+        }
+      }
+    }
+  }
+  if (kok) {
+    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK;
+#pragma unroll
+    for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = dq * 64 + 16 * j + 4 * r;
+        *reinterpret_cast<f32x4*>(drow + d + col) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
+        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
+      }
+  }
+  }   // live
+  __syncthreads();                               // every wave is done with the staged Q / dO rows
+  float* Ks = Qs;                                // [ROWS][LD], plain row order
+  float* Dsh = Os;                               // [PW][TP][TPD], row = query (plain order)
+  if (live) {
+#pragma unroll
+    for (int g = 0; g < DKT; ++g) *reinterpret_cast<f32x4*>(Ks + (slot * TP + key) * LD + g * 16 + 4 * j) = kf[g];
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Dsh[(slot * TP + qt * 16 + 4 * r + j) * TPD + key] = dsk[qt][r];   // accumulator row 4j+r is query 4r+j
+  }
+  __syncthreads();
+  if (!live) return;
+  {
+    const int q = tile * 16 + p;
+    const float* Kp = Ks + slot * TP * LD;
+    const float* Dq = Dsh + (size_t)(slot * TP + q) * TPD;
+    f32x4 dqT[DKT];
+#pragma unroll
+    for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+      const f32x4 dsT = *reinterpret_cast<const f32x4*>(Dq + kt * 16 + 4 * j);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          const f32x4 kv = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dqT[dq * 4 + t] = mfma16(kv[t], dsT[s], dqT[dq * 4 + t]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < T) {
+      float* drow = dqkv + ((size_t)b * T + q) * ldg + h * DK;
+#pragma unroll
+      for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) =
+              f32x4{dqT[dq * 4 + 0][r], dqT[dq * 4 + 1][r], dqT[dq * 4 + 2][r], dqT[dq * 4 + 3][r]};
+    }
+  }
+}
+
+
 // dQ[q][dim] = sum_key dS[q][key] K[key][dim]  (dS already carries 1/sqrt(dk))
 template <int DKT, int NT>
 __global__ __launch_bounds__(256, 3) void attn_seq_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dS,
@@ -552,6 +733,17 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
   const int dk = d / heads, dkt = dk / 16, BH = B * heads;
   const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
   const float scale = 1.0f / sqrtf((float)dk);
+  static const int fused = [] { const char* e = getenv("INTEL_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (fused) {
+    SEQ_DISPATCH3(dkt, nt, ls, {
+      using C = SeqCfg<DKT, NT>;
+      const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + 2 * C::ROWS) * sizeof(float);
+      allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS>), smem);
+      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 28.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv);
+    });
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   SEQ_DISPATCH3(dkt, nt, ls, {
     using C = SeqCfg<DKT, NT>;
     const size_t smem = (size_t)(2 * C::ROWS * C::LD + 2 * C::ROWS) * sizeof(float);
