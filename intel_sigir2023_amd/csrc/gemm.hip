@@ -124,6 +124,7 @@ static double gemm_algorithmic_bytes(const GemmRowsArgs& a) {
   double b = 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
   if (a.ep.res || a.ep.mask || a.ep.accumulate) b += 4.0 * (double)a.M * a.N;
   if (a.ep.xhat) b += 4.0 * (double)a.M * a.N + 4.0 * (double)a.M;
+  if (a.ep.no_out) b -= 4.0 * (double)a.M * a.N;
   return b;
 }
 
@@ -279,12 +280,12 @@ __device__ __forceinline__ void gr_epilogue_ln(const GemmRowsArgs& a, const f32x
       if (ok0) {
         const float xh = d0 * rs;
         if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
-        a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+        if (!ep.no_out) a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
       }
       if (ok1) {
         const float xh = d1 * rs;
         if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
-        a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+        if (!ep.no_out) a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
       }
     }
   }
@@ -552,12 +553,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8_kernel(GemmRowsArgs a) {
           if (ok0) {
             const float xh = d0 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
-            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
           }
           if (ok1) {
             const float xh = d1 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
-            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
           }
         }
       }
@@ -790,12 +791,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
           if (ok0) {
             const float xh = d0 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
-            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
           }
           if (ok1) {
             const float xh = d1 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
-            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
           }
         }
       }
@@ -1361,12 +1362,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_w8g_kernel(GemmRowsArgs a) {
           if (ok0) {
             const float xh = d0 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
-            a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
           }
           if (ok1) {
             const float xh = d1 * rs;
             if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
-            a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
+            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
           }
         }
       }

@@ -31,6 +31,7 @@ struct GemmEpilogue {
   int ldxhat = 0;
   float* rstd = nullptr;          // [M]
   int accumulate = 0;             // C += value instead of C = value
+  int no_out = 0;                 // LayerNorm epilogue only: keep the x-hat / rstd stash, do not store C
   const void* b3 = nullptr;       // optional pre-split bf16 image of B (launch_pack_b3): used when K > 128
 };
 // bf16 three-plane image of a packed fp32 B (any launch_pack_b result) for the K > 128 GEMM on the bf16 pipe

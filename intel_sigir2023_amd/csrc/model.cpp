@@ -112,6 +112,7 @@ struct IntelCtx {
   const float* drop_ext;       // optional 0/1 keep flags, item-tower layers then score-tower layers
   bool fwd_dropout;            // the stashed forward ran with dropout
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
+  bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
 };
 
 namespace {
@@ -327,6 +328,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += Wf(B, D.d_int, I) + Wf(B, I, y.Pin) + Wf(M, d_s, K);             // intent embedding, predictor, score embedding
     a += Wf((size_t)B * H, D.d_int, I) + Wf((size_t)B * Hi, D.d_int, I);  // shared intent embedding from the histories
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
+    a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * (Wf(B, mx, qs) + Wf(B, qs, mx));                             // gate MLPs (cross_attention = 0)
     y.arena_floats = a + 4096;
     y.ARENA = ar.f(y.arena_floats);
@@ -568,6 +570,15 @@ void pack_fp32(Run& r) {
 }
 
 // ---- towers (IntEL.py:182-197) ----------------------------------------------------------------
+// Training forward with cross attention: the output of a tower's last layer is consumed only by the pooling kernel, which can
+// rebuild it from the LayerNorm's x-hat stash (x = x-hat * gamma + beta).  Then the W2 GEMM does not store the output at all,
+// the pooling kernels read x-hat, and the pooling backward applies the LayerNorm backward to its gradient rows in registers:
+// one [B*L, d] write and three reads less per tower (INTEL_FUSE_TAIL=0 turns it off).
+static bool tail_fusable(const IntelCtx* ctx, const IntelDesc& D, int L, int d, bool train) {
+  static const int on = [] { const char* e = getenv("INTEL_FUSE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on && train && D.cross_attention && D.layers > 0 && !(ctx->drop_p > 0.f) && d <= 128 && xatt_ln_fused_supported(L, d);
+}
+
 void tower_fwd(Run& r, TowerBufs& w) {
   const IntelDesc& D = r.D;
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
@@ -600,6 +611,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
       if (r.rc) return;
       RUN(launch_add_layernorm(b.Xout, d, X, d, M, d, e2.gamma, e2.beta, b.Xout, d, b.XH, d, b.RSTD, r.st, b.DM));
     } else if (d <= 128) {
+      if (l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train)) e2.no_out = 1;      // x-hat / rstd only
       lin(r, b.R1, d, M, d, w.pW2, d, b.Xout, d, e2);
     } else {
       GemmEpilogue e2b;
@@ -614,23 +626,26 @@ void tower_fwd(Run& r, TowerBufs& w) {
 }
 
 // dXout (in r.T->dXa) -> dX0 (returned pointer, one of dXa/dXb)
-float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
+float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_done) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const int M = y.M, d = w.d, B = y.B, L = y.L, pb = w.pbase;
   for (int l = D.layers - 1; l >= 0; --l) {
     TowerLayerBufs& b = w.layer[l];
     const float* Xin = l == 0 ? w.X0 : w.layer[l - 1].Xout;
-    {
+    const float* dZ = r.T->dZ;             // gradient behind this layer's LayerNorm
+    if (l == D.layers - 1 && last_ln_done) {
+      dZ = dX;                              // the pooling backward already applied it (fused tail)
+    } else {
       int a = r.acc(pb + T_LNG);
       r.acc(pb + T_LNB);
       if (!r.ok(launch_layernorm_bwd(dX, d, b.XH, d, b.RSTD, M, d, r.P(pb + T_LNG), r.T->dZ, d, r.G(pb + T_LNG), r.G(pb + T_LNB), a,
                                      nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
-    const float* dZd = r.T->dZ;            // gradient behind the dropout: dZ * mask (the residual branch keeps dZ)
+    const float* dZd = dZ;                 // gradient behind the dropout: dZ * mask (the residual branch keeps dZ)
     if (r.ctx->fwd_dropout) {
-      if (!r.ok(launch_mul2(r.T->dZ, b.DM, (long long)M * d, r.T->dA, r.st))) return nullptr;
+      if (!r.ok(launch_mul2(dZ, b.DM, (long long)M * d, r.T->dA, r.st))) return nullptr;
       dZd = r.T->dA;
     }
     wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
@@ -648,7 +663,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt) {
     }
     // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
     GemmEpilogue er;
-    er.res = r.T->dZ; er.ldres = d;
+    er.res = dZ; er.ldres = d;
     er.b3 = w.b3WqkvT;
     lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
@@ -934,7 +949,13 @@ void forward_impl(Run& r, const IntelOut* out) {
       lin(r, y.INTENTS, I, B, I, w.pXq, w.d, w.QV, w.d, e0);
       lin(r, w.QV, w.d, B, w.d, w.pXkT, w.d, w.QK, w.d, e0);
       if (r.rc) return;
-      RUN(launch_xatt_pool_fwd(Xf, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, r.st));
+      if (tail_fusable(r.ctx, D, L, w.d, r.train)) {
+        const int pb = w.pbase;
+        RUN(launch_xatt_pool_fwd(w.layer[D.layers - 1].XH, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, r.st,
+                                 r.P(pb + T_LNG), r.P(pb + T_LNB)));
+      } else {
+        RUN(launch_xatt_pool_fwd(Xf, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, r.st));
+      }
       lin(r, w.XBAR, w.d, B, w.d, w.pXv, w.d, y.FEAT + w.feat_off, y.F, e0);
     } else {
       const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
@@ -1047,7 +1068,16 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1);
       lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, r.T->dVB1, d, e0);          // dxbar
       if (r.rc) return;
-      RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout, r.T->dVB2, r.st));   // dX, dQK
+      if (r.ctx->fused_tail[t]) {       // dXout receives dZ: the gradient BEHIND the last layer's LayerNorm
+        const int pb = w.pbase;
+        TowerLayerBufs& lb = w.layer[D.layers - 1];
+        const int a = r.acc(pb + T_LNG);
+        r.acc(pb + T_LNB);
+        RUN(launch_xatt_pool_ln_bwd(lb.XH, lb.RSTD, r.P(pb + T_LNG), r.P(pb + T_LNB), B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout,
+                                    r.T->dVB2, r.G(pb + T_LNG), r.G(pb + T_LNB), a, r.st, r.ctx->rq));
+      } else {
+        RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout, r.T->dVB2, r.st));   // dX, dQK
+      }
       // QK = QV Wk  (QK[b][j] = sum_i QV[b][i] Wk[i][j])
       wgrad(r, w.QV, d, r.T->dVB2, d, B, d, d, xb + 1, -1);
       lin(r, r.T->dVB2, d, B, d, w.pXk, d, r.T->dVB3, d, e0);                            // dQV
@@ -1068,7 +1098,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   auto item_tower_bwd = [&](Run& r, float* dXout) {
     TowerBufs& w = y.tw[0];
     const int d = w.d;
-    float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa);
+    float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa, r.ctx->fused_tail[0]);
     if (r.rc || !dX0) return;
     if (r.G(INTEL_P_IID_EMB))
       RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
@@ -1168,7 +1198,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       // the score tower's output gradient was parked in dXS by phase 1; tower_bwd ping-pongs dXS <-> dXb
       {
         TowerBufs& w = y.tw[1];
-        float* dX0 = tower_bwd(b0, w, y.dXS, y.tmp[0].dXb);
+        float* dX0 = tower_bwd(b0, w, y.dXS, y.tmp[0].dXb, r.ctx->fused_tail[1]);
         if (!b0.rc && dX0) wgrad(b0, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
       }
       dE0 = encoder_branch(b1, 0);
@@ -1224,6 +1254,7 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->drop_ext = nullptr;
   c->fwd_dropout = false;
   c->iid_row_flags = nullptr;
+  c->fused_tail[0] = c->fused_tail[1] = false;
   c->rq = redq_create();
   if (!c->rq) {
     delete c;
@@ -1299,6 +1330,8 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   const bool dropout = train && ctx->drop_p > 0.f;
   make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay, dropout);
   ctx->fwd_dropout = dropout;
+  ctx->fused_tail[0] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[0].d, train != 0);
+  ctx->fused_tail[1] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[1].d, train != 0);
   if (workspace_bytes < ctx->lay.total) {
     intel_set_error("intel_forward: workspace %zu < %zu bytes", workspace_bytes, ctx->lay.total);
     return INTEL_E_WORKSPACE;

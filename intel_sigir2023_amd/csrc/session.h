@@ -2,8 +2,17 @@
 #pragma once
 #include "common.h"
 
+struct ReduceQueue;
+
 int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
-                         float* xbar, float* attw, hipStream_t st);
+                         float* xbar, float* attw, hipStream_t st, const float* gamma = nullptr,
+                         const float* beta = nullptr);
+// the tower's last LayerNorm folded into the pooling: X given as its x-hat stash (forward: gamma/beta above; backward below)
+bool xatt_ln_fused_supported(int L, int d);
+size_t xatt_ln_bwd_slab_floats(int B, int d);
+int launch_xatt_pool_ln_bwd(const float* XH, const float* rstd, const float* gamma, const float* beta, int B, int L, int d,
+                            const float* qk, const float* attw, const float* dxbar, int ldxb, float scale, float* dZ, float* dqk,
+                            float* dgamma, float* dbeta, int accumulate, hipStream_t st, ReduceQueue* q);
 int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, const float* attw, const float* dxbar,
                          int ldxb, float scale, float* dX, float* dqk, hipStream_t st);
 int launch_ens_fwd(const float* wv, const float* wpad, const float* scores, const int* slen, int B, int L, int K,

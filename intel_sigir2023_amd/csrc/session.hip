@@ -76,19 +76,25 @@ __global__ __launch_bounds__(256) void xatt_pool_fwd_kernel(const float* __restr
 template <int NV, int LP>
 __global__ __launch_bounds__(256) void xatt_pool_fwd_reg_kernel(const float* __restrict__ X, int L, const float* __restrict__ qk,
                                                                 const int* __restrict__ slen, float scale, int B,
-                                                                float* __restrict__ xbar, float* __restrict__ attw) {
+                                                                float* __restrict__ xbar, float* __restrict__ attw,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta) {
   constexpr int d = 64 * NV;
   __shared__ float s_att[4][4 * LP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
   if (b >= B) return;
   const float* Xb = X + (size_t)b * L * d;
   const int len = min(slen[b], L);
   float* att = s_att[wave];
   const int sub = lane & 15, grp = lane >> 4;
-  f32x4 qv[NV];
+  f32x4 qv[NV], gm[NV], bt[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) qv[i] = *reinterpret_cast<const f32x4*>(qk + (size_t)b * d + sub * 4 + 64 * i);
+  for (int i = 0; i < NV; ++i) {
+    qv[i] = *reinterpret_cast<const f32x4*>(qk + (size_t)b * d + sub * 4 + 64 * i);
+    // gamma != nullptr: X holds the x-hat stash of the tower's last LayerNorm and the rows are x-hat * gamma + beta
+    gm[i] = gamma ? *reinterpret_cast<const f32x4*>(gamma + sub * 4 + 64 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    bt[i] = gamma ? *reinterpret_cast<const f32x4*>(beta + sub * 4 + 64 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   f32x4 x[LP][NV];
 #pragma unroll
   for (int p = 0; p < LP; ++p) {
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(256) void xatt_pool_fwd_reg_kernel(const float* __r
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       x[p][i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)lc * d + sub * 4 + 64 * i);
+      if (gamma) x[p][i] = x[p][i] * gm[i] + bt[i];
       const f32x4 t = x[p][i] * qv[i];
       s += (t[0] + t[1]) + (t[2] + t[3]);
     }
@@ -160,14 +167,17 @@ static inline bool xp_aligned(std::initializer_list<const void*> ptrs) {
     }                                                                                       \
   } while (0)
 
+bool xatt_ln_fused_supported(int L, int d) { return (d == 64 || d == 128) && L >= 1 && L <= (d == 64 ? 100 : 52); }
+
 int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
-                         float* xbar, float* attw, hipStream_t st) {
+                         float* xbar, float* attw, hipStream_t st, const float* gamma, const float* beta) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool: list length %d > %d unsupported", L, XP_MAXL);
   INTEL_CHECK_ARG(d % 4 == 0, "xatt_pool: width %d must be a multiple of 4", d);
   if ((d == 64 || d == 128) && L <= (d == 64 ? 100 : 52) && xp_aligned({X, qk, xbar})) {
-    XP_REG_DISPATCH(xatt_pool_fwd_reg_kernel, X, L, qk, slen, scale, B, xbar, attw);
+    XP_REG_DISPATCH(xatt_pool_fwd_reg_kernel, X, L, qk, slen, scale, B, xbar, attw, gamma, beta);
   } else {
+    INTEL_CHECK_ARG(!gamma, "xatt_pool: the x-hat input form needs the register kernel (d=%d, L=%d)", d, L);
     LAUNCH(xatt_pool_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, slen, scale, B, xbar, attw);
   }
   INTEL_CHECK_LAUNCH();
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256) void xatt_pool_bwd_reg_kernel(const float* __r
   constexpr int d = 64 * NV;
   __shared__ float s_g[4][4 * LP];
   __shared__ float s_w[4][4 * LP];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * 4 + wave;
   if (b >= B) return;
   const float* Xb = X + (size_t)b * L * d;
@@ -311,6 +321,187 @@ int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, c
     LAUNCH(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
   }
   INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// xatt_pool backward FUSED with the backward of the LayerNorm that produced X (the last layer of a tower, IntEL.py:187,196):
+// X is given as its x-hat stash (+ gamma, beta, rstd); the gradient row dy_l = w_l dxbar + datt_l scale qk never leaves the
+// registers and the kernel writes dz = rstd (g - mean(g) - xhat mean(g xhat)), g = gamma dy, for ALL L rows, plus per-
+// workgroup column partials of dgamma = sum dy xhat and dbeta = sum dy (slab[blockIdx][2][d]) and dqk.
+template <int NV, int LP>
+__global__ __launch_bounds__(256) void xatt_pool_ln_bwd_reg_kernel(const float* __restrict__ XH, const float* __restrict__ rstd, int L,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   const float* __restrict__ qk, const float* __restrict__ attw,
+                                                                   const float* __restrict__ dxbar, int ldxb, float scale, int B,
+                                                                   float* __restrict__ dZ, float* __restrict__ dqk,
+                                                                   float* __restrict__ slabs) {
+  constexpr int d = 64 * NV;
+  __shared__ float s_g[4][4 * LP];
+  __shared__ float s_w[4][4 * LP];
+  __shared__ float s_gb[2][4][d];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * 4 + wave;
+  const bool live = b < B;
+  const int sub = lane & 15, grp = lane >> 4;
+  f32x4 ag[NV], ab[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const float* Xb = XH + (size_t)b * L * d;
+    float* g = s_g[wave];
+    float* w = s_w[wave];
+    for (int l = lane; l < L; l += 64) w[l] = attw[(size_t)b * L + l];
+    // x_l = xhat_l * gamma + beta is never formed: <x_l, v> = <xhat_l, gamma v> + <beta, v> and
+    // sum_l a_l x_l = gamma (sum_l a_l xhat_l) + beta sum_l a_l -- only the x-hat rows live in registers
+    f32x4 qv[NV], gv[NV], gm[NV], bt[NV], ggv[NV];
+    float cb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      qv[i] = *reinterpret_cast<const f32x4*>(qk + (size_t)b * d + sub * 4 + 64 * i);
+      gv[i] = *reinterpret_cast<const f32x4*>(dxbar + (size_t)b * ldxb + sub * 4 + 64 * i);
+      gm[i] = *reinterpret_cast<const f32x4*>(gamma + sub * 4 + 64 * i);
+      bt[i] = *reinterpret_cast<const f32x4*>(beta + sub * 4 + 64 * i);
+      ggv[i] = gm[i] * gv[i];
+      const f32x4 t = bt[i] * gv[i];
+      cb += (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    cb += __shfl_xor(cb, 1);
+    cb += __shfl_xor(cb, 2);
+    cb += __shfl_xor(cb, 4);
+    cb += __shfl_xor(cb, 8);
+    f32x4 xh[LP][NV];
+#pragma unroll
+    for (int p = 0; p < LP; ++p) {
+      const int l = 4 * p + grp;
+      const int lc = min(l, L - 1);
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        xh[p][i] = *reinterpret_cast<const f32x4*>(Xb + (size_t)lc * d + sub * 4 + 64 * i);
+        const f32x4 t = xh[p][i] * ggv[i];
+        s += (t[0] + t[1]) + (t[2] + t[3]);
+      }
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      s += __shfl_xor(s, 4);
+      s += __shfl_xor(s, 8);
+      if (l < L && sub == 0) g[l] = s + cb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float wg = 0.f;
+    for (int l = lane; l < L; l += 64) wg += w[l] * g[l];
+    wg = wave_sum(wg);
+    __builtin_amdgcn_wave_barrier();
+    for (int l = lane; l < L; l += 64) g[l] = w[l] * (g[l] - wg) * scale;   // = datt_l * scale
+    __builtin_amdgcn_wave_barrier();
+    // dy_l = w_l dxbar + datt_l qk is rank two over the list, so are its column sums: with A = sum_l datt_l xhat_l and
+    // W = sum_l w_l xhat_l: dgamma = dxbar W + qk A, dbeta = dxbar sum w + qk sum datt, dqk = gamma A + beta sum datt
+    f32x4 acc[NV], accw[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = accw[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float inv_n = 1.f / (float)d;
+    float sda = 0.f, sw = 0.f;
+#pragma unroll
+    for (int p = 0; p < LP; ++p) {
+      const int l = 4 * p + grp;
+      const bool ok = l < L;
+      const int lc = min(l, L - 1);
+      const float da = ok ? g[lc] : 0.f, wl = ok ? w[lc] : 0.f;
+      f32x4 gg[NV];
+      float s1 = 0.f, s2 = 0.f;
+      sda += da;
+      sw += wl;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const f32x4 dy = wl * gv[i] + da * qv[i];
+        acc[i] += da * xh[p][i];
+        accw[i] += wl * xh[p][i];
+        gg[i] = dy * gm[i];
+        const f32x4 gh = gg[i] * xh[p][i];
+        s1 += (gg[i][0] + gg[i][1]) + (gg[i][2] + gg[i][3]);
+        s2 += (gh[0] + gh[1]) + (gh[2] + gh[3]);
+      }
+      s1 += __shfl_xor(s1, 1);
+      s1 += __shfl_xor(s1, 2);
+      s1 += __shfl_xor(s1, 4);
+      s1 += __shfl_xor(s1, 8);
+      s2 += __shfl_xor(s2, 1);
+      s2 += __shfl_xor(s2, 2);
+      s2 += __shfl_xor(s2, 4);
+      s2 += __shfl_xor(s2, 8);
+      const float m1 = s1 * inv_n, m2 = s2 * inv_n;
+      if (ok) {
+        const float rs = rstd[(size_t)b * L + l];
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          *reinterpret_cast<f32x4*>(dZ + ((size_t)b * L + l) * d + sub * 4 + 64 * i) = rs * (gg[i] - m1 - xh[p][i] * m2);
+      }
+      __builtin_amdgcn_sched_barrier(0);       // one row group at a time: the x-hat rows already fill the register file
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      ag[i] = gv[i] * accw[i] + qv[i] * acc[i];          // this lane's rows; the row groups are summed below
+      ab[i] = gv[i] * sw + qv[i] * sda;
+    }
+    sda += __shfl_xor(sda, 16);
+    sda += __shfl_xor(sda, 32);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float a = acc[i][e];
+        a += __shfl_xor(a, 16);
+        a += __shfl_xor(a, 32);
+        acc[i][e] = a;
+      }
+      if (grp == 0) *reinterpret_cast<f32x4*>(dqk + (size_t)b * d + sub * 4 + 64 * i) = acc[i] * gm[i] + bt[i] * sda;
+    }
+  }
+  // column partials of dgamma / dbeta: over the row groups of the wave, then over the four sessions of the workgroup
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = ag[i][e], c = ab[i][e];
+      a += __shfl_xor(a, 16);
+      a += __shfl_xor(a, 32);
+      c += __shfl_xor(c, 16);
+      c += __shfl_xor(c, 32);
+      ag[i][e] = a;
+      ab[i][e] = c;
+    }
+    if (grp == 0) {
+      *reinterpret_cast<f32x4*>(&s_gb[0][wave][sub * 4 + 64 * i]) = ag[i];
+      *reinterpret_cast<f32x4*>(&s_gb[1][wave][sub * 4 + 64 * i]) = ab[i];
+    }
+  }
+  __syncthreads();
+  float* slab = slabs + (size_t)blockIdx.x * 2 * d;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    slab[c] = (s_gb[0][0][c] + s_gb[0][1][c]) + (s_gb[0][2][c] + s_gb[0][3][c]);
+    slab[d + c] = (s_gb[1][0][c] + s_gb[1][1][c]) + (s_gb[1][2][c] + s_gb[1][3][c]);
+  }
+}
+
+size_t xatt_ln_bwd_slab_floats(int B, int d) { return (size_t)cdiv(B, 4) * 2 * d; }
+
+// dgamma / dbeta go through the deferred reduction queue (slabs from its arena)
+int launch_xatt_pool_ln_bwd(const float* XH, const float* rstd, const float* gamma, const float* beta, int B, int L, int d,
+                            const float* qk, const float* attw, const float* dxbar, int ldxb, float scale, float* dZ, float* dqk,
+                            float* dgamma, float* dbeta, int accumulate, hipStream_t st, ReduceQueue* q) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(xatt_ln_fused_supported(L, d) && (ldxb & 3) == 0 && xp_aligned({XH, qk, dxbar, dZ, dqk, gamma, beta}) && q,
+                  "xatt_pool_ln_bwd: unsupported shape or alignment (d=%d, L=%d)", d, L);
+  const int nb = cdiv(B, 4);
+  float* slabs = redq_alloc(q, xatt_ln_bwd_slab_floats(B, d));
+  if (!slabs) {
+    intel_set_error("xatt_pool_ln_bwd: reduction arena exhausted");
+    return -2;   // INTEL_E_WORKSPACE
+  }
+  XP_REG_DISPATCH(xatt_pool_ln_bwd_reg_kernel, XH, rstd, L, gamma, beta, qk, attw, dxbar, ldxb, scale, B, dZ, dqk, slabs);
+  INTEL_CHECK_LAUNCH();
+  redq_push(q, slabs, (size_t)2 * d, nb, 1, d, dgamma, d, accumulate);
+  redq_push(q, slabs + d, (size_t)2 * d, nb, 1, d, dbeta, d, accumulate);
   return 0;
 }
 
