@@ -20,7 +20,8 @@
 //   * backward = ONE kernel per item (attn_seq_bwd_fused_kernel): the dK/dV sweep with wave = 16 keys computes S and dP
 //     once and keeps its dS column block in registers; then the waves park K (from registers) and dS in the LDS space of
 //     the dead Q / dO stages and become 16-query tiles for dQ = dS K: 5 tile products instead of the 7 of a recompute
-//     scheme, no dS / K round trip through HBM.  delta = rowsum(dO * O) is folded into the staging of dO.
+//     scheme, no dS / K round trip through HBM.  delta = rowsum(dO * O) = rowsum(P * dP) is summed over the key-tile
+//     waves through LDS, so the attention output O is not read at all.
 //     (attn_seq_bwd_kv_kernel + attn_seq_bwd_q_kernel, the two-kernel form with dS in global memory, stay behind
 //     INTEL_ATTN_FUSED_BWD=0.)
 #include <stdio.h>
@@ -467,9 +468,8 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
   load_row_frags<DKT>(kf, qkv + ((size_t)b * T + key) * ldg + d + h * DK, kok, DK, lane);
   load_row_frags<DKT>(vf, qkv + ((size_t)b * T + key) * ldg + 2 * d + h * DK, kok, DK, lane);
   {
-    // stage Q and dO (permuted rows); delta[row] = sum_d dO * O rides along: the C4 lanes of a row are adjacent
+    // stage Q and dO (permuted rows)
     f32x4 vq[C::ITERS], vo[C::ITERS];
-    float dot[C::ITERS];
 #pragma unroll
     for (int it = 0; it < C::ITERS; ++it) {
       int rl, c4, hcol;
@@ -480,10 +480,8 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 tq = *reinterpret_cast<const f32x4*>(qkv + gr * ldg + hc);
       const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(out + gr * d + hc);
       vq[it] = ok ? tq : zero;
       vo[it] = ok ? to : zero;
-      dot[it] = ok ? (to[0] * w[0] + to[1] * w[1] + to[2] * w[2] + to[3] * w[3]) : 0.f;
     }
 #pragma unroll
     for (int it = 0; it < C::ITERS; ++it) {
@@ -491,10 +489,6 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       const int rl = i / C::C4, c4 = i - rl * C::C4;
       *reinterpret_cast<f32x4*>(Qs + rl * LD + c4 * 4) = vq[it];
       *reinterpret_cast<f32x4*>(Os + rl * LD + c4 * 4) = vo[it];
-      float s = dot[it];
-#pragma unroll
-      for (int m = 1; m < C::C4; m <<= 1) s += __shfl_xor(s, m);
-      if (c4 == 0) Ds[rl] = s;
     }
     if (tid < C::ROWS) {
       const int sl = tid / TP, r = tid - sl * TP, rho = perm16(r), bb = bh0 + sl;
@@ -503,21 +497,20 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
   }
   __syncthreads();
   constexpr int TPD = C::TPD;                    // dS rows in LDS: b128 reads of 16 queries x 4 key groups are conflict-free
-  f32x4 dsk[NT];                                 // this wave's dS column block, query tile by query tile
-  if (live) {
-  const int nkeys = key_len ? min(key_len[b], T) : T;
+  // delta[q] = rowsum(dO * O) = sum_key P[q][key] dP[q][key]: every wave sums its 16 keys, the NT key-tile waves of a pair
+  // meet in LDS (Ds[slot row][tile]) -- the attention output O is not read at all
+  f32x4 prs[NT], dsk[NT];                        // P, then dP -> dS, of this wave's key tile, query tile by query tile
+  f32x4 dkT[DKT];
+  const int nkeys = live ? (key_len ? min(key_len[b], T) : T) : 0;
   const bool key_live = key < nkeys;             // masked keys get exactly zero gradient
   const float* Qp = Qs + slot * TP * LD;
   const float* Op = Os + slot * TP * LD;
   const float* Lp = Ls + slot * TP;
-  const float* Dp = Ds + slot * TP;
-  f32x4 dkT[DKT], dvT[DKT];
+  float* Dp = Ds + slot * TP * NT;
+  if (live) {
+    f32x4 dvT[DKT];
 #pragma unroll
-  for (int i = 0; i < DKT; ++i) {
-    dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  {
+    for (int i = 0; i < DKT; ++i) dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qt = 0; qt < NT; ++qt) {
       f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -532,43 +525,76 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
           dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
         }
       }
-      f32x4 pr, ds;
+      f32x4 pr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = qt * 16 + 4 * j + r;     // staged slot of accumulator row 4j+r; its query is 4r+j
         const float pv = key_live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, Lp[rl])) : 0.f;
         pr[r] = pv;
-        ds[r] = pv * (dp[r] - Dp[rl]) * scale;
+        float x = pv * dp[r];                   // this key's share of delta[rl]; sum over the 16 keys of the tile
+        x += __shfl_xor(x, 1);
+        x += __shfl_xor(x, 2);
+        x += __shfl_xor(x, 4);
+        x += __shfl_xor(x, 8);
+        if (p == 0) Dp[rl * NT + tile] = x;
       }
-      dsk[qt] = ds;
+      prs[qt] = pr;
+      dsk[qt] = dp;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (qt * 4 + s >= NSTEPS) continue;     // queries 4s..4s+3 of the tile are padding (compile-time)
 #pragma unroll
         for (int dq = 0; dq < DQ; ++dq) {
-          const int off = (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p;
-          const f32x4 ov = *reinterpret_cast<const f32x4*>(Op + off);
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qp + off);
+          const f32x4 ov = *reinterpret_cast<const f32x4*>(Op + (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
-            dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
-          }
+          for (int t = 0; t < 4; ++t) dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
         }
       }
     }
-  }
-  if (kok) {
-    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK;
+    if (kok) {
+      float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK + 2 * d;
 #pragma unroll
-    for (int dq = 0; dq < DQ; ++dq)
+      for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
+    }
+  }
+  __syncthreads();                               // the delta shares of all key tiles are in LDS
+  if (live) {
+#pragma unroll
+    for (int i = 0; i < DKT; ++i) dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qt = 0; qt < NT; ++qt) {
+      f32x4 ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int col = dq * 64 + 16 * j + 4 * r;
-        *reinterpret_cast<f32x4*>(drow + d + col) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
-        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
+        const int rl = qt * 16 + 4 * j + r;
+        float delta = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) delta += Dp[rl * NT + t];
+        ds[r] = prs[qt][r] * (dsk[qt][r] - delta) * scale;
       }
-  }
+      dsk[qt] = ds;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (qt * 4 + s >= NSTEPS) continue;
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qp + (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
+        }
+      }
+    }
+    if (kok) {
+      float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK + d;
+#pragma unroll
+      for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
+    }
   }   // live
   __syncthreads();                               // every wave is done with the staged Q / dO rows
   float* Ks = Qs;                                // [ROWS][LD], plain row order
@@ -737,9 +763,9 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
   if (fused) {
     SEQ_DISPATCH3(dkt, nt, ls, {
       using C = SeqCfg<DKT, NT>;
-      const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + 2 * C::ROWS) * sizeof(float);
+      const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + (1 + NT) * C::ROWS) * sizeof(float);
       allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS>), smem);
-      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 28.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv);
+      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv);
     });
     INTEL_CHECK_LAUNCH();
     return 0;
