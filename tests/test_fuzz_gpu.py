@@ -1,0 +1,24 @@
+"""Randomised parity sweep (tools/fuzz_parity.py) as a GPU test: outputs, Int* losses and every parameter gradient of the
+HIP path against the oracle's autograd on shapes the fixtures do not hold."""
+import importlib.util
+import os
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_parity.py'))
+fuzz = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fuzz)
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_random_configs_match_oracle_autograd(seed):
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    rng = random.Random(seed)
+    dev = torch.device('cuda:0')
+    for i in range(6):
+        worst, bad, desc = fuzz.one_case(rng, 1000 * seed + i, dev)
+        assert worst <= 1.0, (worst, bad, desc)
