@@ -1520,6 +1520,14 @@ static inline int wgrad_num_slabs(int M, int N = 128, int K = 128) {
   // Narrow products (N + K <= 128: 30 KB of LDS, 16 KB slabs) are latency-bound instead: two workgroups per CU.
   int cap = (N + K <= 128 && N % 32 == 0 && K % 32 == 0) ? 2 * maxs : maxs;
   if (cap > WG_MAXS) cap = WG_MAXS;
+  // several 128-column blocks of dY against a 128-wide X (the fused q/k/v weight gradient, N = 3d): all S x N/128 workgroups
+  // should be resident at once (two per CU) -- no half-empty second wave, and the column blocks of one slab, which share an
+  // XCD when S is a multiple of 8, read their common X tile through the same L2
+  static const int co = [] { const char* e = getenv("INTEL_WGRAD_CORESIDENT"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (co && N > 128 && K > 64) {
+    const int ny = cdiv(N, 128), fit = ((2 * 256) / ny) & ~7;
+    if (cap > fit) cap = fit;
+  }
   int s = cdiv(M, WG_RT);
   return s < 1 ? 1 : (s > cap ? cap : s);
 }
