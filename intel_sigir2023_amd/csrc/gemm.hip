@@ -1458,6 +1458,10 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
         if (N > 32) return launch_b3<2, true>(a, st);
         return launch_b3<1, true>(a, st);
       }
+      // few row tiles (the B-row products of the pooling / fusion chains): 32-column workgroups, one tile pair per wave --
+      // four times the workgroups and a quarter of the MFMA chain per wave (the A tile is re-read from L2 by the column chunks)
+      static const int small_m = [] { const char* e = getenv("INTEL_GEMM_SMALLM"); return e ? atoi(e) : 8192; }();
+      if (M <= small_m && N > 32) return launch_b3<1, false>(a, st);
       if (N > 64) return launch_b3<4, false>(a, st);
       if (N > 32) return launch_b3<2, false>(a, st);
       return launch_b3<1, false>(a, st);
