@@ -245,7 +245,7 @@ template <int DKT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            int T, int d, int heads, const int* __restrict__ key_len,
-                                                           float scale, float* __restrict__ dqkv) {
+                                                           float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
@@ -304,6 +304,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         const float p = key_live ? expf(sa[r] * scale - Ls[ql]) : 0.f;
         pr[r] = p;
         ds[r] = p * (dp[r] - Ds[ql]) * scale;
+        // the dS tile for the dQ = dS K kernel (row = query, ldS floats per row); keys >= nkeys / queries >= T are never read
+        if (dS && qb + ql < T && kok) dS[((size_t)blockIdx.x * T + qb + ql) * ldS + key] = ds[r];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -329,11 +331,96 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward without recomputation in the dQ pass: dsum = rowsum(dO * O) first (one wave per row), the dK/dV kernel above
+// stores its dS tiles, and dQ = dS K is one product per key tile (5 tile products per pair instead of 7; the dS
+// scratch costs 8 T^2 bytes of traffic per (session, head)).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict__ out, const float* __restrict__ dout, int T, int d,
+                                                        int heads, long long rows, float* __restrict__ dsum) {
+  // 16 lanes per (row, head), four of them per wave, 16-byte loads
+  const int lane = threadIdx.x & 63, sub = lane & 15;
+  const long long i = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);      // (b*T + t, h) flattened
+  const bool ok = i < rows * heads;
+  const long long ic = ok ? i : 0;
+  const long long row = ic / heads;
+  const int h = (int)(ic - row * heads), dk = d / heads;
+  float s = 0.f;
+  for (int c = sub * 4; c < dk; c += 64) {
+    const f32x4 o = *reinterpret_cast<const f32x4*>(out + row * d + h * dk + c);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(dout + row * d + h * dk + c);
+    s += (o[0] * g[0] + o[1] * g[1]) + (o[2] * g[2] + o[3] * g[3]);
+  }
+  s += __shfl_xor(s, 1);
+  s += __shfl_xor(s, 2);
+  s += __shfl_xor(s, 4);
+  s += __shfl_xor(s, 8);
+  if (ok && sub == 0) {
+    const long long b = row / T, t = row - b * T;
+    dsum[(b * heads + h) * T + t] = s;
+  }
+}
+
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_bwd_dq_ds_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
+                                                             int d, int heads, const int* __restrict__ key_len,
+                                                             float* __restrict__ dqkv) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int dk = d / heads, ldg = 3 * d;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const float* base = qkv + (size_t)b * T * ldg;
+  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
+  const bool qok = q < T;
+  const float* dSq = dS + ((size_t)blockIdx.x * T + (qok ? q : 0)) * ldS;
+  f32x4 dqT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < nkeys; kb += AT_KB) {
+    __syncthreads();
+    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
+      if (kb + kt * 16 >= nkeys) continue;
+      const int key0 = kb + kt * 16 + 4 * (lane >> 4);
+      f32x4 dsT = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (qok && key0 < ldS) dsT = *reinterpret_cast<const f32x4*>(dSq + key0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dsT[r] = key0 + r < nkeys ? dsT[r] : 0.f;      // masked / padding keys: nothing was stored
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float* krow = Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
+#pragma unroll
+        for (int dt = 0; dt < DKT; ++dt) dqT[dt] = mfma16(krow[dt * 16], dsT[s], dqT[dt]);
+      }
+    }
+  }
+  if (qok) {
+    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * dk;
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const int col = dt * 16 + 4 * (lane >> 4);
+      if (col < dk) *reinterpret_cast<f32x4*>(drow + col) = dqT[dt];
+    }
+  }
+}
+
+static inline int attn_ds_pitch(int T) { return (T + 3) & ~3; }
+static inline bool attn_ds_scheme() {
+  static const int on = [] { const char* e = getenv("INTEL_ATTN_DS"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on != 0;
+}
+
 static inline bool attn_seq_path(int T, int dk) { return attn_seq_supported(T, dk); }
 
 size_t attn_bwd_scratch_floats(int B, int T, int d, int heads) {
   size_t f = rup_sz((size_t)B * heads * T, 64);
   if (heads > 0 && attn_seq_path(T, d / heads)) f += attn_seq_bwd_scratch_floats(B, T, heads);
+  else if (attn_ds_scheme()) f += (size_t)B * heads * T * attn_ds_pitch(T);
   return f;
 }
 
@@ -387,7 +474,28 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   if (attn_seq_path(T, dk))
     return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st);
   dim3 grid(B * heads, cdiv(T, AT_QB));
-  ATTN_DISPATCH(dkt, {
+  if (attn_ds_scheme()) {
+    float* dS = scratch + rup_sz((size_t)B * heads * T, 64);
+    const int ldS = attn_ds_pitch(T);
+    const long long rows = (long long)B * T;
+    LAUNCH_W(0.0, 8.0 * (double)rows * d, attn_dsum_kernel, dim3((unsigned)((rows * heads + 15) / 16)), dim3(256), 0, st, out, dout, T, d, heads, rows, dsum);
+    INTEL_CHECK_LAUNCH();
+    ATTN_DISPATCH(dkt, {
+      size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
+      allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
+      LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
+                         scale, dqkv, dS, ldS);
+    });
+    INTEL_CHECK_LAUNCH();
+    ATTN_DISPATCH(dkt, {
+      size_t smem = (size_t)AT_KB * AttnSmem<DKT>::LD * sizeof(float);
+      allow_lds(attn_bwd_dq_ds_kernel<DKT>, smem);
+      LAUNCH_S(B * heads, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d + 4.0 * B * heads * (double)T * T, attn_bwd_dq_ds_kernel<DKT>, grid, dim3(256), smem, st, qkv, dS, ldS, T, d, heads, key_len, dqkv);
+    });
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
+    ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_bwd_dq_kernel<DKT>, smem);
     LAUNCH_S(B * heads, T, dk, 6.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dq_kernel<DKT>, grid, dim3(256), smem, st, qkv, out, dout, lse, T, d, heads, key_len,
@@ -398,7 +506,7 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
     size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
     allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
     LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
-                       scale, dqkv);
+                       scale, dqkv, nullptr, 0);
   });
   INTEL_CHECK_LAUNCH();
   return 0;
