@@ -65,10 +65,18 @@ def one_case(rng, idx, dev):
     for k, p in named.items():
         g = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
         r = sd[k].grad if sd[k].grad is not None else torch.zeros(p.shape)
-        # 5e-4 of the largest entry: a relu whose pre-activation rounds to the other side of 0 moves a weight gradient by one
-        # row's contribution (seen once in 70 cases, 1.2e-3 of max|g| on a 300-row batch); the fixture tests keep 2e-4
-        tol = 2e-6 + 5e-4 * float(r.abs().max())
-        err = float((g - r).abs().max())
+        tol = 1e-6 + 2e-4 * float(r.abs().max())            # the fixture tests' tolerance
+        diff = (g - r).abs()
+        err = float(diff.max())
+        if err > tol and diff.dim() >= 1 and diff.shape[0] > 4:
+            # relu-flip signature: ONE hidden unit of one row rounds to the other side of 0 in the two implementations and
+            # moves exactly one row of a W1 gradient (seen twice in 190 cases, row error 200x the median row's): forgive a
+            # single outlying row up to 50x the tolerance, everything else must pass
+            rows = diff.reshape(diff.shape[0], -1).max(dim=1)[0]
+            worst_row = int(rows.argmax())
+            rest = torch.cat([rows[:worst_row], rows[worst_row + 1:]])
+            if float(rest.max()) <= tol and err <= 50 * tol:
+                err = float(rest.max())
         if err / tol > worst:
             worst, bad = err / tol, k
     return worst, bad, desc
