@@ -163,18 +163,19 @@ static inline bool xp_aligned(std::initializer_list<const void*> ptrs) {
       else LAUNCH((KERNEL<1, 25>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__);        \
     } else {                                                                                \
       if (L <= 20) LAUNCH((KERNEL<2, 5>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__); \
-      else LAUNCH((KERNEL<2, 13>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__);        \
+      else if (L <= 52) LAUNCH((KERNEL<2, 13>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__); \
+      else LAUNCH((KERNEL<2, 25>), dim3(cdiv(B, 4)), dim3(256), 0, st, __VA_ARGS__);        \
     }                                                                                       \
   } while (0)
 
-bool xatt_ln_fused_supported(int L, int d) { return (d == 64 || d == 128) && L >= 1 && L <= (d == 64 ? 100 : 52); }
+bool xatt_ln_fused_supported(int L, int d) { return (d == 64 || d == 128) && L >= 1 && L <= 100; }
 
 int launch_xatt_pool_fwd(const float* X, int B, int L, int d, const float* qk, const int* slen, float scale,
                          float* xbar, float* attw, hipStream_t st, const float* gamma, const float* beta) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool: list length %d > %d unsupported", L, XP_MAXL);
   INTEL_CHECK_ARG(d % 4 == 0, "xatt_pool: width %d must be a multiple of 4", d);
-  if ((d == 64 || d == 128) && L <= (d == 64 ? 100 : 52) && xp_aligned({X, qk, xbar})) {
+  if ((d == 64 || d == 128) && L <= 100 && xp_aligned({X, qk, xbar})) {
     XP_REG_DISPATCH(xatt_pool_fwd_reg_kernel, X, L, qk, slen, scale, B, xbar, attw, gamma, beta);
   } else {
     INTEL_CHECK_ARG(!gamma, "xatt_pool: the x-hat input form needs the register kernel (d=%d, L=%d)", d, L);
@@ -315,7 +316,7 @@ int launch_xatt_pool_bwd(const float* X, int B, int L, int d, const float* qk, c
                          int ldxb, float scale, float* dX, float* dqk, hipStream_t st) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(L <= XP_MAXL, "xatt_pool_bwd: list length %d > %d unsupported", L, XP_MAXL);
-  if ((d == 64 || d == 128) && L <= (d == 64 ? 100 : 52) && (ldxb & 3) == 0 && xp_aligned({X, qk, dxbar, dX, dqk})) {
+  if ((d == 64 || d == 128) && L <= 100 && (ldxb & 3) == 0 && xp_aligned({X, qk, dxbar, dX, dqk})) {
     XP_REG_DISPATCH(xatt_pool_bwd_reg_kernel, X, L, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
   } else {
     LAUNCH(xatt_pool_bwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, X, L, d, qk, attw, dxbar, ldxb, scale, B, dX, dqk);
