@@ -188,9 +188,12 @@ int intel_bpr_loss(int B, int L, int K, const float* ens_score, const int* ranki
                    float* loss, int* select, float* d_ens, float* d_weights, void* workspace,
                    size_t workspace_bytes, void* stream);
 /* The same with the tie-breaking noise of BPRloss.py:26 drawn inside the kernel (counter-based generator keyed by
- * seed and the element index) instead of read from a [B,L,L] tensor: the fused training step uses this form. */
+ * seed and the GLOBAL element index ((session0 + b) * L + i) * L + j) instead of read from a [B,L,L] tensor: the fused
+ * training step uses this form.  session0 = global index of this launch's first session: data-parallel rank r passes
+ * r * B with the step's common seed, so the N shards draw exactly what one process draws for the whole batch and no two
+ * sessions of a global batch share their tie-breaks. */
 int intel_bpr_loss_seeded(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
-                          unsigned long long seed, const double* scores_f64, const float* scores_f32,
+                          unsigned long long seed, unsigned long long session0, const double* scores_f64, const float* scores_f32,
                           const float* weights, int cal_diversity, double alpha, float grad_scale,
                           float* loss, int* select, float* d_ens, float* d_weights, void* workspace,
                           size_t workspace_bytes, void* stream);

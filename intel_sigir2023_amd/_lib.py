@@ -23,13 +23,15 @@ def lib():
     """Load the library (once).  Raises IntelHipError when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            try:        # a fresh checkout: compile in-tree once (hipcc cross-compiles without a GPU)
-                from . import build as _build
+        from . import build as _build
+        if not _build.is_current():
+            # a fresh checkout or edited csrc/: compile in-tree (hipcc cross-compiles without a GPU; build_library serialises
+            # concurrent ranks).  A stale library is never loaded silently: if it cannot be rebuilt this raises.
+            try:
                 _build.build_library()
             except Exception as e:
-                raise IntelHipError('libintel_hip.so is missing and could not be built (%s): run `python -c "import '
-                                    '__graft_entry__ as g; g.build()"`; there is no CPU fallback' % e)
+                raise IntelHipError('libintel_hip.so is missing or older than csrc/ and could not be rebuilt (%s): run `python -c '
+                                    '"import __graft_entry__ as g; g.build()"`; there is no CPU fallback' % e)
         try:
             _lib = C.CDLL(LIB_PATH)
         except OSError as e:
@@ -147,7 +149,7 @@ def _declare(l):
     sig('intel_backward', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, vp, vp, vp, C.POINTER(vp), vp])
     sig('intel_backward_phase', i, [vp, C.POINTER(vp), C.POINTER(IntelBatch), vp, sz, vp, vp, vp, C.POINTER(vp), i, vp])
     sig('intel_bpr_loss', i, [i, i, i, vp, vp, vp, vp, vp, vp, vp, i, d, f, vp, vp, vp, vp, vp, sz, vp])
-    sig('intel_bpr_loss_seeded', i, [i, i, i, vp, vp, vp, C.c_ulonglong, vp, vp, vp, i, d, f, vp, vp, vp, vp, vp, sz, vp])
+    sig('intel_bpr_loss_seeded', i, [i, i, i, vp, vp, vp, C.c_ulonglong, C.c_ulonglong, vp, vp, vp, i, d, f, vp, vp, vp, vp, vp, sz, vp])
     sig('intel_list_loss', i, [i, i, i, vp, vp, vp, vp, vp, vp, i, d, f, vp, vp, vp, vp, sz, vp])
     sig('intel_mse_loss', i, [i, i, i, vp, vp, vp, vp, vp, vp, i, d, f, vp, vp, vp, vp, sz, vp])
     sig('intel_intent_loss', i, [i, i, vp, vp, d, d, f, vp, vp, vp, sz, vp])

@@ -40,13 +40,37 @@ def _stamp():
     return h.hexdigest()
 
 
-def build_library(force=False, verbose=False):
-    """Compile every csrc/*.hip|*.cpp and link libintel_hip.so.  Returns the library path."""
+def is_current():
+    """True when libintel_hip.so exists and was built from the sources as they are now."""
     stamp_file = os.path.join(OBJ, 'stamp')
-    stamp = _stamp()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+    try:
+        return os.path.exists(LIB) and open(stamp_file).read() == _stamp()
+    except OSError:
+        return False
+
+
+def build_library(force=False, verbose=False):
+    """Compile every csrc/*.hip|*.cpp and link libintel_hip.so.  Returns the library path.
+    Safe under torchrun: one process builds at a time (fcntl lock on build/lock; the others find the finished library when
+    they get the lock), and the library is linked to a temporary file and renamed into place, so no process can map a
+    half-written file."""
+    import fcntl
+    if not force and is_current():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, 'lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_current():      # another rank built it while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
+    stamp_file = os.path.join(OBJ, 'stamp')
+    stamp = _stamp()
     hipcc = _hipcc()
 
     def compile_one(src):
@@ -60,9 +84,11 @@ def build_library(force=False, verbose=False):
         return obj
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources()))
-    r = subprocess.run([hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', LIB] + objs, capture_output=True, text=True)
+    tmp = LIB + '.tmp%d' % os.getpid()
+    r = subprocess.run([hipcc, '-shared', '-fPIC', '--offload-arch=' + ARCH, '-o', tmp] + objs, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    os.replace(tmp, LIB)
     with open(stamp_file, 'w') as fh:
         fh.write(stamp)
     return LIB

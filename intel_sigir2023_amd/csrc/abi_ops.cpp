@@ -113,13 +113,13 @@ extern "C" int intel_bpr_loss(int B, int L, int K, const float* ens_score, const
 }
 
 extern "C" int intel_bpr_loss_seeded(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,
-                                     unsigned long long seed, const double* scores_f64, const float* scores_f32,
-                                     const float* weights, int cal_diversity, double alpha, float grad_scale, float* loss,
+                                     unsigned long long seed, unsigned long long session0, const double* scores_f64,
+                                     const float* scores_f32, const float* weights, int cal_diversity, double alpha, float grad_scale, float* loss,
                                      int* select, float* d_ens, float* d_weights, void* workspace, size_t workspace_bytes,
                                      void* stream) {
   INTEL_CHECK_ARG(B > 0 && L > 0 && K > 0 && ens_score && ranking && session_len && loss && workspace, "bpr loss: bad argument");
   return launch_bpr_loss(B, L, K, ens_score, ranking, session_len, nullptr, scores_f64, scores_f32, weights, cal_diversity, alpha,
-                         grad_scale, loss, select, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream, seed, 1);
+                         grad_scale, loss, select, d_ens, d_weights, workspace, workspace_bytes, (hipStream_t)stream, seed, 1, session0);
 }
 
 extern "C" int intel_list_loss(int B, int L, int K, const float* ens_score, const int* ranking, const int* session_len,

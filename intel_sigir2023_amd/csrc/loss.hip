@@ -29,6 +29,7 @@ struct LossArgs {
   const float* ens; const int* ranking; const int* slen;
   const float* noise;                       // BPR only; NULL -> counter-based generator keyed by (seed, b, i, j)
   unsigned long long seed;
+  unsigned long long session0;              // global index of this launch's first session (data-parallel shards)
   const double* sc64; const float* sc32;    // base scores (either)
   const float* weights;
   int cal_div; double alpha; float grad_scale;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
       }
     }
     const float* nrow = a.noise ? a.noise + ((size_t)b * L + i) * L : nullptr;
-    const unsigned long long ctr0 = ((unsigned long long)b * L + i) * L;
+    const unsigned long long ctr0 = ((a.session0 + (unsigned long long)b) * L + i) * L;
     float best = -1.f;
     int sel = 0;
     for (int j = 0; j < L; ++j) {
@@ -374,8 +375,9 @@ static int run_pair_loss(bool bpr, LossArgs& a, float* loss, void* ws, size_t ws
 int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const float* noise,
                     const double* sc64, const float* sc32, const float* weights, int cal_div, double alpha,
                     float grad_scale, float* loss, int* select, float* d_ens, float* d_weights, void* ws, size_t ws_bytes,
-                    hipStream_t st, unsigned long long seed, int use_seed) {
+                    hipStream_t st, unsigned long long seed, int use_seed, unsigned long long session0) {
   LossArgs a;
+  a.session0 = session0;
   a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = noise; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = select; a.d_ens = d_ens;
   a.d_weights = d_weights; a.lossb = nullptr; a.divb = nullptr;
@@ -387,7 +389,7 @@ int launch_mse_loss(int B, int L, int K, const float* ens, const int* ranking, c
                     const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                     float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st) {
   LossArgs a;
-  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.sc64 = sc64; a.sc32 = sc32;
+  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.session0 = 0; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = nullptr; a.d_ens = d_ens;
   a.d_weights = d_weights;
   INTEL_CHECK_ARG(ws_bytes >= loss_ws_bytes(B), "loss: workspace too small");
@@ -404,7 +406,7 @@ int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, 
                      const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                      float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st) {
   LossArgs a;
-  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.sc64 = sc64; a.sc32 = sc32;
+  a.B = B; a.L = L; a.K = K; a.ens = ens; a.ranking = ranking; a.slen = slen; a.noise = nullptr; a.seed = 0; a.session0 = 0; a.sc64 = sc64; a.sc32 = sc32;
   a.weights = weights; a.cal_div = cal_div; a.alpha = alpha; a.grad_scale = grad_scale; a.select = nullptr; a.d_ens = d_ens;
   a.d_weights = d_weights; a.lossb = nullptr; a.divb = nullptr;
   return run_pair_loss(false, a, loss, ws, ws_bytes, st);

@@ -45,7 +45,7 @@ size_t intent_ws_bytes(int B);
 int launch_bpr_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const float* noise,
                     const double* sc64, const float* sc32, const float* weights, int cal_div, double alpha,
                     float grad_scale, float* loss, int* select, float* d_ens, float* d_weights, void* ws, size_t ws_bytes,
-                    hipStream_t st, unsigned long long seed = 0, int use_seed = 0);
+                    hipStream_t st, unsigned long long seed = 0, int use_seed = 0, unsigned long long session0 = 0);
 int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
                      const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                      float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st);

@@ -34,7 +34,18 @@ class IntELEngine(object):
         self.cal_diversity, self.alpha = int(g('cal_diversity', 0)), float(g('diversity_alpha', 0.01))
         self.lr, self.l2, self.betas, self.eps = float(lr), float(l2), betas, float(eps)
         self.step_count = 0
-        self.force_phases = False          # kept for tests written against the earlier interface (no effect)
+        # BPR tie-breaking noise (BPRloss.py:26) drawn inside the loss kernel: one generator per engine, seeded from torch's
+        # CPU generator (reproducible under torch.manual_seed) and -- data parallel -- made COMMON to all ranks once, here;
+        # every step then draws the same 64-bit seed on every rank without communication, and the kernel keys its counter by
+        # the GLOBAL session index (session0 = rank * B), so N shards draw what one process draws for the whole batch
+        seed0 = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        if parallel.active():
+            t = seed0.to(next(model.parameters()).device)
+            parallel.broadcast_([t])
+            seed0 = t.cpu()
+        self._noise_gen = torch.Generator()
+        self._noise_gen.manual_seed(int(seed0.item()))
+        self._dp_shape = None
         # two-phase backward + table all-reduce / Adam on a side stream (default); INTEL_OVERLAP_TABLE=0 runs the plain order
         import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
@@ -62,7 +73,7 @@ class IntELEngine(object):
         mode = os.environ.get('INTEL_DP_EXCHANGE', 'auto')
         if mode != 'auto':
             return mode == 'sparse'
-        rows = keep['i_id_s'].numel() + keep['his_item_id'].numel()
+        rows = keep['i_id_s'].numel() + keep['his_item_id'].numel()     # same on every rank: _check_global_shape
         d = self.model.iid_embeddings.weight.shape[1]
         return rows * (4 * d + 4) < 2.0 / world * self.gflat['iid'].numel() * 4
 
@@ -142,14 +153,38 @@ class IntELEngine(object):
         return t
 
     # ---- one training step ---------------------------------------------------------------------------
-    def train_step(self, batch, noise=None):
+    def _check_global_shape(self, ib):
+        """Data parallel: every rank must run the step at the SAME (B, L, H, Hi) -- pad rows are keys, the
+        losses are means over equal shards, and the touched-rows exchange sizes its all-gather from the shape.  Checked with
+        one tiny all-gather when the local shape changes (INTEL_DP_SHAPE_CHECK=always: every step; off: never)."""
+        mode = os.environ.get('INTEL_DP_SHAPE_CHECK', 'change')
+        shape = (ib.B, ib.L, ib.H, ib.Hi)
+        if mode == 'off' or (mode != 'always' and shape == self._dp_shape):
+            return
+        t = torch.tensor(shape, dtype=torch.int32, device=self.device)
+        allt = parallel.allgather(t).cpu().tolist()
+        if any(tuple(s) != shape for s in allt):
+            raise L.IntelHipError('data-parallel ranks disagree on the padded batch shape (B, L, H, Hi): %s -- pad every '
+                                  'batch to the GLOBAL maximum (feed: shape=store.max_shape(); runner: parallel.global_max_)' % allt)
+        self._dp_shape = shape
+
+    def set_lr(self, lr):
+        """StepLR counterpart of the engine path (helpers/BaseRunner.py:238-241)."""
+        self.lr = float(lr)
+
+    def train_step(self, batch, noise=None, noise_seed=None):
         """forward + loss + backward + gradient all-reduce + Adam on one (local) batch.
-        Returns (loss, ensemble_loss, intent_loss) as device tensors (no host sync)."""
+        Returns (loss, ensemble_loss, intent_loss) as device tensors (no host sync).
+        noise: optional [B,L,L] tie-breaking noise of the BPR loss (parity tests pass the reference's draw);
+        noise_seed: optional explicit 64-bit seed of the in-kernel draw (default: the engine's generator)."""
         model = self.model
         lib = L.lib()
         dev = self.device
         world = parallel.world_size()
+        dp = parallel.active()              # exchange steps on (world > 1, or a forced one-rank group: INTEL_DP_FORCE=1)
         ib, keep = model.prepare_batch(batch)
+        if dp:
+            self._check_global_shape(ib)
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
         weights, ens, intents = model.run_forward(ib, keep, params, train=True)
@@ -173,10 +208,11 @@ class IntELEngine(object):
             if noise is None and self._noise_tensor:
                 noise = torch.rand(B, Lmax, Lmax, dtype=torch.float32, device=dev)      # BPRloss.py:26, as a tensor
             if noise is None:
-                # the tie-breaking noise of BPRloss.py:26 is drawn inside the kernel (no [B,L,L] tensor); the seed comes from
-                # torch's CPU generator, so runs are reproducible under torch.manual_seed
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-                L.check(lib.intel_bpr_loss_seeded(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), C.c_ulonglong(seed), L.ptr(sc64),
+                # the tie-breaking noise of BPRloss.py:26 is drawn inside the kernel (no [B,L,L] tensor)
+                seed = int(noise_seed) if noise_seed is not None else int(torch.randint(0, 2 ** 62, (1,), generator=self._noise_gen).item())
+                session0 = parallel.rank() * B
+                L.check(lib.intel_bpr_loss_seeded(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), C.c_ulonglong(seed),
+                                                  C.c_ulonglong(session0), L.ptr(sc64),
                                                   L.ptr(sc32), L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e),
                                                   L.ptr(select), L.ptr(d_ens), L.ptr(d_w), L.ptr(ws), nb, st), 'intel_bpr_loss_seeded')
             else:
@@ -223,8 +259,8 @@ class IntELEngine(object):
             cur = torch.cuda.current_stream(dev)
             side = self._side_stream()
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
-            sparse = world > 1 and self._sparse_exchange(keep, world)
-            work = parallel.allreduce_sum_async(self.gflat['iid']) if (world > 1 and not sparse) else None
+            sparse = dp and self._sparse_exchange(keep, world)
+            work = parallel.allreduce_sum_async(self.gflat['iid']) if (dp and not sparse) else None
             ev = torch.cuda.Event()
             ev.record(cur)
             with torch.cuda.stream(side):
@@ -235,17 +271,17 @@ class IntELEngine(object):
                     self._exchange_touched_rows(keep, L.stream_ptr(dev))
                 adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=work is not None)
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
-            if world > 1:
+            if dp:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
             adam('decay', self.l2, st)
             adam('nodecay', 0.0, st)
             cur.wait_stream(side)
         else:
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
-            if world > 1:
+            if dp:
                 parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
             for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
-                adam(gname, wd, st, dense_reduced=world > 1)
+                adam(gname, wd, st, dense_reduced=dp)
         ens_loss = loss_e.reshape(()).clone()
         if self.with_intent:
             int_loss = out3[0].clone()

@@ -208,13 +208,26 @@ class ColumnarStore(object):
         return out
 
 
-def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shuffle_lists='device', drop_last=False):
+def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shuffle_lists='device', drop_last=False, rank=0, world=1):
     """Batches of one pass over the store: the DataLoader(shuffle=True) + per-access list shuffle of the reference's
-    training loop (helpers/BaseRunner.py:275-277, models/BaseModel.py:194-196), assembled on the device."""
+    training loop (helpers/BaseRunner.py:275-277, models/BaseModel.py:194-196), assembled on the device.
+    Data parallel (world > 1): ``batch_size`` is the GLOBAL batch; rank r assembles sessions [r*B/world, (r+1)*B/world) of
+    every global batch, padded to the GLOBAL batch's shape (pad rows are keys) -- the session order, the list
+    permutations (keyed by the session's corpus index) and the padding are those of the single-process run.  A global batch
+    must split evenly (each rank's loss is a mean over its shard): a ragged last batch is trimmed to a multiple of world."""
     n = store.n_sessions
     order = np.random.RandomState(seed * 1000003 + epoch).permutation(n) if shuffle_sessions else np.arange(n)
     for lo in range(0, n, batch_size):
         idx = order[lo:lo + batch_size]
         if drop_last and len(idx) < batch_size:
             break
-        yield store.collate(idx, shuffle=shuffle_lists, seed=(seed << 20) + epoch * 65537 + lo)
+        shape = None
+        if world > 1:
+            keep = len(idx) - len(idx) % world
+            if keep == 0:
+                break
+            idx = idx[:keep]
+            shape = store.batch_shape(idx)
+            per = keep // world
+            idx = idx[rank * per:(rank + 1) * per]
+        yield store.collate(idx, shuffle=shuffle_lists, seed=(seed << 20) + epoch * 65537 + lo, shape=shape)

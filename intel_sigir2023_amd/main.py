@@ -8,6 +8,8 @@ every batch on the device.  Needs an MI355X; there is no CPU 
 """
 import argparse
 import logging
+import os
+import pickle
 import sys
 
 import numpy as np
@@ -16,6 +18,7 @@ import torch
 from . import loss as loss_mod
 from . import data as data_mod
 from . import feed
+from . import parallel
 from . import synth
 from .model import IntEL
 from .runner import BaseRunner
@@ -38,7 +41,41 @@ def parse_global_args(parser):
     parser.add_argument('--sep', type=str, default='\t')
     parser.add_argument('--intent_note', type=str, default='')
     parser.add_argument('--max_session_len', type=int, default=40)
+    parser.add_argument('--regenerate', type=int, default=0, help='Whether to regenerate intermediate files (the corpus cache).')
     return parser
+
+
+def load_corpus(args, reader_cls, reader_name='SeqReader'):
+    """main.py:64-72 of the reference: the parsed corpus is cached as ``<datapath>/<dataset>/<reader>_<max_session_len><note>.pkl``
+    and re-read unless --regenerate.  Data parallel: rank 0 parses and writes, the other ranks wait and load."""
+    path = os.path.join(args.datapath, args.dataset, '%s_%d%s.pkl' % (reader_name, args.max_session_len, args.intent_note))
+    rank = parallel.rank()
+    corpus = None
+    if rank == 0:
+        if not args.regenerate and os.path.exists(path):
+            logging.info('Load corpus from {}'.format(path))
+            with open(path, 'rb') as fh:
+                corpus = pickle.load(fh)
+            corpus.pos_types = ['c_paynum_i', 'c_favnum_i', 'c_clicknum_i']
+        else:
+            corpus = reader_cls(args)
+            logging.info('Save corpus to {}'.format(path))
+            tmp = path + '.tmp%d' % os.getpid()
+            try:
+                with open(tmp, 'wb') as fh:
+                    pickle.dump(corpus, fh)
+                os.replace(tmp, path)
+            except OSError as e:          # a read-only data directory must not stop the run
+                logging.info('corpus cache not written (%s)' % e)
+    parallel.barrier()
+    if corpus is None:
+        if os.path.exists(path):
+            with open(path, 'rb') as fh:
+                corpus = pickle.load(fh)
+            corpus.pos_types = ['c_paynum_i', 'c_favnum_i', 'c_clicknum_i']
+        else:
+            corpus = reader_cls(args)
+    return corpus
 
 
 def build_parser(argv=None):
@@ -68,12 +105,20 @@ def main(argv=None):
     torch.manual_seed(args.random_seed)
     if not torch.cuda.is_available():
         raise SystemExit('intel_sigir2023_amd needs an MI355X (no CPU path)')
-    args.device = torch.device('cuda', int(args.gpu or 0))
+    # data parallel (torchrun -m intel_sigir2023_amd.main ...): one process per GPU over RCCL; every global batch of
+    # --batch_size sessions is split contiguously over the ranks, so N ranks follow the 1-rank trajectory
+    rank, world, local_rank = parallel.init_distributed()
+    args.device = torch.device('cuda', local_rank if world > 1 else int(args.gpu or 0))
+    torch.cuda.set_device(args.device)
+    if world > 1 and rank != 0:
+        logging.getLogger().setLevel(logging.WARNING)
     if args.dataset:
-        corpus = data_mod.SeqReader(args)
+        corpus = load_corpus(args, data_mod.SeqReader)
     else:
         corpus, _ = synth.make_corpus(args.workload)
     model = MODELS[init_args.model_name](args, corpus).to(args.device)
+    if world > 1:         # identical replicas: rank 0's initialisation everywhere
+        parallel.broadcast_([p.data for p in model.parameters()])
     logging.info('#params: %d' % model.count_variables())
     criterion = LOSSES[init_args.loss_name](args)
     runner = RUNNERS[init_args.runner_name](args, use_engine=bool(args.use_engine))
@@ -82,17 +127,19 @@ def main(argv=None):
                   for p in ('train', 'dev', 'test')}
         logging.info('columnar corpus in HBM: %s' % ', '.join('%s %d sessions / %.1f MB' % (p, s.n_sessions, s.nbytes() / 1e6)
                                                                for p, s in stores.items()))
-        fixed = lambda p: list(feed.epoch_batches(stores[p], args.eval_batch_size, seed=args.random_seed + 1, shuffle_sessions=False))
-        data = {'train': lambda ep: feed.epoch_batches(stores['train'], args.batch_size, epoch=ep, seed=args.random_seed),
+        fixed = lambda p: list(feed.epoch_batches(stores[p], args.eval_batch_size, seed=args.random_seed + 1, shuffle_sessions=False,
+                                                  rank=rank, world=world))
+        data = {'train': lambda ep: feed.epoch_batches(stores['train'], args.batch_size, epoch=ep, seed=args.random_seed, rank=rank, world=world),
                 'dev': fixed('dev'), 'test': fixed('test')}
     else:
-        dev = [synth.make_batch(args.workload, args.eval_batch_size, args.device, seed=10_000 + i, ragged=True) for i in range(2)]
-        data = {'train': lambda ep: [synth.make_batch(args.workload, args.batch_size, args.device, seed=ep * 1000 + i, ragged=True)
-                                     for i in range(args.train_batches)], 'dev': dev, 'test': dev}
-    if args.train > 0:
-        runner.train(model, data, criterion, init_args.loss_name)
+        # synthetic workloads: every rank generates the same global batch (same seed) and keeps its contiguous shard
+        mk = lambda n, seed: parallel.shard_batch(synth.make_batch(args.workload, n, args.device, seed=seed, ragged=True), rank, world)
+        dev = [mk(args.eval_batch_size, 10_000 + i) for i in range(2)]
+        data = {'train': lambda ep: [mk(args.batch_size, ep * 1000 + i) for i in range(args.train_batches)], 'dev': dev, 'test': dev}
+    dev_curve = runner.train(model, data, criterion, init_args.loss_name) if args.train > 0 else []
     loss, res = runner.evaluate(model, data['test'], runner.topk, runner.metrics, criterion)
     logging.info('test loss= %.4f, metrics: %s' % (loss, ', '.join('%s:%.4f' % kv for kv in sorted(res.items()))))
+    main.last_run = {'dev_main_metric': list(dev_curve), 'train_losses': list(getattr(runner, 'train_losses', [])), 'test': res}
     return res
 
 

@@ -358,6 +358,8 @@ class IntEL(nn.Module):
         batch, keep = self.prepare_batch(data)
         items = self.slot_items()
         params = [p for _, _, p in items]
+        # two independent decisions, as in the reference: the activation stash follows autograd (is a backward possible?),
+        # nn.Dropout follows module.training only (IntEL.py:63,187,196) -- run_forward reads self.training itself
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad:
             w, e, i = _IntELFunction.apply(self, batch, keep, *params)
@@ -375,7 +377,9 @@ class IntEL(nn.Module):
         ctx = self._context()
         # nn.Dropout of the tower layers (IntEL.py:63,187,196): training only; a fresh seed per forward from torch's CPU
         # generator (reproducible under torch.manual_seed); tests may pin the keep flags through self._dropout_keep
-        p_drop = float(self.dropout) if train else 0.0
+        p_drop = float(self.dropout) if self.training else 0.0     # module.training, not grad mode
+        if p_drop > 0:
+            train = True        # the dropout path keeps its mask in the stash area (written even when no backward follows)
         keep_flags = getattr(self, '_dropout_keep', None) if p_drop > 0 else None
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if (p_drop > 0 and keep_flags is None) else 0
         L.check(lib.intel_set_dropout(ctx, p_drop, C.c_ulonglong(seed), L.ptr(keep_flags)), 'intel_set_dropout')

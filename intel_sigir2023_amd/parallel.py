@@ -19,7 +19,9 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # INTEL_DP_FORCE=1: build the process group and take every collective branch even with ONE rank (each collective is
+    # then an identity that still runs through RCCL): how the one-GPU test box executes the nccl code paths
+    if (world > 1 or os.environ.get('INTEL_DP_FORCE') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -36,6 +38,11 @@ def init_distributed(backend=None):
 
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def active():
+    """Are the data-parallel exchange steps to be executed?  More than one rank -- or a forced single-rank group."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get('INTEL_DP_FORCE') == '1')
 
 
 def rank():
@@ -68,7 +75,7 @@ def shard_batch(batch, r, w):
 
 def allreduce_sum_(tensors):
     """In-place sum over ranks of each flat gradient bucket (no-op for a single process)."""
-    if world_size() == 1:
+    if not active():
         return
     for t in tensors:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -76,7 +83,7 @@ def allreduce_sum_(tensors):
 
 def allreduce_max_(t):
     """In-place element-wise maximum over ranks (the OR of 0/1 byte flags)."""
-    if world_size() > 1:
+    if active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
 
 
@@ -84,7 +91,7 @@ def allreduce_sum_async(t):
     """Start an in-place sum over ranks and return the work handle (None for a single process).  The collective
     is ordered after everything already enqueued on the current stream; ``handle.wait()`` orders the current
     stream after the collective."""
-    if world_size() == 1:
+    if not active():
         return None
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
@@ -92,7 +99,7 @@ def allreduce_sum_async(t):
 def allgather(t):
     """[world, *t.shape] tensor holding every rank's ``t`` (same shape on all ranks)."""
     w = world_size()
-    if w == 1:
+    if not active():
         return t.unsqueeze(0)
     out = torch.empty((w,) + tuple(t.shape), dtype=t.dtype, device=t.device)
     if dist.get_backend() == 'nccl':
@@ -102,15 +109,56 @@ def allgather(t):
     return out
 
 
-def broadcast_(tensors, src=0):
+def allgather_object(obj):
+    """List of every rank's picklable ``obj`` in rank order (evaluation records; off the hot path)."""
     if world_size() == 1:
+        return [obj]
+    out = [None] * world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def global_max_(values, device):
+    """Element-wise maximum over ranks of a short list of ints (the padded batch shape: pad rows are keys, SURVEY.md 0.5,
+    so every rank must pad to the GLOBAL maximum of the step)."""
+    if world_size() == 1:
+        return [int(v) for v in values]
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def pad_batch_to(batch, L, H, Hi):
+    """Pad a collated batch dict (BaseModel.py:121-142 layout) with the reference's padding values (ids / scores /
+    labels 0: pad_sequence, BaseModel.py:133) up to list length L and history lengths H / Hi."""
+    def pad(t, dim, n):
+        if t.shape[dim] >= n:
+            return t
+        shape = list(t.shape)
+        shape[dim] = n - t.shape[dim]
+        return torch.cat([t, torch.zeros(shape, dtype=t.dtype, device=t.device)], dim=dim)
+    out = dict(batch)
+    for k in ('i_id_s', 'i_class_c', 'scores', 'ranking'):
+        if k in out and torch.is_tensor(out[k]):
+            out[k] = pad(out[k], 1, L)
+    for k in ('his_context_mh', 'his_intents'):
+        if k in out:
+            out[k] = pad(out[k], 1, H)
+    for k in ('his_item_id', 'his_item_int', 'his_item_idx'):
+        if k in out:
+            out[k] = pad(out[k], 1, Hi)
+    return out
+
+
+def broadcast_(tensors, src=0):
+    if not active():
         return
     for t in tensors:
         dist.broadcast(t, src=src)
 
 
 def barrier():
-    if world_size() > 1:
+    if active():
         dist.barrier()
 
 

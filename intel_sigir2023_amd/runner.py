@@ -15,6 +15,7 @@ from time import time
 import numpy as np
 import torch
 
+from . import parallel
 from .engine import IntELEngine
 
 
@@ -170,6 +171,16 @@ class BaseRunner(object):
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.decay_step, gamma=self.decay_lr)
         return optimizer, scheduler
 
+    def step_lr(self, model, epochs_done):
+        """StepLR(step_size=decay_step, gamma=decay_lr) stepped once per epoch (helpers/BaseRunner.py:187,238-241): the
+        torch scheduler on the autograd path, the same schedule in closed form on the engine path."""
+        if self.use_engine and self.engine is not None:
+            lr = self.learning_rate * self.decay_lr ** (epochs_done // self.decay_step)
+            self.engine.set_lr(lr)
+            return lr
+        model.scheduler.step()
+        return model.scheduler.get_last_lr()[0]
+
     def eval_termination(self, criterion):
         return len(criterion) - criterion.index(max(criterion)) > self.early_stop
 
@@ -193,8 +204,10 @@ class BaseRunner(object):
                 loss.backward()
                 model.optimizer.step()
                 losses.append(loss.detach())
-        vals = torch.stack([l.double().reshape(()) for l in losses]).cpu().numpy()
-        return float(np.mean(vals))
+        vals = torch.stack([l.double().reshape(()) for l in losses])
+        if parallel.world_size() > 1:      # each rank holds the mean loss of its (equal) shard of every global batch
+            vals = parallel.allgather(vals).mean(0)
+        return float(np.mean(vals.cpu().numpy()))
 
     # ---- predict / evaluate (helpers/BaseRunner.py:293-355) -----------------------------------------
     @torch.no_grad()
@@ -210,6 +223,12 @@ class BaseRunner(object):
             slens.extend(batch['session_len'].cpu().numpy().tolist())
             true_int.extend(batch['intents'].cpu().numpy())
             pred_int.extend(out['intents'].cpu().numpy())
+        if parallel.world_size() > 1:
+            # data parallel: every rank evaluated its shard of each batch; the metrics are means over ALL sessions, so the
+            # per-session records are gathered (rank order = session order) and every rank computes the same numbers
+            parts = parallel.allgather_object((preds, losses, ranks, true_int, pred_int, slens))
+            preds, ranks, true_int, pred_int, slens = ([x for p in parts for x in p[i]] for i in (0, 2, 3, 4, 5))
+            losses = [float(np.mean([p[1][j] for p in parts])) for j in range(len(losses))]      # equal shards: mean of means
         return preds, float(np.mean(losses)), ranks, true_int, pred_int, slens
 
     def evaluate(self, model, batches, topk, metrics, criterion, pos_nums=None, topk_intent=[1, 5, 10, 30]):
@@ -231,10 +250,12 @@ class BaseRunner(object):
         """helpers/BaseRunner.py:190-266.  ``data`` = {'train': callable -> iterable of batches per epoch,
         'dev': list of batches, 'test': list of batches}."""
         main_results, dev_results = [], []
+        self.train_losses = []
         self._check_time(start=True)
         for epoch in range(self.epoch):
             self._check_time()
             loss = self.fit(model, data['train'](epoch), criterion, loss_name)
+            self.train_losses.append(loss)
             if np.isnan(loss):
                 raise ValueError('Loss is nan!')
             train_t = self._check_time()
@@ -242,8 +263,14 @@ class BaseRunner(object):
             dev_results.append(dev_res)
             main_results.append(dev_res[self.main_metric])
             msg = 'Epoch {:<5} loss={:<.4f} [{:<3.1f} s]\tdev loss={:<.4f}, ({})'.format(epoch + 1, loss, train_t, dev_loss, format_metric(dev_res))
+            if self.test_epoch > 0 and epoch % self.test_epoch == 0 and data.get('test') is not None:      # BaseRunner.py:225-233
+                test_loss, test_res = self.evaluate(model, data['test'], self.topk[:1], self.metrics, criterion, topk_intent=[5])
+                msg += ' test loss={:<.4f}, ({})'.format(test_loss, format_metric(test_res))
+            if self.decay_lr > 0:                                                                           # BaseRunner.py:238-241
+                c_lr = self.step_lr(model, epoch + 1)
+                logging.info('LR: %.4f' % c_lr)
             if len(main_results) == 1 or max(main_results[:-1]) < main_results[-1] - self.stop_tol:
-                if model.model_path:
+                if model.model_path and parallel.rank() == 0:
                     model.save_model()
                 msg += ' *'
             logging.info(msg)
@@ -252,6 +279,7 @@ class BaseRunner(object):
                 break
         best = main_results.index(max(main_results))
         logging.info(os.linesep + 'Best Iter(dev)={:>5}\t dev=({}) [{:<.1f} s] '.format(best + 1, format_metric(dev_results[best]), self.time[1] - self.time[0]))
+        parallel.barrier()                 # rank 0 has written the best model
         if model.model_path and os.path.exists(model.model_path):
             model.load_model()
         return main_results

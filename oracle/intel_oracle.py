@@ -80,14 +80,17 @@ def mha(x, sd, prefix, heads, key_mask=None):
     return o.transpose(1, 2).reshape(B, T, D)
 
 
-def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0):
+def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0, taps=None):
     """models/IntEL/IntEL.py:182-188 / 191-197: the SAME weights are applied ``layers`` times,
     attention is unmasked (padded rows act as keys and queries).  keep: per-layer 0/1 tensors of the
-    training-mode nn.Dropout(p) applied before the residual add (:187, :196); None = evaluation."""
+    training-mode nn.Dropout(p) applied before the residual add (:187, :196); None = evaluation.
+    taps: optional dict; receives the pre-ReLU activations of every layer under the key ``w1`` (tests only)."""
     for l in range(layers):
         res = h
         h = mha(h, sd, attn, heads)
         h = _lin(h, sd, w1)
+        if taps is not None:
+            taps.setdefault(w1, []).append(h.detach())
         h = _lin(torch.relu(h), sd, w2)
         if keep is not None:
             h = h * keep[l] / (1.0 - p)
@@ -95,7 +98,7 @@ def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0):
     return h
 
 
-def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2):
+def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2, taps=None):
     """models/GeneralSeq.py:89-106 with modules/layers.py:82-88 blocks (bias=True, d_ff=d_model)."""
     B, T, D = seq.shape
     ar = torch.arange(T)
@@ -106,7 +109,10 @@ def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2):
         p = '%s.transformer_block.%d' % (prefix, l)
         ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid)
         ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
-        y = _lin(torch.relu(_lin(ctx, sd, p + '.linear1')), sd, p + '.linear2')
+        pre = _lin(ctx, sd, p + '.linear1')
+        if taps is not None:
+            taps.setdefault(p + '.linear1', []).append(pre.detach())
+        y = _lin(torch.relu(pre), sd, p + '.linear2')
         x = F.layer_norm(y + ctx, (D,), sd[p + '.layer_norm2.weight'], sd[p + '.layer_norm2.bias'], 1e-5)
     x = x * valid[:, :, None].float()
     return x[torch.arange(B), lengths - 1]
@@ -152,15 +158,15 @@ def single_query_pool(intent, h, valid, sd, prefix, scale):
 # ----------------------------------------------------------------------------------------
 # forward
 # ----------------------------------------------------------------------------------------
-def predict_intent(sd, data, cfg):
+def predict_intent(sd, data, cfg, taps=None):
     """models/IntEL/IntEL.py:126-155."""
     his = torch.cat([sd['context_embeddings.weight'][data['his_context_mh']],
                      _lin(data['his_intents'].float(), sd, 'intent_embeddings')], dim=-1)
     his_item = torch.cat([sd['iid_embeddings.weight'][data['his_item_id']],
                           _lin(data['his_item_int'].float(), sd, 'intent_embeddings')], dim=-1)
     if cfg.encoder == 'BERT4Rec':
-        hv = bert4rec(his, data['history_len'], sd, 'encoder')
-        hiv = bert4rec(his_item, data['history_item_len'], sd, 'item_encoder')
+        hv = bert4rec(his, data['history_len'], sd, 'encoder', taps=taps)
+        hiv = bert4rec(his_item, data['history_item_len'], sd, 'item_encoder', taps=taps)
     elif cfg.encoder == 'GRU4Rec':
         hv = gru4rec(his, data['history_len'], sd, 'encoder')
         hiv = gru4rec(his_item, data['history_item_len'], sd, 'item_encoder')
@@ -172,7 +178,7 @@ def predict_intent(sd, data, cfg):
     return torch.softmax(logits, dim=-1)
 
 
-def predict_ensemble(sd, data, intent, cfg, dropout_keep=None):
+def predict_ensemble(sd, data, intent, cfg, dropout_keep=None, taps=None):
     """models/IntEL/IntEL.py:158-217."""
     scores = data['scores'].float()
     B, L, K = scores.shape
@@ -182,9 +188,9 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None):
     h_u = torch.relu(sd['uid_embeddings.weight'][data['u_id_c']])[:, None, :].expand(B, L, -1)
     ki, ks = (dropout_keep if dropout_keep is not None else (None, None))
     pd = float(getattr(cfg, 'dropout', 0.0))
-    h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers, ki, pd)
+    h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers, ki, pd, taps)
     h_s = _lin(scores, sd, 'score_embeddings')
-    h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers, ks, pd)
+    h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers, ks, pd, taps)
     if cfg.cross_attention:
         scale = 1.0 / math.sqrt(cfg.cross_attn_qsize)
         item_x = single_query_pool(intent, h_i, valid, sd, 'intent_item_attention', scale)
@@ -202,11 +208,12 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None):
     return weights, ens
 
 
-def forward(sd, data, cfg, dropout_keep=None):
+def forward(sd, data, cfg, dropout_keep=None, taps=None):
     """models/IntEL/IntEL.py:117-124.  dropout_keep = (item-tower keep masks, score-tower keep masks), one 0/1
-    tensor per layer, reproduces a training-mode forward with that nn.Dropout draw."""
-    intent = predict_intent(sd, data, cfg)
-    weights, ens = predict_ensemble(sd, data, intent, cfg, dropout_keep)
+    tensor per layer, reproduces a training-mode forward with that nn.Dropout draw.  taps: optional dict that
+    receives the pre-ReLU activations of every feed-forward block, keyed by the first linear's name (tests only)."""
+    intent = predict_intent(sd, data, cfg, taps)
+    weights, ens = predict_ensemble(sd, data, intent, cfg, dropout_keep, taps)
     return {'weights': weights, 'ens_score': ens, 'intents': intent}
 
 

@@ -22,14 +22,23 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir, exchange='auto'):
+def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=False, overlap='1', tag=''):
+    """One rank of a 2-step training run on its shard of the 'default' fixture batch.  backend='nccl' with world 1 builds
+    a REAL one-rank RCCL group (INTEL_DP_FORCE=1) so that every collective branch of the engine runs through RCCL.
+    seeded: the BPR tie-breaking noise is drawn inside the loss kernel (common seed, counter keyed by the global session
+    index) instead of passed as a tensor."""
     os.environ['INTEL_DP_EXCHANGE'] = exchange
+    os.environ['INTEL_OVERLAP_TABLE'] = overlap
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), INTEL_DIST_BACKEND='gloo', INTEL_SINGLE_DEVICE='1')
+                      LOCAL_RANK=str(rank), INTEL_DIST_BACKEND=backend, INTEL_SINGLE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if backend == 'nccl':
+        os.environ['INTEL_DP_FORCE'] = '1'
     from intel_sigir2023_amd import parallel
     from intel_sigir2023_amd.engine import IntELEngine
-    if world > 1:
-        parallel.init_distributed()
+    if world > 1 or backend == 'nccl':
+        parallel.init_distributed()          # before any other GPU call of this process
+        if backend == 'nccl':
+            assert torch.distributed.get_backend() == 'nccl' and parallel.active()
     dev = torch.device('cuda:0')
     fx = Fixture('default')
     model, args = build_model(fx, dev)
@@ -41,14 +50,19 @@ def _run(rank, world, port, out_dir, exchange='auto'):
     local = parallel.shard_batch(batch, rank, world)
     lo, hi = parallel.shard_range(batch['batch_size'], rank, world)
     losses = []
+    selects = []
     for step in range(2):
-        noise = torch.from_numpy(fx['adam/noise%d' % step]).to(dev)[lo:hi].contiguous()
-        loss, _, _ = eng.train_step(local, noise=noise)
+        if seeded:
+            loss, _, _ = eng.train_step(local, noise_seed=1234567 + step)
+            selects.append(eng._bufs['select'].cpu().clone())
+        else:
+            noise = torch.from_numpy(fx['adam/noise%d' % step]).to(dev)[lo:hi].contiguous()
+            loss, _, _ = eng.train_step(local, noise=noise)
         losses.append(float(loss))
     torch.cuda.synchronize()
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    torch.save({'sd': sd, 'losses': losses}, os.path.join(out_dir, 'w%d_r%d.pt' % (world, rank)))
-    if world > 1:
+    torch.save({'sd': sd, 'losses': losses, 'selects': selects}, os.path.join(out_dir, 'w%d_r%d%s.pt' % (world, rank, tag)))
+    if torch.distributed.is_initialized():
         parallel.barrier()
         torch.distributed.destroy_process_group()
 
@@ -72,3 +86,45 @@ def test_n_rank_engine_equals_single_process(world, exchange):
             continue            # analytically-zero gradient: Adam direction is rounding noise
         err = float((ranks[0]['sd'][k] - v).abs().max())
         assert err < 5e-5, (k, err)
+
+
+def test_seeded_bpr_noise_is_keyed_by_global_session():
+    """The in-kernel BPR tie-breaks (intel_bpr_loss_seeded): 2 ranks on the halves of the batch draw exactly what one
+    process draws for the whole batch (common seed, counter keyed by rank * B_loc + b: SURVEY.md 8-e), so the sampled
+    negatives, the losses and the parameters after 2 steps agree -- and the two shards do NOT repeat each other's draws."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', True), nprocs=1, join=True)
+        mp.spawn(_run, args=(2, _free_port(), d, 'dense', 'gloo', True), nprocs=2, join=True)
+        one = torch.load(os.path.join(d, 'w1_r0.pt'))
+        ranks = [torch.load(os.path.join(d, 'w2_r%d.pt' % r)) for r in range(2)]
+    for s in range(2):
+        whole = one['selects'][s]
+        got = torch.cat([r['selects'][s] for r in ranks])
+        assert torch.equal(whole, got), 'sampled negatives differ between 1 rank and 2 ranks at step %d' % s
+        assert abs(sum(r['losses'][s] for r in ranks) / 2 - one['losses'][s]) < 2e-5
+    for k, v in one['sd'].items():
+        if 'k_linear.bias' in k:
+            continue
+        assert float((ranks[0]['sd'][k] - v).abs().max()) < 5e-5, k
+
+
+@pytest.mark.parametrize('exchange,overlap', [('dense', '1'), ('sparse', '1'), ('dense', '0')])
+def test_rccl_world1_runs_every_collective_branch(exchange, overlap):
+    """RCCL itself: a one-rank `nccl` process group on the test GPU with the engine forced onto its data-parallel branches
+    (INTEL_DP_FORCE=1) -- the asynchronous all-reduce waited for on the side stream, the uint8 MAX all-reduce of the row
+    marks, all_gather_into_tensor of the touched rows, the bucket all-reduces, broadcast and barrier all execute through
+    RCCL (identities at world 1), and the result must equal the plain single-process step bit for bit apart from the
+    atomically accumulated embedding rows."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', False, overlap), nprocs=1, join=True)
+        mp.spawn(_run, args=(1, _free_port(), d, exchange, 'nccl', False, overlap, '_nccl'), nprocs=1, join=True)
+        one = torch.load(os.path.join(d, 'w1_r0.pt'))
+        got = torch.load(os.path.join(d, 'w1_r0_nccl.pt'))
+    assert one['losses'] == got['losses']
+    for k, v in one['sd'].items():
+        if 'embeddings.weight' in k and ('iid' in k or 'uid' in k or 'context' in k or 'item_' in k):
+            assert float((v - got['sd'][k]).abs().max()) < 1e-6, k
+        else:
+            assert torch.equal(v, got['sd'][k]), k

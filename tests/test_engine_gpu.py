@@ -35,8 +35,10 @@ def _dev():
 
 @pytest.mark.parametrize('name', ['default', 'gru_bpr', 'noxatt'])
 def test_two_phase_backward_equals_whole_backward(name):
-    """intel_backward_phase(1) + (2) (the data-parallel overlap path) == intel_backward, bit for bit apart from the
-    atomically accumulated embedding rows."""
+    """intel_backward_phase(1) + (2) with the item-id table's Adam sweep on the side stream (the default, data-parallel
+    overlap path) == ONE intel_backward followed by the three Adam sweeps (overlap_table_update = False: the path
+    bench.py's roofline steps and INTEL_OVERLAP_TABLE=0 take), bit for bit apart from the atomically accumulated
+    embedding rows."""
     from intel_sigir2023_amd.engine import IntELEngine
     fx = Fixture(name)
     dev = _dev()
@@ -46,7 +48,7 @@ def test_two_phase_backward_equals_whole_backward(name):
         model.train()
         args.cal_diversity = 1
         eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
-        eng.force_phases = phased
+        eng.overlap_table_update = phased
         loss, _, _ = eng.train_step(fx.batch(dev), noise=torch.from_numpy(fx['adam/noise0']).to(dev))
         res.append((float(loss), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
     assert res[0][0] == res[1][0]

@@ -75,3 +75,34 @@ def test_store_requires_a_gpu_and_has_no_cpu_path():
         st.collate([0, 1])
     with pytest.raises(Exception):
         st.to(torch.device('cpu'))
+
+
+def test_corpus_pickle_cache_round_trip(tmp_path):
+    """main.load_corpus (the reference's main.py:64-72): the first call parses the CSV / JSON files and writes
+    <reader>_<max_session_len><note>.pkl next to them, the second call reads the cache; --regenerate parses again.
+    The cached corpus feeds the device store exactly like the fresh one."""
+    import shutil
+    from intel_sigir2023_amd import main as cli
+    shutil.copytree(os.path.join(HERE, 'golden', 'minidata'), str(tmp_path / 'minidata'))
+    ns = argparse.Namespace(datapath=str(tmp_path) + os.sep, dataset='minidata', sep='\t', intent_note='_multi', max_session_len=100,
+                            regenerate=0)
+    fresh = cli.load_corpus(ns, data.SeqReader)
+    path = tmp_path / 'minidata' / 'SeqReader_100_multi.pkl'
+    assert path.exists()
+    calls = []
+
+    def counting_reader(a):
+        calls.append(1)
+        return data.SeqReader(a)
+    cached = cli.load_corpus(ns, counting_reader)
+    assert not calls, 'the cache was ignored'
+    assert cached.pos_types == ['c_paynum_i', 'c_favnum_i', 'c_clicknum_i']
+    for phase in ('train', 'dev', 'test'):
+        a = feed.ColumnarStore(fresh, phase, 3, len(fresh.zero_int), 20)
+        b = feed.ColumnarStore(cached, phase, 3, len(cached.zero_int), 20)
+        assert a.host.keys() == b.host.keys()
+        for k in a.host:
+            np.testing.assert_array_equal(a.host[k], b.host[k])
+    ns.regenerate = 1
+    cli.load_corpus(ns, counting_reader)
+    assert calls == [1]

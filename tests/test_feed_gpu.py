@@ -81,11 +81,19 @@ def test_fed_batch_trains():
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
 
 
-def test_cli_trains_on_a_csv_corpus_through_the_device_feed():
+def test_cli_trains_on_a_csv_corpus_through_the_device_feed(tmp_path):
     import os
+    import shutil
     from intel_sigir2023_amd import main as cli
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden') + os.sep
+    shutil.copytree(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'minidata'), str(tmp_path / 'minidata'))
+    root = str(tmp_path) + os.sep              # a copy: the run writes the corpus cache (main.py:64-72) next to the CSVs
     res = cli.main(['--model_name', 'IntEL', '--loss_name', 'IntBPRloss', '--workload', 'tiny', '--dataset', 'minidata', '--datapath', root,
                     '--intent_note', '_multi', '--max_session_len', '100', '--model_num', '3', '--epoch', '2', '--batch_size', '16',
                     '--eval_batch_size', '16'])
     assert res and all(np.isfinite(v) for v in res.values())
+    assert os.path.exists(os.path.join(root, 'minidata', 'SeqReader_100_multi.pkl'))
+    # second run: the corpus comes from the cache and gives the same numbers (same seeds)
+    res2 = cli.main(['--model_name', 'IntEL', '--loss_name', 'IntBPRloss', '--workload', 'tiny', '--dataset', 'minidata', '--datapath', root,
+                     '--intent_note', '_multi', '--max_session_len', '100', '--model_num', '3', '--epoch', '2', '--batch_size', '16',
+                     '--eval_batch_size', '16'])
+    assert res2.keys() == res.keys() and all(abs(res2[k] - res[k]) < 1e-4 for k in res)
