@@ -243,6 +243,22 @@ int intel_rows_add(float* table, int d, const int* idx, int n, const float* rows
  * ndcg[b] per session (linear gains, pads scored 0 / labelled 0, width = max(L, k)). */
 int intel_ndcg(int B, int L, int k, const float* ens_score, const int* ranking, const int* session_len,
                float* ndcg, void* stream);
+/* Every key of BaseRunner.evaluate_method (helpers/BaseRunner.py:56-131) per session, for n_topk cutoffs (topk: HOST array,
+ * n_topk <= 8, cutoffs <= 64):  out[b] = { [behaviour pay, fav, click][cutoff][HR, NDCG], [cutoff] overall NDCG } (7 * n_topk
+ * doubles per session), valid[b][3] = that behaviour has positives in session b (the reference averages a behaviour's keys
+ * over those sessions only, :96-98; the overall NDCG over all sessions, :117-126).
+ *   width      the reference's max_len = max(longest list of the WHOLE evaluation set, largest cutoff) (:66): a session owns
+ *              width - session_len pad slots of score 0 that outrank items with a negative score (0: max(L, largest cutoff));
+ *   pos_nums   [B,3] pay / fav / click counts of the corpus (:59-63,88-94), or NULL: counted from the labels 3 / 2 / 1;
+ *   label_pos  [B,L] slot of item l in the reference's label-descending pre-sort (:78-81), or NULL: the stable form of that
+ *              sort (among equal labels the later list position first).  The order among EQUAL labels is numpy's and decides
+ *              which items count as "fav positives" when a list holds pay and fav items in different numbers; it depends on
+ *              the labels only, so the host computes it once per evaluation set with the reference's own call
+ *              (runner.label_positions) and every evaluation afterwards runs on the device.
+ * Equal predictions rank the later slot of the label order first (a stable ascending argsort read from its end, :86,117). */
+int intel_eval_metrics(int B, int L, int width, int n_topk, const int* topk, const float* ens_score, const int* ranking,
+                       const int* session_len, const int* pos_nums, const int* label_pos, double* out, unsigned char* valid,
+                       void* stream);
 
 /* ---- input feed ------------------------------------------------------------------------------ */
 /* Device-side batch assembly: the work of the reference's per-sample Dataset._get_feed_dict chain

@@ -166,3 +166,10 @@ extern "C" int intel_ndcg(int B, int L, int k, const float* ens_score, const int
   INTEL_CHECK_ARG(ens_score && ranking && session_len && ndcg, "ndcg: null tensor");
   return launch_ndcg(B, L, k, ens_score, ranking, session_len, ndcg, (hipStream_t)stream);
 }
+
+extern "C" int intel_eval_metrics(int B, int L, int width, int n_topk, const int* topk, const float* ens_score, const int* ranking,
+                                  const int* session_len, const int* pos_nums, const int* label_pos, double* out,
+                                  unsigned char* valid, void* stream) {
+  INTEL_CHECK_ARG(topk && ens_score && ranking && session_len && out && valid, "eval_metrics: null tensor");
+  return launch_eval_metrics(B, L, width, n_topk, topk, ens_score, ranking, session_len, pos_nums, label_pos, out, valid, (hipStream_t)stream);
+}

@@ -201,3 +201,170 @@ int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const
   INTEL_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// evaluate_method (helpers/BaseRunner.py:56-131), every key, per session: per-behaviour HR@k / NDCG@k with binary
+// relevance (:88-116) and the overall NDCG@k with linear gains (:117-126), for a list of cutoffs.
+//
+//   * the reference first sorts each list by LABEL, descending (:78-81); "positive for behaviour t" then means
+//     "sits in the first all_pos_t slots of that order" (:93-94), all_pos = the pay / fav count, or the sum of all three
+//     for click (:89-92).  label_pos[b,l] = the slot of item l in that order.  It depends on the labels only, i.e. on
+//     the DATA: the host computes it once per evaluation set with the reference's own numpy call (whose order among
+//     equal labels is numpy's) and passes it in; when it is NULL the kernel uses the stable form of the same sort
+//     (reversed ascending order: among equal labels the LATER list position comes first).
+//   * predictions are padded with 0 and labels with -2 up to `width` = max(longest list of the evaluation set,
+//     largest cutoff) (:66-75): a session owns width - len pad slots, which outrank every item with a negative score.
+//   * rank order = descending prediction; equal predictions resolve to the LATER slot of the label order first (what a
+//     stable ascending argsort read from its end yields, :86 and :117); a pad is the last slot of all.
+//   out[b] = { [behaviour pay,fav,click][cutoff][HR, NDCG] , [cutoff] overall NDCG }, doubles; valid[b][t] = all_pos_t > 0
+//   (the reference averages a behaviour's keys over those sessions only, :96-98).
+// One wave per session, kmax rounds of wave arg-max.
+// ------------------------------------------------------------------------------------------
+#define EM_MAXK 8
+struct EvalArgs {
+  const float* ens; const int* ranking; const int* slen; const int* pos_nums; const int* label_pos;
+  int B, L, width, nk, kmax;
+  int topk[EM_MAXK];
+  double* out; unsigned char* valid;
+};
+
+__global__ __launch_bounds__(256) void eval_metrics_kernel(EvalArgs a) {
+  __shared__ int s_lab[4][64 * ND_MAXPL];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wv;
+  if (b >= a.B) return;
+  const int L = a.L, len = min(a.slen[b], L);
+  float pv[ND_MAXPL];
+  int lp[ND_MAXPL], gain[ND_MAXPL];
+  bool used[ND_MAXPL];
+  int n3 = 0, n2 = 0, n1 = 0, nhi[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < ND_MAXPL; ++i) {
+    const int l = lane + 64 * i;
+    const bool in = l < len;
+    pv[i] = in ? a.ens[(size_t)b * L + l] : 0.f;
+    const int raw = in ? a.ranking[(size_t)b * L + l] : -2;
+    if (l < 64 * ND_MAXPL) s_lab[wv][l] = raw;
+    gain[i] = raw < 0 ? 0 : raw;
+    used[i] = !in;
+    lp[i] = (in && a.label_pos) ? a.label_pos[(size_t)b * L + l] : 0;
+    n3 += in && raw == 3; n2 += in && raw == 2; n1 += in && raw == 1;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) nhi[q] += in && gain[i] == q + 3 + 1;      // labels 4..8 (not used by Tmall / LifeData)
+  }
+  n3 = wave_sum_i(n3); n2 = wave_sum_i(n2); n1 = wave_sum_i(n1);
+#pragma unroll
+  for (int q = 0; q < 5; ++q) nhi[q] = wave_sum_i(nhi[q]);
+  if (!a.label_pos) {        // stable label-descending order, later list position first among equals
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < ND_MAXPL; ++i) {
+      const int l = lane + 64 * i;
+      if (l >= len) continue;
+      const int mine = s_lab[wv][l];
+      int pos = 0;
+      for (int j = 0; j < len; ++j) {
+        const int o = s_lab[wv][j];
+        pos += (o > mine) || (o == mine && j > l);
+      }
+      lp[i] = pos;
+    }
+  }
+  int allpos[3];
+  if (a.pos_nums) {
+    allpos[0] = a.pos_nums[(size_t)b * 3 + 0];
+    allpos[1] = a.pos_nums[(size_t)b * 3 + 1];
+    allpos[2] = allpos[0] + allpos[1] + a.pos_nums[(size_t)b * 3 + 2];
+  } else {
+    allpos[0] = n3; allpos[1] = n2; allpos[2] = n3 + n2 + n1;
+  }
+  double dcg_b[3][EM_MAXK], dcg_all[EM_MAXK];
+  bool hr[3][EM_MAXK];
+#pragma unroll
+  for (int ki = 0; ki < EM_MAXK; ++ki) {
+    dcg_all[ki] = 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { dcg_b[t][ki] = 0.0; hr[t][ki] = false; }
+  }
+  int pads_left = a.width - len;
+  for (int p = 0; p < a.kmax; ++p) {
+    float bv = -INFINITY;
+    int bp = -1, bg = 0;
+#pragma unroll
+    for (int i = 0; i < ND_MAXPL; ++i)
+      if (!used[i] && (pv[i] > bv || (pv[i] == bv && lp[i] > bp))) { bv = pv[i]; bp = lp[i]; bg = gain[i]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int op = __shfl_xor(bp, o), og = __shfl_xor(bg, o);
+      if (op >= 0 && (bp < 0 || ov > bv || (ov == bv && op > bp))) { bv = ov; bp = op; bg = og; }
+    }
+    const bool pad_wins = pads_left > 0 && (bp < 0 || bv <= 0.f);     // a pad scores 0 and sits behind every real slot
+    if (pad_wins) {
+      --pads_left;
+      bp = 0x7fffffff; bg = 0;
+    } else if (bp < 0) {
+      break;                                                            // nothing left (width < cutoff cannot happen)
+    } else {
+#pragma unroll
+      for (int i = 0; i < ND_MAXPL; ++i)
+        if (!used[i] && lp[i] == bp) used[i] = true;                    // label_pos is a permutation: unique per item
+    }
+    const double disc = 1.0 / log2((double)p + 2.0);
+#pragma unroll
+    for (int ki = 0; ki < EM_MAXK; ++ki) {
+      if (ki < a.nk && p < a.topk[ki]) {
+        dcg_all[ki] += (double)bg * disc;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const bool hit = bp < allpos[t];
+          hr[t][ki] = hr[t][ki] || hit;
+          if (hit) dcg_b[t][ki] += disc;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    const int nk = a.nk;
+    double* o = a.out + (size_t)b * (7 * nk);
+    for (int ki = 0; ki < nk; ++ki) {
+      const int k = a.topk[ki];
+      for (int t = 0; t < 3; ++t) {
+        double idcg = 0.0;
+        for (int r = 0; r < k && r < allpos[t]; ++r) idcg += 1.0 / log2((double)r + 2.0);
+        o[(t * nk + ki) * 2 + 0] = hr[t][ki] ? 1.0 : 0.0;
+        o[(t * nk + ki) * 2 + 1] = dcg_b[t][ki] / idcg;
+      }
+      double idcg = 0.0;
+      int r = 0;
+      for (int q = 4; q >= 0; --q)
+        for (int c = 0; c < nhi[q] && r < k; ++c, ++r) idcg += (double)(q + 4) / log2((double)r + 2.0);
+      for (int c = 0; c < n3 && r < k; ++c, ++r) idcg += 3.0 / log2((double)r + 2.0);
+      for (int c = 0; c < n2 && r < k; ++c, ++r) idcg += 2.0 / log2((double)r + 2.0);
+      for (int c = 0; c < n1 && r < k; ++c, ++r) idcg += 1.0 / log2((double)r + 2.0);
+      o[6 * nk + ki] = dcg_all[ki] / idcg;      // 0/0 -> NaN like the reference
+    }
+    for (int t = 0; t < 3; ++t) a.valid[(size_t)b * 3 + t] = allpos[t] > 0;
+  }
+}
+
+int launch_eval_metrics(int B, int L, int width, int nk, const int* topk, const float* ens, const int* ranking, const int* slen,
+                        const int* pos_nums, const int* label_pos, double* out, unsigned char* valid, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(nk >= 1 && nk <= EM_MAXK, "eval_metrics: %d cutoffs unsupported (1..%d)", nk, EM_MAXK);
+  INTEL_CHECK_ARG(L <= 64 * ND_MAXPL, "eval_metrics: list length %d > %d unsupported", L, 64 * ND_MAXPL);
+  EvalArgs a;
+  a.ens = ens; a.ranking = ranking; a.slen = slen; a.pos_nums = pos_nums; a.label_pos = label_pos;
+  a.B = B; a.L = L; a.nk = nk; a.out = out; a.valid = valid;
+  a.kmax = 0;
+  for (int i = 0; i < EM_MAXK; ++i) {
+    a.topk[i] = i < nk ? topk[i] : 0;
+    if (a.topk[i] > a.kmax) a.kmax = a.topk[i];
+  }
+  INTEL_CHECK_ARG(a.kmax >= 1 && a.kmax <= 64, "eval_metrics: cutoff %d unsupported", a.kmax);
+  a.width = width > 0 ? width : max(L, a.kmax);
+  INTEL_CHECK_ARG(a.width >= a.kmax && a.width >= L, "eval_metrics: width %d < max(list length %d, cutoff %d)", a.width, L, a.kmax);
+  LAUNCH(eval_metrics_kernel, dim3(cdiv(B, 4)), dim3(256), 0, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

@@ -60,3 +60,5 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
 int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags, float lr,
                      float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t st);
 int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const int* slen, float* out, hipStream_t st);
+int launch_eval_metrics(int B, int L, int width, int nk, const int* topk, const float* ens, const int* ranking, const int* slen,
+                        const int* pos_nums, const int* label_pos, double* out, unsigned char* valid, hipStream_t st);

@@ -53,6 +53,8 @@ class BaseRunner(object):
         parser.add_argument('--test_ensemble', type=int, default=1)
         parser.add_argument('--decay_lr', type=float, default=0)
         parser.add_argument('--decay_step', type=int, default=1)
+        parser.add_argument('--device_metrics', type=int, default=1,
+                            help='1: HR@k / NDCG@k of evaluate_method on the device; 0: predictions to the host, numpy (reference flow)')
         return parser
 
     # ------------------------------------------------------------------------------------------
@@ -112,6 +114,64 @@ class BaseRunner(object):
             evaluations['NDCG@%d' % k] = (dcg / idcg).mean()
         return evaluations
 
+    # ---- the same 25 keys on the device ------------------------------------------------------------
+    BEHAVIOURS = ('pay', 'fav', 'click')
+
+    @staticmethod
+    def label_positions(ranking_lists, session_len, width):
+        """Slot of every item in the reference's label-descending pre-sort (helpers/BaseRunner.py:66-81): the SAME numpy
+        call on the same padded label matrix, so the order among equal labels is the reference's by construction.  It
+        depends on the labels only -- computed once per evaluation set, then every evaluation runs on the device
+        (intel_eval_metrics).  Returns int32 [n, width]; row i holds the slots of items 0..session_len[i]-1."""
+        n = len(session_len)
+        labels = np.full((n, width), -2, dtype=np.int64)
+        for i in range(n):
+            m = min(int(session_len[i]), len(ranking_lists[i]))
+            labels[i, :m] = np.asarray(ranking_lists[i])[:m]
+        order = np.argsort(labels, axis=1)[:, ::-1]              # order[i, slot] = item
+        pos = np.empty((n, width), dtype=np.int32)
+        pos[np.arange(n).reshape(-1, 1), order] = np.arange(width, dtype=np.int32)
+        return pos
+
+    @staticmethod
+    def evaluate_method_device(ens_score, ranking, session_len, topk, metrics, width=0, pos_nums=None, label_pos=None):
+        """Per-session values of every evaluate_method key for one padded batch, on the device.
+        ens_score [B,L] f32, ranking [B,L] i32, session_len [B] i32, pos_nums [B,3] i32 or None, label_pos [B,L] i32 or None.
+        Returns (values [B, 7*len(topk)] f64, valid [B,3] u8): see BaseRunner.reduce_device_metrics."""
+        import ctypes as C
+        from . import _lib as L
+        B, Lm = ens_score.shape
+        nk = len(topk)
+        out = torch.empty(B, 7 * nk, dtype=torch.float64, device=ens_score.device)
+        valid = torch.empty(B, 3, dtype=torch.uint8, device=ens_score.device)
+        tk = (C.c_int * nk)(*[int(k) for k in topk])
+        L.check(L.lib().intel_eval_metrics(B, Lm, int(width), nk, tk, L.ptr(ens_score.contiguous()), L.ptr(ranking.contiguous()),
+                                           L.ptr(session_len.contiguous()), L.ptr(pos_nums), L.ptr(label_pos), L.ptr(out), L.ptr(valid),
+                                           L.stream_ptr(ens_score.device)), 'intel_eval_metrics')
+        return out, valid
+
+    @staticmethod
+    def reduce_device_metrics(sums, counts, n_sessions, topk, metrics):
+        """sums [7*nk] = column sums of the per-session values (behaviour keys over their valid sessions only), counts [3] =
+        valid sessions per behaviour -> the evaluate_method dict (same keys; NDCG@1 of a behaviour is omitted like the
+        reference does, helpers/BaseRunner.py:107-108)."""
+        nk = len(topk)
+        res = dict()
+        for t, beh in enumerate(BaseRunner.BEHAVIOURS):
+            for ki, k in enumerate(topk):
+                for metric in metrics:
+                    if metric == 'HR':
+                        res['%s_HR@%d' % (beh, k)] = float(sums[(t * nk + ki) * 2]) / float(counts[t]) if counts[t] else float('nan')
+                    elif metric == 'NDCG':
+                        if k == 1:
+                            continue
+                        res['%s_NDCG@%d' % (beh, k)] = float(sums[(t * nk + ki) * 2 + 1]) / float(counts[t]) if counts[t] else float('nan')
+                    else:
+                        raise ValueError('Undefined evaluation metric: {}.'.format(metric))
+        for ki, k in enumerate(topk):
+            res['NDCG@%d' % k] = float(sums[6 * nk + ki]) / float(n_sessions)
+        return res
+
     @staticmethod
     def evaluate_intents(true_intents, predict_intents, topk=[1, 5, 10, 30]):
         """helpers/BaseRunner.py:133-150."""
@@ -153,6 +213,8 @@ class BaseRunner(object):
         self.args = args
         self.engine = None
         self.time = None
+        self.device_metrics = bool(getattr(args, 'device_metrics', 1))      # evaluate_method on the device (intel_eval_metrics)
+        self._eval_sets = {}
 
     def _check_time(self, start=False):
         if self.time is None or start:
@@ -231,7 +293,72 @@ class BaseRunner(object):
             losses = [float(np.mean([p[1][j] for p in parts])) for j in range(len(losses))]      # equal shards: mean of means
         return preds, float(np.mean(losses)), ranks, true_int, pred_int, slens
 
+    def _eval_set(self, batches):
+        """Per-evaluation-set constants of the device metrics, computed once (dev / test batches are fixed lists): the
+        reference's max_len (the GLOBAL longest list, helpers/BaseRunner.py:66) and every batch's label-sort slots."""
+        key = id(batches)
+        hit = self._eval_sets.get(key)
+        if hit is not None and hit[0] is batches:
+            return hit[1], hit[2]
+        slens = [b['session_len'].cpu().numpy() for b in batches]
+        local_max = max(int(s.max()) for s in slens) if slens else 0
+        width = max(parallel.global_max_([local_max], batches[0]['session_len'].device)[0], max(self.topk))
+        lps = []
+        for b, sl in zip(batches, slens):
+            r = b['ranking'].cpu().numpy()
+            Lb = r.shape[1]
+            lp = self.label_positions([r[i] for i in range(len(sl))], np.minimum(sl, Lb), width)[:, :Lb]
+            lps.append(torch.from_numpy(np.ascontiguousarray(lp)).to(b['ranking'].device))
+        self._eval_sets[key] = (batches, width, lps)
+        return width, lps
+
+    @torch.no_grad()
+    def evaluate_on_device(self, model, batches, topk, metrics, criterion, topk_intent=[1, 5, 10, 30]):
+        """evaluate() without the per-batch .cpu().numpy() round trip of the predictions (helpers/BaseRunner.py:338-343):
+        forward, criterion and every evaluate_method key per batch on the device (intel_eval_metrics); only the column sums
+        come back.  Data parallel: sums and counts are all-reduced, so every rank reports the global numbers."""
+        model.eval()
+        width, lps = self._eval_set(batches)
+        dev = batches[0]['session_len'].device
+        nk = len(topk)
+        sums = torch.zeros(7 * nk, dtype=torch.float64, device=dev)
+        counts = torch.zeros(4, dtype=torch.float64, device=dev)      # valid sessions per behaviour, all sessions
+        losses, true_int, pred_int = [], [], []
+        for batch, lp in zip(batches, lps):
+            out = model(batch)
+            loss, _, _ = criterion(out, batch)
+            losses.append(loss.detach().double().reshape(()))
+            rk = batch['ranking'] if batch['ranking'].dtype == torch.int32 else batch['ranking'].to(torch.int32)
+            sl = batch['session_len'] if batch['session_len'].dtype == torch.int32 else batch['session_len'].to(torch.int32)
+            vals, valid = self.evaluate_method_device(out['ens_score'], rk, sl, topk, metrics, width=width, label_pos=lp)
+            w = torch.ones_like(vals)
+            for t in range(3):
+                w[:, t * nk * 2:(t + 1) * nk * 2] = valid[:, t:t + 1].double()
+            sums += torch.where(w > 0, vals, torch.zeros_like(vals)).sum(0)
+            counts[:3] += valid.double().sum(0)
+            counts[3] += vals.shape[0]
+            true_int.append(batch['intents'])
+            pred_int.append(out['intents'])
+        lossv = torch.stack(losses)
+        if parallel.world_size() > 1:
+            parallel.allreduce_sum_([sums, counts])
+            lossv = parallel.allgather(lossv).mean(0)
+        res = dict()
+        if self.test_ensemble:
+            res.update(self.reduce_device_metrics(sums.cpu().numpy(), counts.cpu().numpy()[:3], float(counts[3]), topk, metrics))
+        ti = torch.cat(true_int).cpu().numpy()
+        pi = torch.cat(pred_int).cpu().numpy()
+        if parallel.world_size() > 1:
+            parts = parallel.allgather_object((ti, pi))
+            ti, pi = np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        if len(ti):
+            res.update(self.evaluate_intents(ti, pi, topk=[k for k in topk_intent if k <= ti.shape[1]]))
+        return float(lossv.mean().cpu()), res
+
     def evaluate(self, model, batches, topk, metrics, criterion, pos_nums=None, topk_intent=[1, 5, 10, 30]):
+        if self.device_metrics and pos_nums is None and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda \
+                and len(topk) <= 8 and max(b['i_id_s'].shape[1] for b in batches) <= 512:
+            return self.evaluate_on_device(model, batches, topk, metrics, criterion, topk_intent)
         preds, loss, ranks, true_int, pred_int, slens = self.predict(model, batches, criterion)
         res = dict()
         if self.test_ensemble:
