@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define INTEL_ABI_VERSION 1
+#define INTEL_ABI_VERSION 2
 
 enum {
   INTEL_OK = 0,
@@ -52,7 +52,17 @@ typedef struct IntelDesc {
   int history_max;      /* --history_max                      */
   int enc_layers, enc_heads; /* BERT4Rec: hard-coded 2/2 (IntEL.py:108-109) */
   int gru_hidden;       /* GRU4Rec: hard-coded 128 (IntEL.py:105-106)       */
+  /* ---- ABI version 2 ---- */
+  int weight_norm;      /* softmax applications over the K fusion weights: 0 = none (IntEL.py:214, the parity default),
+                         * 1 = one softmax (SURVEY.md 0.3 `weight_norm=softmax`), 2 = the double softmax of the
+                         * aWELv_IntEL variant (models/supervise/aWELv_IntEL.py:199-200)                              */
+  int pool_mean;        /* 1 = aWELv_IntEL feature: h * g(intent) mean-pooled over ALL L rows, one weight vector per
+                         * session repeated over the list, nothing masked (aWELv_IntEL.py:188-201); needs
+                         * cross_attention = 0 (the gate MLPs are the intent_{item,score}_embeddings slots)           */
+  int dtype;            /* INTEL_DTYPE_F32 (parity mode) | INTEL_DTYPE_BF16 (bf16 storage / single bf16 product)      */
 } IntelDesc;
+#define INTEL_DTYPE_F32 0
+#define INTEL_DTYPE_BF16 1
 
 /* Parameter slots.  Each maps 1:1 to a reference state_dict key.  The arrays
  * passed as `params` / `grads` have INTEL_P_COUNT entries; unused slots are NULL. */

@@ -37,7 +37,7 @@ def lib():
         except OSError as e:
             raise IntelHipError('cannot load %s: %s' % (LIB_PATH, e))
         _declare(_lib)
-        if _lib.intel_abi_version() != 1:
+        if _lib.intel_abi_version() != 2:
             raise IntelHipError('ABI version mismatch')
         sizes = (C.c_int * 4)()
         _lib.intel_abi_sizes(sizes)
@@ -79,7 +79,7 @@ class IntelDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         'model_num', 'intent_num', 'item_num', 'class_num', 'user_num', 'ctx_num',
         'd_id', 'd_im', 'd_u', 'd_s', 'd_c', 'd_int', 'q_size', 'heads', 'layers',
-        'cross_attention', 'encoder', 'history_max', 'enc_layers', 'enc_heads', 'gru_hidden')]
+        'cross_attention', 'encoder', 'history_max', 'enc_layers', 'enc_heads', 'gru_hidden', 'weight_norm', 'pool_mean', 'dtype')]
 
 
 class IntelBatch(C.Structure):

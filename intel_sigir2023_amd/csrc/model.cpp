@@ -80,6 +80,9 @@ struct Layout {
   EncBufs enc[2];           // 0 = "encoder" (session history), 1 = "item_encoder"
   int F, Pin;               // width of the fusion feature / pred_layer input
   float *FEAT, *WV, *WPAD, *FEATFULL, *PREDIN, *LOGITS, *INTENTS;
+  // weight_norm: WVN[s] / WPADN[s] = the valid-row / pad-row weight vectors after softmax s+1 (per-session weights);
+  // WTN[s] = the per-item weights after softmax s+1 (cross_attention = 0 without pool_mean)
+  float *WVN[2], *WPADN[2], *WTN[2];
   float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
   float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN;
   float *dXS;       // gradient w.r.t. the score tower output, parked between the two backward phases
@@ -117,6 +120,8 @@ struct IntelCtx {
 
 namespace {
 
+// one weight vector per session (valid rows; pad rows have their own unless pool_mean) instead of one per item
+inline bool per_session_weights(const IntelDesc& D) { return D.cross_attention || D.pool_mean; }
 inline int enc_slot(int e, int off) { return INTEL_P_ENC0 + e * INTEL_ENC_STRIDE + off; }
 inline int enc_blk_slot(int e, int l, int off) { return enc_slot(e, INTEL_ENC_BLOCK0 + l * INTEL_ENC_BLOCK_STRIDE + off); }
 
@@ -218,12 +223,20 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     } else {
       w.MH = ar.f((size_t)B * D.q_size);
       w.MV = ar.f((size_t)B * w.d);
+      w.XBAR = D.pool_mean ? ar.f((size_t)B * w.d) : nullptr;
     }
   }
+  const bool psw = per_session_weights(D);
   y.FEAT = ar.f((size_t)B * y.F);
   y.WV = ar.f((size_t)B * K);
   y.WPAD = ar.f((size_t)B * K);
-  y.FEATFULL = D.cross_attention ? nullptr : ar.f((size_t)M * y.F);
+  for (int s = 0; s < 2; ++s) {
+    const bool on = s < D.weight_norm;
+    y.WVN[s] = (on && psw) ? ar.f((size_t)B * K) : nullptr;
+    y.WPADN[s] = (on && psw && !D.pool_mean) ? ar.f((size_t)B * K) : nullptr;
+    y.WTN[s] = (on && !psw) ? ar.f((size_t)M * K) : nullptr;
+  }
+  y.FEATFULL = psw ? nullptr : ar.f((size_t)M * y.F);
   y.PREDIN = ar.f((size_t)B * y.Pin);
   y.LOGITS = ar.f((size_t)B * I);
   y.INTENTS = ar.f((size_t)B * I);
@@ -266,8 +279,8 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   y.dFEAT = ar.f((size_t)B * y.F);
   y.dWV = ar.f((size_t)B * K);
   y.dWPAD = ar.f((size_t)B * K);
-  y.dWT = D.cross_attention ? nullptr : ar.f((size_t)M * K);
-  y.dFEATFULL = D.cross_attention ? nullptr : ar.f((size_t)M * y.F);
+  y.dWT = psw ? nullptr : ar.f((size_t)M * K);
+  y.dFEATFULL = psw ? nullptr : ar.f((size_t)M * y.F);
   y.dINTENT = ar.f((size_t)B * I);
   y.dLOGITS = ar.f((size_t)B * I);
   y.dPREDIN = ar.f((size_t)B * y.Pin);
@@ -324,7 +337,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * H, dm0, dm0) + Lf((size_t)B * H, dm0)) + Lf((size_t)B * H, dm0) + Wf((size_t)B * H, H, dm0);
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
     }
-    a += 2 * Wf(D.cross_attention ? B : M, K, y.F);                       // fusion weights (+ pad rows)
+    a += 2 * Wf(psw ? B : M, K, y.F);                                     // fusion weights (+ pad rows)
     a += Wf(B, D.d_int, I) + Wf(B, I, y.Pin) + Wf(M, d_s, K);             // intent embedding, predictor, score embedding
     a += Wf((size_t)B * H, D.d_int, I) + Wf((size_t)B * Hi, D.d_int, I);  // shared intent embedding from the histories
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
@@ -965,7 +978,10 @@ void forward_impl(Run& r, const IntelOut* out) {
       lin(r, y.INTENTS, I, B, I, w.pM0, D.q_size, w.MH, D.q_size, eh);
       lin(r, w.MH, D.q_size, B, D.q_size, w.pM2, w.d, w.MV, w.d, e0);
       if (r.rc) return;
-      RUN(launch_gate_fwd(Xf, w.d, w.MV, B, L, y.FEATFULL, y.F, w.feat_off, r.st));
+      if (D.pool_mean)      // aWELv_IntEL.py:195-198: (h * g(intent)).mean(dim=1), unmasked
+        RUN(launch_gate_mean_fwd(Xf, w.d, w.MV, B, L, w.XBAR, y.FEAT, y.F, w.feat_off, r.st));
+      else
+        RUN(launch_gate_fwd(Xf, w.d, w.MV, B, L, y.FEATFULL, y.F, w.feat_off, r.st));
     }
   };
   fork_streams(r, 1);
@@ -987,15 +1003,31 @@ void forward_impl(Run& r, const IntelOut* out) {
   }
   GemmEpilogue ew;
   ew.bias = r.P(INTEL_P_WE_B);
-  if (D.cross_attention) {
+  if (per_session_weights(D)) {
     lin(r, y.FEAT, y.F, B, y.F, y.pWe, K, y.WV, K, ew);
-    lin(r, y.FEAT + off_u, y.F, B, D.d_u + D.d_int, y.pWePad, K, y.WPAD, K, ew);
+    if (!D.pool_mean) lin(r, y.FEAT + off_u, y.F, B, D.d_u + D.d_int, y.pWePad, K, y.WPAD, K, ew);
     if (r.rc) return;
-    RUN(launch_ens_fwd(y.WV, y.WPAD, bt.scores, bt.session_len, B, L, K, 0, out->weights, out->ens_score, r.st));
+    // weight_norm: softmax over the K weights, once or twice (aWELv_IntEL.py:199-200); with pool_mean
+    // every row of the list, pads included, carries the session's vector (aWELv_IntEL.py:200: .repeat over the list)
+    const float *wv = y.WV, *wpad = D.pool_mean ? y.WV : y.WPAD;
+    for (int s = 0; s < D.weight_norm; ++s) {
+      RUN(launch_softmax_rows(wv, B, K, y.WVN[s], r.st));
+      if (!D.pool_mean) RUN(launch_softmax_rows(wpad, B, K, y.WPADN[s], r.st));
+      wv = y.WVN[s];
+      wpad = D.pool_mean ? y.WVN[s] : y.WPADN[s];
+    }
+    RUN(launch_ens_fwd(wv, wpad, bt.scores, bt.session_len, B, L, K, 0, out->weights, out->ens_score, r.st));
   } else {
     RUN(launch_bcast_rows(y.FEAT + off_u, y.F, D.d_u + D.d_int, B, L, y.FEATFULL, y.F, off_u, r.st));
     lin(r, y.FEATFULL, y.F, M, y.F, y.pWe, K, out->weights, K, ew);
     if (r.rc) return;
+    for (int s = 0; s < D.weight_norm; ++s) {
+      RUN(launch_softmax_rows(s == 0 ? out->weights : y.WTN[s - 1], M, K, y.WTN[s], r.st));
+      if (s == D.weight_norm - 1) {
+        hipError_t e = hipMemcpyAsync(out->weights, y.WTN[s], (size_t)M * K * sizeof(float), hipMemcpyDeviceToDevice, r.st);
+        if (e != hipSuccess) { intel_set_error("weights copy failed: %s", hipGetErrorString(e)); r.rc = (int)e; return; }
+      }
+    }
     RUN(launch_ens_fwd(nullptr, nullptr, bt.scores, bt.session_len, B, L, K, 1, out->weights, out->ens_score, r.st));
   }
   hipError_t e = hipMemcpyAsync(out->intents, y.INTENTS, (size_t)B * I * sizeof(float), hipMemcpyDeviceToDevice, r.st);
@@ -1028,17 +1060,23 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ctx->touched[INTEL_P_UID_EMB] = r.ctx->touched[INTEL_P_CTX_EMB] = 1;
 
     // ===== fusion weights + aggregation (IntEL.py:212-215)
-    if (D.cross_attention) {
+    if (per_session_weights(D)) {
       RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 0, y.dWV, y.dWPAD, nullptr, r.st));
+      if (D.pool_mean) RUN(launch_add2(y.dWV, y.dWPAD, (long long)B * K, y.dWV, r.st));      // pad rows carry the same vector
+      for (int s = D.weight_norm - 1; s >= 0; --s) {                                           // softmax stages, last first
+        RUN(launch_softmax_rows_bwd(y.WVN[s], y.dWV, B, K, y.dWV, r.st));
+        if (!D.pool_mean) RUN(launch_softmax_rows_bwd(y.WPADN[s], y.dWPAD, B, K, y.dWPAD, r.st));
+      }
       wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
       if (r.rc) return;
-      if (r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
+      if (!D.pool_mean && r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
         RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, nullptr, r.st, r.ctx->rq));
       }
       lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
-      lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
+      if (!D.pool_mean) lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
     } else {
       RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 1, nullptr, nullptr, y.dWT, r.st));
+      for (int s = D.weight_norm - 1; s >= 0; --s) RUN(launch_softmax_rows_bwd(y.WTN[s], y.dWT, M, K, y.dWT, r.st));
       wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
       lin(r, y.dWT, K, M, K, y.pWeT, y.F, y.dFEATFULL, y.F, e0);
       if (r.rc) return;
@@ -1085,7 +1123,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       lin(r, r.T->dVB3, d, B, d, w.pXqT, I, dint, I, e0);
     } else {
       const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
-      RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dXout, r.T->dVB1, r.st));    // dX, dMV
+      if (D.pool_mean)
+        RUN(launch_gate_mean_bwd(y.dFEAT, y.F, w.feat_off, w.XBAR, d, w.MV, B, L, dXout, r.T->dVB1, r.st));   // dX (every row), dMV
+      else
+        RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dXout, r.T->dVB1, r.st));    // dX, dMV
       wgrad(r, r.T->dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
       GemmEpilogue em;
       em.mask = w.MH; em.ldmask = D.q_size;
@@ -1224,6 +1265,9 @@ int check_desc(const IntelDesc& d) {
   INTEL_CHECK_ARG(d_i % d.heads == 0 && d.d_s % d.heads == 0, "tower widths must be divisible by num_heads");
   INTEL_CHECK_ARG(d_i % 16 == 0 && d.d_s % 16 == 0, "tower widths (i_emb+im_emb=%d, s_emb=%d) must be multiples of 16", d_i, d.d_s);
   INTEL_CHECK_ARG(d.encoder == INTEL_ENC_BERT4REC || d.encoder == INTEL_ENC_GRU4REC, "Invalid sequence encoder.");
+  INTEL_CHECK_ARG(d.weight_norm >= 0 && d.weight_norm <= 2, "weight_norm %d unsupported (0 none, 1 softmax, 2 double softmax)", d.weight_norm);
+  INTEL_CHECK_ARG(!d.pool_mean || !d.cross_attention, "pool_mean (aWELv_IntEL) uses the gate MLPs: cross_attention must be 0");
+  INTEL_CHECK_ARG(d.dtype == INTEL_DTYPE_F32 || d.dtype == INTEL_DTYPE_BF16, "dtype %d unsupported", d.dtype);
   if (d.encoder == INTEL_ENC_BERT4REC) {
     INTEL_CHECK_ARG(d.enc_layers >= 1 && d.enc_layers <= INTEL_ENC_MAX_BLOCKS, "encoder blocks %d unsupported", d.enc_layers);
     INTEL_CHECK_ARG((d.d_c + d.d_int) % 16 == 0 && (d.d_id + d.d_int) % 16 == 0, "encoder widths must be multiples of 16");

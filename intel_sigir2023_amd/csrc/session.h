@@ -22,6 +22,9 @@ int launch_ens_bwd(const float* d_weights, const float* d_ens, const float* scor
 int launch_gate_fwd(const float* x, int d, const float* vec, int B, int L, float* dst, int ldd, int col0, hipStream_t st);
 int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d, const float* vec, int B, int L, float* dx,
                     float* dvec, hipStream_t st);
+int launch_gate_mean_fwd(const float* x, int d, const float* vec, int B, int L, float* xbar, float* feat, int ldf, int col0, hipStream_t st);
+int launch_gate_mean_bwd(const float* dfeat, int ldf, int col0, const float* xbar, int d, const float* vec, int B, int L, float* dx,
+                         float* dvec, hipStream_t st);
 int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int L, float* out, int ldo, int ocol0,
                           int accumulate, hipStream_t st);
 int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st);

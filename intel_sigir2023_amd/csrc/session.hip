@@ -617,6 +617,48 @@ int launch_gate_bwd(const float* dfeat, int ldf, int col0, const float* x, int d
   return 0;
 }
 
+// mean-pooled gate of the aWELv_IntEL variant (models/supervise/aWELv_IntEL.py:188-197): xatt = h * g(intent), then
+// .mean(dim=1) over ALL L rows (pads included -- nothing is masked there):
+//   xbar[b,c] = mean_l x[b,l,c];  feat[b, col0+c] = xbar[b,c] * vec[b,c]
+// backward: dx[b,l,c] = dfeat[b,col0+c] * vec[b,c] / L  (every row);  dvec[b,c] = dfeat[b,col0+c] * xbar[b,c]
+__global__ __launch_bounds__(256) void gate_mean_fwd_kernel(const float* __restrict__ x, int d, const float* __restrict__ vec, int B, int L,
+                                                            float* __restrict__ xbar, float* __restrict__ feat, int ldf, int col0) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)L;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += x[((size_t)b * L + l) * d + c];
+    const float m = acc * inv;
+    xbar[(size_t)b * d + c] = m;
+    feat[(size_t)b * ldf + col0 + c] = m * vec[(size_t)b * d + c];
+  }
+}
+int launch_gate_mean_fwd(const float* x, int d, const float* vec, int B, int L, float* xbar, float* feat, int ldf, int col0, hipStream_t st) {
+  if (B <= 0) return 0;
+  LAUNCH(gate_mean_fwd_kernel, dim3(B), dim3(256), 0, st, x, d, vec, B, L, xbar, feat, ldf, col0);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+__global__ __launch_bounds__(256) void gate_mean_bwd_kernel(const float* __restrict__ dfeat, int ldf, int col0, const float* __restrict__ xbar,
+                                                            int d, const float* __restrict__ vec, int B, int L, float* __restrict__ dx,
+                                                            float* __restrict__ dvec) {
+  const int b = blockIdx.x;
+  const float inv = 1.f / (float)L;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    const float g = dfeat[(size_t)b * ldf + col0 + c];
+    dvec[(size_t)b * d + c] = g * xbar[(size_t)b * d + c];
+    const float gx = g * vec[(size_t)b * d + c] * inv;
+    for (int l = 0; l < L; ++l) dx[((size_t)b * L + l) * d + c] = gx;
+  }
+}
+int launch_gate_mean_bwd(const float* dfeat, int ldf, int col0, const float* xbar, int d, const float* vec, int B, int L, float* dx,
+                         float* dvec, hipStream_t st) {
+  if (B <= 0) return 0;
+  LAUNCH(gate_mean_bwd_kernel, dim3(B), dim3(256), 0, st, dfeat, ldf, col0, xbar, d, vec, B, L, dx, dvec);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 // out[b, c] = sum_l src[(b*L + l), col0 + c]   (gradient of a per-session vector broadcast over the list)
 __global__ __launch_bounds__(256) void session_colsum_kernel(const float* __restrict__ src, int lds, int col0, int d, int B, int L,
                                                              float* __restrict__ out, int ldo, int ocol0, int accumulate) {

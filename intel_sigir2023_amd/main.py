@@ -20,10 +20,10 @@ from . import data as data_mod
 from . import feed
 from . import parallel
 from . import synth
-from .model import IntEL
+from .model import IntEL, aWELv_IntEL
 from .runner import BaseRunner
 
-MODELS = {'IntEL': IntEL}
+MODELS = {'IntEL': IntEL, 'aWELv_IntEL': aWELv_IntEL}
 LOSSES = {n: getattr(loss_mod, n) for n in ('BPRloss', 'Listloss', 'MSEloss', 'IntBPRloss', 'IntListloss', 'IntMSEloss')}
 RUNNERS = {'BaseRunner': BaseRunner}
 

@@ -100,7 +100,13 @@ class IntEL(nn.Module):
         parser.add_argument('--model_path', type=str, default='', help='Model save path.')
         parser.add_argument('--buffer', type=int, default=1, help='Whether to buffer feed dicts for dev/test')
         parser.add_argument('--model_num', type=int, default=2, help='Number of base models.')
+        parser.add_argument('--weight_norm', type=str, default='none',
+                            help='none: raw fusion weights (IntEL.py:214, the reference); softmax: K-way softmax over them')
         return parser
+
+    # variant switches (class attributes; aWELv_IntEL overrides them)
+    POOL_MEAN = 0             # 1: mean-pooled h * g(intent) feature, one weight vector per session (aWELv_IntEL.py:188-201)
+    FORCE_WEIGHT_NORM = None  # number of softmax applications fixed by the class (aWELv_IntEL: 2)
 
     def __init__(self, args, corpus):
         super().__init__()
@@ -140,7 +146,11 @@ class IntEL(nn.Module):
         self.s_W2 = nn.Linear(self.score_emb_size, self.score_emb_size)
         self.s_layer_norm = nn.LayerNorm(self.score_emb_size)
         self.cross_attn_qsize = args.cross_attn_qsize
-        self.cross_attention = args.cross_attention
+        self.cross_attention = 0 if self.POOL_MEAN else getattr(args, 'cross_attention', 1)
+        wn = getattr(args, 'weight_norm', 'none')
+        if wn not in ('none', 'softmax', 0, 1):
+            raise ValueError('weight_norm must be none or softmax')
+        self.weight_norm = self.FORCE_WEIGHT_NORM if self.FORCE_WEIGHT_NORM is not None else int(wn in ('softmax', 1))
         if self.cross_attention:
             self.intent_score_attention = _CrossAtt(self.intent_num, self.score_emb_size, self.score_emb_size)
             self.intent_item_attention = _CrossAtt(self.intent_num, self.item_emb_size, self.item_emb_size)
@@ -174,9 +184,9 @@ class IntEL(nn.Module):
             ctx_num=_list_product(corpus.contextfnum), d_id=args.i_emb_size, d_im=self.im_emb_size,
             d_u=args.u_emb_size, d_s=args.s_emb_size, d_c=args.context_emb_size, d_int=args.intent_emb_size,
             q_size=args.cross_attn_qsize, heads=args.num_heads, layers=args.num_layers,
-            cross_attention=int(bool(args.cross_attention)),
+            cross_attention=int(bool(self.cross_attention)),
             encoder=0 if self.encoder_name == 'BERT4Rec' else 1, history_max=self.max_his,
-            enc_layers=2, enc_heads=2, gru_hidden=128)
+            enc_layers=2, enc_heads=2, gru_hidden=128, weight_norm=self.weight_norm, pool_mean=int(self.POOL_MEAN), dtype=0)
         self._ctx = None
         self._ws = None
         self._slot_names = self._build_slot_map()
@@ -416,6 +426,26 @@ class IntEL(nn.Module):
         L.check(lib.intel_backward_phase(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), L.ptr(d_weights), L.ptr(d_ens),
                                          L.ptr(d_intents), garr, int(phase), L.stream_ptr(dev)), 'intel_backward')
         return grad_tensors
+
+
+class aWELv_IntEL(IntEL):
+    """The reference's ``models/supervise/aWELv_IntEL.py`` (class ``aWELv_IntEL``): IntEL's towers and intent predictor with
+    aWELv-style fusion weights -- ``h * MLP(intent)`` mean-pooled over the whole list (pads included, nothing is masked,
+    :188-198), ONE weight vector per session, softmax applied twice (:199-200) and repeated over the list.  Same parameter
+    names as IntEL with ``--cross_attention 0`` (``intent_{item,score}_embeddings``), same flags minus ``--cross_attention``
+    (:16-34), same kernels for everything up to the pooling."""
+    POOL_MEAN = 1
+    FORCE_WEIGHT_NORM = 2
+
+    @staticmethod
+    def parse_model_args(parser):
+        IntEL.parse_model_args(parser)
+        for a in list(parser._actions):          # the reference class has neither flag
+            if a.dest in ('cross_attention', 'weight_norm'):
+                parser._remove_action(a)
+                for o in a.option_strings:
+                    parser._option_string_actions.pop(o, None)
+        return parser
 
 
 class _IntELFunction(torch.autograd.Function):

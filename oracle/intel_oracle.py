@@ -41,6 +41,8 @@ class Config(object):
         self.num_layers = 1
         self.cross_attention = 1
         self.dropout = 0.0
+        self.weight_norm = 'none'      # 'softmax': one K-way softmax over the fusion weights (no reference counterpart)
+        self.model_name = 'IntEL'      # 'aWELv_IntEL': models/supervise/aWELv_IntEL.py (mean-pooled gates, double softmax)
         # loss flags (loss/Baseloss.py:9-12, loss/BaseIntloss.py:13-20)
         self.intent_weight = 0.1
         self.ensemble_weight = 1.0
@@ -191,6 +193,18 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None, taps=None):
     h_i = tied_tower(h_i, sd, 'i_attn_head', 'i_W1', 'i_W2', 'i_layer_norm', cfg.num_heads, cfg.num_layers, ki, pd, taps)
     h_s = _lin(scores, sd, 'score_embeddings')
     h_s = tied_tower(h_s, sd, 's_attn_head', 's_W1', 's_W2', 's_layer_norm', cfg.num_heads, cfg.num_layers, ks, pd, taps)
+    if getattr(cfg, 'model_name', 'IntEL') == 'aWELv_IntEL':
+        # models/supervise/aWELv_IntEL.py:188-203: gates from the intent MLPs, mean over ALL rows, softmax twice, no mask
+        def mlp(p):
+            t = torch.relu(_lin(intent, sd, p + '.0'))
+            return F.linear(t, sd[p + '.2.weight'])
+        item_x = (h_i * mlp('intent_item_embeddings')[:, None, :]).mean(dim=1)
+        score_x = (h_s * mlp('intent_score_embeddings')[:, None, :]).mean(dim=1)
+        h_int = torch.relu(_lin(intent, sd, 'intent_embeddings'))
+        feat = torch.cat([item_x, score_x, h_u[:, 0, :], h_int], dim=-1)
+        w_item = torch.softmax(_lin(feat, sd, 'weight_embeddings'), dim=-1)
+        weights = torch.softmax(w_item[:, None, :].repeat(1, L, 1), dim=-1)
+        return weights, (weights * scores).sum(-1)
     if cfg.cross_attention:
         scale = 1.0 / math.sqrt(cfg.cross_attn_qsize)
         item_x = single_query_pool(intent, h_i, valid, sd, 'intent_item_attention', scale)
@@ -204,6 +218,8 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None, taps=None):
     h_int = torch.relu(_lin(intent, sd, 'intent_embeddings'))[:, None, :].expand(B, L, -1)
     feat = torch.cat([item_x, score_x, h_u, h_int], dim=-1)
     weights = _lin(feat, sd, 'weight_embeddings')            # NO softmax (IntEL.py:214)
+    if getattr(cfg, 'weight_norm', 'none') == 'softmax':      # the build's optional K-way normalisation
+        weights = torch.softmax(weights, dim=-1)
     ens = (weights * scores).sum(-1)
     return weights, ens
 

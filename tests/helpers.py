@@ -59,9 +59,9 @@ def make_corpus(shape):
 
 def build_model(fx, device):
     """The product model initialised from a fixture's reference state_dict."""
-    from intel_sigir2023_amd.model import IntEL
+    from intel_sigir2023_amd import model as M
     args = make_args(fx.args, device)
-    model = IntEL(args, make_corpus(fx.shape))
+    model = getattr(M, fx.args.get('model_name', 'IntEL'))(args, make_corpus(fx.shape))
     missing = model.load_state_dict(fx.state_dict(), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model.to(device), args
