@@ -99,6 +99,15 @@ size_t attn_bwd_scratch_floats(int B, int T, int d, int heads);
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
                     int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st);
 
+// ---- one tower layer in one kernel (tower.hip) -------------------------------------------------
+// L <= 64, d in {64, 128}, head dim in {32, 64, 128}; INTEL_FUSE_TOWER=0 turns the fused path off
+bool tower_fused_supported(int L, int d, int heads);
+// W*_b3: bf16 three-plane images (launch_pack_b3) of the packed [d -> 3d] / [d -> d] / [d -> d] weights.  out may be NULL
+// (x-hat / rstd only); train = 0: none of the stash pointers is written.
+int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
+                           const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
+                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st);
+
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu
 int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,

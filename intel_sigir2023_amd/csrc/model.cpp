@@ -42,6 +42,7 @@ struct TowerBufs {
   float *QV, *QK, *XBAR, *ATTW;
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T;
   float* b3WqkvT;           // bf16 three-plane image of pWqkvT (K = 3d > 128: GEMM on the bf16 pipe)
+  float *b3Wqkv, *b3W1, *b3W2;   // images of the forward weights for the one-kernel tower layer (tower.hip)
   float *pXq, *pXqT, *pXk, *pXkT, *pXv, *pXvT;
   // --cross_attention 0
   float *MH, *MV, *pM0, *pM2, *pM2T, *pM0T;
@@ -147,6 +148,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     w.pW2 = ar.f(packed_floats(d, d));
     w.pWqkvT = ar.f(packed_floats(3 * rup(d, 16), d));
     w.b3WqkvT = ar.f(packed_b3_bytes(3 * rup(d, 16), d) / 4);
+    w.b3Wqkv = ar.f(packed_b3_bytes(d, 3 * d) / 4);
+    w.b3W1 = ar.f(packed_b3_bytes(d, d) / 4);
+    w.b3W2 = ar.f(packed_b3_bytes(d, d) / 4);
     w.pW1T = ar.f(packed_floats(d, d));
     w.pW2T = ar.f(packed_floats(d, d));
     if (D.cross_attention) {
@@ -517,6 +521,11 @@ void pack_all(Run& r) {
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
+    if (tower_fused_supported(y.L, w.d, D.heads)) {
+      RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
+      RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
+      RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
+    }
   }
   if (D.encoder == INTEL_ENC_BERT4REC) {
     for (int e = 0; e < 2; ++e) {
@@ -596,7 +605,16 @@ void tower_fwd(Run& r, TowerBufs& w) {
   const IntelDesc& D = r.D;
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
   const float* X = w.X0;
-  for (int l = 0; l < D.layers; ++l) {
+  // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
+  const bool fused = tower_fused_supported(L, d, D.heads) && !(r.train && r.ctx->drop_p > 0.f);
+  for (int l = 0; fused && l < D.layers; ++l) {
+    TowerLayerBufs& b = w.layer[l];
+    const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only
+    RUN(launch_tower_fwd_fused(X, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2, r.P(pb + T_B1), r.P(pb + T_B2), r.P(pb + T_LNG),
+                               r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, b.QKV, b.A, b.LSE, b.R1, b.XH, b.RSTD, r.st));
+    X = b.Xout;
+  }
+  for (int l = 0; !fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     GemmEpilogue e0;
     lin(r, X, d, M, d, w.pWqkv, 3 * d, b.QKV, 3 * d, e0);                       // q,k,v (bias=False, IntEL.py:60)

@@ -1,0 +1,471 @@
+// One tied tower layer of IntEL.predict_ensemble (models/IntEL/IntEL.py:182-188 / 191-197) as ONE kernel per layer:
+//
+//     res = h;  h = MHA(h, h, h)  (no mask, no output projection: modules/layers.py:31-60)
+//     h = W1 h + b1;  h = W2 relu(h) + b2;  h = LayerNorm(h + res)
+//
+// A workgroup owns one session at a time (persistent over sessions): the session's [L <= 64, D] tile is read from HBM
+// once and everything between the read and the LayerNorm output stays on chip --
+//
+//   phase 0  X tile global -> registers (prefetched during the previous session) -> three bf16 planes in LDS
+//   phase 1  [Q | K | V] = X Wqkv^T on the bf16 matrix pipe at fp32 accuracy (hi/mid/lo planes, six plane products, as
+//            gemm_rows_b3_kernel); weight fragments stream from the pre-split bf16 image in L2 (pack_b3), one k-block
+//            ahead of the MFMAs; the result goes to LDS as fp32 rows
+//   phase 2  softmax(Q K^T / sqrt(dk)) V per head in exact fp32 MFMA (v_mfma_f32_16x16x4_f32): wave = one 16-query tile
+//            of one head, S^T in accumulators, base-2 softmax, P^T fed to O^T = V^T P^T straight from registers;
+//            the attention output is split into the planes that phase 3 reads (the X planes are dead by then)
+//   phase 3  R1 = relu(A W1^T + b1) -> bf16 planes (over the dead K / V rows)
+//   phase 4  Z = R1 W2^T + b2 -> fp32 tile (over the dead Q rows)
+//   phase 5  LayerNorm(Z + X) row-wise (the residual rows come back from L2), output / x-hat / rstd to HBM
+//
+// HBM traffic per session and layer: the X tile in, the output tile out (inference); training adds the stash the
+// backward reads (QKV, A, LSE, R1, x-hat / rstd).  The kernel-per-op pipeline it replaces moved 14 tiles.
+// Padded rows (row >= L) are zero rows: their K / V rows are zero (the tower linears have no bias, IntEL.py:60,68) and
+// their keys are masked out of the softmax.
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 hh = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    h[i] = hh;
+    m[i] = mm;
+    l[i] = (__bf16)r2;
+  }
+}
+
+// six plane products of weight >= 2^-16 (hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid), smallest first
+__device__ __forceinline__ f32x4 mma6(const bf16x8& wh, const bf16x8& wm, const bf16x8& wl, const bf16x8& ah, const bf16x8& am,
+                                      const bf16x8& al, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, am, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, al, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ah, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, am, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, ah, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, c, 0, 0, 0);
+  return c;
+}
+
+// The weight images are the same for every session, so the compiler would hoist their fragment loads out of the session
+// loop and keep 240 registers of weights live (spilling everything else).  Laundering the base pointer once per session
+// keeps the loads where they are written: streamed from L2, one k-block ahead of their MFMAs.
+__device__ __forceinline__ const uint4* per_session(const uint4* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+__device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups sharing lane&15
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float gsum16(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+struct TowerFwdArgs {
+  const float* X;            // [B*L, D] layer input
+  int B, L, heads;
+  const uint4* Wqkv;         // pre-split bf16 images (pack_b3 layout, k extent padded to 128): [D -> 3D], [D -> D], [D -> D]
+  const uint4* W1;
+  const uint4* W2;
+  const float* b1; const float* b2; const float* gamma; const float* beta;
+  float* out;                // [B*L, D] or NULL (the caller rebuilds it from x-hat: fused tail)
+  float* QKV;                // training stash (each may be NULL): [B*L, 3D]
+  float* A;                  // [B*L, D] attention output
+  float* LSE;                // [B*heads*L] natural-log softmax normalisers
+  float* R1;                 // [B*L, D] relu(W1 A + b1)
+  float* XH;                 // [B*L, D] LayerNorm x-hat
+  float* RSTD;               // [B*L]
+};
+
+template <int D>
+struct TowerCfg {
+  static constexpr int NW = D / 16;              // waves: 8 (D = 128) or 4 (D = 64)
+  static constexpr int NT = NW * 64;
+  static constexpr int KB = D / 32;              // 32-deep k blocks
+  static constexpr int LDP = D + 8;              // bf16 plane pitch (16-byte fragment reads conflict-free)
+  static constexpr int PLANE = 64 * LDP;         // bf16 elements per plane
+  static constexpr int LQ = D + 4;               // fp32 row pitch of Q / K / V / the LayerNorm tile
+  static constexpr int NJ = 64 * (D / 4) / NT;   // float4 per thread per X tile (= 4)
+  static constexpr size_t P_BYTES = (size_t)3 * PLANE * 2;
+  static constexpr size_t R_BYTES = (size_t)3 * 64 * LQ * 4;
+  static constexpr size_t SMEM = P_BYTES + R_BYTES;
+};
+
+template <int D, int DK, bool TRAIN>
+__global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(TowerFwdArgs a) {      // two waves per SIMD: <= 256 registers
+  using C = TowerCfg<D>;
+  constexpr int NW = C::NW, NT = C::NT, KB = C::KB, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ;
+  constexpr int HEADS = D / DK, DKT = DK / 16;
+  constexpr int KBT = 4;                         // k blocks per column tile in the image (k padded to 128)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* planes = reinterpret_cast<__bf16*>(smem_raw);                 // P: X planes, later the attention-output planes
+  float* Qs = reinterpret_cast<float*>(smem_raw + C::P_BYTES);          // R: Q | K | V rows; later Es (over Q) and R1 planes (over K, V)
+  float* Ks = Qs + 64 * LQ;
+  float* Vs = Ks + 64 * LQ;
+  float* Es = Qs;
+  __bf16* r1planes = reinterpret_cast<__bf16*>(Ks);
+  const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L;
+  const float scale = 1.0f / sqrtf((float)DK);
+  const float c2 = scale * 1.4426950408889634f;
+
+  // X tile staging: float4 #i of the tile = (row i / (D/4), 4 * (i % (D/4)))
+  f32x4 pre[NJ];
+  int trow[NJ], tcol[NJ];
+#pragma unroll
+  for (int jj = 0; jj < NJ; ++jj) {
+    const int i = tid + NT * jj;
+    trow[jj] = i / (D / 4);
+    tcol[jj] = (i - trow[jj] * (D / 4)) * 4;
+  }
+  auto load_x = [&](int b) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int row = min(trow[jj], L - 1);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
+      pre[jj] = trow[jj] < L ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  int b = blockIdx.x;
+  if (b >= a.B) return;
+  load_x(b);
+  for (; b < a.B; b += gridDim.x) {
+    // ---- phase 0: X -> planes
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      bf16x4 h, m, l;
+      split4(pre[jj], h, m, l);
+      const int off = trow[jj] * LDP + tcol[jj];
+      *reinterpret_cast<bf16x4*>(planes + off) = h;
+      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+    }
+    __syncthreads();
+    // ---- phase 1: [Q | K | V] = X Wqkv^T; wave = column tiles 3 wave .. 3 wave + 2, all four row tiles
+    {
+      f32x4 acc[3][4];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint4* Bimg = per_session(a.Wqkv) + ((size_t)(3 * wave) * KBT * 3) * 64 + lane;
+      uint4 bw[2][3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bw[0][c][pl] = Bimg[((size_t)(c * KBT + 0) * 3 + pl) * 64];
+      const __bf16* frag = planes + p * LDP + 8 * j;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 1 < KB) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) bw[(kb + 1) & 1][c][pl] = Bimg[((size_t)(c * KBT + kb + 1) * 3 + pl) * 64];
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            acc[c][rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][1]),
+                              __builtin_bit_cast(bf16x8, bw[kb & 1][c][2]), ah, am, al, acc[c][rt]);
+        }
+      }
+      // epilogue: fp32 rows to LDS (Q | K | V side by side, heads side by side inside each); training: the q/k/v stash
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int n = (3 * wave + c) * 16 + 4 * j;           // column of [q | k | v]
+        const int which = n / D, col = n - which * D;
+        float* dst = Qs + which * 64 * LQ + col;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = rt * 16 + p;
+          *reinterpret_cast<f32x4*>(dst + row * LQ) = acc[c][rt];
+          if (TRAIN && a.QKV && row < L) *reinterpret_cast<f32x4*>(a.QKV + ((size_t)b * L + row) * (3 * D) + n) = acc[c][rt];
+        }
+      }
+    }
+    // the next session's rows travel while this one is computed
+    if (b + (int)gridDim.x < a.B) load_x(b + gridDim.x);
+    __syncthreads();
+    // ---- phase 2: attention; (query tile, head) pairs over the waves
+    for (int pair = wave; pair < 4 * HEADS; pair += NW) {
+      const int tile = pair & 3, h = pair >> 2;
+      if (tile * 16 >= L) continue;                          // wave-uniform: a tile of padding only
+      const float* Qp = Qs + (tile * 16 + p) * LQ + h * DK + 4 * j;
+      const float* Kp = Ks + p * LQ + h * DK + 4 * j;
+      f32x4 st[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < DKT; ++g) {
+        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qp + 16 * g);
+        f32x4 kf[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const f32x4*>(Kp + kt * 16 * LQ + 16 * g);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) st[kt] = mfma16(kf[kt][s], qf[s], st[kt]);
+      }
+      // accumulator register r of tile kt at lane (j, p) = key kt*16 + 4j + r, query tile*16 + p
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (kt * 16 + 4 * j + r) < L ? st[kt][r] : -INFINITY;
+          st[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = gmax16(mx);
+      const float moff = -mx * c2;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], c2, moff));
+          st[kt][r] = e;
+          ps += e;
+        }
+      ps = gsum16(ps);
+      const float inv = 1.f / ps;                            // L >= 1: at least one live key
+      const int q = tile * 16 + p;
+      if constexpr (DK >= 64) {
+        // V read as one b128 along the head dim: lane p takes dims 4p .. 4p+3 of its key row and feeds four MFMAs whose
+        // output row i means dim 4 i + t
+        constexpr int DQ = DK >= 64 ? DK / 64 : 1;
+        f32x4 oT[DQ * 4];
+#pragma unroll
+        for (int i = 0; i < DQ * 4; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Vp = Vs + (4 * j) * LQ + h * DK + 4 * p;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int dq = 0; dq < DQ; ++dq) {
+              const f32x4 vv = *reinterpret_cast<const f32x4*>(Vp + (kt * 16 + r) * LQ + dq * 64);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = mfma16(vv[t], st[kt][r], oT[dq * 4 + t]);
+            }
+          }
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 o = f32x4{oT[dq * 4 + 0][r], oT[dq * 4 + 1][r], oT[dq * 4 + 2][r], oT[dq * 4 + 3][r]} * inv;
+            const int col = h * DK + dq * 64 + 16 * j + 4 * r;
+            bf16x4 hh, mm, ll;
+            split4(o, hh, mm, ll);
+            const int off = q * LDP + col;
+            *reinterpret_cast<bf16x4*>(planes + off) = hh;
+            *reinterpret_cast<bf16x4*>(planes + PLANE + off) = mm;
+            *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = ll;
+            if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
+          }
+      } else {
+        // narrow heads (dk = 32): two output tiles of 16 dims, V read as scalars (lane p = dim, j = key of the k-step)
+        f32x4 oT[2];
+        oT[0] = oT[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Vp = Vs + (4 * j) * LQ + h * DK + p;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) oT[t] = mfma16(Vp[(kt * 16 + r) * LQ + t * 16], st[kt][r], oT[t]);
+          }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 o = oT[t] * inv;                       // register r = dim t*16 + 4j + r of query p
+          const int col = h * DK + t * 16 + 4 * j;
+          bf16x4 hh, mm, ll;
+          split4(o, hh, mm, ll);
+          const int off = q * LDP + col;
+          *reinterpret_cast<bf16x4*>(planes + off) = hh;
+          *reinterpret_cast<bf16x4*>(planes + PLANE + off) = mm;
+          *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = ll;
+          if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
+        }
+      }
+      if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);
+    }
+    // query tiles of padding only were skipped above: their planes still hold X (rows >= L are zero there already)
+    __syncthreads();
+    // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint4* Bimg = per_session(a.W1) + ((size_t)wave * KBT * 3) * 64 + lane;
+      uint4 bw[KB][3];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+      const __bf16* frag = planes + p * LDP + 8 * j;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb][0]), __builtin_bit_cast(bf16x8, bw[kb][1]), __builtin_bit_cast(bf16x8, bw[kb][2]),
+                         ah, am, al, acc[rt]);
+        }
+      const int col = wave * 16 + 4 * j;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + col);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int row = rt * 16 + p;
+        f32x4 x = acc[rt] + bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+        bf16x4 hh, mm, ll;
+        split4(x, hh, mm, ll);
+        const int off = row * LDP + col;
+        *reinterpret_cast<bf16x4*>(r1planes + off) = hh;
+        *reinterpret_cast<bf16x4*>(r1planes + PLANE + off) = mm;
+        *reinterpret_cast<bf16x4*>(r1planes + 2 * PLANE + off) = ll;
+        if (TRAIN && a.R1 && row < L) *reinterpret_cast<f32x4*>(a.R1 + ((size_t)b * L + row) * D + col) = x;
+      }
+    }
+    __syncthreads();
+    // ---- phase 4: Z = R1 W2^T + b2 -> fp32 tile
+    {
+      f32x4 acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
+      uint4 bw[KB][3];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+      const __bf16* frag = r1planes + p * LDP + 8 * j;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+          const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb][0]), __builtin_bit_cast(bf16x8, bw[kb][1]), __builtin_bit_cast(bf16x8, bw[kb][2]),
+                         ah, am, al, acc[rt]);
+        }
+      const int col = wave * 16 + 4 * j;
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b2 + col);
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[rt] + bias;
+    }
+    __syncthreads();
+    // ---- phase 5: LayerNorm(Z + X) over the D columns; wave = 64 / NW rows, lane = columns lane (and lane + 64)
+    {
+      constexpr int RPW = 64 / NW, CPL = D / 64;
+      float res[RPW][CPL];
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = min(wave * RPW + rr, L - 1);
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
+      }
+      float g[CPL], be[CPL];
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) { g[cc] = a.gamma[lane + 64 * cc]; be[cc] = a.beta[lane + 64 * cc]; }
+      const float inv_n = 1.f / (float)D;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
+        if (row >= L) break;                                // wave-uniform
+        float v[CPL], s = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) { v[cc] = Es[row * LQ + lane + 64 * cc] + res[rr][cc]; s += v[cc]; }
+        const float mean = wave_sum(s) * inv_n;
+        float q2 = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) { v[cc] -= mean; q2 += v[cc] * v[cc]; }
+        const float rs = 1.f / sqrtf(wave_sum(q2) * inv_n + 1e-5f);
+        const size_t grow = (size_t)b * L + row;
+        if (TRAIN && a.RSTD && lane == 0) a.RSTD[grow] = rs;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) {
+          const float xh = v[cc] * rs;
+          if (TRAIN && a.XH) a.XH[grow * D + lane + 64 * cc] = xh;
+          if (a.out) a.out[grow * D + lane + 64 * cc] = xh * g[cc] + be[cc];
+        }
+      }
+    }
+    // the next iteration's phase 0 writes the X planes (last read in phase 3) and its first barrier orders the
+    // LayerNorm reads of Es before the next q/k/v rows are stored over them
+  }
+}
+
+int fused_enabled() {
+  static const int on = [] { const char* e = getenv("INTEL_FUSE_TOWER"); return (e && e[0] == '0') ? 0 : 1; }();
+  return on;
+}
+
+template <int D, int DK, bool TRAIN>
+int launch_one(const TowerFwdArgs& a, hipStream_t st) {
+  using C = TowerCfg<D>;
+  const size_t smem = C::SMEM;
+  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN>), smem);
+  const int per_cu = smem <= 80 * 1024 ? 2 : 1;
+  int grid = num_cus() * per_cu;
+  if (grid > a.B) grid = a.B;
+  const double M = (double)a.B * a.L;
+  // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
+  const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
+  double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
+  if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0) + (a.XH ? 1.0 : 0.0));
+  LAUNCH_W(flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN>), dim3(grid), dim3(C::NT), smem, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+bool tower_fused_supported(int L, int d, int heads) {
+  if (!fused_enabled()) return false;
+  if (L < 1 || L > 64 || heads < 1 || d % heads != 0) return false;
+  const int dk = d / heads;
+  return (d == 128 && (dk == 128 || dk == 64)) || (d == 64 && (dk == 64 || dk == 32));
+}
+
+int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
+                           const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
+                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(tower_fused_supported(L, d, heads), "tower_fwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
+  TowerFwdArgs a;
+  a.X = X; a.B = B; a.L = L; a.heads = heads;
+  a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3); a.W2 = reinterpret_cast<const uint4*>(W2_b3);
+  a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+  a.QKV = QKV; a.A = A; a.LSE = LSE; a.R1 = R1; a.XH = XH; a.RSTD = RSTD;
+  const int dk = d / heads;
+  if (d == 128 && dk == 128) return train ? launch_one<128, 128, true>(a, st) : launch_one<128, 128, false>(a, st);
+  if (d == 128 && dk == 64) return train ? launch_one<128, 64, true>(a, st) : launch_one<128, 64, false>(a, st);
+  if (d == 64 && dk == 64) return train ? launch_one<64, 64, true>(a, st) : launch_one<64, 64, false>(a, st);
+  return train ? launch_one<64, 32, true>(a, st) : launch_one<64, 32, false>(a, st);
+}
