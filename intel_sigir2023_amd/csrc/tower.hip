@@ -63,6 +63,14 @@ __device__ __forceinline__ const uint4* per_session(const uint4* p) {
   return p;
 }
 
+// The weight images are the same for every session, so the compiler would hoist their fragment loads out of the session
+// loop and keep 240 registers of weights live (spilling everything else).  Laundering the base pointer once per session
+// keeps the loads where they are written: streamed from L2, ahead of their MFMAs.
+__device__ __forceinline__ const uint4* per_session(const uint4* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 __device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16));
   return fmaxf(v, __shfl_xor(v, 32));
