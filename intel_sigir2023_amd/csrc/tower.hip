@@ -21,6 +21,7 @@
 // backward reads (QKV, A, LSE, R1, x-hat / rstd).  The kernel-per-op pipeline it replaces moved 14 tiles.
 // Padded rows (row >= L) are zero rows: their K / V rows are zero (the tower linears have no bias, IntEL.py:60,68) and
 // their keys are masked out of the softmax.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -63,14 +64,6 @@ __device__ __forceinline__ const uint4* per_session(const uint4* p) {
   return p;
 }
 
-// The weight images are the same for every session, so the compiler would hoist their fragment loads out of the session
-// loop and keep 240 registers of weights live (spilling everything else).  Laundering the base pointer once per session
-// keeps the loads where they are written: streamed from L2, ahead of their MFMAs.
-__device__ __forceinline__ const uint4* per_session(const uint4* p) {
-  asm volatile("" : "+s"(p));
-  return p;
-}
-
 __device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16));
   return fmaxf(v, __shfl_xor(v, 32));
@@ -78,6 +71,22 @@ __device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups s
 __device__ __forceinline__ float gsum16(float v) {
   v += __shfl_xor(v, 16);
   return v + __shfl_xor(v, 32);
+}
+
+// sum over the 64 lanes without the LDS crossbar: four DPP steps give every lane its 16-lane row's sum (quad_perm 1,0,3,2 /
+// 2,3,0,1, row_half_mirror, row_mirror), four v_readlane gather the rows.  (__shfl_xor is ds_bpermute: ~100 cycles a step)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_mov<0xB1>(v);
+  v += dpp_mov<0x4E>(v);
+  v += dpp_mov<0x141>(v);
+  v += dpp_mov<0x140>(v);
+  const int iv = __builtin_bit_cast(int, v);
+  return (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16))) +
+         (__builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48)));
 }
 
 struct TowerFwdArgs {
@@ -94,6 +103,7 @@ struct TowerFwdArgs {
   float* R1;                 // [B*L, D] relu(W1 A + b1)
   float* XH;                 // [B*L, D] LayerNorm x-hat
   float* RSTD;               // [B*L]
+  unsigned long long* dbg;   // INTEL_TOWER_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
 };
 
 template <int D>
@@ -149,6 +159,16 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
   int b = blockIdx.x;
   if (b >= a.B) return;
   load_x(b);
+  unsigned long long tstamp = 0;
+  const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int ph) {
+    if (probe) {
+      const unsigned long long now = clock64();
+      if (ph >= 0) a.dbg[ph] += now - tstamp;
+      tstamp = now;
+    }
+  };
+  mark(-1);
   for (; b < a.B; b += gridDim.x) {
     // ---- phase 0: X -> planes
 #pragma unroll
@@ -161,6 +181,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
     }
     __syncthreads();
+    mark(0);
     // ---- phase 1: [Q | K | V] = X Wqkv^T; wave = column tiles 3 wave .. 3 wave + 2, all four row tiles
     {
       f32x4 acc[3][4];
@@ -211,8 +232,18 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     }
     // the next session's rows travel while this one is computed
     if (b + (int)gridDim.x < a.B) load_x(b + gridDim.x);
+    mark(1);
     __syncthreads();
-    // ---- phase 2: attention; (query tile, head) pairs over the waves
+    mark(6);
+    // ---- phase 2: attention; (query tile, head) pairs over the waves.  The W1 fragments of phase 3 travel meanwhile.
+    uint4 bw1[KB][3];
+    {
+      const uint4* Bimg = per_session(a.W1) + ((size_t)wave * KBT * 3) * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bw1[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+    }
     for (int pair = wave; pair < 4 * HEADS; pair += NW) {
       const int tile = pair & 3, h = pair >> 2;
       if (tile * 16 >= L) continue;                          // wave-uniform: a tile of padding only
@@ -317,18 +348,22 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);
     }
     // query tiles of padding only were skipped above: their planes still hold X (rows >= L are zero there already)
+    mark(2);
     __syncthreads();
-    // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles
+    mark(7);
+    // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles (the W2 fragments of phase 4 travel meanwhile)
+    uint4 bw2[KB][3];
+    {
+      const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bw2[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+    }
     {
       f32x4 acc[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const uint4* Bimg = per_session(a.W1) + ((size_t)wave * KBT * 3) * 64 + lane;
-      uint4 bw[KB][3];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
       const __bf16* frag = planes + p * LDP + 8 * j;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
-          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb][0]), __builtin_bit_cast(bf16x8, bw[kb][1]), __builtin_bit_cast(bf16x8, bw[kb][2]),
+          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw1[kb][0]), __builtin_bit_cast(bf16x8, bw1[kb][1]), __builtin_bit_cast(bf16x8, bw1[kb][2]),
                          ah, am, al, acc[rt]);
         }
       const int col = wave * 16 + 4 * j;
@@ -359,17 +394,12 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       }
     }
     __syncthreads();
+    mark(3);
     // ---- phase 4: Z = R1 W2^T + b2 -> fp32 tile
     {
       f32x4 acc[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
-      uint4 bw[KB][3];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
       const __bf16* frag = r1planes + p * LDP + 8 * j;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
@@ -379,7 +409,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
-          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb][0]), __builtin_bit_cast(bf16x8, bw[kb][1]), __builtin_bit_cast(bf16x8, bw[kb][2]),
+          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw2[kb][0]), __builtin_bit_cast(bf16x8, bw2[kb][1]), __builtin_bit_cast(bf16x8, bw2[kb][2]),
                          ah, am, al, acc[rt]);
         }
       const int col = wave * 16 + 4 * j;
@@ -388,6 +418,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[rt] + bias;
     }
     __syncthreads();
+    mark(4);
     // ---- phase 5: LayerNorm(Z + X) over the D columns; wave = 64 / NW rows, lane = columns lane (and lane + 64)
     {
       constexpr int RPW = 64 / NW, CPL = D / 64;
@@ -402,28 +433,43 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) { g[cc] = a.gamma[lane + 64 * cc]; be[cc] = a.beta[lane + 64 * cc]; }
       const float inv_n = 1.f / (float)D;
+      // all rows of the wave advance together: the reductions of different rows are independent and overlap
+      float v[RPW][CPL], mean[RPW], rs[RPW];
 #pragma unroll
       for (int rr = 0; rr < RPW; ++rr) {
         const int row = wave * RPW + rr;
-        if (row >= L) break;                                // wave-uniform
-        float v[CPL], s = 0.f;
+        float s = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) { v[cc] = Es[row * LQ + lane + 64 * cc] + res[rr][cc]; s += v[cc]; }
-        const float mean = wave_sum(s) * inv_n;
+        for (int cc = 0; cc < CPL; ++cc) { v[rr][cc] = Es[row * LQ + lane + 64 * cc] + res[rr][cc]; s += v[rr][cc]; }
+        mean[rr] = s;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) mean[rr] = wave_sum_dpp(mean[rr]) * inv_n;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
         float q2 = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) { v[cc] -= mean; q2 += v[cc] * v[cc]; }
-        const float rs = 1.f / sqrtf(wave_sum(q2) * inv_n + 1e-5f);
-        const size_t grow = (size_t)b * L + row;
-        if (TRAIN && a.RSTD && lane == 0) a.RSTD[grow] = rs;
+        for (int cc = 0; cc < CPL; ++cc) { v[rr][cc] -= mean[rr]; q2 += v[rr][cc] * v[rr][cc]; }
+        rs[rr] = q2;
+      }
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) {
-          const float xh = v[cc] * rs;
-          if (TRAIN && a.XH) a.XH[grow * D + lane + 64 * cc] = xh;
-          if (a.out) a.out[grow * D + lane + 64 * cc] = xh * g[cc] + be[cc];
+      for (int rr = 0; rr < RPW; ++rr) rs[rr] = 1.f / sqrtf(wave_sum_dpp(rs[rr]) * inv_n + 1e-5f);
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
+        if (row < L) {                                      // wave-uniform
+          const size_t grow = (size_t)b * L + row;
+          if (TRAIN && a.RSTD && lane == 0) a.RSTD[grow] = rs[rr];
+#pragma unroll
+          for (int cc = 0; cc < CPL; ++cc) {
+            const float xh = v[rr][cc] * rs[rr];
+            if (TRAIN && a.XH) a.XH[grow * D + lane + 64 * cc] = xh;
+            if (a.out) a.out[grow * D + lane + 64 * cc] = xh * g[cc] + be[cc];
+          }
         }
       }
     }
+    mark(5);
     // the next iteration's phase 0 writes the X planes (last read in phase 3) and its first barrier orders the
     // LayerNorm reads of Es before the next q/k/v rows are stored over them
   }
@@ -447,8 +493,24 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
   if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0) + (a.XH ? 1.0 : 0.0));
-  LAUNCH_W(flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN>), dim3(grid), dim3(C::NT), smem, st, a);
+  static const int dbg_on = [] { const char* e = getenv("INTEL_TOWER_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  TowerFwdArgs aa = a;
+  static unsigned long long* dbg_buf = nullptr;
+  if (dbg_on) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_buf, 0, 8 * sizeof(unsigned long long), st);
+    aa.dbg = dbg_buf;
+  }
+  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN>), dim3(grid), dim3(C::NT), smem, st, aa);
   INTEL_CHECK_LAUNCH();
+  if (dbg_on) {          // tools/tower_probe.py
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const int iters = (a.B + grid - 1) / grid;
+    fprintf(stderr, "tower_fwd D=%d dk=%d train=%d grid=%d iters=%d  cycles/session: p0 %llu  qkv %llu (+bar %llu)  attn %llu (+bar %llu)  w1 %llu  w2 %llu  ln %llu\n",
+            D, DK, (int)TRAIN, grid, iters, h[0] / iters, h[1] / iters, h[6] / iters, h[2] / iters, h[7] / iters, h[3] / iters, h[4] / iters, h[5] / iters);
+  }
   return 0;
 }
 
@@ -470,7 +532,7 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
   a.X = X; a.B = B; a.L = L; a.heads = heads;
   a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3); a.W2 = reinterpret_cast<const uint4*>(W2_b3);
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
-  a.QKV = QKV; a.A = A; a.LSE = LSE; a.R1 = R1; a.XH = XH; a.RSTD = RSTD;
+  a.QKV = QKV; a.A = A; a.LSE = LSE; a.R1 = R1; a.XH = XH; a.RSTD = RSTD; a.dbg = nullptr;
   const int dk = d / heads;
   if (d == 128 && dk == 128) return train ? launch_one<128, 128, true>(a, st) : launch_one<128, 128, false>(a, st);
   if (d == 128 && dk == 64) return train ? launch_one<128, 64, true>(a, st) : launch_one<128, 64, false>(a, st);
