@@ -21,6 +21,7 @@ HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15      # FLOP/s dense bf16 MFMA
 B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel')
+FUSED_KERNELS = ('tower_fwd_fused_kernel',)
 MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
                 'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_kv_kernel',
                 'attn_seq_bwd_q_kernel')
@@ -70,49 +71,111 @@ def algorithmic_bytes_per_session(flags, corpus, shape, train, e=4):
 
 
 def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
-    """The oracle (CPU restatement, kind='port') timed on this host: full training step on a bounded
-    sample (B=512 sessions per step, same synthetic generator), ~budget_s seconds of CPU work."""
+    """The oracle (CPU restatement, kind='port') timed on this host's cores on a bounded sample of the same synthetic
+    workload: B = 512 and B = 4096 sessions per step, each split into forward + loss / + backward / full
+    training step (forward, loss, autograd, torch Adam -- the dense Adam sweep over the 1 M-row table dominates).
+    `value` = full-step sessions/s at B = 512 (the published scripts' batch size)."""
     import torch
     from intel_sigir2023_amd import synth
     from intel_sigir2023_amd.model import IntEL
     from oracle import intel_oracle as O
     torch.manual_seed(0)
     cpu = torch.device('cpu')
-    B = 512
     flags = {k: v for k, v in vars(args_ns).items() if k != 'device'}
     cfg = O.Config(**flags)
-    # parameters with the product's default init (CPU copy)
     a = argparse.Namespace(**vars(args_ns))
     a.device = cpu
     m = IntEL(a, corpus)
     sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
     del m
-    batch = synth.to_reference_layout(synth.make_batch(workload, B, cpu, seed=99), cinfo['I'])
     opt = torch.optim.Adam(O.adam_groups(list(sd.items()), 1e-4), lr=1e-3)
 
-    def step():
-        opt.zero_grad()
+    def loss_of(batch, B):
         out = O.forward(sd, batch, cfg)
         if 'BPR' in loss_name:
             noise = torch.rand(B, batch['i_id_s'].shape[1], batch['i_id_s'].shape[1])
-            loss, _, _ = O.int_bpr_loss(out, batch, cfg, noise)
-        else:
-            loss, _, _ = O.int_list_loss(out, batch, cfg)
+            return O.int_bpr_loss(out, batch, cfg, noise)[0]
+        return O.int_list_loss(out, batch, cfg)[0]
+
+    def stage(batch, B, kind):
+        if kind == 'fwd_loss':
+            with torch.no_grad():
+                return float(loss_of(batch, B))
+        opt.zero_grad()
+        loss = loss_of(batch, B)
         loss.backward()
-        opt.step()
+        if kind == 'full_step':
+            opt.step()
         return float(loss.detach())
-    step()                                  # warm-up (allocations, lazy init)
-    t0 = time.perf_counter()
-    n = 0
-    while True:
-        step()
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or n >= 50:
-            break
-    return {'value': round(B * n / el, 2), 'unit': 'sessions/s', 'cores': int(torch.get_num_threads()), 'kind': 'port',
-            'sample': '%d training steps of B=%d synthetic %s sessions (oracle/intel_oracle.py: fwd+loss+autograd+torch Adam), %.1f s'
-                      % (n, B, workload, el)}
+
+    def timed(batch, B, kind, budget, max_n):
+        stage(batch, B, kind)                  # warm-up (allocations, lazy init)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            stage(batch, B, kind)
+            n += 1
+            el = time.perf_counter() - t0
+            if el >= budget or n >= max_n:
+                return n, el
+    stages, total = {}, 0.0
+    for B, share, max_n in ((512, 0.5, 40), (4096, 0.5, 6)):
+        batch = synth.to_reference_layout(synth.make_batch(workload, B, cpu, seed=99), cinfo['I'])
+        st = {}
+        for kind, frac in (('fwd_loss', 0.2), ('fwd_loss_bwd', 0.3), ('full_step', 0.5)):
+            n, el = timed(batch, B, kind, budget_s * share * frac, max_n)
+            st[kind] = {'sessions_per_s': round(B * n / el, 2), 'ms_per_step': round(1e3 * el / n, 1), 'steps': n}
+            total += el
+        stages['B%d' % B] = st
+    return {'value': stages['B512']['full_step']['sessions_per_s'], 'unit': 'sessions/s', 'cores': int(torch.get_num_threads()),
+            'kind': 'port', 'stages': stages,
+            'sample': 'oracle/intel_oracle.py on synthetic %s sessions: B=512 and B=4096 per step, each timed as forward+loss, '
+                      '+autograd backward, full step with torch Adam (%d / %d timed full steps), %.1f s of CPU work in total; '
+                      'value = full step at B=512' % (workload, stages['B512']['full_step']['steps'],
+                                                      stages['B4096']['full_step']['steps'], total)}
+
+
+def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_shape):
+    """`roofline` object for the kernel with the largest total time among the profiled launches: achieved = algorithmic bytes
+    (or flops) / launch duration (HIP events on the launch stream), traffic = HBM bytes per launch from the committed PMC passes."""
+    prof = {}                       # aggregate the shape-tagged records by kernel
+    for k, v in prof_shapes.items():
+        d = prof.setdefault(k.split('[')[0].strip('()').split('<')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        for f in d:
+            d[f] += v[f]
+    tot = sum(v['ms'] for v in prof.values())
+    name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
+    avg_ms = dom['ms'] / dom['launches']
+    if name in B3_KERNELS:
+        # fp32-accurate products on the bf16 pipe (three-plane split, 6 bf16 MFMAs per fp32 product): the matrix pipe is
+        # far from its 2.5 PFLOP/s roof (reported as `bf16_mfma_frac`); the binding roof is HBM
+        ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(ach / (HBM_PEAK / 1e9), 5),
+                'traffic': None, 'bf16_mfma_frac': round(6.0 * dom['flops'] / (dom['ms'] * 1e-3) / BF16_MFMA_PEAK, 5),
+                'fp32_equivalent_TFLOPs': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
+    elif name in MFMA_KERNELS:
+        ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': round(ach / (F32_MFMA_PEAK / 1e12), 5), 'traffic': None}
+    elif name in FUSED_KERNELS:
+        # the one-kernel tower layer: six bf16 plane products per linear + exact fp32-MFMA attention; priced against the
+        # dense bf16 MFMA peak with the six-fold plane work counted (the HBM side is reported next to it)
+        eq = 6.0 * dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(eq, 2), 'peak': BF16_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
+                'frac': round(eq / (BF16_MFMA_PEAK / 1e12), 5), 'traffic': None,
+                'fp32_equivalent_TFLOPs': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2),
+                'hbm_GBps': round(dom['bytes'] / (dom['ms'] * 1e-3) / 1e9, 1)}
+    else:
+        ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+        roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                'frac': round(ach / (HBM_PEAK / 1e9), 5), 'traffic': None}
+    if pmc_kernels and name in pmc_kernels and exact_shape:
+        roof['traffic'] = pmc_kernels[name]['hbm_bytes_per_launch']
+        roof['traffic_source'] = pmc_source
+    roof.update({'kernel': name, 'launches_per_step': dom['launches'] / psteps, 'avg_launch_ms': round(avg_ms, 5),
+                 'share_of_kernel_time': round(dom['ms'] / tot, 4),
+                 'algorithmic_per_launch': (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches']})
+    return roof, prof
 
 
 def main():
@@ -120,15 +183,17 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', type=str, default='tmall', help='tmall | lifedata | stress | tiny')
-    ap.add_argument('--batch', type=int, default=4096, help='sessions per GPU per step (weak scaling)')
+    ap.add_argument('--workload', type=str, default='tmall', help='tmall | tmall_pub | lifedata | stress | tiny')
+    ap.add_argument('--batch', type=int, default=0, help='sessions per GPU per step (weak scaling); 0: 4096, or 512 for tmall_pub')
     ap.add_argument('--loss', type=str, default='IntBPRloss')
-    ap.add_argument('--cal_diversity', type=int, default=0)
+    ap.add_argument('--cal_diversity', type=int, default=-1, help='-1: the workload default')
     ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
+    ap.add_argument('--dtype', type=str, default='f32', help='f32: the parity mode (headline); bf16: single bf16 product per linear')
+    ap.add_argument('--nbatches', type=int, default=8, help='distinct resident batches cycled by the timed loop')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
-    ap.add_argument('--cpu_budget', type=float, default=20.0)
+    ap.add_argument('--cpu_budget', type=float, default=24.0)
     ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
     ap.add_argument('--encoder', type=str, default='', help='override the sequence encoder: BERT4Rec | GRU4Rec')
     a = ap.parse_args()
@@ -146,18 +211,29 @@ def main():
     torch.cuda.set_device(dev)
     _lib.lib()
     w = synth.WORKLOADS[a.workload]
-    over = dict(cal_diversity=a.cal_diversity)
+    over = {}
+    if a.cal_diversity >= 0:
+        over['cal_diversity'] = a.cal_diversity
     if a.encoder:
         over['encoder'] = a.encoder
+    if a.dtype != 'f32':
+        over['dtype'] = a.dtype
     args_ns = synth.make_args(a.workload, dev, **over)
     corpus, cinfo = synth.make_corpus(a.workload)
     torch.manual_seed(0)
     model = IntEL(args_ns, corpus).to(dev)
-    eng = IntELEngine(model, a.loss, args_ns, lr=1e-3, l2=1e-4)
+    lr, l2 = w.get('optim', (1e-3, 1e-4))
+    eng = IntELEngine(model, a.loss, args_ns, lr=lr, l2=l2)
     parallel.broadcast_(eng.param_buckets())
-    B = a.batch
-    nbatches = 2
+    B = a.batch or w.get('bench_batch', 4096)
+    # distinct resident batches (inputs in HBM before the timed region): 8 x 73 MB of gathered item rows at the headline shape,
+    # so the embedding gather is not served by the 256 MB Infinity Cache from one step to the next.  The reference-layout ->
+    # ABI narrowing (model.prepare_batch: a no-op for the feed's int32 / fp32 batches) happens once per batch, here
+    nbatches = max(1, a.nbatches)
     batches = [synth.make_batch(a.workload, B, dev, seed=rank * 1000 + i, zipf=bool(a.zipf)) for i in range(nbatches)]
+    for bt in batches:
+        bt['_intel'] = model.prepare_batch(bt)
+        bt['_intel'][1]['ranking_i32'] = bt['ranking']
     Lmax = w['batch']['L']
 
     def one_step(i):
@@ -178,6 +254,9 @@ def main():
     last_loss = float(loss[0])
 
     # ---- eval throughput (forward + on-device NDCG@3), not part of `value`
+    model.eval()
+    for i in range(2):
+        eng.eval_step(batches[i % nbatches], k=3)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     ev_steps = max(3, a.steps // 2)
@@ -186,9 +265,10 @@ def main():
     torch.cuda.synchronize()
     ev_el = parallel.allreduce_max_float(time.perf_counter() - t1, dev)
     ndcg3 = float(nd.float().nan_to_num(0).mean())
+    model.train()
 
     # ---- per-kernel profile: EVERY rank runs the same extra steps (they contain the gradient all-reduce)
-    prof_shapes, psteps = None, 3
+    prof_shapes, prof_eval, psteps = None, None, 3
     if not a.no_roofline:
         lib = _lib.lib()
         lib.intel_set_concurrency(model._context(), 0)     # price kernels one at a time on one stream
@@ -197,22 +277,33 @@ def main():
         for i in range(psteps):
             one_step(i)
         prof_shapes = json.loads(lib.intel_prof_collect().decode())
+        model.eval()
+        for i in range(psteps):
+            eng.eval_step(batches[i % nbatches], k=3)
+        prof_eval = json.loads(lib.intel_prof_collect().decode())
+        model.train()
         lib.intel_prof_enable(0)
         eng.overlap_table_update = ov
         lib.intel_set_concurrency(model._context(), 1)
     if rank != 0:
         return
+    f = w['flags']
+    bf16 = a.dtype == 'bf16'
+    arith = ('bf16 arithmetic: every linear / weight gradient is ONE bf16 MFMA product (operands rounded to bf16, fp32 accumulate); fp32 master '
+             'weights, Adam moments, residual / LayerNorm / softmax; gated by NDCG@3 against the fp32 build (tests/test_bf16_gpu.py)') if bf16 else \
+            ('fp32 storage and accumulation; the large products run as three-plane bf16 splits (hi+mid+lo, six plane products) on the bf16 '
+             'MFMA pipe = fp32 accuracy, same parity thresholds as the fp32-MFMA kernels')
     res = {
-        'metric': 'train sessions/sec, IntEL fwd+BPR loss+bwd+Adam, synthetic Tmall-shape list=%d K=%d d=64' % (Lmax, w['flags']['model_num']),
+        'metric': 'train sessions/sec, IntEL fwd+BPR loss+bwd+Adam, synthetic Tmall-shape list=%d K=%d d=64' % (Lmax, f['model_num']),
         'value': round(world * B * a.steps / el, 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(1e3 * el / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, d=64, fp32, %s loss, cal_diversity=%d, %s item ids'
-                               % (a.workload + ('/' + a.encoder if a.encoder else ''), cinfo['items'], Lmax, w['flags']['model_num'], cinfo['I'], w['batch']['H'], a.loss,
-                                  a.cal_diversity, 'zipf' if a.zipf else 'uniform'),
-                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world,
-                   'arithmetic': 'fp32 storage and accumulation; the large products run as three-plane bf16 splits (hi+mid+lo, six plane '
-                                 'products) on the bf16 MFMA pipe = fp32 accuracy, same parity thresholds as the fp32-MFMA kernels'},
+        'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, emb %d/%d/%d/%d (id/meta/score/ctx), %s, %d heads x %d tied '
+                               'layers, %s, %s loss, cal_diversity=%d, %s item ids, %d resident batches'
+                               % (a.workload, cinfo['items'], Lmax, f['model_num'], cinfo['I'], w['batch']['H'], f['i_emb_size'], f['im_emb_size'],
+                                  f['s_emb_size'], f['context_emb_size'], args_ns.encoder, f['num_heads'], f['num_layers'], a.dtype, a.loss,
+                                  int(args_ns.cal_diversity), 'zipf(1.05)' if a.zipf else 'uniform', nbatches),
+                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'arithmetic': arith},
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
     }
@@ -222,42 +313,22 @@ def main():
     res['gather_roofline'] = {'bytes_per_session': bytes_train, 'achieved_GBps': round(bytes_train * res['value'] / world / 1e9, 3),
                               'peak_GBps': HBM_PEAK / 1e9, 'frac': round(bytes_train * res['value'] / world / HBM_PEAK, 6)}
     if prof_shapes is not None:
-        prof = {}                       # aggregate the shape-tagged GEMM records by kernel
-        for k, v in prof_shapes.items():
-            d = prof.setdefault(k.split('[')[0].strip('()').split('<')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
-            for f in d:
-                d[f] += v[f]
-        tot = sum(v['ms'] for v in prof.values())
-        name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
-        avg_ms = dom['ms'] / dom['launches']
-        if name in B3_KERNELS:
-            # fp32-accurate products on the bf16 pipe (three-plane split, 6 bf16 MFMAs per fp32 product): the matrix pipe is
-            # far from its 2.5 PFLOP/s roof (reported as `bf16_mfma_frac`); the binding roof is HBM
-            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(ach / (HBM_PEAK / 1e9), 5),
-                    'traffic': None, 'bf16_mfma_frac': round(6.0 * dom['flops'] / (dom['ms'] * 1e-3) / BF16_MFMA_PEAK, 5),
-                    'fp32_equivalent_TFLOPs': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
-        elif name in MFMA_KERNELS:
-            ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
-                    'frac': round(ach / (F32_MFMA_PEAK / 1e12), 5), 'traffic': None}
-        else:
-            ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-            roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': round(ach / (HBM_PEAK / 1e9), 5), 'traffic': None}
-        # HBM traffic of the same kernel from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))['kernels']
-            key = name
-            if key in pmc and a.workload == 'tmall' and B == 4096:
-                roof['traffic'] = pmc[key]['hbm_bytes_per_launch']
-                roof['traffic_source'] = 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH x2 on gfx950), bytes per launch'
+        pmc, pmc_eval, src = None, None, None
+        try:        # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
+            src = 'profiles/r02_pmc_traffic.json'
+            j = json.load(open(os.path.join(ROOT, src)))
+            pmc, pmc_eval = j.get('kernels'), j.get('kernels_eval', j.get('kernels'))
+            src += ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950), bytes per launch'
         except Exception:
             pass
-        roof.update({'kernel': name, 'launches_per_step': dom['launches'] / psteps, 'avg_launch_ms': round(avg_ms, 5),
-                     'share_of_kernel_time': round(dom['ms'] / tot, 4),
-                     'algorithmic_per_launch': (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches']})
+        exact = a.workload == 'tmall' and B == 4096 and not bf16
+        roof, prof = price_dominant_kernel(prof_shapes, psteps, pmc, src, exact)
         res['roofline'] = roof
+        eroof, eprof = price_dominant_kernel(prof_eval, psteps, pmc_eval, src, exact)
+        eroof['eval_bytes_per_session'] = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], False)
+        eroof['gather_frac'] = round(eroof['eval_bytes_per_session'] * res['eval_sessions_per_s'] / world / HBM_PEAK, 6)
+        res['eval_roofline'] = eroof
+        res['eval_kernel_ms_per_step'] = {k: round(v['ms'] / psteps, 4) for k, v in sorted(eprof.items(), key=lambda kv: -kv[1]['ms'])[:8]}
         res['kernel_ms_per_step'] = {k: round(v['ms'] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16]}
         res['kernel_rate'] = {k: ('%.1f TF/s' % (v['flops'] / v['ms'] / 1e9) if v['flops'] > 0 else '%.0f GB/s' % (v['bytes'] / v['ms'] / 1e6))
                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])[:16] if v['flops'] > 0 or v['bytes'] > 0}
@@ -265,10 +336,10 @@ def main():
             res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f us, %.1f TF/s, %.0f GB/s' % (v['ms'] / psteps, v['launches'] // psteps, 1e3 * v['ms'] / v['launches'],
                                                                                                       v['flops'] / v['ms'] / 1e9, v['bytes'] / v['ms'] / 1e6)
                                   for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01 and v['flops'] > 0}
-        if a.shapes:
             res['kernel_table'] = {k: '%d launches/step, %.4f ms/step, avg %.1f us' % (v['launches'] // psteps, v['ms'] / psteps, 1e3 * v['ms'] / max(1, v['launches']))
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
+        res['eval_kernel_launches_per_step'] = round(sum(v['launches'] for v in eprof.values()) / psteps, 1)
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)
     print(json.dumps(res))

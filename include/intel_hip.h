@@ -224,6 +224,11 @@ int intel_intent_loss(int B, int I, const float* pred, const double* label, doub
                       float grad_scale, double* out3, float* d_pred, void* workspace, size_t workspace_bytes,
                       void* stream);
 size_t intel_loss_workspace_bytes(int B, int L, int K);
+/* The three values IntBPRloss / IntListloss / IntMSEloss.forward return (loss/IntBPRloss.py:15-20):
+ * out3 = {ensemble_loss * ensemble_weight + intent_loss * intent_weight (float64), ensemble_loss, intent_loss};
+ * intent_out3 = the out3 of intel_intent_loss, or NULL for the losses without the intent term (all three = ensemble loss). */
+int intel_loss_total(const float* ensemble_loss, const double* intent_out3, double ensemble_weight, double intent_weight,
+                     double* out3, void* stream);
 
 /* ---- optimizer ---------------------------------------------------------------------------- */
 /* torch.optim.Adam.step as configured by BaseRunner._build_optimizer (helpers/BaseRunner.py:182-188)

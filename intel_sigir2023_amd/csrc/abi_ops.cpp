@@ -173,3 +173,9 @@ extern "C" int intel_eval_metrics(int B, int L, int width, int n_topk, const int
   INTEL_CHECK_ARG(topk && ens_score && ranking && session_len && out && valid, "eval_metrics: null tensor");
   return launch_eval_metrics(B, L, width, n_topk, topk, ens_score, ranking, session_len, pos_nums, label_pos, out, valid, (hipStream_t)stream);
 }
+
+extern "C" int intel_loss_total(const float* ensemble_loss, const double* intent_out3, double ensemble_weight, double intent_weight,
+                                double* out3, void* stream) {
+  INTEL_CHECK_ARG(ensemble_loss && out3, "loss_total: null tensor");
+  return launch_loss_total(ensemble_loss, intent_out3, ensemble_weight, intent_weight, out3, (hipStream_t)stream);
+}

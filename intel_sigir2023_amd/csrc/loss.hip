@@ -519,3 +519,25 @@ int launch_intent_loss(int B, int I, const float* pred, const double* label, dou
   INTEL_CHECK_LAUNCH();
   return 0;
 }
+
+// (loss, ensemble_loss, intent_loss) of IntBPRloss / IntListloss / IntMSEloss.forward (loss/IntBPRloss.py:15-20): the float64
+// total = ens * ensemble_weight + intent * intent_weight next to its two parts, in one tiny launch (instead of five torch
+// elementwise kernels per step).  out3_int == NULL (BPRloss / Listloss / MSEloss alone): all three = the ensemble loss.
+__global__ void loss_total_kernel(const float* __restrict__ loss_e, const double* __restrict__ out3_int, double w_e, double w_i,
+                                  double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const double e = (double)loss_e[0];
+    if (out3_int) {
+      out[0] = e * w_e + out3_int[0] * w_i;
+      out[1] = e;
+      out[2] = out3_int[0];
+    } else {
+      out[0] = out[1] = out[2] = e;
+    }
+  }
+}
+int launch_loss_total(const float* loss_e, const double* out3_int, double w_e, double w_i, double* out, hipStream_t st) {
+  LAUNCH(loss_total_kernel, dim3(1), dim3(64), 0, st, loss_e, out3_int, w_e, w_i, out);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}

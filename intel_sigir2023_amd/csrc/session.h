@@ -55,6 +55,7 @@ int launch_list_loss(int B, int L, int K, const float* ens, const int* ranking, 
 int launch_mse_loss(int B, int L, int K, const float* ens, const int* ranking, const int* slen, const double* sc64,
                     const float* sc32, const float* weights, int cal_div, double alpha, float grad_scale, float* loss,
                     float* d_ens, float* d_weights, void* ws, size_t ws_bytes, hipStream_t st);
+int launch_loss_total(const float* loss_e, const double* out3_int, double w_e, double w_i, double* out, hipStream_t st);
 int launch_intent_loss(int B, int I, const float* pred, const double* label, double kl_weight, double kl_temp,
                        float grad_scale, double* out3, float* d_pred, void* ws, size_t ws_bytes, hipStream_t st);
 // optim.hip

@@ -282,11 +282,11 @@ class IntELEngine(object):
                 parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
             for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
                 adam(gname, wd, st, dense_reduced=dp)
-        ens_loss = loss_e.reshape(()).clone()
-        if self.with_intent:
-            int_loss = out3[0].clone()
-            return ens_loss.double() * self.ensemble_weight + int_loss * self.intent_weight, ens_loss, int_loss
-        return ens_loss, ens_loss, ens_loss
+        # (loss, ensemble_loss, intent_loss) like the reference's criterion: one tiny launch into a fresh 3-vector (the
+        # caller may keep every step's values: runner.fit averages them at the end of the epoch)
+        tot = torch.empty(3, dtype=torch.float64, device=dev)
+        L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), st), 'intel_loss_total')
+        return tot[0], tot[1], tot[2]
 
     # ---- evaluation -----------------------------------------------------------------------------------
     @torch.no_grad()

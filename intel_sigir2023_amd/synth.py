@@ -19,6 +19,13 @@ WORKLOADS = {
                              encoder='BERT4Rec', history_max=20),
                   corpus=dict(items=1000000, users=100000, classes=357, ctx=931, I=30),
                   batch=dict(L=50, H=20)),
+    # the same corpus with the PUBLISHED IntEL-BPR hyper-parameters (script/IntEL.sh:15 of the reference): GRU4Rec encoders, 2 heads,
+    # 2 tied layers, 16/16/32/32-wide embeddings, context 64, intent 32, cal_diversity 1 (alpha 1e-5), batch 512, lr 1e-4, l2 1e-4
+    'tmall_pub': dict(flags=dict(model_num=3, context_emb_size=64, i_emb_size=16, u_emb_size=32, s_emb_size=32, im_emb_size=16,
+                                 intent_emb_size=32, cross_attn_qsize=32, num_heads=2, num_layers=2, encoder='GRU4Rec', history_max=20,
+                                 cal_diversity=1, diversity_alpha=1e-5, intent_weight=0.01),
+                      corpus=dict(items=1000000, users=100000, classes=357, ctx=931, I=30),
+                      batch=dict(L=50, H=20), bench_batch=512, optim=(1e-4, 1e-4)),
     # configs[3]: LifeData-shape (K=5, 10 intents, list=100)
     'lifedata': dict(flags=dict(model_num=5, context_emb_size=64, i_emb_size=64, u_emb_size=64, s_emb_size=64,
                                 im_emb_size=64, intent_emb_size=64, cross_attn_qsize=64, num_heads=1, num_layers=1,
