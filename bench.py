@@ -109,7 +109,8 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
         return float(loss.detach())
 
     def timed(batch, B, kind, budget, max_n):
-        stage(batch, B, kind)                  # warm-up (allocations, lazy init)
+        if B <= 512:
+            stage(batch, B, kind)              # warm-up (allocations, lazy init); a B=4096 step takes 4-20 s, its warm-up is skipped
         t0 = time.perf_counter()
         n = 0
         while True:
