@@ -191,6 +191,7 @@ def main():
     ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
     ap.add_argument('--dtype', type=str, default='f32', help='f32: the parity mode (headline); bf16: single bf16 product per linear')
     ap.add_argument('--nbatches', type=int, default=8, help='distinct resident batches cycled by the timed loop')
+    ap.add_argument('--eval_steps', type=int, default=-1, help='evaluation steps timed after the training loop (-1: max(3, steps/2); 0: none)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
@@ -239,6 +240,7 @@ def main():
 
     def one_step(i):
         return eng.train_step(batches[i % nbatches])
+    loss = None
     for i in range(a.warmup):
         loss = one_step(i)
     torch.cuda.synchronize()
@@ -252,20 +254,22 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     el = parallel.allreduce_max_float(el, dev)
-    last_loss = float(loss[0])
+    last_loss = float(loss[0]) if (a.steps + a.warmup) > 0 else float('nan')
 
     # ---- eval throughput (forward + on-device NDCG@3), not part of `value`
     model.eval()
-    for i in range(2):
-        eng.eval_step(batches[i % nbatches], k=3)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    ev_steps = max(3, a.steps // 2)
-    for i in range(ev_steps):
-        out, nd = eng.eval_step(batches[i % nbatches], k=3)
-    torch.cuda.synchronize()
-    ev_el = parallel.allreduce_max_float(time.perf_counter() - t1, dev)
-    ndcg3 = float(nd.float().nan_to_num(0).mean())
+    ev_steps = a.eval_steps if a.eval_steps >= 0 else max(3, a.steps // 2)
+    ev_el, ndcg3 = float('inf'), float('nan')
+    if ev_steps > 0:
+        for i in range(2 if a.warmup > 0 else 0):
+            eng.eval_step(batches[i % nbatches], k=3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(ev_steps):
+            out, nd = eng.eval_step(batches[i % nbatches], k=3)
+        torch.cuda.synchronize()
+        ev_el = parallel.allreduce_max_float(time.perf_counter() - t1, dev)
+        ndcg3 = float(nd.float().nan_to_num(0).mean())
     model.train()
 
     # ---- per-kernel profile: EVERY rank runs the same extra steps (they contain the gradient all-reduce)
@@ -296,8 +300,8 @@ def main():
              'MFMA pipe = fp32 accuracy, same parity thresholds as the fp32-MFMA kernels')
     res = {
         'metric': 'train sessions/sec, IntEL fwd+BPR loss+bwd+Adam, synthetic Tmall-shape list=%d K=%d d=64' % (Lmax, f['model_num']),
-        'value': round(world * B * a.steps / el, 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
-        'warmup': a.warmup, 'ms_per_step': round(1e3 * el / a.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
+        'value': round(world * B * a.steps / max(el, 1e-9), 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
+        'warmup': a.warmup, 'ms_per_step': round(1e3 * el / max(1, a.steps), 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, emb %d/%d/%d/%d (id/meta/score/ctx), %s, %d heads x %d tied '
                                'layers, %s, %s loss, cal_diversity=%d, %s item ids, %d resident batches'

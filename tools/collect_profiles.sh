@@ -1,20 +1,32 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): GPU tests, the default bench line, rocprofv3 kernel stats (single stream and
-# concurrent branches), the two PMC passes (each counter in its own run, kernel-trace only) and the other workloads.
-# Everything lands under gpurun_out/<tag>/; copy what should be judged into profiles/ afterwards.
-tag=${1:-r01}
+# Runs on the GPU box (through gpurun): the default bench line, rocprofv3 kernel stats (single stream and concurrent
+# branches), the PMC passes (each counter in its own run, kernel-trace only; training steps and evaluation steps
+# separately) and the other workloads.  Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py and a copy into
+# profiles/ follow in the build container.
+tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q > $out/tests.log 2>&1 < /dev/null
-tail -2 $out/tests.log
-timeout 600 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
-INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_feed > $out/stats1s.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_roofline --no_feed > $out/stats.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline --no_feed > $out/fetch.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline --no_roofline --no_feed > $out/write.log 2>&1 < /dev/null
+timeout 900 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
+PMCARGS="--no_cpu_baseline --no_roofline --no_feed"
+INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats.log 2>&1 < /dev/null
+INTEL_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 10 $PMCARGS > $out/stats_eval.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -- python3 bench.py --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 4 $PMCARGS > $out/fetch_eval.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 4 $PMCARGS > $out/write_eval.log 2>&1 < /dev/null
+if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload lifedata --batch 2048 --no_cpu_baseline > $out/bench_lifedata.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 256 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --loss IntListloss --cal_diversity 1 --no_cpu_baseline > $out/bench_pl.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline > $out/bench_gru.json 2>/dev/null < /dev/null
-ls $out
+timeout 600 python bench.py --workload stress --batch 1024 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress_b1024.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --loss IntListloss --cal_diversity 1 --no_cpu_baseline > $out/bench_pl_div.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline > $out/bench_gru4rec.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload tmall_pub --no_cpu_baseline > $out/bench_tmall_pub.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --zipf 1 --no_cpu_baseline > $out/bench_zipf.json 2>/dev/null < /dev/null
+INTEL_FUSE_TOWER=0 timeout 600 python bench.py --no_cpu_baseline > $out/bench_unfused.json 2>/dev/null < /dev/null
+fi
+# keep the merge small: only the summaries travel back
+find $out -name "*.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
+find $out -name "*.db" -delete 2>/dev/null
+ls -R $out | head -60
