@@ -104,6 +104,13 @@ int launch_pack_b(const float* W, int ldw, int Kd, int Nd, int trans, float* P, 
 // ------------------------------------------------------------------------------------------
 // gemm_rows
 // ------------------------------------------------------------------------------------------
+// Arithmetic mode of the matrix-pipe products (set per call by the model plan from IntelDesc.dtype):
+//   3 = fp32 accuracy (hi + mid + lo bf16 planes, six plane products) -- the parity mode;
+//   1 = bf16 mode: operands rounded to bf16, ONE product, fp32 accumulate.
+static thread_local int g_planes = 3;
+void gemm_set_planes(int planes) { g_planes = planes == 1 ? 1 : 3; }
+int gemm_planes() { return g_planes; }
+
 #define GR_BM 64
 #define GR_KC 128
 #define GR_LDA (GR_KC + 4)
@@ -607,7 +614,7 @@ __device__ __forceinline__ bf16x8 b3_cat(const bf16x4& a, const bf16x4& b) {
   return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int RT, bool LN, int KBN>
+template <int RT, bool LN, int KBN, int NP = 3>
 __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
   constexpr int RG = 4 / RT;
   constexpr int CT = 8 / RG;
@@ -678,8 +685,10 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
       }
       const int off = trow[jj] * B3_LDP + tcol[jj];
       *reinterpret_cast<bf16x4*>(planes + off) = h;
-      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
-      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      if (NP == 3) {
+        *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+        *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      }
     }
   };
   const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
@@ -707,6 +716,10 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
         for (int rt = 0; rt < RT; ++rt) {
           const __bf16* fp = (B3_ABLATE & 32) ? frag : frag + rt * 16 * B3_LDP + kb * 32;
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+          if (NP == 1) {            // bf16 mode: one product of the bf16-rounded operands
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[kb], ah, acc[rt], 0, 0, 0);
+            continue;
+          }
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
           f32x4 c = acc[rt];
@@ -897,7 +910,7 @@ int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st)
   return 0;
 }
 
-template <int RT>
+template <int RT, int NP = 3>
 __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
   constexpr int RG = 4 / RT;
   constexpr int CT = 8 / RG;
@@ -941,8 +954,10 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
       b3_split4(pre[jj], h, m, l);
       const int off = trow[jj] * B3_LDP + tcol[jj];
       *reinterpret_cast<bf16x4*>(planes + off) = h;
-      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
-      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      if (NP == 3) {
+        *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+        *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      }
     }
   };
   const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
@@ -965,7 +980,7 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bw[kb][pl] = Bimg[((size_t)(c * 4 + kb) * 3 + pl) * 64];
+      for (int pl = 0; pl < NP; ++pl) bw[kb][pl] = Bimg[((size_t)(c * 4 + kb) * 3 + pl) * 64];
     store_iter();
     __syncthreads();
     {   // prefetch the next (tile, chunk)
@@ -977,7 +992,14 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
       const __bf16* frag = planes + ((rg * RT) * 16 + (lane & 15)) * B3_LDP + 8 * (lane >> 4);
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-        const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[kb][0]), bm = __builtin_bit_cast(bf16x8, bw[kb][1]), bl = __builtin_bit_cast(bf16x8, bw[kb][2]);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, bw[kb][0]);
+        if (NP == 1) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, *reinterpret_cast<const bf16x8*>(frag + rt * 16 * B3_LDP + kb * 32), acc[rt], 0, 0, 0);
+          continue;
+        }
+        const bf16x8 bm = __builtin_bit_cast(bf16x8, bw[kb][1]), bl = __builtin_bit_cast(bf16x8, bw[kb][2]);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const __bf16* fp = frag + rt * 16 * B3_LDP + kb * 32;
@@ -1039,6 +1061,13 @@ static int launch_b3k(const GemmRowsArgs& a, hipStream_t st) {
   int gx = ntiles < 512 ? ntiles : 512;
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);
+  if (g_planes == 1) {
+    allow_lds((gemm_rows_b3k_kernel<RT, 1>), smem);
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
+             (gemm_rows_b3k_kernel<RT, 1>), dim3(gx, nchunks), dim3(512), smem, st, a);
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   allow_lds(gemm_rows_b3k_kernel<RT>, smem);
   LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
            gemm_rows_b3k_kernel<RT>, dim3(gx, nchunks), dim3(512), smem, st, a);
@@ -1399,6 +1428,19 @@ static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   int gx = ntiles < 512 ? ntiles : 512;
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);      // >= the LayerNorm staging tile (64 x 132 floats)
+  if (g_planes == 1) {          // bf16 mode (the LayerNorm epilogue tile still needs the full staging area)
+    if (a.K == 128) {
+      allow_lds((gemm_rows_b3_kernel<RT, LN, 4, 1>), smem);
+      LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
+               (gemm_rows_b3_kernel<RT, LN, 4, 1>), dim3(gx, nchunks), dim3(512), smem, st, a);
+    } else {
+      allow_lds((gemm_rows_b3_kernel<RT, LN, 2, 1>), smem);
+      LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
+               (gemm_rows_b3_kernel<RT, LN, 2, 1>), dim3(gx, nchunks), dim3(512), smem, st, a);
+    }
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   if (a.K == 128) {
     allow_lds((gemm_rows_b3_kernel<RT, LN, 4>), smem);
     LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
@@ -1804,7 +1846,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
-template <int NTW, int KTW>
+template <int NTW, int KTW, int NP = 3>
 __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
@@ -1848,8 +1890,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
       b3_split4(colv, h, m, l);
       const int off = (colbase + 4 * cb + c) * WB_LDT + 4 * rb;
       *reinterpret_cast<bf16x4*>(planes + off) = h;
-      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
-      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      if (NP == 3) {
+        *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
+        *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      }
     }
   };
   auto store_tile = [&]() {
@@ -1891,13 +1935,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     for (int j = 0; j < KTW; ++j) {
       const __bf16* q = fx + j * 16 * WB_LDT;
       xh[j] = *reinterpret_cast<const bf16x8*>(q);
-      xm[j] = *reinterpret_cast<const bf16x8*>(q + PLANE);
-      xl[j] = *reinterpret_cast<const bf16x8*>(q + 2 * PLANE);
+      if (NP == 3) {
+        xm[j] = *reinterpret_cast<const bf16x8*>(q + PLANE);
+        xl[j] = *reinterpret_cast<const bf16x8*>(q + 2 * PLANE);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NTW; ++i) {
       const __bf16* q = fy + i * 16 * WB_LDT;
       const bf16x8 yh = *reinterpret_cast<const bf16x8*>(q);
+      if (NP == 1) {            // bf16 mode: one product of the bf16-rounded operands
+#pragma unroll
+        for (int j = 0; j < KTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xh[j], acc[i][j], 0, 0, 0);
+        continue;
+      }
       const bf16x8 ym = *reinterpret_cast<const bf16x8*>(q + PLANE);
       const bf16x8 yl = *reinterpret_cast<const bf16x8*>(q + 2 * PLANE);
 #pragma unroll
@@ -2281,9 +2332,14 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
       size_t smem = (size_t)3 * 32 * (ntw + ktw) * WB_LDT * sizeof(__bf16);
       if (smem < (size_t)8 * 32 * ntw * sizeof(float)) smem = (size_t)8 * 32 * ntw * sizeof(float);
 #define WB_CASE(A_, B_)                                                                                             \
-  if (ntw == A_ && ktw == B_) {                                                                                     \
+  if (ntw == A_ && ktw == B_ && g_planes == 3) {                                                                    \
     allow_lds((wgrad_b3_kernel<A_, B_>), smem);                                                                     \
     LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_>), grid, \
+             dim3(256), smem, st, a);                                                                               \
+  }                                                                                                                 \
+  if (ntw == A_ && ktw == B_ && g_planes == 1) {                                                                    \
+    allow_lds((wgrad_b3_kernel<A_, B_, 1>), smem);                                                                  \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, 1>), grid, \
              dim3(256), smem, st, a);                                                                               \
   }
       WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)

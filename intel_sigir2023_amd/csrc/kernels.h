@@ -34,6 +34,9 @@ struct GemmEpilogue {
   int no_out = 0;                 // LayerNorm epilogue only: keep the x-hat / rstd stash, do not store C
   const void* b3 = nullptr;       // optional pre-split bf16 image of B (launch_pack_b3): used when K > 128
 };
+// arithmetic mode of the matrix-pipe products: 3 = fp32 accuracy (three bf16 planes, six products), 1 = bf16 (one product)
+void gemm_set_planes(int planes);
+int gemm_planes();
 // bf16 three-plane image of a packed fp32 B (any launch_pack_b result) for the K > 128 GEMM on the bf16 pipe
 size_t packed_b3_bytes(int Kd, int Nd);
 int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st);   // records; pack_b3_flush launches

@@ -1400,7 +1400,9 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   }
   ctx->have_layout = true;
   Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], train};
+  gemm_set_planes(ctx->d.dtype == INTEL_DTYPE_BF16 ? 1 : 3);
   forward_impl(r, out);
+  gemm_set_planes(3);
   ctx->fwd_done = (r.rc == 0) && train;
   ctx->fB = batch->B; ctx->fL = batch->L; ctx->fH = batch->H; ctx->fHi = batch->Hi;
   ctx->f_ws = workspace;
@@ -1422,7 +1424,9 @@ static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelB
   if (workspace_bytes < ctx->lay.total) return INTEL_E_WORKSPACE;
   INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
   Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], 1};
+  gemm_set_planes(ctx->d.dtype == INTEL_DTYPE_BF16 ? 1 : 3);
   backward_impl(r, d_weights, d_ens_score, d_intents, phase);
+  gemm_set_planes(3);
   return r.rc;
 }
 

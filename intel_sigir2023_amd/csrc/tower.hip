@@ -64,6 +64,23 @@ __device__ __forceinline__ const uint4* per_session(const uint4* p) {
   return p;
 }
 
+template <int NP, int PLANE>
+__device__ __forceinline__ void store_planes(__bf16* dst, const bf16x4& h, const bf16x4& m, const bf16x4& l) {
+  *reinterpret_cast<bf16x4*>(dst) = h;
+  if (NP == 3) {
+    *reinterpret_cast<bf16x4*>(dst + PLANE) = m;
+    *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = l;
+  }
+}
+
+// NP = 3: the six plane products; NP = 1 (bf16 mode): the one product of the bf16-rounded operands
+template <int NP>
+__device__ __forceinline__ f32x4 mma(const bf16x8& wh, const bf16x8& wm, const bf16x8& wl, const bf16x8& ah, const bf16x8& am,
+                                     const bf16x8& al, f32x4 c) {
+  if (NP == 1) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ah, c, 0, 0, 0);
+  return mma6(wh, wm, wl, ah, am, al, c);
+}
+
 __device__ __forceinline__ float gmax16(float v) {   // over the 4 lane groups sharing lane&15
   v = fmaxf(v, __shfl_xor(v, 16));
   return fmaxf(v, __shfl_xor(v, 32));
@@ -120,7 +137,7 @@ struct TowerCfg {
   static constexpr size_t SMEM = P_BYTES + R_BYTES;
 };
 
-template <int D, int DK, bool TRAIN>
+template <int D, int DK, bool TRAIN, int NP = 3>
 __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(TowerFwdArgs a) {      // two waves per SIMD: <= 256 registers
   using C = TowerCfg<D>;
   constexpr int NW = C::NW, NT = C::NT, KB = C::KB, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ;
@@ -176,9 +193,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       bf16x4 h, m, l;
       split4(pre[jj], h, m, l);
       const int off = trow[jj] * LDP + tcol[jj];
-      *reinterpret_cast<bf16x4*>(planes + off) = h;
-      *reinterpret_cast<bf16x4*>(planes + PLANE + off) = m;
-      *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = l;
+      store_planes<NP, PLANE>(planes + off, h, m, l);
     }
     __syncthreads();
     mark(0);
@@ -212,7 +227,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
 #pragma unroll
           for (int c = 0; c < 3; ++c)
-            acc[c][rt] = mma6(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][1]),
+            acc[c][rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][1]),
                               __builtin_bit_cast(bf16x8, bw[kb & 1][c][2]), ah, am, al, acc[c][rt]);
         }
       }
@@ -315,9 +330,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
             bf16x4 hh, mm, ll;
             split4(o, hh, mm, ll);
             const int off = q * LDP + col;
-            *reinterpret_cast<bf16x4*>(planes + off) = hh;
-            *reinterpret_cast<bf16x4*>(planes + PLANE + off) = mm;
-            *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = ll;
+            store_planes<NP, PLANE>(planes + off, hh, mm, ll);
             if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
           }
       } else {
@@ -339,9 +352,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           bf16x4 hh, mm, ll;
           split4(o, hh, mm, ll);
           const int off = q * LDP + col;
-          *reinterpret_cast<bf16x4*>(planes + off) = hh;
-          *reinterpret_cast<bf16x4*>(planes + PLANE + off) = mm;
-          *reinterpret_cast<bf16x4*>(planes + 2 * PLANE + off) = ll;
+          store_planes<NP, PLANE>(planes + off, hh, mm, ll);
           if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
         }
       }
@@ -373,7 +384,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
-          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw1[kb][0]), __builtin_bit_cast(bf16x8, bw1[kb][1]), __builtin_bit_cast(bf16x8, bw1[kb][2]),
+          acc[rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw1[kb][0]), __builtin_bit_cast(bf16x8, bw1[kb][1]), __builtin_bit_cast(bf16x8, bw1[kb][2]),
                          ah, am, al, acc[rt]);
         }
       const int col = wave * 16 + 4 * j;
@@ -387,9 +398,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         bf16x4 hh, mm, ll;
         split4(x, hh, mm, ll);
         const int off = row * LDP + col;
-        *reinterpret_cast<bf16x4*>(r1planes + off) = hh;
-        *reinterpret_cast<bf16x4*>(r1planes + PLANE + off) = mm;
-        *reinterpret_cast<bf16x4*>(r1planes + 2 * PLANE + off) = ll;
+        store_planes<NP, PLANE>(r1planes + off, hh, mm, ll);
         if (TRAIN && a.R1 && row < L) *reinterpret_cast<f32x4*>(a.R1 + ((size_t)b * L + row) * D + col) = x;
       }
     }
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
           const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
           const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
-          acc[rt] = mma6(__builtin_bit_cast(bf16x8, bw2[kb][0]), __builtin_bit_cast(bf16x8, bw2[kb][1]), __builtin_bit_cast(bf16x8, bw2[kb][2]),
+          acc[rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw2[kb][0]), __builtin_bit_cast(bf16x8, bw2[kb][1]), __builtin_bit_cast(bf16x8, bw2[kb][2]),
                          ah, am, al, acc[rt]);
         }
       const int col = wave * 16 + 4 * j;
@@ -480,11 +489,12 @@ int fused_enabled() {
   return on;
 }
 
-template <int D, int DK, bool TRAIN>
+template <int D, int DK, bool TRAIN, int NP = 3>
 int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   using C = TowerCfg<D>;
   const size_t smem = C::SMEM;
-  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN>), smem);
+  if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1>(a, st);      // bf16 mode
+  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP>), smem);
   const int per_cu = smem <= 80 * 1024 ? 2 : 1;
   int grid = num_cus() * per_cu;
   if (grid > a.B) grid = a.B;
@@ -501,7 +511,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(dbg_buf, 0, 8 * sizeof(unsigned long long), st);
     aa.dbg = dbg_buf;
   }
-  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN>), dim3(grid), dim3(C::NT), smem, st, aa);
+  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN, NP>), dim3(grid), dim3(C::NT), smem, st, aa);
   INTEL_CHECK_LAUNCH();
   if (dbg_on) {          // tools/tower_probe.py
     unsigned long long h[8];

@@ -100,6 +100,9 @@ class IntEL(nn.Module):
         parser.add_argument('--model_path', type=str, default='', help='Model save path.')
         parser.add_argument('--buffer', type=int, default=1, help='Whether to buffer feed dicts for dev/test')
         parser.add_argument('--model_num', type=int, default=2, help='Number of base models.')
+        parser.add_argument('--dtype', type=str, default='f32',
+                            help='f32: the parity mode; bf16: every linear / weight gradient is ONE bf16 MFMA product (operands rounded '
+                                 'to bf16, fp32 accumulate; fp32 master weights, Adam moments, residuals, LayerNorm, softmax)')
         parser.add_argument('--weight_norm', type=str, default='none',
                             help='none: raw fusion weights (IntEL.py:214, the reference); softmax: K-way softmax over them')
         return parser
@@ -186,7 +189,8 @@ class IntEL(nn.Module):
             q_size=args.cross_attn_qsize, heads=args.num_heads, layers=args.num_layers,
             cross_attention=int(bool(self.cross_attention)),
             encoder=0 if self.encoder_name == 'BERT4Rec' else 1, history_max=self.max_his,
-            enc_layers=2, enc_heads=2, gru_hidden=128, weight_norm=self.weight_norm, pool_mean=int(self.POOL_MEAN), dtype=0)
+            enc_layers=2, enc_heads=2, gru_hidden=128, weight_norm=self.weight_norm, pool_mean=int(self.POOL_MEAN),
+            dtype={'f32': 0, 'fp32': 0, 'bf16': 1}[str(getattr(args, 'dtype', 'f32'))])
         self._ctx = None
         self._ws = None
         self._slot_names = self._build_slot_map()
