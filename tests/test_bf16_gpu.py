@@ -16,7 +16,7 @@ def _dev():
     return torch.device('cuda:0')
 
 
-@pytest.mark.parametrize('name', ['tmall64', 'gru_bpr', 'noxatt'])
+@pytest.mark.parametrize('name', ['tmall64', 'gru_bpr', 'stress'])
 def test_bf16_forward_and_gradients_track_fp32(name):
     from intel_sigir2023_amd import loss as LS
     from intel_sigir2023_amd.model import IntEL
@@ -41,24 +41,32 @@ def test_bf16_forward_and_gradients_track_fp32(name):
         ref = outs['f32'][k]
         err = float((outs['bf16'][k] - ref).abs().max()) / max(1.0, float(ref.abs().max()))
         assert 0 < err < 3e-2, (k, err)                       # differs (one bf16 product), by bf16 rounding only
-    worst = 0.0
+    worst, wk = 0.0, None
+    gmax = max(float(g.norm()) for g in grads['f32'].values())
     for k, g in grads['f32'].items():
-        den = float(g.norm()) + 1e-12
-        worst = max(worst, float((grads['bf16'][k] - g).norm()) / den)
-    assert worst < 0.15, worst                                # every gradient tensor within 15 % in norm
+        if 'k_linear.bias' in k or float(g.norm()) < 1e-4 * gmax:
+            continue            # analytically-zero (attention key bias) or negligible gradients are rounding noise in both builds
+        rel = float((grads['bf16'][k] - g).norm()) / float(g.norm())
+        if rel > worst:
+            worst, wk = rel, k
+    assert worst < 0.15, (wk, worst)                          # every gradient tensor within 15 % in norm
 
 
 def test_bf16_training_reaches_the_fp32_ndcg():
     """The gate of the mode: 300 fused training steps on a planted ranking signal (labels = top items of base ranker 0) with
-    identical data, initialisation and BPR tie-breaks; held-out NDCG@3 of the bf16 build within 1e-2 of the fp32 build's and
+    identical data, initialisation and BPR tie-breaks; held-out NDCG@3 of the bf16 build within 1e-3 of the fp32 build's and
     the loss trajectories within 2 % of each other on average."""
     from intel_sigir2023_amd import synth
     from intel_sigir2023_amd.engine import IntELEngine
     from intel_sigir2023_amd.model import IntEL
     dev = _dev()
+    # the headline widths (64-d embeddings: every tower / encoder linear is a K = 64 / 128 product, where the mode applies) on a
+    # small corpus
+    synth.WORKLOADS['tiny64'] = dict(flags=dict(synth.WORKLOADS['tmall']['flags']), corpus=dict(synth.WORKLOADS['tiny']['corpus']),
+                                     batch=dict(synth.WORKLOADS['tiny']['batch']))
 
     def planted(seed):
-        b = synth.make_batch('tiny', 256, dev, seed=seed, ragged=True)
+        b = synth.make_batch('tiny64', 256, dev, seed=seed, ragged=True)
         s0 = b['scores'][:, :, 0].float()
         valid = torch.arange(s0.shape[1], device=dev)[None, :] < b['session_len'][:, None]
         order = torch.where(valid, s0, torch.full_like(s0, -1.0)).argsort(dim=1, descending=True)
@@ -71,8 +79,8 @@ def test_bf16_training_reaches_the_fp32_ndcg():
     res = {}
     for dt in ('f32', 'bf16'):
         torch.manual_seed(3)
-        args = synth.make_args('tiny', dev, dtype=dt)
-        corpus, _ = synth.make_corpus('tiny')
+        args = synth.make_args('tiny64', dev, dtype=dt)
+        corpus, _ = synth.make_corpus('tiny64')
         model = IntEL(args, corpus).to(dev)
         eng = IntELEngine(model, 'IntBPRloss', args, lr=2e-3, l2=0.0)
         model.train()
@@ -81,7 +89,7 @@ def test_bf16_training_reaches_the_fp32_ndcg():
         nd = float(torch.cat([eng.eval_step(h)[1].float() for h in held]).mean())
         res[dt] = (np.array(losses), nd)
     (l32, n32), (l16, n16) = res['f32'], res['bf16']
-    print('NDCG@3 fp32 %.4f bf16 %.4f; mean |dloss| / loss = %.4f' % (n32, n16, float(np.mean(np.abs(l16 - l32) / l32))))
-    assert n32 > 0.85
-    assert abs(n16 - n32) <= 1e-2, (n32, n16)
+    print('NDCG@3 fp32 %.5f bf16 %.5f; mean |dloss| / loss = %.2e' % (n32, n16, float(np.mean(np.abs(l16 - l32) / l32))))
+    assert n32 > 0.85 and float(np.abs(l16 - l32).max()) > 0      # the mode is really on
+    assert abs(n16 - n32) <= 1e-3, (n32, n16)
     assert float(np.mean(np.abs(l16 - l32) / l32)) < 2e-2
