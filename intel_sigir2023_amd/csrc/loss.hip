@@ -1,8 +1,8 @@
 // Loss kernels: BPR (loss/BPRloss.py), Plackett-Luce listwise (loss/Listloss.py) and the intent
 // CE/KL loss (loss/BaseIntloss.py), forward and hand-derived backward in one launch per loss.
 //
-// One 256-thread workgroup per session; thread i owns candidate i (rows i, i+256, ... for long
-// lists), the per-list vectors live in LDS, per-list reductions are wave shuffles + one LDS hop.
+// One workgroup per session -- a single wave for lists of up to 64 candidates, four waves for longer ones; thread i owns
+// candidate i (rows i, i+NT, ...), the per-list vectors live in LDS, per-list reductions are wave shuffles (+ one LDS hop).
 // The [B,L,L] and [B,L,L,K] float64 intermediates of the reference are never materialised.
 // The float64 "diversity" terms are evaluated in double like the reference (BPRloss.py:14-18,
 // Listloss.py:18-23); everything else is fp32 in the same operation order.
@@ -13,11 +13,16 @@
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
 
-template <typename T>
+// sum over the NT threads of the workgroup (NT = 256: four waves through LDS; NT = 64: one wave, shuffles only)
+template <typename T, int NT = 256>
 __device__ __forceinline__ T block_sum(T v, T* red /* [4] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (NT == 64) {
+    __syncthreads();        // callers rely on the barrier (LDS vectors written before, read after)
+    return v;
+  }
   __syncthreads();
   if (lane == 0) red[wave] = v;
   __syncthreads();
@@ -45,7 +50,8 @@ __device__ __forceinline__ double score_at(const LossArgs& a, size_t idx) {
 // ------------------------------------------------------------------------------------------
 // BPR
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void bpr_loss_kernel(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, K = a.K, b = blockIdx.x, tid = threadIdx.x;
   float* s_s = reinterpret_cast<float*>(smem_raw);       // [L] ens
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
   __shared__ int redi[4];
   const int len = min(a.slen[b], L);
   int npos_l = 0;
-  for (int i = tid; i < L; i += 256) {
+  for (int i = tid; i < L; i += NT) {
     s_s[i] = a.ens[(size_t)b * L + i];
     const int r = max(a.ranking[(size_t)b * L + i], 0);
     s_r[i] = r;
@@ -69,12 +75,12 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
     if ((tid & 63) == 0) redi[tid >> 6] = v;
     __syncthreads();
   }
-  const int npos = redi[0] + redi[1] + redi[2] + redi[3];
+  const int npos = NT == 64 ? redi[0] : redi[0] + redi[1] + redi[2] + redi[3];
   const float inv_npos = 1.f / (float)npos;     // npos == 0 -> inf/NaN like the reference (0/0)
   const float c = a.grad_scale / ((float)a.B * (float)npos);
   float loss_l = 0.f;
   double div_l = 0.0;
-  for (int i = tid; i < L; i += 256) {
+  for (int i = tid; i < L; i += NT) {
     const int ri = s_r[i];
     const bool vi = i < len;
     // closest lower tier among valid j: smallest positive D = ri - rj
@@ -133,16 +139,16 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
     }
     s_g[i] = g;
   }
-  const float loss_b = block_sum<float>(loss_l, redf) * inv_npos;
+  const float loss_b = block_sum<float, NT>(loss_l, redf) * inv_npos;
   double div_b = 0.0;
-  if (a.cal_div) div_b = block_sum<double>(div_l, redd) / (double)npos;
+  if (a.cal_div) div_b = block_sum<double, NT>(div_l, redd) / (double)npos;
   if (tid == 0) {
     a.lossb[b] = loss_b;
     a.divb[b] = div_b;
   }
   __syncthreads();
   if (a.d_ens) {
-    for (int j = tid; j < L; j += 256) {
+    for (int j = tid; j < L; j += NT) {
       float acc = s_g[j];
       for (int i = 0; i < L; ++i)
         if (s_sel[i] == j) acc -= s_g[i];
@@ -154,7 +160,8 @@ __global__ __launch_bounds__(256) void bpr_loss_kernel(LossArgs a) {
 // ------------------------------------------------------------------------------------------
 // Plackett-Luce listwise
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void list_loss_kernel(LossArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void list_loss_kernel(LossArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int L = a.L, K = a.K, b = blockIdx.x, tid = threadIdx.x;
   double* s_sc = reinterpret_cast<double*>(smem_raw);            // [L][K] base scores (diversity only)
@@ -168,25 +175,25 @@ __global__ __launch_bounds__(256) void list_loss_kernel(LossArgs a) {
   __shared__ int redi[4];
   const int len = min(a.slen[b], L);
   int npos_l = 0;
-  for (int i = tid; i < L; i += 256) {
+  for (int i = tid; i < L; i += NT) {
     s_s[i] = a.ens[(size_t)b * L + i];
     const int r = max(a.ranking[(size_t)b * L + i], 0);
     s_r[i] = r;
     npos_l += r > 0;
   }
   if (a.cal_div)
-    for (int i = tid; i < L * K; i += 256) s_sc[i] = score_at(a, (size_t)b * L * K + i);
+    for (int i = tid; i < L * K; i += NT) s_sc[i] = score_at(a, (size_t)b * L * K + i);
   {
     int v = wave_sum_i(npos_l);
     __syncthreads();
     if ((tid & 63) == 0) redi[tid >> 6] = v;
     __syncthreads();
   }
-  const int npos = redi[0] + redi[1] + redi[2] + redi[3];
+  const int npos = NT == 64 ? redi[0] : redi[0] + redi[1] + redi[2] + redi[3];
   const float c = a.grad_scale / ((float)a.B * (float)npos);
   float loss_l = 0.f;
   double div_l = 0.0;
-  for (int i = tid; i < L; i += 256) {
+  for (int i = tid; i < L; i += NT) {
     const int ri = s_r[i];
     const bool vi = i < len, pos = ri > 0;
     const float si = s_s[i];
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(256) void list_loss_kernel(LossArgs a) {
       for (int k = 0; k < K; ++k) a.d_weights[((size_t)b * L + i) * K + k] = 0.f;
     }
   }
-  const float loss_b = block_sum<float>(loss_l, redf) / (float)npos;
+  const float loss_b = block_sum<float, NT>(loss_l, redf) / (float)npos;
   double div_b = 0.0;
-  if (a.cal_div) div_b = block_sum<double>(div_l, redd) / (double)npos;
+  if (a.cal_div) div_b = block_sum<double, NT>(div_l, redd) / (double)npos;
   if (tid == 0) {
     a.lossb[b] = loss_b;
     a.divb[b] = div_b;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(256) void list_loss_kernel(LossArgs a) {
   __syncthreads();
   if (!a.d_ens) return;
   // G(i,j) = dLoss/dz_ij for pairs with M_ij (i positive); d_ens[t] = sum_j G(t,j) - sum_i G(i,t)
-  for (int t = tid; t < L; t += 256) {
+  for (int t = tid; t < L; t += NT) {
     float acc = 0.f;
     if (t < len) {
       const int rt = s_r[t];
@@ -358,13 +365,24 @@ static int run_pair_loss(bool bpr, LossArgs& a, float* loss, void* ws, size_t ws
   size_t smem;
   if (bpr) {
     smem = (size_t)a.L * 4 * sizeof(float);
-    allow_lds(bpr_loss_kernel, smem);
-    LAUNCH(bpr_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
+    // lists of up to 64 candidates (Tmall shape): ONE wave per session -- lane = candidate, every per-list reduction is a
+    // wave reduction -- instead of a 256-thread workgroup with 50 busy lanes; longer lists keep four waves
+    if (a.L <= 64) {
+      LAUNCH(bpr_loss_kernel<64>, dim3(a.B), dim3(64), smem, st, a);
+    } else {
+      allow_lds(bpr_loss_kernel<256>, smem);
+      LAUNCH(bpr_loss_kernel<256>, dim3(a.B), dim3(256), smem, st, a);
+    }
   } else {
     smem = (size_t)a.L * 3 * sizeof(float) + (a.cal_div ? ((size_t)2 * a.L * a.K + a.L) * sizeof(double) : 0);
     INTEL_CHECK_ARG(smem <= 150 * 1024, "list loss: L=%d K=%d does not fit LDS", a.L, a.K);
-    allow_lds(list_loss_kernel, smem);
-    LAUNCH(list_loss_kernel, dim3(a.B), dim3(256), smem, st, a);
+    if (a.L <= 64) {
+      allow_lds(list_loss_kernel<64>, smem);
+      LAUNCH(list_loss_kernel<64>, dim3(a.B), dim3(64), smem, st, a);
+    } else {
+      allow_lds(list_loss_kernel<256>, smem);
+      LAUNCH(list_loss_kernel<256>, dim3(a.B), dim3(256), smem, st, a);
+    }
   }
   INTEL_CHECK_LAUNCH();
   LAUNCH(loss_finalize_kernel, dim3(1), dim3(256), 0, st, a.lossb, a.divb, a.B, a.cal_div, a.alpha, loss);
