@@ -446,13 +446,14 @@ static int check_attn_shape(int T, int d, int heads) {
   }
 
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
-                    hipStream_t st) {
+                    hipStream_t st, const int* row_off) {
   if (B <= 0) return 0;
   int rc = check_attn_shape(T, d, heads);
   if (rc) return rc;
   const int dk = d / heads, dkt = cdiv(dk, 16);
   const float scale = 1.0f / sqrtf((float)dk);
-  if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st);
+  if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
+  INTEL_CHECK_ARG(!row_off, "attention: packed rows are supported by the whole-sequence kernels only (T <= 64, head dim 64 / 128)");
   dim3 grid(B * heads, cdiv(T, AT_QB));
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
@@ -464,7 +465,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
 }
 
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st) {
+                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off) {
   if (B <= 0) return 0;
   int rc = check_attn_shape(T, d, heads);
   if (rc) return rc;
@@ -472,7 +473,8 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   const float scale = 1.0f / sqrtf((float)dk);
   float* dsum = scratch;
   if (attn_seq_path(T, dk))
-    return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st);
+    return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st, row_off);
+  INTEL_CHECK_ARG(!row_off, "attention: packed rows are supported by the whole-sequence kernels only");
   dim3 grid(B * heads, cdiv(T, AT_QB));
   if (attn_ds_scheme()) {
     float* dS = scratch + rup_sz((size_t)B * heads * T, 64);

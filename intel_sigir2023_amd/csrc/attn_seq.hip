@@ -97,8 +97,10 @@ __device__ __forceinline__ void split_pair(int bh, int heads, int& b, int& h) {
 // ------------------------------------------------------------------------------------------
 template <int DKT, int NT, int LS>
 __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restrict__ qkv, int BH, int T, int d, int heads,
-                                                           const int* __restrict__ key_len, float c2, float scale,
-                                                           float* __restrict__ out, float* __restrict__ lse) {
+                                                           const int* __restrict__ key_len, const int* __restrict__ row_off, float c2,
+                                                           float scale, float* __restrict__ out, float* __restrict__ lse) {
+  // row_off != NULL: PACKED rows -- session b owns rows row_off[b] .. row_off[b] + key_len[b] - 1 of qkv / out (no padding rows
+  // in memory); otherwise session b owns rows b*T .. b*T + T - 1.  lse stays indexed [pair][T].
   using C = SeqP<DKT, NT>;
   constexpr int DK = C::DK, DQ = DKT / 4, NSTEPS = (NT - 1) * 4 + LS;
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [stage][K | V][ROWS][DK]
@@ -117,8 +119,10 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
       if (!((ds.live >> jj) & 1u)) continue;
       int b, h;
       split_pair(min(it * C::PW + ds.slot[jj], BH - 1), heads, b, h);
+      const size_t base = row_off ? (size_t)row_off[b] : (size_t)b * T;
+      const int tb = row_off ? max(min(key_len[b], T), 1) : T;
       // (pointers in plain locals: the builtin's argument check mishandles template-dependent expressions)
-      const float* srck = qkv + ((size_t)b * T + ds.rho[jj]) * ldg + d + h * DK + ds.col[jj];
+      const float* srck = qkv + (base + min(ds.rho[jj], tb - 1)) * ldg + d + h * DK + ds.col[jj];
       const float* srcv = srck + d;
       float* dstk = stage + (wave * C::IPW + jj) * 256;
       float* dstv = dstk + C::BUF;
@@ -129,7 +133,9 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
   auto load_q = [&](int it, f32x4 (&qf)[DKT]) {
     int b, h;
     split_pair(min(it * C::PW + slot, BH - 1), heads, b, h);
-    const float* rowp = qkv + ((size_t)b * T + min(tile * 16 + p, T - 1)) * ldg + h * DK + 4 * j;
+    const size_t base = row_off ? (size_t)row_off[b] : (size_t)b * T;
+    const int tb = row_off ? max(min(key_len[b], T), 1) : T;
+    const float* rowp = qkv + (base + min(tile * 16 + p, tb - 1)) * ldg + h * DK + 4 * j;
 #pragma unroll
     for (int g = 0; g < DKT; ++g) qf[g] = *reinterpret_cast<const f32x4*>(rowp + g * 16);
   };
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
     int b, h;
     split_pair(live ? bh : 0, heads, b, h);
     const int q = tile * 16 + p;
-    const bool qok = live && q < T;
     const int nkeys = key_len ? min(key_len[b], T) : T;
+    const bool qok = live && q < (row_off ? nkeys : T);
+    const size_t obase = row_off ? (size_t)row_off[b] : (size_t)b * T;
     f32x4 st[NT];
     f32x4 oT[DKT];
     float ps = 0.f, mref = 0.f;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
     __builtin_amdgcn_sched_barrier(0);
     if (qok) {
       const float inv = ps > 0.f ? 1.f / ps : 0.f;
-      float* orow = out + ((size_t)b * T + q) * d + h * DK;
+      float* orow = out + (obase + q) * d + h * DK;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -266,7 +273,8 @@ struct SeqCfg {
 
 // address of float4 #i of the staged block: LDS row rl (pair slot, row in pair), source row, validity
 template <int DKT, int NT, bool PERM>
-__device__ __forceinline__ bool seq_src(int i, int bh0, int BH, int T, int heads, int& rl, int& c4, size_t& grow, int& hcol) {
+__device__ __forceinline__ bool seq_src(int i, int bh0, int BH, int T, int heads, int& rl, int& c4, size_t& grow, int& hcol,
+                                        const int* __restrict__ row_off = nullptr, const int* __restrict__ key_len = nullptr) {
   using C = SeqCfg<DKT, NT>;
   rl = i / C::C4;
   c4 = i - rl * C::C4;
@@ -275,8 +283,13 @@ __device__ __forceinline__ bool seq_src(int i, int bh0, int BH, int T, int heads
   const int bh = bh0 + sl;
   int b = bh, h = 0;
   if (heads > 1) { b = bh / heads; h = bh - b * heads; }
-  grow = (size_t)b * T + rho;
   hcol = h * C::DK + c4 * 4;
+  if (row_off) {       // packed rows: session b owns row_off[b] .. + key_len[b] - 1
+    if (bh >= BH) { grow = 0; return false; }
+    grow = (size_t)row_off[b] + rho;
+    return rho < min(key_len[b], T);
+  }
+  grow = (size_t)b * T + rho;
   return bh < BH && rho < T;
 }
 
@@ -448,7 +461,9 @@ template <int DKT, int NT, int LS>
 __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               int BH, int T, int d, int heads, const int* __restrict__ key_len,
-                                                              float c2, float scale, float* __restrict__ dqkv) {
+                                                              const int* __restrict__ row_off, float c2, float scale,
+                                                              float* __restrict__ dqkv) {
+  // row_off != NULL: packed rows (see attn_seq_fwd_kernel): qkv / dout / dqkv rows of session b start at row_off[b]
   using C = SeqCfg<DKT, NT>;
   constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP, NSTEPS = (NT - 1) * 4 + LS;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -463,10 +478,12 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
   int b = live ? bh : 0, h = 0;
   if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
   const int key = tile * 16 + p;
-  const bool kok = live && key < T;
+  const size_t base = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  const int tb = row_off ? min(key_len[b], T) : T;            // rows of this session that exist in memory
+  const bool kok = live && key < tb;
   f32x4 kf[DKT], vf[DKT];
-  load_row_frags<DKT>(kf, qkv + ((size_t)b * T + key) * ldg + d + h * DK, kok, DK, lane);
-  load_row_frags<DKT>(vf, qkv + ((size_t)b * T + key) * ldg + 2 * d + h * DK, kok, DK, lane);
+  load_row_frags<DKT>(kf, qkv + (base + key) * ldg + d + h * DK, kok, DK, lane);
+  load_row_frags<DKT>(vf, qkv + (base + key) * ldg + 2 * d + h * DK, kok, DK, lane);
   {
     // stage Q and dO (permuted rows)
     f32x4 vq[C::ITERS], vo[C::ITERS];
@@ -474,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
     for (int it = 0; it < C::ITERS; ++it) {
       int rl, c4, hcol;
       size_t grow;
-      const bool ok = seq_src<DKT, NT, true>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol);
+      const bool ok = seq_src<DKT, NT, true>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol, row_off, key_len);
       const size_t gr = ok ? grow : 0;
       const int hc = ok ? hcol : 0;
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -492,7 +509,8 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
     }
     if (tid < C::ROWS) {
       const int sl = tid / TP, r = tid - sl * TP, rho = perm16(r), bb = bh0 + sl;
-      Ls[tid] = (bb < BH && rho < T) ? -1.44269504088896340736f * lse[(size_t)bb * T + rho] : -INFINITY;   // -lse in base 2
+      const int tbb = (row_off && bb < BH) ? min(key_len[heads > 1 ? bb / heads : bb], T) : T;
+      Ls[tid] = (bb < BH && rho < tbb) ? -1.44269504088896340736f * lse[(size_t)bb * T + rho] : -INFINITY;   // -lse in base 2
     }
   }
   __syncthreads();
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       }
     }
     if (kok) {
-      float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK + 2 * d;
+      float* drow = dqkv + (base + key) * ldg + h * DK + 2 * d;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -588,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       }
     }
     if (kok) {
-      float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK + d;
+      float* drow = dqkv + (base + key) * ldg + h * DK + d;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -629,8 +647,8 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (q < T) {
-      float* drow = dqkv + ((size_t)b * T + q) * ldg + h * DK;
+    if (q < tb) {
+      float* drow = dqkv + (base + q) * ldg + h * DK;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -732,7 +750,8 @@ bool attn_seq_supported(int T, int dk) {
 }
 
 int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
-                        hipStream_t st) {
+                        hipStream_t st, const int* row_off) {
+  INTEL_CHECK_ARG(!row_off || key_len, "attn_seq: packed rows need the session lengths");
   const int dk = d / heads, dkt = dk / 16, BH = B * heads;
   const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
   const float scale = 1.0f / sqrtf((float)dk);
@@ -742,7 +761,7 @@ int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const 
     const int per_cu = (int)((size_t)160 * 1024 / smem);
     const int grid = min(cdiv(BH, C::PW), num_cus() * (per_cu < 1 ? 1 : per_cu));
     allow_lds((attn_seq_fwd_kernel<DKT, NT, LS>), smem);
-    LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, out, lse);
+    LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, out, lse);
   });
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -754,8 +773,14 @@ size_t attn_seq_bwd_scratch_floats(int B, int T, int heads) {
 }
 
 // scratch: attn_seq_bwd_scratch_floats(B, T, heads) floats (the dS tiles)
+bool attn_seq_packed_supported(int T, int dk) {
+  static const int fused = [] { const char* e = getenv("INTEL_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
+  return fused && attn_seq_supported(T, dk);
+}
+
 int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st) {
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off) {
+  INTEL_CHECK_ARG(!row_off || (key_len && attn_seq_packed_supported(T, d / heads)), "attn_seq: packed rows need the fused backward and the session lengths");
   const int dk = d / heads, dkt = dk / 16, BH = B * heads;
   const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
   const float scale = 1.0f / sqrtf((float)dk);
@@ -765,7 +790,7 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
       using C = SeqCfg<DKT, NT>;
       const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + (1 + NT) * C::ROWS) * sizeof(float);
       allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS>), smem);
-      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv);
+      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
     });
     INTEL_CHECK_LAUNCH();
     return 0;

@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
   const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
-  const int ntiles = a.M / WG_RT, S = gridDim.x;
+  const int ntiles = (a.M + WG_RT - 1) / WG_RT, S = gridDim.x;      // a ragged last tile is padded with zero rows
   // staging blocks of this thread: block b -> rows 4*(b % 8) .., columns 4*(b / 8) ..  (row block fastest: the stores of
   // eight adjacent lanes fill one column's 64 bytes)
   f32x4 py[YPT][4], px[XPT][4];
@@ -1873,13 +1873,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     for (int u = 0; u < YPT; ++u) {
       const int b = min(tid + 256 * u, YBL - 1), rb = b & 7, cb = b >> 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) py[u][r] = *reinterpret_cast<const f32x4*>(a.dY + (m0 + 4 * rb + r) * a.lddy + n0 + 4 * cb);
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = m0 + 4 * rb + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + min(row, (size_t)a.M - 1) * a.lddy + n0 + 4 * cb);
+        py[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
       const int b = min(tid + 256 * u, XBL - 1), rb = b & 7, cb = b >> 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) px[u][r] = *reinterpret_cast<const f32x4*>(a.X + (m0 + 4 * rb + r) * a.ldx + k0 + 4 * cb);
+      for (int r = 0; r < 4; ++r) {
+        const size_t row = m0 + 4 * rb + r;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + min(row, (size_t)a.M - 1) * a.ldx + k0 + 4 * cb);
+        px[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto store_block = [&](const f32x4 (&v)[4], int colbase, int rb, int cb) {
@@ -2326,7 +2334,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
                          ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
     static const int use_wb3 = [] { const char* e = getenv("INTEL_WGRAD_B3"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (use_wb3 && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
+    if (use_wb3 && aligned && M >= 1 && N % 32 == 0 && K % 32 == 0) {      // any row count: the last tile is zero-padded in the kernel
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
       size_t smem = (size_t)3 * 32 * (ntw + ktw) * WB_LDT * sizeof(__bf16);

@@ -88,19 +88,22 @@ int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int 
 
 // ---- attention (attn.hip) -------------------------------------------------------------------
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
+// row_off (optional, [B]): PACKED rows -- session b owns rows row_off[b] .. row_off[b] + key_len[b] - 1 of qkv / out / dout /
+// dqkv instead of rows b*T .. b*T + T - 1 (no padding rows in memory); whole-sequence kernels only
+bool attn_seq_packed_supported(int T, int dk);
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
-                    hipStream_t st);
+                    hipStream_t st, const int* row_off = nullptr);
 // whole-sequence kernels (attn_seq.hip): T <= 64, head dim 64 / 128
 bool attn_seq_supported(int T, int dk);
 int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
-                        hipStream_t st);
+                        hipStream_t st, const int* row_off = nullptr);
 size_t attn_seq_bwd_scratch_floats(int B, int T, int heads);
 int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st);
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off = nullptr);
 // scratch: attn_bwd_scratch_floats(B, T, d, heads) floats (row sums of dO*O; dS tiles of the whole-sequence path)
 size_t attn_bwd_scratch_floats(int B, int T, int d, int heads);
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st);
+                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off = nullptr);
 
 // ---- one tower layer in one kernel (tower.hip) -------------------------------------------------
 // L <= 64, d in {64, 128}, head dim in {32, 64, 128}; INTEL_FUSE_TOWER=0 turns the fused path off

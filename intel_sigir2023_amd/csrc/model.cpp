@@ -62,6 +62,9 @@ struct EncLastBufs {
 struct EncBufs {
   int T, dm, d_tab, pbase, predin_off;
   float* E0;
+  // packed history (IntelBatch.his_off): ids / intent indices / intent rows of the valid positions only, position of each row
+  int *pkIds, *pkIdx2, *rowT;
+  float* pkVec;
   EncBlockBufs blk[INTEL_ENC_MAX_BLOCKS];
   EncLastBufs last;
   GruBufs gru;
@@ -117,6 +120,8 @@ struct IntelCtx {
   bool fwd_dropout;            // the stashed forward ran with dropout
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
   bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
+  bool enc_packed[2];          // this forward ran encoder e on the valid history rows only (IntelBatch.his_off / hisitem_off)
+  int enc_rows[2];             // rows of encoder e: B * T, or the packed total
 };
 
 namespace {
@@ -251,6 +256,10 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     EncBufs& n = y.enc[e];
     const size_t rows = (size_t)B * n.T, md = rows * n.dm;
     n.E0 = ar.f(md);
+    n.pkIds = reinterpret_cast<int*>(ar.f(rows));
+    n.pkIdx2 = reinterpret_cast<int*>(ar.f(rows));
+    n.rowT = reinterpret_cast<int*>(ar.f(rows));
+    n.pkVec = ar.f(rows * I);
     if (md > maxMD) maxMD = md;
     if (D.encoder == INTEL_ENC_BERT4REC) {
       {
@@ -707,9 +716,13 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
 void bert_fwd(Run& r, int e) {
   const IntelDesc& D = r.D;
   EncBufs& n = r.y.enc[e];
-  const int B = r.y.B, T = n.T, dm = n.dm, rows = B * T;
+  const int B = r.y.B, T = n.T, dm = n.dm, rows = r.ctx->enc_rows[e];
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
-  RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
+  const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
+  if (off)
+    RUN(launch_add_pos_rows(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), n.rowT, rows, r.st));
+  else
+    RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
   const float* X = n.E0;
   for (int l = 0; l + 1 < D.enc_layers; ++l) {
     EncBlockBufs& k = n.blk[l];
@@ -719,7 +732,7 @@ void bert_fwd(Run& r, int e) {
       lin(r, X, dm, rows, dm, k.pWqkv, 3 * dm, k.QKV, 3 * dm, eb);
       if (r.rc) return;
     }
-    RUN(launch_attn_fwd(k.QKV, B, T, dm, D.enc_heads, len, k.A, k.LSE, r.st));
+    RUN(launch_attn_fwd(k.QKV, B, T, dm, D.enc_heads, len, k.A, k.LSE, r.st, off));
     RUN(launch_add_layernorm(k.A, dm, X, dm, rows, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)),
                              r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), k.C, dm, r.train ? k.XH1 : nullptr, dm, r.train ? k.RSTD1 : nullptr, r.st));
     GemmEpilogue e1;
@@ -754,12 +767,12 @@ void bert_fwd(Run& r, int e) {
     ekv.bias = k.bQKV + dm;
     lin(r, X, dm, rows, dm, k.pWqkv + third, 2 * dm, q.KV, 2 * dm, ekv);            // [k | v] for every row
     if (r.rc) return;
-    RUN(launch_select_last(X, dm, len, B, T, q.XLAST, dm, 0, r.st));
+    RUN(launch_select_last(X, dm, len, B, T, q.XLAST, dm, 0, r.st, off));
     GemmEpilogue eq;
     eq.bias = k.bQKV;
     lin(r, q.XLAST, dm, B, dm, k.pWqkv, dm, q.QLAST, dm, eq);
     if (r.rc) return;
-    RUN(launch_attn_lastq_fwd(q.KV, q.QLAST, len, B, T, dm, D.enc_heads, q.OL, q.PL, r.st));
+    RUN(launch_attn_lastq_fwd(q.KV, q.QLAST, len, B, T, dm, D.enc_heads, q.OL, q.PL, r.st, off));
     RUN(launch_add_layernorm(q.OL, dm, q.XLAST, dm, B, dm, r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)),
                              r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B)), q.CL, dm, q.XH1, dm, q.RSTD1, r.st));
     GemmEpilogue e1;
@@ -791,8 +804,9 @@ float* bert_bwd(Run& r, int e) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   EncBufs& n = y.enc[e];
-  const int B = y.B, T = n.T, dm = n.dm, rows = B * T;
+  const int B = y.B, T = n.T, dm = n.dm, rows = r.ctx->enc_rows[e];
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
+  const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
   float *dX = r.T->dXa, *dXalt = r.T->dXb;
   {   // ---- last block, pruned (see bert_fwd): gradient of one output row per session
     const int l = D.enc_layers - 1;
@@ -825,7 +839,7 @@ float* bert_bwd(Run& r, int e) {
         return nullptr;
     }
     // attention of the single query row: dS is both d(attention output) and the residual into Xlast
-    if (!r.ok(launch_attn_lastq_bwd(q.KV, q.QLAST, q.PL, dSl, len, B, T, dm, D.enc_heads, dQl, r.T->dQKV, r.st))) return nullptr;
+    if (!r.ok(launch_attn_lastq_bwd(q.KV, q.QLAST, q.PL, dSl, len, B, T, dm, D.enc_heads, dQl, r.T->dQKV, r.st, off))) return nullptr;
     wgrad(r, dQl, dm, q.XLAST, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_BQ));
     GemmEpilogue exl;
     exl.res = dSl; exl.ldres = dm;
@@ -839,7 +853,7 @@ float* bert_bwd(Run& r, int e) {
     e0.b3 = q.b3WkvT;
     lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dX = dKV [Wk;Wv]
     if (r.rc) return nullptr;
-    if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st))) return nullptr;
+    if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st, off))) return nullptr;
   }
   for (int l = D.enc_layers - 2; l >= 0; --l) {
     EncBlockBufs& k = n.blk[l];
@@ -870,7 +884,7 @@ float* bert_bwd(Run& r, int e) {
       if (!r.ok(launch_layernorm_bwd(r.T->dA, dm, k.XH1, dm, k.RSTD1, rows, dm, r.P(sg), r.T->dZ, dm, r.G(sg), r.G(sb), a, nullptr, r.st, r.ctx->rq)))
         return nullptr;
     }
-    if (!r.ok(launch_attn_bwd(k.QKV, k.A, r.T->dZ, k.LSE, B, T, dm, D.enc_heads, len, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
+    if (!r.ok(launch_attn_bwd(k.QKV, k.A, r.T->dZ, k.LSE, B, T, dm, D.enc_heads, len, r.T->dQKV, r.T->DSUM, r.st, off))) return nullptr;
     {
       const int ws[3] = {enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
       const int bs[3] = {enc_blk_slot(e, l, INTEL_ENC_BQ), enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
@@ -888,7 +902,7 @@ float* bert_bwd(Run& r, int e) {
   // position embedding gradient: dpos[p,:] = sum over rows at position p = onehot^T dE (MFMA wgrad)
   if (r.G(enc_slot(e, INTEL_ENC_POS))) {
     const int ps = enc_slot(e, INTEL_ENC_POS);
-    if (!r.ok(launch_make_onehot(nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;
+    if (!r.ok(launch_make_onehot(off ? n.rowT : nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;
     if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
     r.acc(ps);
     if (!r.ok(launch_wgrad(r.T->ONEHOT, T, dX, dm, rows, T, dm, r.G(ps), dm, nullptr, 0, nullptr, r.st, r.ctx->rq))) return nullptr;
@@ -909,21 +923,26 @@ void forward_impl(Run& r, const IntelOut* out) {
   fork_streams(r, 3);
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
-    const int rows = B * n.T, dm = n.dm;
+    const int rows = r.ctx->enc_rows[e], dm = n.dm;
+    const bool pk = r.ctx->enc_packed[e];
     GemmEpilogue eb;
     eb.bias = r.P(INTEL_P_INTENT_B);
     if (e == 0) {
-      RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st));
+      if (pk) RUN(launch_his_pack(bt.history_len, bt.his_off, B, n.T, bt.his_context_mh, n.pkIds, nullptr, nullptr, bt.his_intents, I, n.pkVec, n.rowT, r.st));
+      const float* hint = pk ? n.pkVec : bt.his_intents;
+      RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, pk ? n.pkIds : bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st));
       if (smallk_supported(D.d_int, I))
-        RUN(launch_linear_smallk(bt.his_intents, I, rows, I, r.P(INTEL_P_INTENT_W), eb.bias, D.d_int, n.E0 + D.d_c, dm, 0, r.st));
+        RUN(launch_linear_smallk(hint, I, rows, I, r.P(INTEL_P_INTENT_W), eb.bias, D.d_int, n.E0 + D.d_c, dm, 0, r.st));
       else
-        lin(r, bt.his_intents, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
+        lin(r, hint, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
     } else {
-      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
+      if (pk) RUN(launch_his_pack(bt.history_item_len, bt.hisitem_off, B, n.T, bt.his_item_id, n.pkIds, bt.his_item_idx, n.pkIdx2,
+                                  bt.his_item_idx ? nullptr : bt.his_item_int, I, n.pkVec, n.rowT, r.st));
+      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
       if (bt.his_item_idx)
-        RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st));
+        RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, pk ? n.pkIdx2 : bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st));
       else
-        lin(r, bt.his_item_int, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_id, dm, eb);
+        lin(r, pk ? n.pkVec : bt.his_item_int, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_id, dm, eb);
     }
     if (r.rc) return;
     if (D.encoder == INTEL_ENC_BERT4REC) {
@@ -1167,7 +1186,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   // ===== one sequence encoder: returns dE (gradient w.r.t. its input rows), scatters the table part
   auto encoder_branch = [&](Run& r, int e) -> float* {
     EncBufs& n = y.enc[e];
-    const int rows = B * n.T, dm = n.dm;
+    const int rows = r.ctx->enc_rows[e], dm = n.dm;
+    const bool pk = r.ctx->enc_packed[e];
     float* dE = nullptr;
     if (D.encoder == INTEL_ENC_BERT4REC) {
       dE = bert_bwd(r, e);
@@ -1184,26 +1204,27 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     if (r.rc || !dE) return nullptr;
     if (e == 0) {
       if (r.G(INTEL_P_CTX_EMB))
-        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_c, bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_c, pk ? n.pkIds : bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     } else {
       if (r.G(INTEL_P_IID_EMB))
-        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
+        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, pk ? n.pkIds : bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
     }
     return dE;
   };
   // gradient of the SHARED intent_embeddings weight from one encoder's input rows (main stream, fixed order)
   auto intent_wgrad = [&](Run& r, int e, float* dE) {
     const EncBufs& n = y.enc[e];
-    const int rows = B * n.T;
+    const int rows = r.ctx->enc_rows[e];
+    const bool pk = r.ctx->enc_packed[e];
     if (e == 0) {
-      wgrad(r, dE + D.d_c, n.dm, bt.his_intents, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+      wgrad(r, dE + D.d_c, n.dm, pk ? n.pkVec : bt.his_intents, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
     } else if (bt.his_item_idx) {
       if (r.G(INTEL_P_INTENT_W)) {   // dW[c][j] = sum_m dE[m][c] onehot[m][j]: the dense wgrad on a materialised one-hot
-        RUN(launch_make_onehot(bt.his_item_idx, nullptr, 0, rows, I, y.ONEHOT2, r.st));
+        RUN(launch_make_onehot(pk ? n.pkIdx2 : bt.his_item_idx, nullptr, 0, rows, I, y.ONEHOT2, r.st));
         wgrad(r, dE + D.d_id, n.dm, y.ONEHOT2, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
       }
     } else {
-      wgrad(r, dE + D.d_id, n.dm, bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
+      wgrad(r, dE + D.d_id, n.dm, pk ? n.pkVec : bt.his_item_int, I, rows, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
     }
   };
 
@@ -1392,6 +1413,19 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   const bool dropout = train && ctx->drop_p > 0.f;
   make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay, dropout);
   ctx->fwd_dropout = dropout;
+  {   // run the BERT4Rec encoders on the valid history rows only when the caller supplied the row offsets (INTEL_PACK_HISTORY=0: never)
+    static const int pack_on = [] { const char* e = getenv("INTEL_PACK_HISTORY"); return (e && e[0] == '0') ? 0 : 1; }();
+    const IntelDesc& D = ctx->d;
+    for (int e = 0; e < 2; ++e) {
+      const int T = e == 0 ? batch->H : batch->Hi, dm = e == 0 ? D.d_c + D.d_int : D.d_id + D.d_int;
+      const int* off = e == 0 ? batch->his_off : batch->hisitem_off;
+      const int nrows = e == 0 ? batch->n_his_rows : batch->n_hisitem_rows;
+      const bool pk = pack_on && off && nrows > 0 && nrows <= batch->B * T && D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 1 &&
+                      attn_seq_packed_supported(T, dm / D.enc_heads);
+      ctx->enc_packed[e] = pk;
+      ctx->enc_rows[e] = pk ? nrows : batch->B * T;
+    }
+  }
   ctx->fused_tail[0] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[0].d, train != 0);
   ctx->fused_tail[1] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[1].d, train != 0);
   if (workspace_bytes < ctx->lay.total) {

@@ -31,12 +31,18 @@ int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, in
 int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
                          int col0, hipStream_t st);
 int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, float* oh, hipStream_t st);
+// row_off (optional, [B]): packed history rows (kernels.h)
 int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
-                          float* P, hipStream_t st);
+                          float* P, hipStream_t st, const int* row_off = nullptr);
 int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const float* d_out, const int* len, int B, int T,
-                          int dm, int heads, float* dq, float* dkv, hipStream_t st);
-int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st);
-int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st);
+                          int dm, int heads, float* dq, float* dkv, hipStream_t st, const int* row_off = nullptr);
+int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st,
+                       const int* row_off = nullptr);
+int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st,
+                       const int* row_off = nullptr);
+int launch_add_pos_rows(float* E, int dm, const float* pos, const int* row_t, int rows, hipStream_t st);
+int launch_his_pack(const int* len, const int* off, int B, int T, const int* ids, int* ids_out, const int* idx2, int* idx2_out,
+                    const float* vec, int w, float* vec_out, int* row_t, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,
                      const float* relu_out, int ldr, int rcol0, int accumulate, hipStream_t st);
 int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,

@@ -699,6 +699,50 @@ int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, in
   INTEL_CHECK_LAUNCH();
   return 0;
 }
+// the same over PACKED history rows: E[row] += pos[row_t[row]] (row_t = position of the row inside its session)
+__global__ void add_pos_rows_kernel(float* __restrict__ E, int dm, const float* __restrict__ pos, const int* __restrict__ row_t, int rows) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)rows * dm) return;
+  const int c = (int)(i % dm);
+  const int m = (int)(i / dm);
+  E[i] += pos[(size_t)row_t[m] * dm + c];
+}
+int launch_add_pos_rows(float* E, int dm, const float* pos, const int* row_t, int rows, hipStream_t st) {
+  long long n = (long long)rows * dm;
+  if (n <= 0) return 0;
+  LAUNCH(add_pos_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, E, dm, pos, row_t, rows);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// Packing of one history: the padded positions t >= len[b] of a BERT4Rec input never reach a valid row (their keys are masked,
+// GeneralSeq.py:100; everything else is row-wise; the output is multiplied by `valid` and only row len-1 is used, :103-105), so
+// the encoder can run on the valid rows alone.  Session b's rows move from [b*T, b*T + len[b]) to [off[b], off[b] + len[b]):
+//   ids_out[row] = ids[b*T + t];  idx2_out[row] = idx2[b*T + t] (optional);  vec_out[row, :] = vec[b*T + t, :] (optional, w wide);
+//   row_t[row] = t.   One workgroup per session.
+__global__ __launch_bounds__(256) void his_pack_kernel(const int* __restrict__ len, const int* __restrict__ off, int B, int T,
+                                                       const int* __restrict__ ids, int* __restrict__ ids_out,
+                                                       const int* __restrict__ idx2, int* __restrict__ idx2_out,
+                                                       const float* __restrict__ vec, int w, float* __restrict__ vec_out,
+                                                       int* __restrict__ row_t) {
+  const int b = blockIdx.x;
+  const int n = min(max(len[b], 0), T), base = off[b];
+  for (int t = threadIdx.x; t < n; t += 256) {
+    ids_out[base + t] = ids[(size_t)b * T + t];
+    if (idx2) idx2_out[base + t] = idx2[(size_t)b * T + t];
+    row_t[base + t] = t;
+  }
+  if (vec)
+    for (int i = threadIdx.x; i < n * w; i += 256) vec_out[(size_t)base * w + i] = vec[(size_t)b * T * w + i];
+}
+int launch_his_pack(const int* len, const int* off, int B, int T, const int* ids, int* ids_out, const int* idx2, int* idx2_out,
+                    const float* vec, int w, float* vec_out, int* row_t, hipStream_t st) {
+  if (B <= 0) return 0;
+  LAUNCH(his_pack_kernel, dim3(B), dim3(256), 0, st, len, off, B, T, ids, ids_out, idx2, idx2_out, vec, w, vec_out, row_t);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 // one-hot intent rows of the item history (IntEL.py:142 with his_item_int one-hot):
 // E[m, col0:col0+d_int] = Wint[:, idx[m]] + bint   (idx < 0: bias only)
 __global__ void onehot_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int d_int, int I,
@@ -744,7 +788,7 @@ int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, floa
 
 // vec[b,:] = E[b*T + len_b - 1, :] * 1   (GeneralSeq.py:103-105; the selected row is always valid)
 __global__ void select_last_kernel(const float* __restrict__ E, int dm, const int* __restrict__ len, int B, int T,
-                                   float* __restrict__ out, int ldo, int col0) {
+                                   float* __restrict__ out, int ldo, int col0, const int* __restrict__ row_off) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * dm) return;
   const int b = i / dm, c = i - b * dm;
@@ -752,11 +796,13 @@ __global__ void select_last_kernel(const float* __restrict__ E, int dm, const in
   t = t < 0 ? T + t : t;            // torch negative indexing when len == 0
   t = min(max(t, 0), T - 1);
   const float valid = (t < len[b]) ? 1.f : 0.f;
-  out[(size_t)b * ldo + col0 + c] = E[((size_t)b * T + t) * dm + c] * valid;
+  const size_t base = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  out[(size_t)b * ldo + col0 + c] = valid > 0.f ? E[(base + t) * dm + c] : 0.f;
 }
-int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st) {
+int launch_select_last(const float* E, int dm, const int* len, int B, int T, float* out, int ldo, int col0, hipStream_t st,
+                       const int* row_off) {
   if (B * dm <= 0) return 0;
-  LAUNCH(select_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, E, dm, len, B, T, out, ldo, col0);
+  LAUNCH(select_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, E, dm, len, B, T, out, ldo, col0, row_off);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -792,7 +838,8 @@ int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, f
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const float* __restrict__ kv, const float* __restrict__ q,
                                                              const int* __restrict__ len, int B, int T, int dm, int heads,
-                                                             float scale, float* __restrict__ out, float* __restrict__ P) {
+                                                             float scale, float* __restrict__ out, float* __restrict__ P,
+                                                             const int* __restrict__ row_off) {
   __shared__ float s_att[4][XP_MAXL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.x * 4 + wave;
@@ -801,7 +848,7 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const float* __rest
   const int dk = dm / heads;
   const int n = min(max(len[b], 0), T);
   const float* qh = q + (size_t)b * dm + h * dk;
-  const float* kb = kv + (size_t)b * T * 2 * dm + h * dk;
+  const float* kb = kv + (row_off ? (size_t)row_off[b] : (size_t)b * T) * 2 * dm + h * dk;      // packed rows: see kernels.h
   const float* vb = kb + dm;
   float* att = s_att[wave];
   const int sub = lane & 15, grp = lane >> 4;
@@ -842,12 +889,12 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const float* __rest
   }
 }
 int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
-                          float* P, hipStream_t st) {
+                          float* P, hipStream_t st, const int* row_off) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(T <= XP_MAXL, "attn_lastq: history length %d > %d unsupported", T, XP_MAXL);
   INTEL_CHECK_ARG(dm % heads == 0 && (dm / heads) % 4 == 0, "attn_lastq: head dim must be a multiple of 4");
   const float scale = 1.0f / sqrtf((float)(dm / heads));
-  LAUNCH(attn_lastq_fwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, len, B, T, dm, heads, scale, out, P);
+  LAUNCH(attn_lastq_fwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, len, B, T, dm, heads, scale, out, P, row_off);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -856,7 +903,8 @@ int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B
 __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __restrict__ kv, const float* __restrict__ q,
                                                              const float* __restrict__ P, const float* __restrict__ d_out,
                                                              const int* __restrict__ len, int B, int T, int dm, int heads,
-                                                             float scale, float* __restrict__ dq, float* __restrict__ dkv) {
+                                                             float scale, float* __restrict__ dq, float* __restrict__ dkv,
+                                                             const int* __restrict__ row_off) {
   __shared__ float s_ds[4][XP_MAXL];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int bh = blockIdx.x * 4 + wave;
@@ -866,7 +914,9 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __rest
   const int n = min(max(len[b], 0), T);
   const float* qh = q + (size_t)b * dm + h * dk;
   const float* doh = d_out + (size_t)b * dm + h * dk;
-  const float* kb = kv + (size_t)b * T * 2 * dm + h * dk;
+  const size_t rbase = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  const int twr = row_off ? n : T;               // rows written: packed sessions own exactly n rows
+  const float* kb = kv + rbase * 2 * dm + h * dk;
   const float* vb = kb + dm;
   const float* p = P + (size_t)bh * T;
   float* ds = s_ds[wave];
@@ -894,11 +944,11 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __rest
   __builtin_amdgcn_wave_barrier();
   for (int j = lane; j < T; j += 64) ds[j] = j < n ? p[j] * (ds[j] - dsum) * scale : 0.f;
   __builtin_amdgcn_wave_barrier();
-  float* dkb = dkv + (size_t)b * T * 2 * dm + h * dk;
+  float* dkb = dkv + rbase * 2 * dm + h * dk;
   for (int c = lane; c < dk; c += 64) {
     const float qc = qh[c], gc = doh[c];
     float acc = 0.f;
-    for (int j = 0; j < T; ++j) {
+    for (int j = 0; j < twr; ++j) {
       const float dsj = ds[j];
       const float pj = j < n ? p[j] : 0.f;
       if (j < n) acc += dsj * kb[(size_t)j * 2 * dm + c];
@@ -909,29 +959,30 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __rest
   }
 }
 int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const float* d_out, const int* len, int B, int T,
-                          int dm, int heads, float* dq, float* dkv, hipStream_t st) {
+                          int dm, int heads, float* dq, float* dkv, hipStream_t st, const int* row_off) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(T <= XP_MAXL, "attn_lastq_bwd: history length %d > %d unsupported", T, XP_MAXL);
   const float scale = 1.0f / sqrtf((float)(dm / heads));
-  LAUNCH(attn_lastq_bwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, P, d_out, len, B, T, dm, heads, scale, dq, dkv);
+  LAUNCH(attn_lastq_bwd_kernel, dim3(cdiv(B * heads, 4)), dim3(256), 0, st, kv, q, P, d_out, len, B, T, dm, heads, scale, dq, dkv, row_off);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
 
 // dX[b*T + len_b - 1, :] += src[b, :]
 __global__ void add_at_last_kernel(const float* __restrict__ src, int lds, int dm, const int* __restrict__ len, int B, int T,
-                                   float* __restrict__ dX) {
+                                   float* __restrict__ dX, const int* __restrict__ row_off) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * dm) return;
   const int b = i / dm, c = i - b * dm;
   int t = len[b] - 1;
   t = t < 0 ? T + t : t;
   t = min(max(t, 0), T - 1);
-  if (t < len[b]) dX[((size_t)b * T + t) * dm + c] += src[(size_t)b * lds + c];
+  const size_t base = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (t < len[b]) dX[(base + t) * dm + c] += src[(size_t)b * lds + c];
 }
-int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st) {
+int launch_add_at_last(const float* src, int lds, int dm, const int* len, int B, int T, float* dX, hipStream_t st, const int* row_off) {
   if (B * dm <= 0) return 0;
-  LAUNCH(add_at_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, src, lds, dm, len, B, T, dX);
+  LAUNCH(add_at_last_kernel, dim3(cdiv(B * dm, 256)), dim3(256), 0, st, src, lds, dm, len, B, T, dX, row_off);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

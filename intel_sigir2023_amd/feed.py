@@ -204,6 +204,9 @@ class ColumnarStore(object):
                                            C.byref(fo), L.stream_ptr(dev)), 'intel_feed_collate')
         out['batch_size'] = B
         out['phase'] = self.phase
+        if idx_host is not None:          # host-known totals of the valid history rows (model.prepare_batch: packed encoders)
+            hl, hil = self.history_lens(idx_host)
+            out['his_rows'], out['hisitem_rows'] = int(hl.sum()), int(hil.sum())
         out['_keep'] = (idx_dev, perm_dev)          # inputs of the asynchronous launch
         return out
 

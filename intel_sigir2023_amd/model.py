@@ -356,6 +356,14 @@ class IntEL(nn.Module):
             keep['his_item_int'] = self._f32(data['his_item_int'])
         H, Hi = keep['his_context_mh'].shape[1], keep['his_item_id'].shape[1]
         b = L.IntelBatch(B=Bsz, L=Lmax, H=H, Hi=Hi)
+        # packed histories: when the producer of the batch knows the total number of valid history rows on the HOST (the device
+        # feed, the synthetic generator and data.collate_batch do: 'his_rows' / 'hisitem_rows'), the BERT4Rec encoders run on those
+        # rows only.  The offsets are two small prefix sums; nothing here synchronises with the device
+        if 'his_rows' in data and 'hisitem_rows' in data and self.encoder_name == 'BERT4Rec':
+            for key, lens, total in (('his_off', keep['history_len'], data['his_rows']), ('hisitem_off', keep['history_item_len'], data['hisitem_rows'])):
+                c = torch.cumsum(lens, 0, dtype=torch.int32)
+                keep[key] = (c - lens).contiguous()
+            b.n_his_rows, b.n_hisitem_rows = int(data['his_rows']), int(data['hisitem_rows'])
         for k, v in keep.items():
             setattr(b, k, v.data_ptr())
         prepared = (b, keep)

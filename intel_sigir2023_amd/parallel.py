@@ -70,6 +70,9 @@ def shard_batch(batch, r, w):
         else:
             out[k] = v
     out['batch_size'] = hi - lo
+    out.pop('his_rows', None)             # totals of the WHOLE batch: the shard runs its histories padded
+    out.pop('hisitem_rows', None)
+    out.pop('_intel', None)
     return out
 
 
