@@ -1869,24 +1869,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
   auto load_tile = [&](int tt) {
     const size_t m0 = (size_t)tt * WG_RT;
+    const bool full = (tt + 1) * WG_RT <= a.M;          // workgroup-uniform: only a ragged last tile takes the guarded loads
 #pragma unroll
     for (int u = 0; u < YPT; ++u) {
       const int b = min(tid + 256 * u, YBL - 1), rb = b & 7, cb = b >> 3;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t row = m0 + 4 * rb + r;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + min(row, (size_t)a.M - 1) * a.lddy + n0 + 4 * cb);
-        py[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) py[u][r] = *reinterpret_cast<const f32x4*>(a.dY + (m0 + 4 * rb + r) * a.lddy + n0 + 4 * cb);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t row = m0 + 4 * rb + r;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + min(row, (size_t)a.M - 1) * a.lddy + n0 + 4 * cb);
+          py[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < XPT; ++u) {
       const int b = min(tid + 256 * u, XBL - 1), rb = b & 7, cb = b >> 3;
+      if (full) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const size_t row = m0 + 4 * rb + r;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + min(row, (size_t)a.M - 1) * a.ldx + k0 + 4 * cb);
-        px[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) px[u][r] = *reinterpret_cast<const f32x4*>(a.X + (m0 + 4 * rb + r) * a.ldx + k0 + 4 * cb);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t row = m0 + 4 * rb + r;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + min(row, (size_t)a.M - 1) * a.ldx + k0 + 4 * cb);
+          px[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
