@@ -1846,7 +1846,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
-template <int NTW, int KTW, int NP = 3>
+template <int NTW, int KTW, int NP = 3, bool TAIL = false>      // TAIL: M is not a multiple of 32 (zero-padded last tile)
 __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
   auto load_tile = [&](int tt) {
     const size_t m0 = (size_t)tt * WG_RT;
-    const bool full = (tt + 1) * WG_RT <= a.M;          // workgroup-uniform: only a ragged last tile takes the guarded loads
+    const bool full = !TAIL || (tt + 1) * WG_RT <= a.M;  // workgroup-uniform: only a ragged last tile takes the guarded loads
 #pragma unroll
     for (int u = 0; u < YPT; ++u) {
       const int b = min(tid + 256 * u, YBL - 1), rb = b & 7, cb = b >> 3;
@@ -2350,19 +2350,23 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
       size_t smem = (size_t)3 * 32 * (ntw + ktw) * WB_LDT * sizeof(__bf16);
       if (smem < (size_t)8 * 32 * ntw * sizeof(float)) smem = (size_t)8 * 32 * ntw * sizeof(float);
+#define WB_LAUNCH(A_, B_, P_, T_)                                                                                   \
+  do {                                                                                                              \
+    allow_lds((wgrad_b3_kernel<A_, B_, P_, T_>), smem);                                                             \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
+             dim3(256), smem, st, a);                                                                               \
+  } while (0)
 #define WB_CASE(A_, B_)                                                                                             \
-  if (ntw == A_ && ktw == B_ && g_planes == 3) {                                                                    \
-    allow_lds((wgrad_b3_kernel<A_, B_>), smem);                                                                     \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_>), grid, \
-             dim3(256), smem, st, a);                                                                               \
-  }                                                                                                                 \
-  if (ntw == A_ && ktw == B_ && g_planes == 1) {                                                                    \
-    allow_lds((wgrad_b3_kernel<A_, B_, 1>), smem);                                                                  \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, 1>), grid, \
-             dim3(256), smem, st, a);                                                                               \
+  if (ntw == A_ && ktw == B_) {                                                                                     \
+    const bool tail = M % WG_RT != 0;                                                                               \
+    if (g_planes == 3 && !tail) WB_LAUNCH(A_, B_, 3, false);                                                        \
+    else if (g_planes == 3) WB_LAUNCH(A_, B_, 3, true);                                                             \
+    else if (!tail) WB_LAUNCH(A_, B_, 1, false);                                                                    \
+    else WB_LAUNCH(A_, B_, 1, true);                                                                                \
   }
       WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
 #undef WB_CASE
+#undef WB_LAUNCH
       INTEL_CHECK_LAUNCH();
       goto reduce;
     }
