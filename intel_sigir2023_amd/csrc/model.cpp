@@ -530,7 +530,7 @@ void pack_all(Run& r) {
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
-    if (tower_fused_supported(y.L, w.d, D.heads)) {
+    if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train)) {
       RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
       RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
       RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
@@ -615,7 +615,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
   const float* X = w.X0;
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
-  const bool fused = tower_fused_supported(L, d, D.heads) && !(r.train && r.ctx->drop_p > 0.f);
+  const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train) && !(r.train && r.ctx->drop_p > 0.f);
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only

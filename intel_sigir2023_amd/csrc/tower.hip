@@ -484,9 +484,14 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
   }
 }
 
-int fused_enabled() {
-  static const int on = [] { const char* e = getenv("INTEL_FUSE_TOWER"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on;
+// INTEL_FUSE_TOWER: 0 = never, 1 = always, unset / auto = where it is the faster path (measured on one box, same process):
+//   inference:              fused   (+4 % sessions/s in fp32, +22 % in bf16 mode)
+//   training, bf16 mode:    fused   (same step time, 1.1 GB less HBM traffic per step)
+//   training, fp32 mode:    kernel-per-op pipeline (the one-kernel layer saves the same 1.1 GB but its six-product MFMA work,
+//                           the L2 -> CU weight stream and one workgroup per CU make the step 3.5 % slower: DESIGN.md 6)
+int fused_mode() {
+  static const int m = [] { const char* e = getenv("INTEL_FUSE_TOWER"); return !e || !e[0] || e[0] == 'a' ? 2 : (e[0] == '0' ? 0 : 1); }();
+  return m;
 }
 
 template <int D, int DK, bool TRAIN, int NP = 3>
@@ -526,8 +531,14 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
 
 }  // namespace
 
+bool tower_fused_wanted(int train) {
+  const int m = fused_mode();
+  if (m != 2) return m == 1;
+  return !train || gemm_planes() == 1;
+}
+
 bool tower_fused_supported(int L, int d, int heads) {
-  if (!fused_enabled()) return false;
+  if (fused_mode() == 0) return false;
   if (L < 1 || L > 64 || heads < 1 || d % heads != 0) return false;
   const int dk = d / heads;
   return (d == 128 && (dk == 128 || dk == 64)) || (d == 64 && (dk == 64 || dk == 32));
