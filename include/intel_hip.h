@@ -134,6 +134,15 @@ typedef struct IntelBatch {
   const int* his_off;
   const int* hisitem_off;
   int n_his_rows, n_hisitem_rows;
+  /* optional: the batch's ids sorted ascending with their row indices (device int arrays; NULL = unsorted scatter).  The
+   * dense embedding gradients are accumulated with float atomics; with the pairs sorted, runs of equal ids
+   * are summed in registers first, so a popular id costs one atomic row per 16 hits instead of one per hit:
+   *   iid_sort_*      keys i_id_s [B*L]            (row = b*L + l)
+   *   cls_sort_*      keys i_class_c [B*L]
+   *   hisitem_sort_*  keys his_item_id [B*Hi]      (row = b*Hi + t; padded positions are skipped through history_item_len) */
+  const int* iid_sort_ids;     const int* iid_sort_rows;
+  const int* cls_sort_ids;     const int* cls_sort_rows;
+  const int* hisitem_sort_ids; const int* hisitem_sort_rows;
 } IntelBatch;
 
 /* Outputs of IntEL.forward (IntEL.py:117-124). */

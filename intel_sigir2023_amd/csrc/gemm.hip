@@ -1427,6 +1427,11 @@ static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
   int gx = ntiles < 512 ? ntiles : 512;
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
+  // several column chunks per row tile (N = 3d: the fused q/k/v projection): workgroup (x, y) has linear id x + y * gx and lands
+  // on XCD id % 8, so with gx a multiple of 8 the chunks of one row tile -- which walk the same row tiles in step -- share an
+  // XCD and its L2: the A tile comes from HBM once instead of once per chunk
+  static const int xcd_align = [] { const char* e = getenv("INTEL_GEMM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (xcd_align && nchunks > 1 && gx >= 16) gx &= ~7;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);      // >= the LayerNorm staging tile (64 x 132 floats)
   if (g_planes == 1) {          // bf16 mode (the LayerNorm epilogue tile still needs the full staging area)
     if (a.K == 128) {

@@ -125,6 +125,11 @@ int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst
 // grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
                             const float* relu_out, int ldr, int rcol0, hipStream_t st, unsigned char* row_flags = nullptr);
+// the same with (id, source row) pairs sorted by id: runs of equal ids are summed in registers before the atomics
+// (row_off / len / T: the source rows are packed history rows, pair row b*T + t -> source row row_off[b] + t)
+int launch_scatter_add_sorted(const float* src, int lds, int col0, int d, const int* sorted_ids, const int* sorted_rows, int n,
+                              float* grad_table, hipStream_t st, unsigned char* row_flags = nullptr, const int* row_off = nullptr,
+                              const int* len = nullptr, int T = 0);
 // y = LN(x + r) rows
 int launch_add_layernorm(const float* x, int ldx, const float* r, int ldr, int M, int N, const float* gamma,
                          const float* beta, float* y, int ldy, float* xhat, int ldxh, float* rstd, hipStream_t st,

@@ -1178,10 +1178,20 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     const int d = w.d;
     float* dX0 = tower_bwd(r, w, dXout, dXout == r.T->dXa ? r.T->dXb : r.T->dXa, r.ctx->fused_tail[0]);
     if (r.rc || !dX0) return;
-    if (r.G(INTEL_P_IID_EMB))
-      RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
-    if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB))
-      RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
+    const bool vec = (D.d_id % 16 == 0) && D.d_id <= 128 && (D.d_id & (D.d_id - 1)) == 0;
+    const bool vecm = (D.d_im % 16 == 0) && D.d_im <= 128 && (D.d_im & (D.d_im - 1)) == 0;
+    if (r.G(INTEL_P_IID_EMB)) {
+      if (bt.iid_sort_ids && bt.iid_sort_rows && vec)
+        RUN(launch_scatter_add_sorted(dX0, d, 0, D.d_id, bt.iid_sort_ids, bt.iid_sort_rows, M, r.G(INTEL_P_IID_EMB), r.st, r.ctx->iid_row_flags));
+      else
+        RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
+    }
+    if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB)) {
+      if (bt.cls_sort_ids && bt.cls_sort_rows && vecm)
+        RUN(launch_scatter_add_sorted(dX0, d, D.d_id, D.d_im, bt.cls_sort_ids, bt.cls_sort_rows, M, r.G(INTEL_P_ITEM_EMB), r.st));
+      else
+        RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
+    }
   };
   // ===== one sequence encoder: returns dE (gradient w.r.t. its input rows), scatters the table part
   auto encoder_branch = [&](Run& r, int e) -> float* {
@@ -1206,8 +1216,14 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       if (r.G(INTEL_P_CTX_EMB))
         r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_c, pk ? n.pkIds : bt.his_context_mh, rows, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     } else {
-      if (r.G(INTEL_P_IID_EMB))
-        r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, pk ? n.pkIds : bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
+      const bool vec = (D.d_id % 16 == 0) && D.d_id <= 128 && (D.d_id & (D.d_id - 1)) == 0;
+      if (r.G(INTEL_P_IID_EMB)) {
+        if (bt.hisitem_sort_ids && bt.hisitem_sort_rows && vec)
+          r.ok(launch_scatter_add_sorted(dE, dm, 0, D.d_id, bt.hisitem_sort_ids, bt.hisitem_sort_rows, B * n.T, r.G(INTEL_P_IID_EMB), r.st,
+                                         r.ctx->iid_row_flags, pk ? bt.hisitem_off : nullptr, bt.history_item_len, n.T));
+        else
+          r.ok(launch_scatter_add_rows(dE, dm, 0, D.d_id, pk ? n.pkIds : bt.his_item_id, rows, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
+      }
     }
     return dE;
   };

@@ -262,6 +262,11 @@ class Dataset(torch.utils.data.Dataset):
             out.pop(k)
         out['batch_size'] = len(feed_dicts)
         out['phase'] = self.phase
+        # host-side totals of the valid history rows (not in the reference's dict): model.prepare_batch runs the BERT4Rec
+        # encoders on those rows only when they are present
+        if 'history_len' in out and 'history_item_len' in out:
+            out['his_rows'] = int(out['history_len'].sum())
+            out['hisitem_rows'] = int(out['history_item_len'].sum())
         return out
 
 

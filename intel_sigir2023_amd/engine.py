@@ -50,6 +50,8 @@ class IntELEngine(object):
         import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
         self._side = None
+        self._sort_side = None
+        self._sorted_scatter = os.environ.get('INTEL_SCATTER_SORTED', '1') != '0'      # A/B switch: 0 = unsorted atomics
         self._noise_tensor = os.environ.get('INTEL_BPR_NOISE', 'kernel') == 'tensor'     # A/B switch: draw the BPR noise with torch.rand
         self.device = next(model.parameters()).device
         L.require_gpu(next(model.parameters()))
@@ -102,6 +104,27 @@ class IntELEngine(object):
         if self._iid_flags is not None:                   # rows of the other ranks (row 0 for the -1 padding: harmless)
             self._iid_flags.index_fill_(0, all_idx.reshape(-1).clamp_min(0).long(), 1)
         self._bufs['xch_keep'] = (all_idx, all_rows)      # alive until the kernels have run
+
+    def _sort_scatter_ids(self, ib, keep):
+        """The batch's item / class / history-item ids sorted with their row indices, on a side stream under the forward pass
+        (the backward's embedding scatter then sums runs of equal ids in registers before its float atomics: popular items --
+        Zipf -- no longer serialise on one address).  Returns the event the backward must wait for (None: switched off)."""
+        if not self._sorted_scatter:
+            return None
+        dev = self.device
+        if self._sort_side is None:
+            self._sort_side = torch.cuda.Stream(device=dev)
+        side, cur = self._sort_side, torch.cuda.current_stream(dev)
+        side.wait_stream(cur)               # also orders the reuse of last step's index buffers after that step's backward
+        with torch.cuda.stream(side):
+            for key, src in (('iid', keep['i_id_s']), ('cls', keep['i_class_c']), ('hisitem', keep['his_item_id'])):
+                v, i = torch.sort(src.reshape(-1))
+                keep[key + '_sort_ids'], keep[key + '_sort_rows'] = v, i.to(torch.int32)
+                setattr(ib, key + '_sort_ids', v.data_ptr())
+                setattr(ib, key + '_sort_rows', keep[key + '_sort_rows'].data_ptr())
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ev
 
     def _side_stream(self):
         if self._side is None:
@@ -187,6 +210,7 @@ class IntELEngine(object):
             self._check_global_shape(ib)
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
+        sort_ev = self._sort_scatter_ids(ib, keep)
         weights, ens, intents = model.run_forward(ib, keep, params, train=True)
         model._generation = getattr(model, '_generation', 0) + 1
         st = L.stream_ptr(dev)
@@ -238,6 +262,8 @@ class IntELEngine(object):
                     'intel_intent_loss')
         self.step_count += 1
         b1, b2 = self.betas
+        if sort_ev is not None:
+            torch.cuda.current_stream(dev).wait_event(sort_ev)
 
         def adam(gname, wd, stream_ptr, dense_reduced=False):
             n = self.flat[gname].numel()
