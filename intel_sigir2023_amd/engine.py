@@ -51,7 +51,8 @@ class IntELEngine(object):
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
         self._side = None
         self._sort_side = None
-        self._sorted_scatter = os.environ.get('INTEL_SCATTER_SORTED', '1') != '0'      # A/B switch: 0 = unsorted atomics
+        self._sorted_scatter = os.environ.get('INTEL_SCATTER_SORTED', 'auto')      # auto | 1 (always sort) | 0 (unsorted atomics)
+        self._dup_share = None
         self._noise_tensor = os.environ.get('INTEL_BPR_NOISE', 'kernel') == 'tensor'     # A/B switch: draw the BPR noise with torch.rand
         self.device = next(model.parameters()).device
         L.require_gpu(next(model.parameters()))
@@ -109,7 +110,19 @@ class IntELEngine(object):
         """The batch's item / class / history-item ids sorted with their row indices, on a side stream under the forward pass
         (the backward's embedding scatter then sums runs of equal ids in registers before its float atomics: popular items --
         Zipf -- no longer serialise on one address).  Returns the event the backward must wait for (None: switched off)."""
-        if not self._sorted_scatter:
+        mode = self._sorted_scatter
+        if mode == 'auto':
+            # sorting costs ~0.16 ms of side-stream work per step and pays only when ids repeat (Zipf popularity: 6.55 -> 4.68 ms
+            # per step; uniform ids: 4.02 -> 4.18 ms): decide from the share of repeated ids in a 16 384-id sample of the batch,
+            # measured on the first step and every 256th (one host synchronisation each time)
+            if self._dup_share is None or self.step_count % 256 == 0:
+                sample = keep['i_id_s'].reshape(-1)[:16384]
+                self._dup_share = 1.0 - float(torch.unique(sample).numel()) / float(sample.numel())
+            mode = '1' if self._dup_share > 0.2 else '0'
+        if mode != '1':
+            for key in ('iid', 'hisitem'):
+                setattr(ib, key + '_sort_ids', None)
+                setattr(ib, key + '_sort_rows', None)
             return None
         dev = self.device
         if self._sort_side is None:
@@ -117,7 +130,7 @@ class IntELEngine(object):
         side, cur = self._sort_side, torch.cuda.current_stream(dev)
         side.wait_stream(cur)               # also orders the reuse of last step's index buffers after that step's backward
         with torch.cuda.stream(side):
-            for key, src in (('iid', keep['i_id_s']), ('cls', keep['i_class_c']), ('hisitem', keep['his_item_id'])):
+            for key, src in (('iid', keep['i_id_s']), ('hisitem', keep['his_item_id'])):
                 v, i = torch.sort(src.reshape(-1))
                 keep[key + '_sort_ids'], keep[key + '_sort_rows'] = v, i.to(torch.int32)
                 setattr(ib, key + '_sort_ids', v.data_ptr())
