@@ -111,10 +111,14 @@ __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const float* __
                                                                  const int* __restrict__ sorted_ids, const int* __restrict__ sorted_rows,
                                                                  int n, float* __restrict__ grad_table, unsigned char* __restrict__ row_flags,
                                                                  const int* __restrict__ row_off, const int* __restrict__ len, int T) {
-  const int gt = blockIdx.x * 256 + threadIdx.x;
-  const int grp = gt / LPR, sub = gt - grp * LPR;
-  const int e0 = grp * SS_CH;
-  if (e0 >= n) return;
+  // A workgroup owns 256 / LPR groups x SS_CH consecutive pairs.  Runs that lie inside one group's chunk are flushed by that group;
+  // the first and the last run of every chunk may continue in the neighbouring chunks, so they meet in LDS and one group merges
+  // them across the workgroup: a hot id costs one atomic row per WORKGROUP span (256 pairs at d = 64), not one per 16 pairs.
+  constexpr int NG = 256 / LPR;
+  __shared__ int s_id[NG][2];
+  __shared__ __attribute__((aligned(16))) float s_sum[NG][2][LPR * 4];
+  const int g = threadIdx.x / LPR, sub = threadIdx.x - g * LPR;
+  const int e0 = (blockIdx.x * NG + g) * SS_CH;
   int ids[SS_CH];
   f32x4 val[SS_CH];
 #pragma unroll
@@ -130,28 +134,56 @@ __global__ __launch_bounds__(256) void scatter_add_sorted_kernel(const float* __
     ids[e] = id;
     val[e] = id >= 0 ? *reinterpret_cast<const f32x4*>(src + (size_t)r * lds + col0 + 4 * sub) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  int cur = -1;
-  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto flush = [&]() {
-    if (cur < 0) return;
-    float* dst = grad_table + (size_t)cur * d + 4 * sub;
+  auto flush = [&](int id, const f32x4& acc) {
+    if (id < 0) return;
+    float* dst = grad_table + (size_t)id * d + 4 * sub;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (acc[c] != 0.f) atomicAdd(dst + c, acc[c]);
-    if (row_flags && sub == 0) row_flags[cur] = 1;
+    if (row_flags && sub == 0) row_flags[id] = 1;
   };
+  // runs of this chunk: the first goes to LDS slot 0, the last (if different from the first) to slot 1, the ones between are flushed
+  int cur = -1, nruns = 0;
+  f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+  int first_id = -1;
+  f32x4 first_sum = acc;
 #pragma unroll
   for (int e = 0; e < SS_CH; ++e) {
     if (ids[e] < 0) continue;
     if (ids[e] != cur) {
-      flush();
+      if (nruns == 1) { first_id = cur; first_sum = acc; }
+      else if (nruns > 1) flush(cur, acc);
       cur = ids[e];
       acc = val[e];
+      ++nruns;
     } else {
       acc += val[e];
     }
   }
-  flush();
+  if (nruns == 1) { first_id = cur; first_sum = acc; cur = -1; }      // a single run: it is both first and last
+  if (sub == 0) { s_id[g][0] = first_id; s_id[g][1] = cur; }
+  *reinterpret_cast<f32x4*>(&s_sum[g][0][4 * sub]) = first_sum;
+  *reinterpret_cast<f32x4*>(&s_sum[g][1][4 * sub]) = acc;
+  __syncthreads();
+  if (g == 0) {               // merge the boundary runs of the workgroup in order
+    int mid = -1;
+    f32x4 macc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int gg = 0; gg < NG; ++gg)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        const int id = s_id[gg][w];
+        if (id < 0) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&s_sum[gg][w][4 * sub]);
+        if (id == mid) {
+          macc += v;
+        } else {
+          flush(mid, macc);
+          mid = id;
+          macc = v;
+        }
+      }
+    flush(mid, macc);
+  }
 }
 int launch_scatter_add_sorted(const float* src, int lds, int col0, int d, const int* sorted_ids, const int* sorted_rows, int n,
                               float* grad_table, hipStream_t st, unsigned char* row_flags, const int* row_off, const int* len, int T) {
@@ -159,8 +191,8 @@ int launch_scatter_add_sorted(const float* src, int lds, int col0, int d, const 
   INTEL_CHECK_ARG(d == 16 || d == 32 || d == 64 || d == 128, "scatter_add_sorted: row width %d unsupported", d);
   INTEL_CHECK_ARG(((lds | col0) & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0, "scatter_add_sorted: unaligned source");
   const int lpr = d / 4;
-  const long long threads = (long long)cdiv(n, SS_CH) * lpr;
-  const dim3 grid((unsigned)((threads + 255) / 256));
+  const int per_block = (256 / lpr) * SS_CH;            // pairs per workgroup
+  const dim3 grid((unsigned)cdiv(n, per_block));
   const double bytes = 8.0 * (double)n * d + 8.0 * n;
   switch (lpr) {
     case 4: LAUNCH_W(0.0, bytes, scatter_add_sorted_kernel<4>, grid, dim3(256), 0, st, src, lds, col0, d, sorted_ids, sorted_rows, n, grad_table, row_flags, row_off, len, T); break;

@@ -383,3 +383,37 @@ def test_flagged_row_adam_equals_dense_adam(workload, B, monkeypatch):
     for a, b in ((p1, p0), (m1[:p1.numel()].view(-1, d), m0[:p0.numel()].view(-1, d)), (v1[:p1.numel()].view(-1, d), v0[:p0.numel()].view(-1, d))):
         assert torch.equal(a[~t1], b[~t1])
         assert float((a[t1] - b[t1]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize('packed', [True, False])
+def test_sorted_embedding_scatter_equals_unsorted(packed, monkeypatch):
+    """The id-sorted embedding-gradient scatter (runs of equal ids summed in registers, boundary runs merged through LDS) == the
+    plain atomic scatter on a batch with heavily repeated item ids (Zipf popularity), for the tower rows and for the packed and
+    padded item-history rows: the parameters after two fused steps agree up to the order of the float additions."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    over = dict(items=5000, users=500)
+    res = []
+    for mode in ('0', '1'):
+        monkeypatch.setenv('INTEL_SCATTER_SORTED', mode)
+        torch.manual_seed(4)
+        args = synth.make_args('tmall', dev)
+        corpus, _ = synth.make_corpus('tmall', **over)
+        model = IntEL(args, corpus).to(dev)
+        eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+        for step in range(2):
+            batch = synth.make_batch('tmall', 96, dev, seed=30 + step, ragged=True, zipf=True, corpus_over=over)
+            batch['his_item_id'] = batch['i_id_s'][:, :batch['his_item_id'].shape[1]].clone() * (batch['his_item_id'] > 0)   # repeated ids in the histories too
+            if not packed:
+                batch.pop('his_rows'), batch.pop('hisitem_rows')
+            eng.train_step(batch, noise_seed=99 + step)
+        torch.cuda.synchronize()
+        ids = batch['i_id_s'].reshape(-1)
+        assert torch.unique(ids).numel() < 0.5 * ids.numel()                 # the batch does repeat its ids
+        res.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+    for k, v in res[0].items():
+        if 'k_linear.bias' in k:
+            continue
+        assert float((v - res[1][k]).abs().max()) < 2e-6, k
