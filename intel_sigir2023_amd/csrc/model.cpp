@@ -899,8 +899,13 @@ float* bert_bwd(Run& r, int e) {
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
   }
-  // position embedding gradient: dpos[p,:] = sum over rows at position p = onehot^T dE (MFMA wgrad)
-  if (r.G(enc_slot(e, INTEL_ENC_POS))) {
+  // position embedding gradient: dpos[p,:] = sum of dE over the rows at position p (per-workgroup LDS tables + one atomic per entry)
+  if (r.G(enc_slot(e, INTEL_ENC_POS)) && pos_grad_supported(T, dm)) {
+    const int ps = enc_slot(e, INTEL_ENC_POS);
+    if (!r.ok(launch_fill(r.G(ps), (long long)(D.history_max + 1) * dm, 0.f, r.st))) return nullptr;
+    r.acc(ps);
+    if (!r.ok(launch_pos_grad(dX, dm, off ? n.rowT : nullptr, len, T, rows, r.G(ps), r.st))) return nullptr;
+  } else if (r.G(enc_slot(e, INTEL_ENC_POS))) {      // table too large for LDS: onehot^T dE through the weight-gradient kernel
     const int ps = enc_slot(e, INTEL_ENC_POS);
     if (!r.ok(launch_make_onehot(off ? n.rowT : nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;
     if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;

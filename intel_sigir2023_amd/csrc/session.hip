@@ -743,6 +743,53 @@ int launch_his_pack(const int* len, const int* off, int B, int T, const int* ids
   return 0;
 }
 
+// gradient of the position embedding (GeneralSeq.py:95-97): dpos[t, :] += sum of dE[row, :] over the rows at position t.  Rows
+// arrive in session order, so positions are spread evenly over any row range: every workgroup sums its rows into a [T, dm] table
+// in LDS (ds_add_f32, no hot address) and adds the table to dpos with one global atomic per entry.  row_t: position of each
+// packed row, or NULL for padded [B, T] rows (position = t if t < len[b] else 0, like the forward).  dpos must be zeroed before.
+__global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ row_t,
+                                                       const int* __restrict__ len, int T, int rows, float* __restrict__ dpos) {
+  extern __shared__ __attribute__((aligned(16))) float s_tab[];      // [T][dm]
+  const int n = T * dm;
+  for (int i = threadIdx.x; i < n; i += 256) s_tab[i] = 0.f;
+  __syncthreads();
+  const int c4 = dm / 4;                       // float4 per row
+  const long long total = (long long)rows * c4;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int row = (int)(i / c4), c = (int)(i - (long long)row * c4) * 4;
+    int t;
+    if (row_t) {
+      t = row_t[row];
+    } else {
+      const int b = row / T;
+      t = row - b * T;
+      if (t >= len[b]) t = 0;
+    }
+    const f32x4 v = *reinterpret_cast<const f32x4*>(dE + (size_t)row * dm + c);
+    float* dst = s_tab + t * dm + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (v[k] != 0.f) atomicAdd(dst + k, v[k]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = s_tab[i];
+    if (v != 0.f) atomicAdd(dpos + i, v);
+  }
+}
+bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * sizeof(float) <= 150 * 1024; }
+int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st) {
+  if (rows <= 0) return 0;
+  INTEL_CHECK_ARG(pos_grad_supported(T, dm), "pos_grad: table %d x %d does not fit LDS", T, dm);
+  const size_t smem = (size_t)T * dm * sizeof(float);
+  allow_lds(pos_grad_kernel, smem);
+  int grid = cdiv(rows, 256);
+  if (grid > 2 * num_cus()) grid = 2 * num_cus();
+  LAUNCH_W(0.0, 4.0 * (double)rows * dm, pos_grad_kernel, dim3(grid), dim3(256), smem, st, dE, dm, row_t, len, T, rows, dpos);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 // one-hot intent rows of the item history (IntEL.py:142 with his_item_int one-hot):
 // E[m, col0:col0+d_int] = Wint[:, idx[m]] + bint   (idx < 0: bias only)
 __global__ void onehot_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int d_int, int I,
