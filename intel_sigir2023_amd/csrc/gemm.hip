@@ -1459,28 +1459,6 @@ static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   return 0;
 }
 
-// Thin products (an output or an input of at most 32 columns: the K = 3 fusion weights, the I = 30 intent logits and their
-// gradients) on the VALU: one thread per output element, the weight element read from the packed MFMA layout.  The MFMA fallback
-// spent 11-32 us per launch on these (a 64 x 128 tile per workgroup for 3 or 30 useful columns).
-__global__ __launch_bounds__(256) void gemm_rows_thin_kernel(GemmRowsArgs a) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)a.M * a.N) return;
-  const int m = (int)(i / a.N), n = (int)(i - (long long)m * a.N);
-  const int KG = (a.K + 15) >> 4;
-  // packed B: P[((nt*KG + g)*64 + lane)*4 + s] = B[g*16 + 4*(lane>>4) + s][nt*16 + (lane&15)]
-  const float* Pn = a.Bp + ((size_t)(n >> 4) * KG * 64 + (n & 15)) * 4;
-  const float* Am = a.A + (size_t)m * a.lda;
-  float acc = 0.f;
-  for (int k = 0; k < a.K; ++k) acc = fmaf(Am[k], Pn[((size_t)(k >> 4) * 64 + ((k & 15) >> 2) * 16) * 4 + (k & 3)], acc);
-  const GemmEpilogue& ep = a.ep;
-  float x = acc + (ep.bias ? ep.bias[n] : 0.f);
-  if (ep.relu) x = fmaxf(x, 0.f);
-  if (ep.mask) x = (ep.mask[(size_t)m * ep.ldmask + n] > 0.f) ? x : 0.f;
-  if (ep.res) x += ep.res[(size_t)m * ep.ldres + n];
-  float* dst = a.C + (size_t)m * a.ldc + n;
-  *dst = ep.accumulate ? (*dst + x) : x;
-}
-
 template <int RT, bool LN>
 static int launch_w8(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
@@ -1566,13 +1544,6 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 64) return launch_w8k<4>(a, st);
     if (N > 32) return launch_w8k<2>(a, st);
     return launch_w8k<1>(a, st);
-  }
-  static const int use_thin = [] { const char* e = getenv("INTEL_GEMM_THIN"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (use_thin && !ep.gamma && (N <= 32 || K <= 32)) {
-    const long long n_out = (long long)M * N;
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), gemm_rows_thin_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, a);
-    INTEL_CHECK_LAUNCH();
-    return 0;
   }
   size_t smem = (size_t)(GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_kernel, smem);
