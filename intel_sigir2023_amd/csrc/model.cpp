@@ -348,6 +348,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += (size_t)D.layers * (5 * Wf(M, d_s, d_s) + Lf(M, d_s));
     if (D.encoder == INTEL_ENC_BERT4REC) {
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * H, dm0, dm0) + Lf((size_t)B * H, dm0)) + Lf((size_t)B * H, dm0) + Wf((size_t)B * H, H, dm0);
+      a += rup_sz((size_t)128 * H * dm0, 64) + rup_sz((size_t)128 * Hi * dm1, 64);      // position-embedding gradient tables
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
     }
     a += 2 * Wf(psw ? B : M, K, y.F);                                     // fusion weights (+ pad rows)
@@ -902,9 +903,9 @@ float* bert_bwd(Run& r, int e) {
   // position embedding gradient: dpos[p,:] = sum of dE over the rows at position p (per-workgroup LDS tables + one atomic per entry)
   if (r.G(enc_slot(e, INTEL_ENC_POS)) && pos_grad_supported(T, dm)) {
     const int ps = enc_slot(e, INTEL_ENC_POS);
-    if (!r.ok(launch_fill(r.G(ps), (long long)(D.history_max + 1) * dm, 0.f, r.st))) return nullptr;
+    if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
     r.acc(ps);
-    if (!r.ok(launch_pos_grad(dX, dm, off ? n.rowT : nullptr, len, T, rows, r.G(ps), r.st))) return nullptr;
+    if (!r.ok(launch_pos_grad(dX, dm, off ? n.rowT : nullptr, len, T, rows, r.G(ps), r.st, r.ctx->rq))) return nullptr;
   } else if (r.G(enc_slot(e, INTEL_ENC_POS))) {      // table too large for LDS: onehot^T dE through the weight-gradient kernel
     const int ps = enc_slot(e, INTEL_ENC_POS);
     if (!r.ok(launch_make_onehot(off ? n.rowT : nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;

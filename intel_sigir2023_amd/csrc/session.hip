@@ -745,10 +745,11 @@ int launch_his_pack(const int* len, const int* off, int B, int T, const int* ids
 
 // gradient of the position embedding (GeneralSeq.py:95-97): dpos[t, :] += sum of dE[row, :] over the rows at position t.  Rows
 // arrive in session order, so positions are spread evenly over any row range: every workgroup sums its rows into a [T, dm] table
-// in LDS (ds_add_f32, no hot address) and adds the table to dpos with one global atomic per entry.  row_t: position of each
-// packed row, or NULL for padded [B, T] rows (position = t if t < len[b] else 0, like the forward).  dpos must be zeroed before.
+// in LDS (ds_add_f32, no hot address) and writes it as one slab; the slabs are summed by the batched slab reduction like every
+// other weight gradient (fixed order).  row_t: position of each packed row, or NULL for padded [B, T] rows (position = t if
+// t < len[b] else 0, like the forward).
 __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ row_t,
-                                                       const int* __restrict__ len, int T, int rows, float* __restrict__ dpos) {
+                                                       const int* __restrict__ len, int T, int rows, float* __restrict__ slabs) {
   extern __shared__ __attribute__((aligned(16))) float s_tab[];      // [T][dm]
   const int n = T * dm;
   for (int i = threadIdx.x; i < n; i += 256) s_tab[i] = 0.f;
@@ -772,21 +773,30 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
       if (v[k] != 0.f) atomicAdd(dst + k, v[k]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = s_tab[i];
-    if (v != 0.f) atomicAdd(dpos + i, v);
-  }
+  float* slab = slabs + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += 256) slab[i] = s_tab[i];
+}
+int pos_grad_slabs(int rows) {
+  int s = cdiv(rows, 1024);
+  return s < 1 ? 1 : (s > 128 ? 128 : s);
 }
 bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * sizeof(float) <= 150 * 1024; }
-int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st) {
+// dpos[0:T, :] = the sum (valid after redq_flush); needs pos_grad_slabs(rows) * T * dm floats of the queue's arena
+int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st,
+                    ReduceQueue* q) {
   if (rows <= 0) return 0;
-  INTEL_CHECK_ARG(pos_grad_supported(T, dm), "pos_grad: table %d x %d does not fit LDS", T, dm);
+  INTEL_CHECK_ARG(pos_grad_supported(T, dm) && q, "pos_grad: table %d x %d does not fit LDS", T, dm);
   const size_t smem = (size_t)T * dm * sizeof(float);
   allow_lds(pos_grad_kernel, smem);
-  int grid = cdiv(rows, 256);
-  if (grid > 2 * num_cus()) grid = 2 * num_cus();
-  LAUNCH_W(0.0, 4.0 * (double)rows * dm, pos_grad_kernel, dim3(grid), dim3(256), smem, st, dE, dm, row_t, len, T, rows, dpos);
+  const int S = pos_grad_slabs(rows);
+  float* slabs = redq_alloc(q, (size_t)S * T * dm);
+  if (!slabs) {
+    intel_set_error("pos_grad: reduction arena exhausted");
+    return -2;
+  }
+  LAUNCH_W(0.0, 4.0 * (double)rows * dm, pos_grad_kernel, dim3(S), dim3(256), smem, st, dE, dm, row_t, len, T, rows, slabs);
   INTEL_CHECK_LAUNCH();
+  redq_push(q, slabs, (size_t)T * dm, S, T, dm, dpos, dm, 0);
   return 0;
 }
 
