@@ -754,10 +754,10 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
   const int n = T * dm;
   for (int i = threadIdx.x; i < n; i += 256) s_tab[i] = 0.f;
   __syncthreads();
-  const int c4 = dm / 4;                       // float4 per row
-  const long long total = (long long)rows * c4;
+  // lane = column (consecutive lanes hit consecutive LDS banks: a float4 per lane would put 32 lanes on 8 banks)
+  const long long total = (long long)rows * dm;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int row = (int)(i / c4), c = (int)(i - (long long)row * c4) * 4;
+    const int row = (int)(i / dm), c = (int)(i - (long long)row * dm);
     int t;
     if (row_t) {
       t = row_t[row];
@@ -766,18 +766,14 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
       t = row - b * T;
       if (t >= len[b]) t = 0;
     }
-    const f32x4 v = *reinterpret_cast<const f32x4*>(dE + (size_t)row * dm + c);
-    float* dst = s_tab + t * dm + c;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      if (v[k] != 0.f) atomicAdd(dst + k, v[k]);
+    atomicAdd(s_tab + t * dm + c, dE[i]);
   }
   __syncthreads();
   float* slab = slabs + (size_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += 256) slab[i] = s_tab[i];
 }
 int pos_grad_slabs(int rows) {
-  int s = cdiv(rows, 1024);
+  int s = cdiv(rows, 256);
   return s < 1 ? 1 : (s > 128 ? 128 : s);
 }
 bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * sizeof(float) <= 150 * 1024; }
