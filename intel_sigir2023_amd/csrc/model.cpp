@@ -348,7 +348,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += (size_t)D.layers * (5 * Wf(M, d_s, d_s) + Lf(M, d_s));
     if (D.encoder == INTEL_ENC_BERT4REC) {
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * H, dm0, dm0) + Lf((size_t)B * H, dm0)) + Lf((size_t)B * H, dm0) + Wf((size_t)B * H, H, dm0);
-      a += rup_sz((size_t)128 * H * dm0, 64) + rup_sz((size_t)128 * Hi * dm1, 64);      // position-embedding gradient tables
+      a += rup_sz((size_t)512 * H * dm0, 64) + rup_sz((size_t)512 * Hi * dm1, 64);      // position-embedding gradient tables
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
     }
     a += 2 * Wf(psw ? B : M, K, y.F);                                     // fusion weights (+ pad rows)

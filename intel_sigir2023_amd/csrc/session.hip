@@ -755,26 +755,38 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
   for (int i = threadIdx.x; i < n; i += 256) s_tab[i] = 0.f;
   __syncthreads();
   // lane = column (consecutive lanes hit consecutive LDS banks: a float4 per lane would put 32 lanes on 8 banks)
-  const long long total = (long long)rows * dm;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int row = (int)(i / dm), c = (int)(i - (long long)row * dm);
-    int t;
-    if (row_t) {
-      t = row_t[row];
-    } else {
-      const int b = row / T;
-      t = row - b * T;
-      if (t >= len[b]) t = 0;
+  const long long total = (long long)rows * dm, stride = (long long)gridDim.x * 256;
+  for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    float v[4];
+    int dst[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {          // four independent (position, value) loads in flight
+      const long long i = i0 + u * stride;
+      const bool ok = i < total;
+      const long long ic = ok ? i : 0;
+      const int row = (int)(ic / dm), c = (int)(ic - (long long)row * dm);
+      int t;
+      if (row_t) {
+        t = row_t[row];
+      } else {
+        const int b = row / T;
+        t = row - b * T;
+        if (t >= len[b]) t = 0;
+      }
+      dst[u] = ok ? t * dm + c : -1;
+      v[u] = dE[ic];
     }
-    atomicAdd(s_tab + t * dm + c, dE[i]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dst[u] >= 0) unsafeAtomicAdd(s_tab + dst[u], v[u]);      // ds_add_f32 (plain atomicAdd on LDS floats is a compare-and-swap loop)
   }
   __syncthreads();
   float* slab = slabs + (size_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += 256) slab[i] = s_tab[i];
 }
 int pos_grad_slabs(int rows) {
-  int s = cdiv(rows, 256);
-  return s < 1 ? 1 : (s > 128 ? 128 : s);
+  int s = cdiv(rows, 64);
+  return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * sizeof(float) <= 150 * 1024; }
 // dpos[0:T, :] = the sum (valid after redq_flush); needs pos_grad_slabs(rows) * T * dm floats of the queue's arena
