@@ -355,6 +355,13 @@ class IntEL(nn.Module):
         else:
             keep['his_item_int'] = self._f32(data['his_item_int'])
         H, Hi = keep['his_context_mh'].shape[1], keep['his_item_id'].shape[1]
+        if os.environ.get('INTEL_CHECK_IDS') == '1':
+            # nn.Embedding raises on an out-of-range id; the gather / scatter kernels do not look: opt-in check (synchronises)
+            for key, hi in (('i_id_s', self.item_num), ('his_item_id', self.item_num), ('i_class_c', max(self.itemfnum, 1)),
+                            ('u_id_c', self.user_num), ('context_mh', self._desc.ctx_num), ('his_context_mh', self._desc.ctx_num)):
+                t = keep[key]
+                if t.numel() and (int(t.max()) >= hi or int(t.min()) < 0):
+                    raise L.IntelHipError('batch[%r] holds ids outside [0, %d)' % (key, hi))
         b = L.IntelBatch(B=Bsz, L=Lmax, H=H, Hi=Hi)
         # packed histories: when the producer of the batch knows the total number of valid history rows on the HOST (the device
         # feed, the synthetic generator and data.collate_batch do: 'his_rows' / 'hisitem_rows'), the BERT4Rec encoders run on those
