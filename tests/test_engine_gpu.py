@@ -417,3 +417,24 @@ def test_sorted_embedding_scatter_equals_unsorted(packed, monkeypatch):
         if 'k_linear.bias' in k:
             continue
         assert float((v - res[1][k]).abs().max()) < 2e-6, k
+
+
+def test_out_of_range_ids_raise_when_checked(monkeypatch):
+    """INTEL_CHECK_IDS=1: an id outside the table raises before any kernel runs, as nn.Embedding does (the gather / scatter
+    kernels themselves do not look)."""
+    from intel_sigir2023_amd import _lib, synth
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    args = synth.make_args('tiny', dev)
+    corpus, c = synth.make_corpus('tiny')
+    model = IntEL(args, corpus).to(dev)
+    batch = synth.make_batch('tiny', 4, dev, seed=1)
+    monkeypatch.setenv('INTEL_CHECK_IDS', '1')
+    with torch.no_grad():
+        model(batch)                                   # in range: fine
+    bad = dict(batch)
+    bad['i_id_s'] = batch['i_id_s'].clone()
+    bad['i_id_s'][0, 0] = c['items']                   # one past the last row
+    with pytest.raises(_lib.IntelHipError):
+        with torch.no_grad():
+            model(bad)

@@ -123,11 +123,3 @@ print('same-init-ok')
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert 'same-init-ok' in out.stdout, out.stderr[-2000:]
 
-
-def test_id_range_check_is_opt_in(monkeypatch):
-    """INTEL_CHECK_IDS=1: an out-of-range id raises before any kernel runs (nn.Embedding's behaviour); the check needs no GPU
-    for the batch conversion itself, so it is exercised here up to the device requirement."""
-    from intel_sigir2023_amd import _lib
-    from intel_sigir2023_amd.model import IntEL
-    src = open(IntEL.prepare_batch.__code__.co_filename).read()
-    assert "INTEL_CHECK_IDS" in src and 'holds ids outside' in src
