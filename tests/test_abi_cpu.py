@@ -82,3 +82,14 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.cpp', '.hip', '.h')):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in txt and 'from oracle' not in txt and 'oracle/' not in txt.replace('# ', ''), f
+
+
+def test_dispatcher_ops_are_registered():
+    """`torch.ops.intel_mi355x.*` exist with schemas after importing the package's ops module (no GPU needed to register)."""
+    from intel_sigir2023_amd import ops
+    assert ops.REGISTERED_OPS == ['linear', 'linear_dgrad', 'linear_wgrad', 'attention', 'attention_bwd', 'add_layernorm', 'ndcg'], \
+        getattr(ops, '_REGISTER_ERROR', None)
+    for name in ops.REGISTERED_OPS:
+        assert getattr(torch.ops.intel_mi355x, name).default._schema.name == 'intel_mi355x::' + name
+    with pytest.raises(Exception):          # no CPU implementation: the product has no CPU path
+        torch.ops.intel_mi355x.linear(torch.zeros(4, 16), torch.zeros(8, 16), torch.zeros(8), False)
