@@ -73,6 +73,21 @@ __device__ __forceinline__ void store_planes(__bf16* dst, const bf16x4& h, const
   }
 }
 
+// c += sum over the four k-steps s and the four lane groups j of a[s] * b[s]: four exact fp32 MFMAs (16x16x4) in the parity mode,
+// ONE bf16 MFMA (v_mfma_f32_16x16x16_bf16: lane (i, j) supplies k = 4j .. 4j+3, the same element order) in bf16 mode
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int NP>
+__device__ __forceinline__ f32x4 mma4(const f32x4& a, const f32x4& b, f32x4 c) {
+  if (NP == 1) {
+    const bf16x4 ab = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+    const bf16x4 bb = bf16x4{(__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ab), __builtin_bit_cast(s16x4, bb), c, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) c = mfma16(a[s], b[s], c);
+  return c;
+}
+
 // NP = 3: the six plane products; NP = 1 (bf16 mode): the one product of the bf16-rounded operands
 template <int NP>
 __device__ __forceinline__ f32x4 mma(const bf16x8& wh, const bf16x8& wm, const bf16x8& wl, const bf16x8& ah, const bf16x8& am,
@@ -274,9 +289,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const f32x4*>(Kp + kt * 16 * LQ + 16 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) st[kt] = mfma16(kf[kt][s], qf[s], st[kt]);
+        for (int kt = 0; kt < 4; ++kt) st[kt] = mma4<NP>(kf[kt], qf, st[kt]);
       }
       // accumulator register r of tile kt at lane (j, p) = key kt*16 + 4j + r, query tile*16 + p
       float mx = -INFINITY;
@@ -313,13 +326,13 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
+          for (int dq = 0; dq < DQ; ++dq) {
+            f32x4 vv[4];                   // the four keys kt*16 + 4j + r of this lane group, dims 4p .. 4p+3
 #pragma unroll
-            for (int dq = 0; dq < DQ; ++dq) {
-              const f32x4 vv = *reinterpret_cast<const f32x4*>(Vp + (kt * 16 + r) * LQ + dq * 64);
+            for (int r = 0; r < 4; ++r) vv[r] = *reinterpret_cast<const f32x4*>(Vp + (kt * 16 + r) * LQ + dq * 64);
 #pragma unroll
-              for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = mfma16(vv[t], st[kt][r], oT[dq * 4 + t]);
-            }
+            for (int t = 0; t < 4; ++t)
+              oT[dq * 4 + t] = mma4<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, st[kt], oT[dq * 4 + t]);
           }
 #pragma unroll
         for (int dq = 0; dq < DQ; ++dq)
@@ -341,10 +354,9 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) oT[t] = mfma16(Vp[(kt * 16 + r) * LQ + t * 16], st[kt][r], oT[t]);
-          }
+          for (int t = 0; t < 2; ++t)
+            oT[t] = mma4<NP>(f32x4{Vp[(kt * 16 + 0) * LQ + t * 16], Vp[(kt * 16 + 1) * LQ + t * 16], Vp[(kt * 16 + 2) * LQ + t * 16],
+                                   Vp[(kt * 16 + 3) * LQ + t * 16]}, st[kt], oT[t]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const f32x4 o = oT[t] * inv;                       // register r = dim t*16 + 4j + r of query p
