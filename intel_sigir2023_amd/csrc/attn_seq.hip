@@ -40,6 +40,23 @@ __device__ __forceinline__ float gsum16(float v) {
   return v + __shfl_xor(v, 32);
 }
 
+// c += sum over the four k-steps s (and the four lane groups) of a[s] * b[s]: four exact fp32 MFMAs (16x16x4) in the parity mode;
+// in bf16 mode ONE v_mfma_f32_16x16x16_bf16, whose lane (i, j) supplies k = 4j .. 4j+3 -- the same element order -- so the
+// accumulator-to-operand tricks of these kernels carry over unchanged
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+template <bool BF>
+__device__ __forceinline__ f32x4 mma4(const f32x4& a, const f32x4& b, f32x4 c) {
+  if (BF) {
+    const bf16x4s ab = bf16x4s{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+    const bf16x4s bb = bf16x4s{(__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ab), __builtin_bit_cast(s16x4, bb), c, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) c = mfma16(a[s], b[s], c);
+  return c;
+}
+
 template <int DKT, int NT>
 struct SeqP {
   static constexpr int DK = DKT * 16;
@@ -95,7 +112,7 @@ __device__ __forceinline__ void split_pair(int bh, int heads, int& b, int& h) {
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int DKT, int NT, int LS>
+template <int DKT, int NT, int LS, bool BF = false>
 __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restrict__ qkv, int BH, int T, int d, int heads,
                                                            const int* __restrict__ key_len, const int* __restrict__ row_off, float c2,
                                                            float scale, float* __restrict__ out, float* __restrict__ lse) {
@@ -180,10 +197,15 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
             kf[(g + 1) & 1][kt] = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + p) * DK + ((((g + 1) * 4 + j) ^ p) << 2));
         }
         __builtin_amdgcn_sched_barrier(0);      // the prefetch stays above the MFMAs it overlaps
+        if (BF) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+          for (int kt = 0; kt < NT; ++kt) st[kt] = mma4<true>(kf[g & 1][kt], qf[g], st[kt]);
+        } else {
 #pragma unroll
-          for (int kt = 0; kt < NT; ++kt) st[kt] = mfma16(kf[g & 1][kt][s], qf[g][s], st[kt]);
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int kt = 0; kt < NT; ++kt) st[kt] = mfma16(kf[g & 1][kt][s], qf[g][s], st[kt]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       // first V fragment rides under the softmax
@@ -218,6 +240,28 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
       ps = gsum16(ps);
 #pragma unroll
       for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (BF) {
+        // one bf16 MFMA per (key tile, output tile): the four k-steps of a key tile are the four registers of st[kt]; the
+        // steps of the last tile that hold only padding carry P = 0 and zero V rows
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          f32x4 v4[4][DQ];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (kt == 0 && r == 0) {
+#pragma unroll
+              for (int dq = 0; dq < DQ; ++dq) v4[0][dq] = vv[0][dq];
+            } else {
+              load_v(kt * 4 + r, v4[r]);
+            }
+          }
+#pragma unroll
+          for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              oT[dq * 4 + t] = mma4<true>(f32x4{v4[0][dq][t], v4[1][dq][t], v4[2][dq][t], v4[3][dq][t]}, st[kt], oT[dq * 4 + t]);
+        }
+      } else {
 #pragma unroll
       for (int step = 0; step < NSTEPS; ++step) {
         if (step + 1 < NSTEPS) load_v(step + 1, vv[(step + 1) & 1]);
@@ -227,6 +271,7 @@ __global__ __launch_bounds__(256) void attn_seq_fwd_kernel(const float* __restri
 #pragma unroll
           for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = mfma16(vv[step & 1][dq][t], st[step >> 2][step & 3], oT[dq * 4 + t]);
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
     }
     // the copy into the other stage (issued one item ago) and the next query fragments had this whole compute
@@ -457,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __
 // The whole backward of one item in ONE kernel: the dK/dV sweep above, then -- the staged Q / dO rows being dead -- every
 // wave parks its 16 K rows (still in registers) and its dS column block in their LDS space and turns into a 16-QUERY
 // tile for dQ = dS K.  Neither dS nor K makes a round trip through HBM (bwd_kv + bwd_q: 0.6 GB per Tmall-shape step).
-template <int DKT, int NT, int LS>
+template <int DKT, int NT, int LS, bool BF = false>
 __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               int BH, int T, int d, int heads, const int* __restrict__ key_len,
@@ -537,10 +582,15 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
         const int off = (qt * 16 + p) * LD + g * 16 + 4 * j;
         const f32x4 qa = *reinterpret_cast<const f32x4*>(Qp + off);
         const f32x4 oa = *reinterpret_cast<const f32x4*>(Op + off);
+        if (BF) {
+          sa = mma4<true>(qa, kf[g], sa);
+          dp = mma4<true>(oa, vf[g], dp);
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sa = mfma16(qa[s], kf[g][s], sa);     // S[query slot][key]
-          dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
+          for (int s = 0; s < 4; ++s) {
+            sa = mfma16(qa[s], kf[g][s], sa);     // S[query slot][key]
+            dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
+          }
         }
       }
       f32x4 pr;
@@ -558,6 +608,16 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       }
       prs[qt] = pr;
       dsk[qt] = dp;
+      if (BF) {        // the four k-steps (queries 4j+s of the tile) in one bf16 MFMA; padded queries carry P = 0 and zero dO rows
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          f32x4 ov[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) ov[s] = *reinterpret_cast<const f32x4*>(Op + (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dvT[dq * 4 + t] = mma4<true>(f32x4{ov[0][t], ov[1][t], ov[2][t], ov[3][t]}, pr, dvT[dq * 4 + t]);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (qt * 4 + s >= NSTEPS) continue;     // queries 4s..4s+3 of the tile are padding (compile-time)
@@ -567,6 +627,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
 #pragma unroll
           for (int t = 0; t < 4; ++t) dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
         }
+      }
       }
     }
     if (kok) {
@@ -594,6 +655,16 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
         ds[r] = prs[qt][r] * (dsk[qt][r] - delta) * scale;
       }
       dsk[qt] = ds;
+      if (BF) {
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          f32x4 qv[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) qv[s] = *reinterpret_cast<const f32x4*>(Qp + (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dkT[dq * 4 + t] = mma4<true>(f32x4{qv[0][t], qv[1][t], qv[2][t], qv[3][t]}, ds, dkT[dq * 4 + t]);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (qt * 4 + s >= NSTEPS) continue;
@@ -603,6 +674,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
 #pragma unroll
           for (int t = 0; t < 4; ++t) dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
         }
+      }
       }
     }
     if (kok) {
@@ -637,6 +709,16 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
       const f32x4 dsT = *reinterpret_cast<const f32x4*>(Dq + kt * 16 + 4 * j);
+      if (BF) {
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq) {
+          f32x4 kv[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) kv[s] = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) dqT[dq * 4 + t] = mma4<true>(f32x4{kv[0][t], kv[1][t], kv[2][t], kv[3][t]}, dsT, dqT[dq * 4 + t]);
+        }
+      } else {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -645,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
 #pragma unroll
           for (int t = 0; t < 4; ++t) dqT[dq * 4 + t] = mfma16(kv[t], dsT[s], dqT[dq * 4 + t]);
         }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (q < tb) {
@@ -760,8 +843,13 @@ int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const 
     const size_t smem = (size_t)4 * C::BUF * sizeof(float);
     const int per_cu = (int)((size_t)160 * 1024 / smem);
     const int grid = min(cdiv(BH, C::PW), num_cus() * (per_cu < 1 ? 1 : per_cu));
-    allow_lds((attn_seq_fwd_kernel<DKT, NT, LS>), smem);
-    LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, out, lse);
+    if (gemm_planes() == 1) {       // bf16 mode: the two products as single bf16 MFMAs (softmax stays fp32)
+      allow_lds((attn_seq_fwd_kernel<DKT, NT, LS, true>), smem);
+      LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS, true>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, out, lse);
+    } else {
+      allow_lds((attn_seq_fwd_kernel<DKT, NT, LS>), smem);
+      LAUNCH_S(BH, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_fwd_kernel<DKT, NT, LS>), dim3(grid), dim3(256), smem, st, qkv, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, out, lse);
+    }
   });
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -789,8 +877,13 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
     SEQ_DISPATCH3(dkt, nt, ls, {
       using C = SeqCfg<DKT, NT>;
       const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + (1 + NT) * C::ROWS) * sizeof(float);
-      allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS>), smem);
-      LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
+      if (gemm_planes() == 1) {
+        allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS, true>), smem);
+        LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS, true>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
+      } else {
+        allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS>), smem);
+        LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
+      }
     });
     INTEL_CHECK_LAUNCH();
     return 0;
