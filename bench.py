@@ -193,6 +193,7 @@ def main():
     ap.add_argument('--nbatches', type=int, default=8, help='distinct resident batches cycled by the timed loop')
     ap.add_argument('--eval_steps', type=int, default=-1, help='evaluation steps timed after the training loop (-1: max(3, steps/2); 0: none)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_bf16_line', action='store_true', help='skip the bf16-mode measurement appended to the fp32 line at N=1')
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
     ap.add_argument('--cpu_budget', type=float, default=24.0)
@@ -345,6 +346,35 @@ def main():
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
         res['eval_kernel_launches_per_step'] = round(sum(v['launches'] for v in eprof.values()) / psteps, 1)
+    if world == 1 and not bf16 and not a.no_bf16_line:
+        # the same workload in the bf16 arithmetic mode (BASELINE.json configs[1] names it), measured in the same run on the same
+        # resident batches: a second model + engine (own fp32 master weights and Adam state), same timing brackets
+        args_bf = synth.make_args(a.workload, dev, **dict(over, dtype='bf16'))
+        torch.manual_seed(0)
+        model_bf = IntEL(args_bf, corpus).to(dev)
+        eng_bf = IntELEngine(model_bf, a.loss, args_bf, lr=lr, l2=l2)
+        for i in range(a.warmup):
+            eng_bf.train_step(batches[i % nbatches])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            lb = eng_bf.train_step(batches[i % nbatches])
+        torch.cuda.synchronize()
+        el_bf = time.perf_counter() - t0
+        model_bf.eval()
+        for i in range(2):
+            eng_bf.eval_step(batches[i % nbatches], k=3)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(max(1, ev_steps)):
+            _, nd_bf = eng_bf.eval_step(batches[i % nbatches], k=3)
+        torch.cuda.synchronize()
+        ev_bf = time.perf_counter() - t1
+        res['bf16_mode'] = {'value': round(B * a.steps / max(el_bf, 1e-9), 1), 'unit': 'sessions/s', 'ms_per_step': round(1e3 * el_bf / max(1, a.steps), 4),
+                            'eval_sessions_per_s': round(B * max(1, ev_steps) / ev_bf, 1), 'ndcg3_random_init': round(float(nd_bf.float().nan_to_num(0).mean()), 5),
+                            'loss_last_step': round(float(lb[0]), 6) if a.steps else None,
+                            'note': 'python bench.py --dtype bf16 gives this mode its own full line (roofline, kernel table); not `value`'}
+        del eng_bf, model_bf
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)
     print(json.dumps(res))

@@ -387,6 +387,124 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmRowsArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// gemm_rows, the odd products of the B-row chains (intent logits: N = I = 30; fusion weights: N = K = 3; their
+// transposes with a 30- or 3-wide reduction): few rows, and an N or a K that is no multiple of four.  The 64-row
+// workgroups of the generic kernel leave 3/4 of the chip idle at 4096 rows and (for N <= 32) two of their four waves
+// without a column tile; here a workgroup owns 16 rows (256 workgroups at 4096 rows) and
+//   THIN (N <= 32): the four waves split the reduction (k group g goes to wave g % 4), read their A fragments straight
+//         from global memory (every element is used by one wave only) and sum their partial tiles through LDS;
+//   wide (K <= 128): the 16 x K tile is staged once, every wave keeps its A fragments in registers and sweeps the
+//         column tiles ct = wave, wave + 4, ...
+// Exact fp32 MFMA (16x16x4) like the generic kernel.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void small_tile_epilogue(const GemmRowsArgs& a, const f32x4& acc, int row, int col) {
+  if (row >= a.M || col >= a.N) return;
+  const GemmEpilogue& ep = a.ep;
+  if (a.vec_ep && col + 3 < a.N) {
+    f32x4 x = acc;
+    if (ep.bias) x += *reinterpret_cast<const f32x4*>(ep.bias + col);
+    if (ep.relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+    }
+    if (ep.mask) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(ep.mask + (size_t)row * ep.ldmask + col);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[r] = m[r] > 0.f ? x[r] : 0.f;
+    }
+    if (ep.res) x += *reinterpret_cast<const f32x4*>(ep.res + (size_t)row * ep.ldres + col);
+    f32x4* dst = reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col);
+    if (ep.accumulate) x += *dst;
+    *dst = x;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cc = col + r;
+    if (cc >= a.N) continue;
+    float x = acc[r] + (ep.bias ? ep.bias[cc] : 0.f);
+    if (ep.relu) x = fmaxf(x, 0.f);
+    if (ep.mask) x = (ep.mask[(size_t)row * ep.ldmask + cc] > 0.f) ? x : 0.f;
+    if (ep.res) x += ep.res[(size_t)row * ep.ldres + cc];
+    float* dst = a.C + (size_t)row * a.ldc + cc;
+    *dst = ep.accumulate ? (*dst + x) : x;
+  }
+}
+
+template <bool THIN>
+__global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmRowsArgs a) {
+  __shared__ __attribute__((aligned(16))) float sm[THIN ? 4 * 2 * 64 * 4 : 16 * GR_LDA];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * 16;
+  const int Kp = (a.K + 15) & ~15, KG = Kp >> 4;
+  const int NT = (a.N + 15) >> 4;
+  const int row = m0 + (lane & 15), kq = 4 * (lane >> 4);
+  const f32x4* bp = reinterpret_cast<const f32x4*>(a.Bp);
+  if (THIN) {
+    const bool vecA = ((a.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0);
+    const float* ap = a.A + (size_t)min(row, a.M - 1) * a.lda + kq;
+    const bool two = NT > 1;
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    for (int g = wave; g < KG; g += 4) {
+      const int k0 = g * 16 + kq;
+      f32x4 av = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (vecA && k0 + 3 < a.K) {
+        av = *reinterpret_cast<const f32x4*>(ap + g * 16);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (k0 + r < a.K) av[r] = ap[g * 16 + r];
+      }
+      const f32x4 b0 = bp[(size_t)g * 64 + lane];
+      f32x4 b1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (two) b1 = bp[((size_t)KG + g) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc0 = mfma16(b0[q], av[q], acc0);
+      if (two) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc1 = mfma16(b1[q], av[q], acc1);
+      }
+    }
+    f32x4* red = reinterpret_cast<f32x4*>(sm);
+    red[(wave * 2 + 0) * 64 + lane] = acc0;
+    red[(wave * 2 + 1) * 64 + lane] = acc1;
+    __syncthreads();
+    if (wave < NT) {
+      f32x4 x = red[(0 * 2 + wave) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) x += red[(w * 2 + wave) * 64 + lane];
+      small_tile_epilogue(a, x, row, wave * 16 + kq);
+    }
+    return;
+  }
+  // wide: K <= 128
+  for (int i = tid; i < 16 * Kp; i += 256) {
+    const int r = i / Kp, c = i - r * Kp;
+    float v = 0.f;
+    if (m0 + r < a.M && c < a.K) v = a.A[(size_t)(m0 + r) * a.lda + c];
+    sm[r * GR_LDA + c] = v;
+  }
+  __syncthreads();
+  f32x4 af[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g)
+    af[g] = g < KG ? *reinterpret_cast<const f32x4*>(sm + (lane & 15) * GR_LDA + g * 16 + kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ct = wave; ct < NT; ct += 4) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g < KG) {
+        const f32x4 b = bp[((size_t)ct * KG + g) * 64 + lane];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = mfma16(b[q], af[g][q], acc);
+      }
+    }
+    small_tile_epilogue(a, acc, row, ct * 16 + kq);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // gemm_rows, B-stationary persistent form (K <= 128, 16-byte aligned A).
 //
 // 512-thread workgroup = 8 waves; wave (ct, rg) owns ONE 16-column tile and RT of the four 16-row
@@ -1544,6 +1662,19 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 64) return launch_w8k<4>(a, st);
     if (N > 32) return launch_w8k<2>(a, st);
     return launch_w8k<1>(a, st);
+  }
+  static const int use_small = [] { const char* e = getenv("INTEL_GEMM_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (use_small && !ep.gamma && M <= 16384) {      // B-row chains: 16-row workgroups (see gemm_rows_small_kernel)
+    if (N <= 32) {
+      LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), gemm_rows_small_kernel<true>, dim3(cdiv(M, 16)), dim3(256), 0, st, a);
+      INTEL_CHECK_LAUNCH();
+      return 0;
+    }
+    if (rup(K, 16) <= GR_KC) {
+      LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), gemm_rows_small_kernel<false>, dim3(cdiv(M, 16)), dim3(256), 0, st, a);
+      INTEL_CHECK_LAUNCH();
+      return 0;
+    }
   }
   size_t smem = (size_t)(GR_BM * GR_LDA) * sizeof(float);
   allow_lds(gemm_rows_kernel, smem);

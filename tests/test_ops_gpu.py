@@ -28,7 +28,10 @@ def _close(got, ref, tol=2e-5, name=''):
                                    (1000, 128, 384), (65, 1071, 16), (50, 64, 200), (700, 384, 128), (4100, 256, 64), (130, 192, 64), (333, 320, 32),
                                    # the branch-free DMA weight-gradient kernel: M % 32 == 0, N and K multiples of 32, every tile-count pair
                                    (256, 128, 128), (96, 64, 64), (4096, 64, 128), (320, 96, 32), (64, 128, 64), (128, 32, 32), (8192, 128, 128),
-                                   (2048, 32, 128), (1024, 64, 32), (32, 256, 384), (20480, 64, 64)])
+                                   (2048, 32, 128), (1024, 64, 32), (32, 256, 384), (20480, 64, 64),
+                                   # the 16-row workgroups of the B-row chains (N <= 32 split-K, or a ragged K <= 128)
+                                   (4096, 384, 30), (4096, 320, 3), (4096, 30, 384), (4096, 3, 320), (4099, 30, 128), (1000, 130, 30), (37, 1000, 3),
+                                   (515, 30, 30), (16, 3, 3), (4096, 127, 64)])
 def test_linear_fwd_dgrad_wgrad(M, K, N):
     from intel_sigir2023_amd import ops
     dev = _dev()

@@ -8,7 +8,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
-PMCARGS="--no_cpu_baseline --no_roofline --no_feed"
+PMCARGS="--no_cpu_baseline --no_roofline --no_feed --no_bf16_line"
 INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats.log 2>&1 < /dev/null
 INTEL_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 10 $PMCARGS > $out/stats_eval.log 2>&1 < /dev/null
