@@ -465,7 +465,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
 }
 
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off) {
+                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off, int h16) {
   if (B <= 0) return 0;
   int rc = check_attn_shape(T, d, heads);
   if (rc) return rc;
@@ -473,8 +473,8 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   const float scale = 1.0f / sqrtf((float)dk);
   float* dsum = scratch;
   if (attn_seq_path(T, dk))
-    return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st, row_off);
-  INTEL_CHECK_ARG(!row_off, "attention: packed rows are supported by the whole-sequence kernels only");
+    return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st, row_off, h16);
+  INTEL_CHECK_ARG(!row_off && !h16, "attention: packed rows / bf16-stored q,k,v are supported by the whole-sequence kernels only");
   dim3 grid(B * heads, cdiv(T, AT_QB));
   if (attn_ds_scheme()) {
     float* dS = scratch + rup_sz((size_t)B * heads * T, 64);

@@ -57,6 +57,21 @@ __device__ __forceinline__ f32x4 mma4(const f32x4& a, const f32x4& b, f32x4 c) {
   return c;
 }
 
+// four consecutive elements at element offset `off` of an fp32 or (H) bf16 array
+template <bool H>
+__device__ __forceinline__ f32x4 ldx4(const float* __restrict__ base, size_t off) {
+  if (H) {
+    const bf16x4s v = *reinterpret_cast<const bf16x4s*>(reinterpret_cast<const __bf16*>(base) + off);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  }
+  return *reinterpret_cast<const f32x4*>(base + off);
+}
+template <bool H>
+__device__ __forceinline__ void stx4(float* __restrict__ base, size_t off, const f32x4& v) {
+  if (H) *reinterpret_cast<bf16x4s*>(reinterpret_cast<__bf16*>(base) + off) = bf16x4s{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  else *reinterpret_cast<f32x4*>(base + off) = v;
+}
+
 template <int DKT, int NT>
 struct SeqP {
   static constexpr int DK = DKT * 16;
@@ -502,7 +517,8 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __
 // The whole backward of one item in ONE kernel: the dK/dV sweep above, then -- the staged Q / dO rows being dead -- every
 // wave parks its 16 K rows (still in registers) and its dS column block in their LDS space and turns into a 16-QUERY
 // tile for dQ = dS K.  Neither dS nor K makes a round trip through HBM (bwd_kv + bwd_q: 0.6 GB per Tmall-shape step).
-template <int DKT, int NT, int LS, bool BF = false>
+// BF: the products as single bf16 MFMAs (bf16 mode); H16 (with BF): q/k/v are read and dq/dk/dv written as bf16 arrays
+template <int DKT, int NT, int LS, bool BF = false, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               int BH, int T, int d, int heads, const int* __restrict__ key_len,
@@ -527,8 +543,15 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
   const int tb = row_off ? min(key_len[b], T) : T;            // rows of this session that exist in memory
   const bool kok = live && key < tb;
   f32x4 kf[DKT], vf[DKT];
-  load_row_frags<DKT>(kf, qkv + (base + key) * ldg + d + h * DK, kok, DK, lane);
-  load_row_frags<DKT>(vf, qkv + (base + key) * ldg + 2 * d + h * DK, kok, DK, lane);
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) {
+    const int col = g * 16 + 4 * j;
+    const bool ok = kok && col < DK;
+    const size_t off = ok ? (base + key) * ldg + d + h * DK + col : 0;
+    const f32x4 tk = ldx4<H16>(qkv, off), tv = ldx4<H16>(qkv, off + (ok ? d : 0));
+    kf[g] = ok ? tk : f32x4{0.f, 0.f, 0.f, 0.f};
+    vf[g] = ok ? tv : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   {
     // stage Q and dO (permuted rows)
     f32x4 vq[C::ITERS], vo[C::ITERS];
@@ -540,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       const size_t gr = ok ? grow : 0;
       const int hc = ok ? hcol : 0;
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 tq = *reinterpret_cast<const f32x4*>(qkv + gr * ldg + hc);
+      const f32x4 tq = ldx4<H16>(qkv, gr * ldg + hc);
       const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
       vq[it] = ok ? tq : zero;
       vo[it] = ok ? to : zero;
@@ -631,12 +654,12 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       }
     }
     if (kok) {
-      float* drow = dqkv + (base + key) * ldg + h * DK + 2 * d;
+      const size_t drow = (base + key) * ldg + h * DK + 2 * d;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
+          stx4<H16>(dqkv, drow + dq * 64 + 16 * j + 4 * r, f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]});
     }
   }
   __syncthreads();                               // the delta shares of all key tiles are in LDS
@@ -678,12 +701,12 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       }
     }
     if (kok) {
-      float* drow = dqkv + (base + key) * ldg + h * DK + d;
+      const size_t drow = (base + key) * ldg + h * DK + d;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
+          stx4<H16>(dqkv, drow + dq * 64 + 16 * j + 4 * r, f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]});
     }
   }   // live
   __syncthreads();                               // every wave is done with the staged Q / dO rows
@@ -731,13 +754,12 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       __builtin_amdgcn_sched_barrier(0);
     }
     if (q < tb) {
-      float* drow = dqkv + (base + q) * ldg + h * DK;
+      const size_t drow = (base + q) * ldg + h * DK;
 #pragma unroll
       for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) =
-              f32x4{dqT[dq * 4 + 0][r], dqT[dq * 4 + 1][r], dqT[dq * 4 + 2][r], dqT[dq * 4 + 3][r]};
+          stx4<H16>(dqkv, drow + dq * 64 + 16 * j + 4 * r, f32x4{dqT[dq * 4 + 0][r], dqT[dq * 4 + 1][r], dqT[dq * 4 + 2][r], dqT[dq * 4 + 3][r]});
     }
   }
 }
@@ -866,8 +888,11 @@ bool attn_seq_packed_supported(int T, int dk) {
   return fused && attn_seq_supported(T, dk);
 }
 
+bool attn_seq_h16_supported(int T, int dk) { return attn_seq_packed_supported(T, dk) && gemm_planes() == 1; }
+
 int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off) {
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off, int h16) {
+  INTEL_CHECK_ARG(!h16 || attn_seq_h16_supported(T, d / heads), "attn_seq: bf16-stored q/k/v need the fused backward in bf16 mode");
   INTEL_CHECK_ARG(!row_off || (key_len && attn_seq_packed_supported(T, d / heads)), "attn_seq: packed rows need the fused backward and the session lengths");
   const int dk = d / heads, dkt = dk / 16, BH = B * heads;
   const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
@@ -877,7 +902,10 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
     SEQ_DISPATCH3(dkt, nt, ls, {
       using C = SeqCfg<DKT, NT>;
       const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + (1 + NT) * C::ROWS) * sizeof(float);
-      if (gemm_planes() == 1) {
+      if (h16) {
+        allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS, true, true>), smem);
+        LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS, true, true>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
+      } else if (gemm_planes() == 1) {
         allow_lds((attn_seq_bwd_fused_kernel<DKT, NT, LS, true>), smem);
         LAUNCH_S(BH, T, dk, 10.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, (attn_seq_bwd_fused_kernel<DKT, NT, LS, true>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, row_off, scale * 1.44269504088896340736f, scale, dqkv);
       } else {

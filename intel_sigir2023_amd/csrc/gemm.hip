@@ -1028,7 +1028,8 @@ int launch_pack_b3(const float* Pf32, int Kd, int Nd, void* Pb3, hipStream_t st)
   return 0;
 }
 
-template <int RT, int NP = 3>
+// A16 (bf16 mode only): the A operand is a bf16 array [M, lda] (the q/k/v gradients written by the attention backward)
+template <int RT, int NP = 3, bool A16 = false>
 __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
   constexpr int RG = 4 / RT;
   constexpr int CT = 8 / RG;
@@ -1061,7 +1062,13 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3k_kernel(GemmRowsArgs a) {
     for (int jj = 0; jj < NJ; ++jj) {
       const int row = min(tt * GR_BM + trow[jj], a.M - 1);
       const int col = c * 128 + tcol[jj];
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + min(col, a.K - 4));
+      f32x4 v;
+      if (A16) {
+        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.A) + (size_t)row * a.lda + min(col, a.K - 4));
+        v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+      } else {
+        v = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + min(col, a.K - 4));
+      }
       pre[jj] = col < a.K ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -1179,6 +1186,14 @@ static int launch_b3k(const GemmRowsArgs& a, hipStream_t st) {
   int gx = ntiles < 512 ? ntiles : 512;
   if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);
+  if (a.ep.a_bf16) {
+    INTEL_CHECK_ARG(g_planes == 1, "gemm_rows: a bf16-stored A operand needs the bf16 mode");
+    allow_lds((gemm_rows_b3k_kernel<RT, 1, true>), smem);
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a) - 2.0 * a.M * (double)a.K,
+             (gemm_rows_b3k_kernel<RT, 1, true>), dim3(gx, nchunks), dim3(512), smem, st, a);
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   if (g_planes == 1) {
     allow_lds((gemm_rows_b3k_kernel<RT, 1>), smem);
     LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
@@ -1650,6 +1665,8 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 32) return launch_w8<2, false>(a, st);
     return launch_w8<1, false>(a, st);
   }
+  INTEL_CHECK_ARG(!ep.a_bf16 || (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && ep.b3 && (K & 3) == 0 && !ep.accumulate && !ep.mask),
+                  "gemm_rows: a bf16-stored A operand is supported by the K > 128 bf16-pipe kernel only");
   if (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && !((ep.mask || ep.res) && ep.accumulate) &&
       !(ep.mask && ep.res)) {
     static int use_b3k = -1;
@@ -1718,6 +1735,7 @@ size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M
 struct WgradArgs {
   const float* dY; int lddy; const float* X; int ldx; int M, N, K;
   float* slabs; int S; int want_db;
+  int dy_bf16;      // bf16 mode: dY is a bf16 array (wgrad_b3_kernel<.., Y16> only)
 };
 
 // the next 32-row tile is prefetched global -> registers (16-byte loads when the operands are aligned)
@@ -1982,7 +2000,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
-template <int NTW, int KTW, int NP = 3, bool TAIL = false>      // TAIL: M is not a multiple of 32 (zero-padded last tile)
+// TAIL: M is not a multiple of 32 (zero-padded last tile); Y16 (bf16 mode): dY is a bf16 array [M, lddy]
+template <int NTW, int KTW, int NP = 3, bool TAIL = false, bool Y16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
@@ -2003,6 +2022,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   for (int u = 0; u < YPT; ++u)
 #pragma unroll
     for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+  auto ldy = [&](size_t row, int col) -> f32x4 {
+    if (Y16) {
+      const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.dY) + row * a.lddy + col);
+      return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    }
+    return *reinterpret_cast<const f32x4*>(a.dY + row * a.lddy + col);
+  };
   auto load_tile = [&](int tt) {
     const size_t m0 = (size_t)tt * WG_RT;
     const bool full = !TAIL || (tt + 1) * WG_RT <= a.M;  // workgroup-uniform: only a ragged last tile takes the guarded loads
@@ -2011,12 +2037,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
       const int b = min(tid + 256 * u, YBL - 1), rb = b & 7, cb = b >> 3;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) py[u][r] = *reinterpret_cast<const f32x4*>(a.dY + (m0 + 4 * rb + r) * a.lddy + n0 + 4 * cb);
+        for (int r = 0; r < 4; ++r) py[u][r] = ldy(m0 + 4 * rb + r, n0 + 4 * cb);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t row = m0 + 4 * rb + r;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(a.dY + min(row, (size_t)a.M - 1) * a.lddy + n0 + 4 * cb);
+          const f32x4 v = ldy(min(row, (size_t)a.M - 1), n0 + 4 * cb);
           py[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -2474,6 +2500,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   WgradArgs a;
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.slabs = slabs;
   a.S = wgrad_num_slabs(M, N, K); a.want_db = db != nullptr;
+  a.dy_bf16 = split ? split->dy_bf16 : 0;
   {
     // fast path: exact 32-row tiles, widths in 32-float steps, 16-byte aligned operands
     static const int use_dma = [] { const char* e = getenv("INTEL_WGRAD_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2481,6 +2508,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
                          ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
     static const int use_wb3 = [] { const char* e = getenv("INTEL_WGRAD_B3"); return (e && e[0] == '0') ? 0 : 1; }();
+    INTEL_CHECK_ARG(!a.dy_bf16 || g_planes == 1, "wgrad: a bf16-stored dY needs the bf16 mode");
     if (use_wb3 && aligned && M >= 1 && N % 32 == 0 && K % 32 == 0) {      // any row count: the last tile is zero-padded in the kernel
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
@@ -2492,10 +2520,18 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
     LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
              dim3(256), smem, st, a);                                                                               \
   } while (0)
+#define WB_LAUNCH16(A_, B_, T_)                                                                                     \
+  do {                                                                                                              \
+    allow_lds((wgrad_b3_kernel<A_, B_, 1, T_, true>), smem);                                                        \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + 0.5 * (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, 1, T_, true>), grid, \
+             dim3(256), smem, st, a);                                                                               \
+  } while (0)
 #define WB_CASE(A_, B_)                                                                                             \
   if (ntw == A_ && ktw == B_) {                                                                                     \
     const bool tail = M % WG_RT != 0;                                                                               \
-    if (g_planes == 3 && !tail) WB_LAUNCH(A_, B_, 3, false);                                                        \
+    if (a.dy_bf16 && !tail) WB_LAUNCH16(A_, B_, false);                                                             \
+    else if (a.dy_bf16) WB_LAUNCH16(A_, B_, true);                                                                  \
+    else if (g_planes == 3 && !tail) WB_LAUNCH(A_, B_, 3, false);                                                   \
     else if (g_planes == 3) WB_LAUNCH(A_, B_, 3, true);                                                             \
     else if (!tail) WB_LAUNCH(A_, B_, 1, false);                                                                    \
     else WB_LAUNCH(A_, B_, 1, true);                                                                                \
@@ -2503,9 +2539,11 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
       WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
 #undef WB_CASE
 #undef WB_LAUNCH
+#undef WB_LAUNCH16
       INTEL_CHECK_LAUNCH();
       goto reduce;
     }
+    INTEL_CHECK_ARG(!a.dy_bf16, "wgrad: a bf16-stored dY needs the bf16-pipe kernel (aligned operands, N and K multiples of 32)");
     if (use_dma && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));

@@ -33,6 +33,7 @@ struct GemmEpilogue {
   int accumulate = 0;             // C += value instead of C = value
   int no_out = 0;                 // LayerNorm epilogue only: keep the x-hat / rstd stash, do not store C
   const void* b3 = nullptr;       // optional pre-split bf16 image of B (launch_pack_b3): used when K > 128
+  int a_bf16 = 0;                 // bf16 mode, K > 128 only: A is a bf16 array [M, lda] (elements), not fp32
 };
 // arithmetic mode of the matrix-pipe products: 3 = fp32 accuracy (three bf16 planes, six products), 1 = bf16 (one product)
 void gemm_set_planes(int planes);
@@ -74,7 +75,7 @@ int redq_flush(ReduceQueue* q, hipStream_t st);
 // partials go to the queue's arena and dW / db are valid only after redq_flush
 // split: the N columns of dY are the stacked outputs of several weights that share the input X (fused q/k/v): one
 // product, one reduction job per weight (dW[p] is [N/n, K]; db[p] all null or all set).  Needs the queue.
-struct WgradSplit { int n; float* dW[4]; float* db[4]; int acc[4]; };
+struct WgradSplit { int n; float* dW[4]; float* db[4]; int acc[4]; int dy_bf16 = 0; };   // dy_bf16 (bf16 mode): dY is a bf16 array [M, lddy]
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
                  float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr, const WgradSplit* split = nullptr);
 
@@ -98,12 +99,14 @@ bool attn_seq_supported(int T, int dk);
 int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                         hipStream_t st, const int* row_off = nullptr);
 size_t attn_seq_bwd_scratch_floats(int B, int T, int heads);
+// h16 (bf16 mode, fused backward only: attn_seq_h16_supported): qkv is read and dqkv written as bf16 arrays of the same shape
+bool attn_seq_h16_supported(int T, int dk);
 int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off = nullptr);
+                        int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off = nullptr, int h16 = 0);
 // scratch: attn_bwd_scratch_floats(B, T, d, heads) floats (row sums of dO*O; dS tiles of the whole-sequence path)
 size_t attn_bwd_scratch_floats(int B, int T, int d, int heads);
 int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
-                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off = nullptr);
+                    int heads, const int* key_len, float* dqkv, float* scratch, hipStream_t st, const int* row_off = nullptr, int h16 = 0);
 
 // ---- one tower layer in one kernel (tower.hip) -------------------------------------------------
 // L <= 64, d in {64, 128}, head dim in {32, 64, 128}; INTEL_FUSE_TOWER=0 turns the fused path off
@@ -114,7 +117,7 @@ bool tower_fused_wanted(int train);
 // (x-hat / rstd only); train = 0: none of the stash pointers is written.
 int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
-                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st);
+                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16 = 0);
 
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu

@@ -121,6 +121,7 @@ struct IntelCtx {
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
   bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
   bool enc_packed[2];          // this forward ran encoder e on the valid history rows only (IntelBatch.his_off / hisitem_off)
+  bool tw_qkv16[2] = {false, false};   // this forward stored tower t's q/k/v stash as bf16 (bf16 mode; the backward reads it and writes dQKV the same way)
   int enc_rows[2];             // rows of encoder e: B * T, or the packed total
 };
 
@@ -463,9 +464,10 @@ void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, in
 // the weight gradients of n linears that share the input X and whose output gradients sit side by side in dY
 // (fused q/k/v): one product over the stacked columns
 void wgrad_split(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, int Nsub, int K, int n, const int* w_slots,
-                 const int* b_slots) {
+                 const int* b_slots, int dy_bf16 = 0) {
   WgradSplit sp;
   sp.n = n;
+  sp.dy_bf16 = dy_bf16;
   bool any = false, all = true;
   for (int p = 0; p < n; ++p) {
     sp.dW[p] = r.G(w_slots[p]);
@@ -476,6 +478,11 @@ void wgrad_split(Run& r, const float* dY, int lddy, const float* X, int ldx, int
   bool bias_uniform = true;
   for (int p = 1; p < n; ++p) bias_uniform = bias_uniform && ((sp.db[p] != nullptr) == (sp.db[0] != nullptr));
   if (!any) return;
+  if (dy_bf16 && (!all || !bias_uniform || smallk_supported(Nsub, K))) {
+    r.ok(INTEL_E_ARG);
+    intel_set_error("wgrad_split: a bf16-stored dY needs all the stacked weights trainable");
+    return;
+  }
   if (!all || !bias_uniform || smallk_supported(Nsub, K)) {      // mixed cases: one product per weight
     for (int p = 0; p < n; ++p) wgrad(r, dY + p * Nsub, lddy, X, ldx, M, Nsub, K, w_slots[p], b_slots[p]);
     return;
@@ -617,11 +624,16 @@ void tower_fwd(Run& r, TowerBufs& w) {
   const float* X = w.X0;
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
   const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train) && !(r.train && r.ctx->drop_p > 0.f);
+  // bf16 mode: q/k/v (and, in the backward, their gradients) live in HBM as bf16 arrays -- every consumer rounds them to bf16
+  // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)
+  static const int h16_on = [] { const char* e = getenv("INTEL_BF16_QKV"); return (e && e[0] == '0') ? 0 : 1; }();
+  const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
+  r.ctx->tw_qkv16[tw_i] = fused && r.train && h16_on && gemm_planes() == 1 && attn_seq_h16_supported(L, d / D.heads) && d % 32 == 0;
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only
     RUN(launch_tower_fwd_fused(X, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2, r.P(pb + T_B1), r.P(pb + T_B2), r.P(pb + T_LNG),
-                               r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, b.QKV, b.A, b.LSE, b.R1, b.XH, b.RSTD, r.st));
+                               r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, b.QKV, b.A, b.LSE, b.R1, b.XH, b.RSTD, r.st, r.ctx->tw_qkv16[tw_i]));
     X = b.Xout;
   }
   for (int l = 0; !fused && l < D.layers; ++l) {
@@ -697,15 +709,17 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     GemmEpilogue e0;
     lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
     if (r.rc) return nullptr;
-    if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st))) return nullptr;
+    const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
+    if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st, nullptr, h16))) return nullptr;
     {
       const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
-      wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs);
+      wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs, h16);
     }
     // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
     GemmEpilogue er;
     er.res = dZ; er.ldres = d;
     er.b3 = w.b3WqkvT;
+    er.a_bf16 = h16;
     lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;

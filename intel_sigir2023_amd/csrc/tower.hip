@@ -130,6 +130,7 @@ struct TowerFwdArgs {
   const float* b1; const float* b2; const float* gamma; const float* beta;
   float* out;                // [B*L, D] or NULL (the caller rebuilds it from x-hat: fused tail)
   float* QKV;                // training stash (each may be NULL): [B*L, 3D]
+  int qkv16;                 // bf16 mode: the q/k/v stash is a bf16 array (read back by the attention backward as such)
   float* A;                  // [B*L, D] attention output
   float* LSE;                // [B*heads*L] natural-log softmax normalisers
   float* R1;                 // [B*L, D] relu(W1 A + b1)
@@ -256,7 +257,15 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         for (int rt = 0; rt < 4; ++rt) {
           const int row = rt * 16 + p;
           *reinterpret_cast<f32x4*>(dst + row * LQ) = acc[c][rt];
-          if (TRAIN && a.QKV && row < L) *reinterpret_cast<f32x4*>(a.QKV + ((size_t)b * L + row) * (3 * D) + n) = acc[c][rt];
+          if (TRAIN && a.QKV && row < L) {
+            const size_t off = ((size_t)b * L + row) * (3 * D) + n;
+            if (NP == 1 && a.qkv16) {
+              const f32x4& v = acc[c][rt];
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.QKV) + off) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            } else {
+              *reinterpret_cast<f32x4*>(a.QKV + off) = acc[c][rt];
+            }
+          }
         }
       }
     }
@@ -519,7 +528,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
-  if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0) + (a.XH ? 1.0 : 0.0));
+  if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? (a.qkv16 ? 1.5 : 3.0) : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0) + (a.XH ? 1.0 : 0.0));
   static const int dbg_on = [] { const char* e = getenv("INTEL_TOWER_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
   TowerFwdArgs aa = a;
   static unsigned long long* dbg_buf = nullptr;
@@ -558,13 +567,15 @@ bool tower_fused_supported(int L, int d, int heads) {
 
 int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
-                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st) {
+                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower_fused_supported(L, d, heads), "tower_fwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
   TowerFwdArgs a;
   a.X = X; a.B = B; a.L = L; a.heads = heads;
   a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3); a.W2 = reinterpret_cast<const uint4*>(W2_b3);
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
+  a.qkv16 = (qkv16 && gemm_planes() == 1) ? 1 : 0;
+  INTEL_CHECK_ARG(!qkv16 || a.qkv16, "tower_fwd: the bf16 q/k/v stash needs the bf16 mode");
   a.QKV = QKV; a.A = A; a.LSE = LSE; a.R1 = R1; a.XH = XH; a.RSTD = RSTD; a.dbg = nullptr;
   const int dk = d / heads;
   if (d == 128 && dk == 128) return train ? launch_one<128, 128, true>(a, st) : launch_one<128, 128, false>(a, st);
