@@ -79,7 +79,7 @@ struct Temps {
 
 struct Layout {
   int B, L, H, Hi, M;
-  Temps tmp[2];
+  Temps tmp[3];            // 0 / 1: tower-sized sets of the two concurrent branches; 2: encoder-sized (the third backward branch)
   TowerBufs tw[2];          // 0 = item tower, 1 = score tower
   EncBufs enc[2];           // 0 = "encoder" (session history), 1 = "item_encoder"
   int F, Pin;               // width of the fusion feature / pred_layer input
@@ -322,14 +322,16 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   if (lnslab > slab) slab = lnslab;
   const int Tm = H > Hi ? H : Hi;
   const int Rm = I > Tm ? I : Tm;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     Temps& t = y.tmp[i];
-    t.dXa = ar.f(maxMD);
-    t.dXb = ar.f(maxMD);
-    t.dZ = ar.f(maxMD);
-    t.dF1 = ar.f(maxMD);
-    t.dA = ar.f(maxMD);
-    t.dQKV = ar.f(3 * maxMD);
+    // set 2 only ever holds the session-history encoder's backward (rows B*H, width dm0)
+    const size_t mds = i < 2 ? maxMD : rup_sz((size_t)B * H * dm0, 64);
+    t.dXa = ar.f(mds);
+    t.dXb = ar.f(mds);
+    t.dZ = ar.f(mds);
+    t.dF1 = ar.f(mds);
+    t.dA = ar.f(mds);
+    t.dQKV = ar.f(3 * mds);
     t.DSUM = ar.f(maxLSE);
     t.dVB1 = ar.f((size_t)B * vmax);
     t.dVB2 = ar.f((size_t)B * vmax);
@@ -1264,6 +1266,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     }
   };
 
+  static const bool enc0_early = [] { const char* e = getenv("INTEL_ENC0_PHASE"); return !(e && e[0] == '2'); }();
   if (phase != 2) {
     // cross-attention backward of both towers first: d(intent) is then complete and the intent path can
     // start while the (heavy) tower layers are still running
@@ -1290,25 +1293,30 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
     // phase 1 branches: item tower layers (main, set 0) || item-history encoder (side 0, set 1): after the
     // join the item-id table gradient is complete
-    float* dE1 = nullptr;
-    fork_streams(r, 1);
+    // Both encoders' backward chains are long runs of small launches (B*H rows): the session-history encoder joins phase 1 on a
+    // third stream (set 2) instead of trailing the score tower in phase 2, where it was the critical path (INTEL_ENC0_PHASE=2
+    // restores that order).
+    float *dE1 = nullptr, *dE0 = nullptr;
+    fork_streams(r, enc0_early ? 2 : 1);
     {
-      Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
+      Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1), b2 = branch(r, 1, 2);
       item_tower_bwd(b0, y.tmp[0].dXa);
       dE1 = encoder_branch(b1, 1);
-      r.ok(b0.rc); r.ok(b1.rc);
+      if (enc0_early) dE0 = encoder_branch(b2, 0);
+      r.ok(b0.rc); r.ok(b1.rc); r.ok(b2.rc);
     }
-    join_streams(r, 1);
-    if (r.rc || !dE1) return;
+    join_streams(r, enc0_early ? 2 : 1);
+    if (r.rc || !dE1 || (enc0_early && !dE0)) return;
     r.T = &y.tmp[0];
     intent_wgrad(r, 1, dE1);
+    if (enc0_early) intent_wgrad(r, 0, dE0);
     if (r.rc) return;
     RUN(redq_flush(r.ctx->rq, r.st));
   }
   if (phase != 1) {
-    // phase 2 branches: score tower layers (main, set 0) || session-history encoder (side 0, set 1)
+    // phase 2: score tower layers (main, set 0) [|| session-history encoder (side 0, set 1) with INTEL_ENC0_PHASE=2]
     float* dE0 = nullptr;
-    fork_streams(r, 1);
+    if (!enc0_early) fork_streams(r, 1);
     {
       Run b0 = branch(r, -1, 0), b1 = branch(r, 0, 1);
       // the score tower's output gradient was parked in dXS by phase 1; tower_bwd ping-pongs dXS <-> dXb
@@ -1317,13 +1325,13 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         float* dX0 = tower_bwd(b0, w, y.dXS, y.tmp[0].dXb, r.ctx->fused_tail[1]);
         if (!b0.rc && dX0) wgrad(b0, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
       }
-      dE0 = encoder_branch(b1, 0);
+      if (!enc0_early) dE0 = encoder_branch(b1, 0);
       r.ok(b0.rc); r.ok(b1.rc);
     }
-    join_streams(r, 1);
-    if (r.rc || !dE0) return;
+    if (!enc0_early) join_streams(r, 1);
+    if (r.rc || (!enc0_early && !dE0)) return;
     r.T = &y.tmp[0];
-    intent_wgrad(r, 0, dE0);
+    if (!enc0_early) intent_wgrad(r, 0, dE0);
     if (r.rc) return;
     RUN(redq_flush(r.ctx->rq, r.st));
   }
