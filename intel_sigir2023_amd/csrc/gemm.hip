@@ -479,11 +479,21 @@ __global__ __launch_bounds__(256) void gemm_rows_small_kernel(GemmRowsArgs a) {
     return;
   }
   // wide: K <= 128
-  for (int i = tid; i < 16 * Kp; i += 256) {
-    const int r = i / Kp, c = i - r * Kp;
-    float v = 0.f;
-    if (m0 + r < a.M && c < a.K) v = a.A[(size_t)(m0 + r) * a.lda + c];
-    sm[r * GR_LDA + c] = v;
+  if (((a.lda & 3) == 0) && ((a.K & 3) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0)) {
+    const int c4n = Kp >> 2;
+    for (int i = tid; i < 16 * c4n; i += 256) {
+      const int r = i / c4n, c = (i - r * c4n) * 4;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (m0 + r < a.M && c < a.K) v = *reinterpret_cast<const f32x4*>(a.A + (size_t)(m0 + r) * a.lda + c);
+      *reinterpret_cast<f32x4*>(sm + r * GR_LDA + c) = v;
+    }
+  } else {
+    for (int i = tid; i < 16 * Kp; i += 256) {
+      const int r = i / Kp, c = i - r * Kp;
+      float v = 0.f;
+      if (m0 + r < a.M && c < a.K) v = a.A[(size_t)(m0 + r) * a.lda + c];
+      sm[r * GR_LDA + c] = v;
+    }
   }
   __syncthreads();
   f32x4 af[8];
