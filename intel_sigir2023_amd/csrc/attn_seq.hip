@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __
 // The whole backward of one item in ONE kernel: the dK/dV sweep above, then -- the staged Q / dO rows being dead -- every
 // wave parks its 16 K rows (still in registers) and its dS column block in their LDS space and turns into a 16-QUERY
 // tile for dQ = dS K.  Neither dS nor K makes a round trip through HBM (bwd_kv + bwd_q: 0.6 GB per Tmall-shape step).
-// BF: the products as single bf16 MFMAs (bf16 mode); H16 (with BF): q/k/v are read and dq/dk/dv written as bf16 arrays
+// BF: the products as single bf16 MFMAs (bf16 mode); H16 (with BF): q/k/v and dO are read and dq/dk/dv written as bf16 arrays
 template <int DKT, int NT, int LS, bool BF = false, bool H16 = false>
 __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
       const int hc = ok ? hcol : 0;
       const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 tq = ldx4<H16>(qkv, gr * ldg + hc);
-      const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
+      const f32x4 to = ldx4<H16>(dout, gr * d + hc);
       vq[it] = ok ? tq : zero;
       vo[it] = ok ? to : zero;
     }

@@ -132,6 +132,9 @@ static double gemm_algorithmic_bytes(const GemmRowsArgs& a) {
   if (a.ep.res || a.ep.mask || a.ep.accumulate) b += 4.0 * (double)a.M * a.N;
   if (a.ep.xhat) b += 4.0 * (double)a.M * a.N + 4.0 * (double)a.M;
   if (a.ep.no_out) b -= 4.0 * (double)a.M * a.N;
+  if (a.ep.a_bf16) b -= 2.0 * (double)a.M * a.K;
+  if (a.ep.c_bf16) b -= 2.0 * (double)a.M * a.N;
+  if (a.ep.mask && a.ep.mask_bf16) b -= 2.0 * (double)a.M * a.N;
   return b;
 }
 
@@ -799,7 +802,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const int row = min(tt * GR_BM + trow[jj], a.M - 1);
-      pre[jj] = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + tcol[jj]);
+      if (NP == 1 && !LN && ep.a_bf16) {       // bf16 mode: A stored as bf16 (dF1)
+        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.A) + (size_t)row * a.lda + tcol[jj]);
+        pre[jj] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+      } else {
+        pre[jj] = *reinterpret_cast<const f32x4*>(a.A + (size_t)row * a.lda + tcol[jj]);
+      }
     }
   };
   auto store_tile = [&]() {            // split into the three planes on the way into LDS
@@ -872,7 +880,13 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
-          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if (NP == 1 && mode == 1 && ep.mask_bf16) {      // bf16 mode: the relu stash is a bf16 array
+            const bf16x4 hv = row < a.M ? *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(auxp) + (size_t)row * auxld + col)
+                                        : bf16x4{(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            aux[rt] = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+          } else {
+            aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
         }
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -888,7 +902,12 @@ __global__ __launch_bounds__(512, 4) void gemm_rows_b3_kernel(GemmRowsArgs a) {
           } else {
             x += aux[rt];
           }
-          if (row < a.M && !((B3_ABLATE & 1) && x[0] != 12345.678f)) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+          if (row < a.M && !((B3_ABLATE & 1) && x[0] != 12345.678f)) {
+            if (NP == 1 && ep.c_bf16)
+              *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.C) + (size_t)row * a.ldc + col) = bf16x4{(__bf16)x[0], (__bf16)x[1], (__bf16)x[2], (__bf16)x[3]};
+            else
+              *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
+          }
         }
       }
     } else {
@@ -1199,7 +1218,7 @@ static int launch_b3k(const GemmRowsArgs& a, hipStream_t st) {
   if (a.ep.a_bf16) {
     INTEL_CHECK_ARG(g_planes == 1, "gemm_rows: a bf16-stored A operand needs the bf16 mode");
     allow_lds((gemm_rows_b3k_kernel<RT, 1, true>), smem);
-    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a) - 2.0 * a.M * (double)a.K,
+    LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
              (gemm_rows_b3k_kernel<RT, 1, true>), dim3(gx, nchunks), dim3(512), smem, st, a);
     INTEL_CHECK_LAUNCH();
     return 0;
@@ -1675,8 +1694,14 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 32) return launch_w8<2, false>(a, st);
     return launch_w8<1, false>(a, st);
   }
-  INTEL_CHECK_ARG(!ep.a_bf16 || (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && ep.b3 && (K & 3) == 0 && !ep.accumulate && !ep.mask),
-                  "gemm_rows: a bf16-stored A operand is supported by the K > 128 bf16-pipe kernel only");
+  if (ep.a_bf16 || ep.c_bf16 || ep.mask_bf16) {
+    static int use_b3x = -1;
+    if (use_b3x < 0) { const char* e = getenv("INTEL_GEMM_B3"); use_b3x = (e && e[0] == '0') ? 0 : 1; }
+    const bool common = g_planes == 1 && use_b3x && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && !ep.accumulate && !(ep.mask && ep.res);
+    const bool big_k = rup(K, 16) > GR_KC && ep.b3 && (K & 3) == 0 && !ep.c_bf16 && !ep.mask_bf16;      // gemm_rows_b3k: A only
+    const bool small_k = (K == 128 || K == 64);                                                          // gemm_rows_b3: A, C, mask
+    INTEL_CHECK_ARG(common && (big_k || small_k), "gemm_rows: bf16-stored operands need the bf16 mode and a bf16-pipe kernel (K = 64, 128, or K > 128 with a weight image)");
+  }
   if (rup(K, 16) > GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !ep.gamma && !((ep.mask || ep.res) && ep.accumulate) &&
       !(ep.mask && ep.res)) {
     static int use_b3k = -1;
@@ -1745,7 +1770,7 @@ size_t wgrad_slab_floats(int M, int N, int K) { return (size_t)wgrad_num_slabs(M
 struct WgradArgs {
   const float* dY; int lddy; const float* X; int ldx; int M, N, K;
   float* slabs; int S; int want_db;
-  int dy_bf16;      // bf16 mode: dY is a bf16 array (wgrad_b3_kernel<.., Y16> only)
+  int dy_bf16, x_bf16;      // bf16 mode: dY / X is a bf16 array (wgrad_b3_kernel with NP = 1 only)
 };
 
 // the next 32-row tile is prefetched global -> registers (16-byte loads when the operands are aligned)
@@ -2010,8 +2035,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
-// TAIL: M is not a multiple of 32 (zero-padded last tile); Y16 (bf16 mode): dY is a bf16 array [M, lddy]
-template <int NTW, int KTW, int NP = 3, bool TAIL = false, bool Y16 = false>
+// TAIL: M is not a multiple of 32 (zero-padded last tile); bf16 mode (NP = 1): a.dy_bf16 / a.x_bf16 mark operands stored as bf16 arrays
+template <int NTW, int KTW, int NP = 3, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
@@ -2032,12 +2057,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   for (int u = 0; u < YPT; ++u)
 #pragma unroll
     for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
+  const bool y16 = NP == 1 && a.dy_bf16, x16 = NP == 1 && a.x_bf16;      // workgroup-uniform
   auto ldy = [&](size_t row, int col) -> f32x4 {
-    if (Y16) {
+    if (y16) {
       const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.dY) + row * a.lddy + col);
       return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
     }
     return *reinterpret_cast<const f32x4*>(a.dY + row * a.lddy + col);
+  };
+  auto ldxv = [&](size_t row, int col) -> f32x4 {
+    if (x16) {
+      const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.X) + row * a.ldx + col);
+      return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+    }
+    return *reinterpret_cast<const f32x4*>(a.X + row * a.ldx + col);
   };
   auto load_tile = [&](int tt) {
     const size_t m0 = (size_t)tt * WG_RT;
@@ -2062,12 +2095,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
       const int b = min(tid + 256 * u, XBL - 1), rb = b & 7, cb = b >> 3;
       if (full) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) px[u][r] = *reinterpret_cast<const f32x4*>(a.X + (m0 + 4 * rb + r) * a.ldx + k0 + 4 * cb);
+        for (int r = 0; r < 4; ++r) px[u][r] = ldxv(m0 + 4 * rb + r, k0 + 4 * cb);
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t row = m0 + 4 * rb + r;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + min(row, (size_t)a.M - 1) * a.ldx + k0 + 4 * cb);
+          const f32x4 v = ldxv(min(row, (size_t)a.M - 1), k0 + 4 * cb);
           px[u][r] = row < (size_t)a.M ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
       }
@@ -2494,7 +2527,7 @@ int redq_flush(ReduceQueue* q, hipStream_t st) {
 }
 
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q, const WgradSplit* split) {
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q, const WgradSplit* split, int io16) {
   if (N <= 0 || K <= 0) return 0;
   if (split) {
     INTEL_CHECK_ARG(q && split->n >= 1 && split->n <= 4 && N % split->n == 0, "wgrad: a split product needs the reduce queue and N divisible by the number of parts");
@@ -2510,7 +2543,8 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   WgradArgs a;
   a.dY = dY; a.lddy = lddy; a.X = X; a.ldx = ldx; a.M = M; a.N = N; a.K = K; a.slabs = slabs;
   a.S = wgrad_num_slabs(M, N, K); a.want_db = db != nullptr;
-  a.dy_bf16 = split ? split->dy_bf16 : 0;
+  a.dy_bf16 = split ? split->dy_bf16 : (io16 & 1);
+  a.x_bf16 = (io16 >> 1) & 1;
   {
     // fast path: exact 32-row tiles, widths in 32-float steps, 16-byte aligned operands
     static const int use_dma = [] { const char* e = getenv("INTEL_WGRAD_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2518,7 +2552,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
                          ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
     static const int use_wb3 = [] { const char* e = getenv("INTEL_WGRAD_B3"); return (e && e[0] == '0') ? 0 : 1; }();
-    INTEL_CHECK_ARG(!a.dy_bf16 || g_planes == 1, "wgrad: a bf16-stored dY needs the bf16 mode");
+    INTEL_CHECK_ARG((!a.dy_bf16 && !a.x_bf16) || g_planes == 1, "wgrad: bf16-stored operands need the bf16 mode");
     if (use_wb3 && aligned && M >= 1 && N % 32 == 0 && K % 32 == 0) {      // any row count: the last tile is zero-padded in the kernel
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
@@ -2527,21 +2561,13 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 #define WB_LAUNCH(A_, B_, P_, T_)                                                                                   \
   do {                                                                                                              \
     allow_lds((wgrad_b3_kernel<A_, B_, P_, T_>), smem);                                                             \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
-             dim3(256), smem, st, a);                                                                               \
-  } while (0)
-#define WB_LAUNCH16(A_, B_, T_)                                                                                     \
-  do {                                                                                                              \
-    allow_lds((wgrad_b3_kernel<A_, B_, 1, T_, true>), smem);                                                        \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + 0.5 * (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, 1, T_, true>), grid, \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, (a.x_bf16 ? 2.0 : 4.0) * (double)M * K + (a.dy_bf16 ? 2.0 : 4.0) * (double)M * N + 4.0 * (double)K * N, (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
              dim3(256), smem, st, a);                                                                               \
   } while (0)
 #define WB_CASE(A_, B_)                                                                                             \
   if (ntw == A_ && ktw == B_) {                                                                                     \
     const bool tail = M % WG_RT != 0;                                                                               \
-    if (a.dy_bf16 && !tail) WB_LAUNCH16(A_, B_, false);                                                             \
-    else if (a.dy_bf16) WB_LAUNCH16(A_, B_, true);                                                                  \
-    else if (g_planes == 3 && !tail) WB_LAUNCH(A_, B_, 3, false);                                                   \
+    if (g_planes == 3 && !tail) WB_LAUNCH(A_, B_, 3, false);                                                        \
     else if (g_planes == 3) WB_LAUNCH(A_, B_, 3, true);                                                             \
     else if (!tail) WB_LAUNCH(A_, B_, 1, false);                                                                    \
     else WB_LAUNCH(A_, B_, 1, true);                                                                                \
@@ -2549,11 +2575,10 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
       WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
 #undef WB_CASE
 #undef WB_LAUNCH
-#undef WB_LAUNCH16
       INTEL_CHECK_LAUNCH();
       goto reduce;
     }
-    INTEL_CHECK_ARG(!a.dy_bf16, "wgrad: a bf16-stored dY needs the bf16-pipe kernel (aligned operands, N and K multiples of 32)");
+    INTEL_CHECK_ARG(!a.dy_bf16 && !a.x_bf16, "wgrad: bf16-stored operands need the bf16-pipe kernel (aligned operands, N and K multiples of 32)");
     if (use_dma && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
       const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
       const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));

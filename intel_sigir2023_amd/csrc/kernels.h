@@ -33,7 +33,10 @@ struct GemmEpilogue {
   int accumulate = 0;             // C += value instead of C = value
   int no_out = 0;                 // LayerNorm epilogue only: keep the x-hat / rstd stash, do not store C
   const void* b3 = nullptr;       // optional pre-split bf16 image of B (launch_pack_b3): used when K > 128
-  int a_bf16 = 0;                 // bf16 mode, K > 128 only: A is a bf16 array [M, lda] (elements), not fp32
+  // bf16 mode (gemm_set_planes(1)), bf16-pipe kernels only: operands stored as bf16 arrays of the same shape and leading dimension
+  int a_bf16 = 0;                 // A [M, lda]  (K = 64 / 128, or K > 128 with b3)
+  int c_bf16 = 0;                 // C [M, ldc]  (K = 64 / 128)
+  int mask_bf16 = 0;              // mask [M, ldmask]  (K = 64 / 128)
 };
 // arithmetic mode of the matrix-pipe products: 3 = fp32 accuracy (three bf16 planes, six products), 1 = bf16 (one product)
 void gemm_set_planes(int planes);
@@ -77,7 +80,8 @@ int redq_flush(ReduceQueue* q, hipStream_t st);
 // product, one reduction job per weight (dW[p] is [N/n, K]; db[p] all null or all set).  Needs the queue.
 struct WgradSplit { int n; float* dW[4]; float* db[4]; int acc[4]; int dy_bf16 = 0; };   // dy_bf16 (bf16 mode): dY is a bf16 array [M, lddy]
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
-                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr, const WgradSplit* split = nullptr);
+                 float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr, const WgradSplit* split = nullptr,
+                 int io16 = 0);      // bf16 mode, bf16-pipe kernel only: bit 0 dY, bit 1 X stored as bf16 arrays (WgradSplit.dy_bf16 likewise)
 
 // ---- tiny input width (smallk.hip): K <= 32, N <= 128, raw (unpacked) weights W[N, K] ---------------------
 bool smallk_supported(int N, int K);
@@ -99,7 +103,7 @@ bool attn_seq_supported(int T, int dk);
 int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                         hipStream_t st, const int* row_off = nullptr);
 size_t attn_seq_bwd_scratch_floats(int B, int T, int heads);
-// h16 (bf16 mode, fused backward only: attn_seq_h16_supported): qkv is read and dqkv written as bf16 arrays of the same shape
+// h16 (bf16 mode, fused backward only: attn_seq_h16_supported): qkv and dout are read and dqkv written as bf16 arrays of the same shape
 bool attn_seq_h16_supported(int T, int dk);
 int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, const float* lse, int B, int T, int d,
                         int heads, const int* key_len, float* dqkv, float* dS, hipStream_t st, const int* row_off = nullptr, int h16 = 0);

@@ -450,17 +450,17 @@ void lin(Run& r, const float* A, int lda, int M, int K, const float* Bp, int N, 
 }
 
 // dW (+)= dY^T X for parameter slots (w_slot, b_slot or -1)
-void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, int w_slot, int b_slot) {
+void wgrad(Run& r, const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, int w_slot, int b_slot, int io16 = 0) {
   float* dW = r.G(w_slot);
   float* db = b_slot >= 0 ? r.G(b_slot) : nullptr;
   if (!dW) return;
   int a = r.acc(w_slot);
   if (b_slot >= 0) { int ab = r.acc(b_slot); (void)ab; }
-  if (smallk_supported(N, K) && K <= 32 && M >= 4096 && (K % 16 != 0)) {     // tiny input width: VALU kernel (smallk.hip)
+  if (!io16 && smallk_supported(N, K) && K <= 32 && M >= 4096 && (K % 16 != 0)) {     // tiny input width: VALU kernel (smallk.hip)
     RUN(launch_wgrad_smallk(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
     return;
   }
-  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq));
+  RUN(launch_wgrad(dY, lddy, X, ldx, M, N, K, dW, K, db, a, nullptr, r.st, r.ctx->rq, nullptr, io16));
 }
 
 // the weight gradients of n linears that share the input X and whose output gradients sit side by side in dY
@@ -630,7 +630,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
   // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)
   static const int h16_on = [] { const char* e = getenv("INTEL_BF16_QKV"); return (e && e[0] == '0') ? 0 : 1; }();
   const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
-  r.ctx->tw_qkv16[tw_i] = fused && r.train && h16_on && gemm_planes() == 1 && attn_seq_h16_supported(L, d / D.heads) && d % 32 == 0;
+  r.ctx->tw_qkv16[tw_i] = fused && r.train && h16_on && gemm_planes() == 1 && attn_seq_h16_supported(L, d / D.heads) && (d == 64 || d == 128);
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only
@@ -703,15 +703,19 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
       if (!r.ok(launch_mul2(dZ, b.DM, (long long)M * d, r.T->dA, r.st))) return nullptr;
       dZd = r.T->dA;
     }
-    wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2);
+    // bf16 mode: the stashes read only by matrix products (A, R1 -- R1 also as a sign test) and the gradients consumed only by
+    // matrix products (dF1, dA, dQKV) are bf16 arrays; dZ stays fp32 (it is also the residual gradient)
+    const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
+    wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2, h16 ? 2 : 0);
     GemmEpilogue em;
     em.mask = b.R1; em.ldmask = d;
+    em.mask_bf16 = h16; em.c_bf16 = h16;
     lin(r, dZd, d, M, d, w.pW2T, d, r.T->dF1, d, em);                     // d(pre-relu) = (dZ W2) * [R1 > 0]
-    wgrad(r, r.T->dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1);
+    wgrad(r, r.T->dF1, d, b.A, d, M, d, d, pb + T_W1, pb + T_B1, h16 ? 3 : 0);
     GemmEpilogue e0;
+    e0.a_bf16 = h16; e0.c_bf16 = h16;
     lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
     if (r.rc) return nullptr;
-    const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
     if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st, nullptr, h16))) return nullptr;
     {
       const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};

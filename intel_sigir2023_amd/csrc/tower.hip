@@ -130,7 +130,7 @@ struct TowerFwdArgs {
   const float* b1; const float* b2; const float* gamma; const float* beta;
   float* out;                // [B*L, D] or NULL (the caller rebuilds it from x-hat: fused tail)
   float* QKV;                // training stash (each may be NULL): [B*L, 3D]
-  int qkv16;                 // bf16 mode: the q/k/v stash is a bf16 array (read back by the attention backward as such)
+  int qkv16;                 // bf16 mode: the QKV / A / R1 stashes are bf16 arrays (their only readers are matrix products / a sign test)
   float* A;                  // [B*L, D] attention output
   float* LSE;                // [B*heads*L] natural-log softmax normalisers
   float* R1;                 // [B*L, D] relu(W1 A + b1)
@@ -152,6 +152,15 @@ struct TowerCfg {
   static constexpr size_t R_BYTES = (size_t)3 * 64 * LQ * 4;
   static constexpr size_t SMEM = P_BYTES + R_BYTES;
 };
+
+// training stash store: four consecutive values at element offset `off`, as fp32 or (bf16 mode) bf16
+template <int NP>
+__device__ __forceinline__ void stash4(float* base, size_t off, const f32x4& v, int h16) {
+  if (NP == 1 && h16)
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + off) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  else
+    *reinterpret_cast<f32x4*>(base + off) = v;
+}
 
 template <int D, int DK, bool TRAIN, int NP = 3>
 __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(TowerFwdArgs a) {      // two waves per SIMD: <= 256 registers
@@ -257,15 +266,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         for (int rt = 0; rt < 4; ++rt) {
           const int row = rt * 16 + p;
           *reinterpret_cast<f32x4*>(dst + row * LQ) = acc[c][rt];
-          if (TRAIN && a.QKV && row < L) {
-            const size_t off = ((size_t)b * L + row) * (3 * D) + n;
-            if (NP == 1 && a.qkv16) {
-              const f32x4& v = acc[c][rt];
-              *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.QKV) + off) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-            } else {
-              *reinterpret_cast<f32x4*>(a.QKV + off) = acc[c][rt];
-            }
-          }
+          if (TRAIN && a.QKV && row < L) stash4<NP>(a.QKV, ((size_t)b * L + row) * (3 * D) + n, acc[c][rt], a.qkv16);
         }
       }
     }
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
             split4(o, hh, mm, ll);
             const int off = q * LDP + col;
             store_planes<NP, PLANE>(planes + off, hh, mm, ll);
-            if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
+            if (TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
           }
       } else {
         // narrow heads (dk = 32): two output tiles of 16 dims, V read as scalars (lane p = dim, j = key of the k-step)
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
           split4(o, hh, mm, ll);
           const int off = q * LDP + col;
           store_planes<NP, PLANE>(planes + off, hh, mm, ll);
-          if (TRAIN && a.A && q < L) *reinterpret_cast<f32x4*>(a.A + ((size_t)b * L + q) * D + col) = o;
+          if (TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
         }
       }
       if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         split4(x, hh, mm, ll);
         const int off = row * LDP + col;
         store_planes<NP, PLANE>(r1planes + off, hh, mm, ll);
-        if (TRAIN && a.R1 && row < L) *reinterpret_cast<f32x4*>(a.R1 + ((size_t)b * L + row) * D + col) = x;
+        if (TRAIN && a.R1 && row < L) stash4<NP>(a.R1, ((size_t)b * L + row) * D + col, x, a.qkv16);
       }
     }
     __syncthreads();
@@ -528,7 +529,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
-  if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? (a.qkv16 ? 1.5 : 3.0) : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0) + (a.XH ? 1.0 : 0.0));
+  if (TRAIN) bytes += 4.0 * M * D * (((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0)) * (a.qkv16 ? 0.5 : 1.0) + (a.XH ? 1.0 : 0.0));
   static const int dbg_on = [] { const char* e = getenv("INTEL_TOWER_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
   TowerFwdArgs aa = a;
   static unsigned long long* dbg_buf = nullptr;
