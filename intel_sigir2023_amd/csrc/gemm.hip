@@ -2035,8 +2035,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // ------------------------------------------------------------------------------------------
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
-// TAIL: M is not a multiple of 32 (zero-padded last tile); bf16 mode (NP = 1): a.dy_bf16 / a.x_bf16 mark operands stored as bf16 arrays
-template <int NTW, int KTW, int NP = 3, bool TAIL = false>
+// TAIL: M is not a multiple of 32 (zero-padded last tile); Y16 / X16 (bf16 mode, NP = 1): dY / X is stored as a bf16 array
+// (compile-time: a run-time choice in the tile loader costs this kernel 80 % of its speed)
+template <int NTW, int KTW, int NP = 3, bool TAIL = false, bool Y16 = false, bool X16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
@@ -2057,16 +2058,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   for (int u = 0; u < YPT; ++u)
 #pragma unroll
     for (int c = 0; c < 4; ++c) dbacc[u][c] = 0.f;
-  const bool y16 = NP == 1 && a.dy_bf16, x16 = NP == 1 && a.x_bf16;      // workgroup-uniform
   auto ldy = [&](size_t row, int col) -> f32x4 {
-    if (y16) {
+    if (Y16) {
       const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.dY) + row * a.lddy + col);
       return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
     }
     return *reinterpret_cast<const f32x4*>(a.dY + row * a.lddy + col);
   };
   auto ldxv = [&](size_t row, int col) -> f32x4 {
-    if (x16) {
+    if (X16) {
       const bf16x4 hv = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.X) + row * a.ldx + col);
       return f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
     }
@@ -2561,9 +2561,30 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 #define WB_LAUNCH(A_, B_, P_, T_)                                                                                   \
   do {                                                                                                              \
     allow_lds((wgrad_b3_kernel<A_, B_, P_, T_>), smem);                                                             \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, (a.x_bf16 ? 2.0 : 4.0) * (double)M * K + (a.dy_bf16 ? 2.0 : 4.0) * (double)M * N + 4.0 * (double)K * N, (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_b3_kernel<A_, B_, P_, T_>), grid, \
              dim3(256), smem, st, a);                                                                               \
   } while (0)
+#define WB_LAUNCH16(A_, B_, T_, Y_, X_)                                                                             \
+  do {                                                                                                              \
+    allow_lds((wgrad_b3_kernel<A_, B_, 1, T_, Y_, X_>), smem);                                                      \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, (X_ ? 2.0 : 4.0) * (double)M * K + (Y_ ? 2.0 : 4.0) * (double)M * N + 4.0 * (double)K * N, \
+             (wgrad_b3_kernel<A_, B_, 1, T_, Y_, X_>), grid, dim3(256), smem, st, a);                               \
+  } while (0)
+#define WB_CASE16(A_, B_)                                                                                           \
+  if (ntw == A_ && ktw == B_) {                                                                                     \
+    const bool tail = M % WG_RT != 0;                                                                               \
+    done16 = true;                                                                                                  \
+    if (a.dy_bf16 && a.x_bf16) { if (tail) WB_LAUNCH16(A_, B_, true, true, true); else WB_LAUNCH16(A_, B_, false, true, true); }        \
+    else if (a.dy_bf16) { if (tail) WB_LAUNCH16(A_, B_, true, true, false); else WB_LAUNCH16(A_, B_, false, true, false); }             \
+    else { if (tail) WB_LAUNCH16(A_, B_, true, false, true); else WB_LAUNCH16(A_, B_, false, false, true); }                            \
+  }
+      if (a.dy_bf16 || a.x_bf16) {          // bf16-stored operands: the square tower shapes only (d = 128, d = 64; N = d or 3d)
+        bool done16 = false;
+        WB_CASE16(4, 4) WB_CASE16(2, 2)
+        INTEL_CHECK_ARG(done16, "wgrad: bf16-stored operands are supported for 64- and 128-wide products only");
+        INTEL_CHECK_LAUNCH();
+        goto reduce;
+      }
 #define WB_CASE(A_, B_)                                                                                             \
   if (ntw == A_ && ktw == B_) {                                                                                     \
     const bool tail = M % WG_RT != 0;                                                                               \
@@ -2574,7 +2595,9 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   }
       WB_CASE(4, 4) WB_CASE(4, 2) WB_CASE(4, 1) WB_CASE(2, 4) WB_CASE(2, 2) WB_CASE(2, 1) WB_CASE(1, 4) WB_CASE(1, 2) WB_CASE(1, 1)
 #undef WB_CASE
+#undef WB_CASE16
 #undef WB_LAUNCH
+#undef WB_LAUNCH16
       INTEL_CHECK_LAUNCH();
       goto reduce;
     }
