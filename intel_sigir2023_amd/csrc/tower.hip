@@ -162,6 +162,11 @@ __device__ __forceinline__ void stash4(float* base, size_t off, const f32x4& v, 
     *reinterpret_cast<f32x4*>(base + off) = v;
 }
 
+// Workgroup barrier over the LDS tile only.  __syncthreads() also waits for every global access of the wave (s_waitcnt
+// vmcnt(0)): here that would be the next session's X prefetch and the stash stores, whose latency the phases exist to hide.
+// Nothing one wave writes to global memory is read by another wave of this kernel.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int D, int DK, bool TRAIN, int NP = 3>
 __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(TowerFwdArgs a) {      // two waves per SIMD: <= 256 registers
   using C = TowerCfg<D>;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       const int off = trow[jj] * LDP + tcol[jj];
       store_planes<NP, PLANE>(planes + off, h, m, l);
     }
-    __syncthreads();
+    lds_barrier();
     mark(0);
     // ---- phase 1: [Q | K | V] = X Wqkv^T; wave = column tiles 3 wave .. 3 wave + 2, all four row tiles
     {
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     // the next session's rows travel while this one is computed
     if (b + (int)gridDim.x < a.B) load_x(b + gridDim.x);
     mark(1);
-    __syncthreads();
+    lds_barrier();
     mark(6);
     // ---- phase 2: attention; (query tile, head) pairs over the waves.  The W1 fragments of phase 3 travel meanwhile.
     uint4 bw1[KB][3];
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     }
     // query tiles of padding only were skipped above: their planes still hold X (rows >= L are zero there already)
     mark(2);
-    __syncthreads();
+    lds_barrier();
     mark(7);
     // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles (the W2 fragments of phase 4 travel meanwhile)
     uint4 bw2[KB][3];
@@ -424,8 +429,17 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         if (TRAIN && a.R1 && row < L) stash4<NP>(a.R1, ((size_t)b * L + row) * D + col, x, a.qkv16);
       }
     }
-    __syncthreads();
+    lds_barrier();
     mark(3);
+    // the residual rows of phase 5 come back from L2 while the W2 product runs
+    constexpr int RPW = 64 / NW, CPL = D / 64;
+    float res[RPW][CPL];
+#pragma unroll
+    for (int rr = 0; rr < RPW; ++rr) {
+      const int row = min(wave * RPW + rr, L - 1);
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
+    }
     // ---- phase 4: Z = R1 W2^T + b2 -> fp32 tile
     {
       f32x4 acc[4];
@@ -448,18 +462,10 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[rt] + bias;
     }
-    __syncthreads();
+    lds_barrier();
     mark(4);
     // ---- phase 5: LayerNorm(Z + X) over the D columns; wave = 64 / NW rows, lane = columns lane (and lane + 64)
     {
-      constexpr int RPW = 64 / NW, CPL = D / 64;
-      float res[RPW][CPL];
-#pragma unroll
-      for (int rr = 0; rr < RPW; ++rr) {
-        const int row = min(wave * RPW + rr, L - 1);
-#pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
-      }
       float g[CPL], be[CPL];
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) { g[cc] = a.gamma[lane + 64 * cc]; be[cc] = a.beta[lane + 64 * cc]; }
