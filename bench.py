@@ -342,6 +342,9 @@ def main():
             res['gemm_shapes'] = {k: '%.3f ms/step, %d launches/step, %.1f us, %.1f TF/s, %.0f GB/s' % (v['ms'] / psteps, v['launches'] // psteps, 1e3 * v['ms'] / v['launches'],
                                                                                                       v['flops'] / v['ms'] / 1e9, v['bytes'] / v['ms'] / 1e6)
                                   for k, v in sorted(prof_shapes.items(), key=lambda kv: -kv[1]['ms']) if '[' in k and v['ms'] / psteps > 0.01 and v['flops'] > 0}
+            res['eval_shapes'] = {k: '%.4f ms/step, %d launches/step, %.1f us, %.0f GB/s' % (v['ms'] / psteps, v['launches'] // psteps, 1e3 * v['ms'] / max(1, v['launches']),
+                                                                                             v['bytes'] / max(v['ms'], 1e-9) / 1e6)
+                                  for k, v in sorted(prof_eval.items(), key=lambda kv: -kv[1]['ms']) if v['ms'] / psteps > 0.004}
             res['kernel_table'] = {k: '%d launches/step, %.4f ms/step, avg %.1f us' % (v['launches'] // psteps, v['ms'] / psteps, 1e3 * v['ms'] / max(1, v['launches']))
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)

@@ -139,7 +139,7 @@ struct TowerFwdArgs {
   unsigned long long* dbg;   // INTEL_TOWER_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
 };
 
-template <int D>
+template <int D, int NP = 3>
 struct TowerCfg {
   static constexpr int NW = D / 16;              // waves: 8 (D = 128) or 4 (D = 64)
   static constexpr int NT = NW * 64;
@@ -148,9 +148,14 @@ struct TowerCfg {
   static constexpr int PLANE = 64 * LDP;         // bf16 elements per plane
   static constexpr int LQ = D + 4;               // fp32 row pitch of Q / K / V / the LayerNorm tile
   static constexpr int NJ = 64 * (D / 4) / NT;   // float4 per thread per X tile (= 4)
-  static constexpr size_t P_BYTES = (size_t)3 * PLANE * 2;
-  static constexpr size_t R_BYTES = (size_t)3 * 64 * LQ * 4;
+  // parity mode: three planes, fp32 q/k/v rows.  bf16 mode (NP = 1): one plane, q/k/v rows as bf16 (the attention rounds them
+  // anyway) -- 69.6 KB instead of 153.6 KB at D = 128, so two workgroups share a CU (four at D = 64)
+  static constexpr size_t P_BYTES = (size_t)NP * PLANE * 2;
+  static constexpr size_t R_BYTES = NP == 1 ? (size_t)3 * PLANE * 2 : (size_t)3 * 64 * LQ * 4;
+  static constexpr size_t ES_BYTES = (size_t)64 * LQ * 4;          // the LayerNorm tile (over the dead q rows)
   static constexpr size_t SMEM = P_BYTES + R_BYTES;
+  static_assert(NP != 1 || ES_BYTES + (size_t)PLANE * 2 <= R_BYTES, "bf16 mode: LayerNorm tile + R1 plane must fit the q/k/v region");
+  static constexpr int WAVES_PER_SIMD = NP == 1 ? 4 : 2;           // bf16 mode: <= 128 registers
 };
 
 // training stash store: four consecutive values at element offset `off`, as fp32 or (bf16 mode) bf16
@@ -168,8 +173,8 @@ __device__ __forceinline__ void stash4(float* base, size_t off, const f32x4& v, 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int D, int DK, bool TRAIN, int NP = 3>
-__global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(TowerFwdArgs a) {      // two waves per SIMD: <= 256 registers
-  using C = TowerCfg<D>;
+__global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_SIMD)) void tower_fwd_fused_kernel(TowerFwdArgs a) {
+  using C = TowerCfg<D, NP>;
   constexpr int NW = C::NW, NT = C::NT, KB = C::KB, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ;
   constexpr int HEADS = D / DK, DKT = DK / 16;
   constexpr int KBT = 4;                         // k blocks per column tile in the image (k padded to 128)
@@ -179,7 +184,10 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
   float* Ks = Qs + 64 * LQ;
   float* Vs = Ks + 64 * LQ;
   float* Es = Qs;
-  __bf16* r1planes = reinterpret_cast<__bf16*>(Ks);
+  __bf16* Q16 = reinterpret_cast<__bf16*>(smem_raw + C::P_BYTES);       // bf16 mode: q | k | v rows with the plane pitch
+  __bf16* K16 = Q16 + PLANE;
+  __bf16* V16 = K16 + PLANE;
+  __bf16* r1planes = NP == 1 ? reinterpret_cast<__bf16*>(smem_raw + C::P_BYTES + C::ES_BYTES) : reinterpret_cast<__bf16*>(Ks);
   const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = a.L;
@@ -228,7 +236,36 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     lds_barrier();
     mark(0);
     // ---- phase 1: [Q | K | V] = X Wqkv^T; wave = column tiles 3 wave .. 3 wave + 2, all four row tiles
-    {
+    if constexpr (NP == 1) {
+      // bf16 mode runs four waves per SIMD (<= 128 registers): one column tile at a time, the A fragments are re-read
+      const uint4* Bimg = per_session(a.Wqkv) + ((size_t)(3 * wave) * KBT * 3) * 64 + lane;
+      const __bf16* frag = planes + p * LDP + 8 * j;
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {
+        uint4 bw[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) bw[kb] = Bimg[((size_t)(c * KBT + kb) * 3) * 64];
+        f32x4 acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[kb]),
+                                                              *reinterpret_cast<const bf16x8*>(frag + rt * 16 * LDP + kb * 32), acc[rt], 0, 0, 0);
+        const int n = (3 * wave + c) * 16 + 4 * j;           // column of [q | k | v]
+        const int which = n / D, col = n - which * D;
+        __bf16* dst16 = Q16 + which * PLANE + col;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = rt * 16 + p;
+          const f32x4& v = acc[rt];
+          *reinterpret_cast<bf16x4*>(dst16 + row * LDP) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+          if (TRAIN && a.QKV && row < L) stash4<NP>(a.QKV, ((size_t)b * L + row) * (3 * D) + n, v, a.qkv16);
+        }
+      }
+    } else {
       f32x4 acc[3][4];
 #pragma unroll
       for (int c = 0; c < 3; ++c)
@@ -282,7 +319,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     mark(6);
     // ---- phase 2: attention; (query tile, head) pairs over the waves.  The W1 fragments of phase 3 travel meanwhile.
     uint4 bw1[KB][3];
-    {
+    if constexpr (NP != 1) {
       const uint4* Bimg = per_session(a.W1) + ((size_t)wave * KBT * 3) * 64 + lane;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
@@ -297,6 +334,19 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       f32x4 st[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (NP == 1) {
+        const __bf16* Qh = Q16 + (tile * 16 + p) * LDP + h * DK + 4 * j;
+        const __bf16* Kh = K16 + p * LDP + h * DK + 4 * j;
+#pragma unroll
+        for (int g = 0; g < DKT; ++g) {
+          const s16x4 qf = *reinterpret_cast<const s16x4*>(Qh + 16 * g);
+          s16x4 kf[4];
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const s16x4*>(Kh + kt * 16 * LDP + 16 * g);
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) st[kt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kf[kt], qf, st[kt], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int g = 0; g < DKT; ++g) {
         const f32x4 qf = *reinterpret_cast<const f32x4*>(Qp + 16 * g);
@@ -305,6 +355,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         for (int kt = 0; kt < 4; ++kt) kf[kt] = *reinterpret_cast<const f32x4*>(Kp + kt * 16 * LQ + 16 * g);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) st[kt] = mma4<NP>(kf[kt], qf, st[kt]);
+      }
       }
       // accumulator register r of tile kt at lane (j, p) = key kt*16 + 4j + r, query tile*16 + p
       float mx = -INFINITY;
@@ -338,6 +389,32 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
 #pragma unroll
         for (int i = 0; i < DQ * 4; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* Vp = Vs + (4 * j) * LQ + h * DK + 4 * p;
+        if constexpr (NP == 1) {
+          // one 64-dim block of the head at a time (register budget): P as bf16 once, V rows read as 8-byte bf16 groups
+          const __bf16* Vh = V16 + (4 * j) * LDP + h * DK + 4 * p;
+          s16x4 pb[4];
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+            pb[kt] = __builtin_bit_cast(s16x4, bf16x4{(__bf16)st[kt][0], (__bf16)st[kt][1], (__bf16)st[kt][2], (__bf16)st[kt][3]});
+#pragma unroll
+          for (int dq = 0; dq < DQ; ++dq) {
+            f32x4 o4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+              s16x4 vv[4];                 // the four keys kt*16 + 4j + r of this lane group, dims 4p .. 4p+3
+#pragma unroll
+              for (int r = 0; r < 4; ++r) vv[r] = *reinterpret_cast<const s16x4*>(Vh + (kt * 16 + r) * LDP + dq * 64);
+#pragma unroll
+              for (int t = 0; t < 4; ++t)
+                o4[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, pb[kt], o4[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = o4[t];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        } else {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -349,6 +426,7 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
             for (int t = 0; t < 4; ++t)
               oT[dq * 4 + t] = mma4<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, st[kt], oT[dq * 4 + t]);
           }
+        }
 #pragma unroll
         for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -366,12 +444,18 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
         f32x4 oT[2];
         oT[0] = oT[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* Vp = Vs + (4 * j) * LQ + h * DK + p;
+        const __bf16* Vh = V16 + (4 * j) * LDP + h * DK + p;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-            oT[t] = mma4<NP>(f32x4{Vp[(kt * 16 + 0) * LQ + t * 16], Vp[(kt * 16 + 1) * LQ + t * 16], Vp[(kt * 16 + 2) * LQ + t * 16],
-                                   Vp[(kt * 16 + 3) * LQ + t * 16]}, st[kt], oT[t]);
+          for (int t = 0; t < 2; ++t) {
+            if (NP == 1)
+              oT[t] = mma4<NP>(f32x4{(float)Vh[(kt * 16 + 0) * LDP + t * 16], (float)Vh[(kt * 16 + 1) * LDP + t * 16], (float)Vh[(kt * 16 + 2) * LDP + t * 16],
+                                     (float)Vh[(kt * 16 + 3) * LDP + t * 16]}, st[kt], oT[t]);
+            else
+              oT[t] = mma4<NP>(f32x4{Vp[(kt * 16 + 0) * LQ + t * 16], Vp[(kt * 16 + 1) * LQ + t * 16], Vp[(kt * 16 + 2) * LQ + t * 16],
+                                     Vp[(kt * 16 + 3) * LQ + t * 16]}, st[kt], oT[t]);
+          }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const f32x4 o = oT[t] * inv;                       // register r = dim t*16 + 4j + r of query p
@@ -391,12 +475,16 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
     mark(7);
     // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles (the W2 fragments of phase 4 travel meanwhile)
     uint4 bw2[KB][3];
-    {
+    if constexpr (NP != 1) {
       const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bw2[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+    } else {      // bf16 mode (register budget): the fragments of both products are fetched where they are used
+      const uint4* Bimg = per_session(a.W1) + ((size_t)wave * KBT * 3) * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bw1[kb][0] = Bimg[((size_t)kb * 3) * 64];
     }
     {
       f32x4 acc[4];
@@ -441,6 +529,11 @@ __global__ __launch_bounds__(TowerCfg<D>::NT, 2) void tower_fwd_fused_kernel(Tow
       for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
     }
     // ---- phase 4: Z = R1 W2^T + b2 -> fp32 tile
+    if constexpr (NP == 1) {
+      const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bw2[kb][0] = Bimg[((size_t)kb * 3) * 64];
+    }
     {
       f32x4 acc[4];
 #pragma unroll
@@ -524,12 +617,17 @@ int fused_mode() {
 
 template <int D, int DK, bool TRAIN, int NP = 3>
 int launch_one(const TowerFwdArgs& a, hipStream_t st) {
-  using C = TowerCfg<D>;
+  using C = TowerCfg<D, NP>;
   const size_t smem = C::SMEM;
   if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1>(a, st);      // bf16 mode
   allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP>), smem);
-  const int per_cu = smem <= 80 * 1024 ? 2 : 1;
+  // resident workgroups per CU: LDS (160 KB) and wave slots (NW waves each, WAVES_PER_SIMD per SIMD by the launch bounds)
+  int per_cu = (int)((160 * 1024) / smem);
+  if (per_cu > 4 * C::WAVES_PER_SIMD / C::NW) per_cu = 4 * C::WAVES_PER_SIMD / C::NW;
+  if (per_cu < 1) per_cu = 1;
   int grid = num_cus() * per_cu;
+  static const int grid_cap = [] { const char* e = getenv("INTEL_TOWER_GRID"); return e ? atoi(e) : 0; }();      // experiments: leave CUs to the other branches
+  if (grid_cap > 0 && grid > grid_cap * per_cu) grid = grid_cap * per_cu;
   if (grid > a.B) grid = a.B;
   const double M = (double)a.B * a.L;
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
