@@ -625,12 +625,14 @@ void tower_fwd(Run& r, TowerBufs& w) {
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
   const float* X = w.X0;
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
-  const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train) && !(r.train && r.ctx->drop_p > 0.f);
+  // bf16-mode training: the one-kernel layer leaves its stashes as bf16 arrays, which needs the whole-sequence attention backward
+  const bool h16_ok = attn_seq_h16_supported(L, d / D.heads) && (d == 64 || d == 128);
+  const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train) && !(r.train && r.ctx->drop_p > 0.f) &&
+                     !(r.train && gemm_planes() == 1 && !h16_ok);
   // bf16 mode: q/k/v (and, in the backward, their gradients) live in HBM as bf16 arrays -- every consumer rounds them to bf16
   // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)
-  static const int h16_on = [] { const char* e = getenv("INTEL_BF16_QKV"); return (e && e[0] == '0') ? 0 : 1; }();
   const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
-  r.ctx->tw_qkv16[tw_i] = fused && r.train && h16_on && gemm_planes() == 1 && attn_seq_h16_supported(L, d / D.heads) && (d == 64 || d == 128);
+  r.ctx->tw_qkv16[tw_i] = fused && r.train && gemm_planes() == 1;
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only

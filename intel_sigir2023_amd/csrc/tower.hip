@@ -172,6 +172,20 @@ __device__ __forceinline__ void stash4(float* base, size_t off, const f32x4& v, 
 // Nothing one wave writes to global memory is read by another wave of this kernel.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// bf16 mode: the training stashes are the bf16 rows the phases leave in LDS -- copied out row-contiguous, 16 bytes per lane
+// (src: [rows][ldp] bf16 in LDS, nmat matrices PLANE elements apart side by side in the destination row)
+template <int D, int LDP, int PLANE, int NT>
+__device__ __forceinline__ void stash_rows16(const __bf16* src, int nmat, __bf16* dst, int ldd, int rows, int tid) {
+  constexpr int CPR = D / 8;                       // 16-byte chunks per matrix row
+  const int total = rows * nmat * CPR;
+  for (int i = tid; i < total; i += NT) {
+    const int row = i / (nmat * CPR), c = i - row * (nmat * CPR);
+    const int which = c / CPR, cc = c - which * CPR;
+    *reinterpret_cast<uint4*>(dst + (size_t)row * ldd + which * D + cc * 8) =
+        *reinterpret_cast<const uint4*>(src + which * PLANE + row * LDP + cc * 8);
+  }
+}
+
 template <int D, int DK, bool TRAIN, int NP = 3>
 __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_SIMD)) void tower_fwd_fused_kernel(TowerFwdArgs a) {
   using C = TowerCfg<D, NP>;
@@ -262,7 +276,6 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
           const int row = rt * 16 + p;
           const f32x4& v = acc[rt];
           *reinterpret_cast<bf16x4*>(dst16 + row * LDP) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-          if (TRAIN && a.QKV && row < L) stash4<NP>(a.QKV, ((size_t)b * L + row) * (3 * D) + n, v, a.qkv16);
         }
       }
     } else {
@@ -317,6 +330,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     mark(1);
     lds_barrier();
     mark(6);
+    if constexpr (NP == 1 && TRAIN) {
+      if (a.QKV) stash_rows16<D, LDP, PLANE, NT>(Q16, 3, reinterpret_cast<__bf16*>(a.QKV) + (size_t)b * L * (3 * D), 3 * D, L, tid);
+    }
     // ---- phase 2: attention; (query tile, head) pairs over the waves.  The W1 fragments of phase 3 travel meanwhile.
     uint4 bw1[KB][3];
     if constexpr (NP != 1) {
@@ -437,7 +453,7 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
             split4(o, hh, mm, ll);
             const int off = q * LDP + col;
             store_planes<NP, PLANE>(planes + off, hh, mm, ll);
-            if (TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
+            if (NP != 1 && TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
           }
       } else {
         // narrow heads (dk = 32): two output tiles of 16 dims, V read as scalars (lane p = dim, j = key of the k-step)
@@ -464,7 +480,7 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
           split4(o, hh, mm, ll);
           const int off = q * LDP + col;
           store_planes<NP, PLANE>(planes + off, hh, mm, ll);
-          if (TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
+          if (NP != 1 && TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
         }
       }
       if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);
@@ -473,6 +489,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     mark(2);
     lds_barrier();
     mark(7);
+    if constexpr (NP == 1 && TRAIN) {
+      if (a.A) stash_rows16<D, LDP, PLANE, NT>(planes, 1, reinterpret_cast<__bf16*>(a.A) + (size_t)b * L * D, D, L, tid);
+    }
     // ---- phase 3: R1 = relu(A W1^T + b1); wave = one column tile, four row tiles (the W2 fragments of phase 4 travel meanwhile)
     uint4 bw2[KB][3];
     if constexpr (NP != 1) {
@@ -514,11 +533,14 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
         split4(x, hh, mm, ll);
         const int off = row * LDP + col;
         store_planes<NP, PLANE>(r1planes + off, hh, mm, ll);
-        if (TRAIN && a.R1 && row < L) stash4<NP>(a.R1, ((size_t)b * L + row) * D + col, x, a.qkv16);
+        if (NP != 1 && TRAIN && a.R1 && row < L) stash4<NP>(a.R1, ((size_t)b * L + row) * D + col, x, a.qkv16);
       }
     }
     lds_barrier();
     mark(3);
+    if constexpr (NP == 1 && TRAIN) {
+      if (a.R1) stash_rows16<D, LDP, PLANE, NT>(r1planes, 1, reinterpret_cast<__bf16*>(a.R1) + (size_t)b * L * D, D, L, tid);
+    }
     // the residual rows of phase 5 come back from L2 while the W2 product runs
     constexpr int RPW = 64 / NW, CPL = D / 64;
     float res[RPW][CPL];
@@ -681,6 +703,7 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
   a.qkv16 = (qkv16 && gemm_planes() == 1) ? 1 : 0;
   INTEL_CHECK_ARG(!qkv16 || a.qkv16, "tower_fwd: the bf16 q/k/v stash needs the bf16 mode");
+  INTEL_CHECK_ARG(!(train && gemm_planes() == 1 && (QKV || A || R1)) || a.qkv16, "tower_fwd: in bf16 mode the training stashes are bf16 arrays (qkv16 = 1)");
   a.QKV = QKV; a.A = A; a.LSE = LSE; a.R1 = R1; a.XH = XH; a.RSTD = RSTD; a.dbg = nullptr;
   const int dk = d / heads;
   if (d == 128 && dk == 128) return train ? launch_one<128, 128, true>(a, st) : launch_one<128, 128, false>(a, st);
