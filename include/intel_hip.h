@@ -168,6 +168,13 @@ void intel_destroy(IntelCtx* ctx);
  * the caller's stream (bench.py does this while it prices single kernels).  Default: on. */
 void intel_set_concurrency(IntelCtx* ctx, int on);
 
+/* A promise for the following intel_forward calls: the parameter VALUES equal those of the previous intel_forward on this
+ * context.  The forward then reuses the packed weight images that call left in the workspace, provided the workspace
+ * pointer, the batch shape and `train` are unchanged too (evaluation loops over a frozen model, helpers/BaseRunner.py:328-343:
+ * about 5 % of a forward).  Default off; every forward under on = 0 repacks.  The caller owns the promise: parameters updated
+ * in place behind it are not noticed. */
+void intel_set_params_unchanged(IntelCtx* ctx, int on);
+
 /* nn.Dropout(--dropout) of the two tower layers (models/IntEL/IntEL.py:63,187,196) for the following
  * intel_forward(train=1) calls: p = 0 (default) disables it; evaluation never drops.  keep_flags (optional, device):
  * 0/1 floats -- item-tower layers [layers][B*L][d_i] then score-tower layers [layers][B*L][d_s] -- replace the

@@ -121,6 +121,10 @@ struct IntelCtx {
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
   bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
   bool enc_packed[2];          // this forward ran encoder e on the valid history rows only (IntelBatch.his_off / hisitem_off)
+  // intel_set_params_unchanged: the packed weight images of the previous forward (same workspace, same batch shape) are reused
+  bool params_unchanged = false, pack_ok = false, pack_train = false;
+  const void* pack_ws = nullptr;
+  int pack_shape[5] = {0, 0, 0, 0, 0};      // B, L, H, Hi, dropout layout
   bool tw_qkv16[2] = {false, false};   // this forward stored tower t's q/k/v stash as bf16 (bf16 mode; the backward reads it and writes dQKV the same way)
   int enc_rows[2];             // rows of encoder e: B * T, or the packed total
 };
@@ -944,8 +948,21 @@ void forward_impl(Run& r, const IntelOut* out) {
   Layout& y = r.y;
   const IntelBatch& bt = *r.bt;
   const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
-  pack_all(r);
-  if (r.rc) return;
+  {
+    IntelCtx* c = r.ctx;
+    const int shape[5] = {y.B, y.L, y.H, y.Hi, (r.train && c->drop_p > 0.f) ? 1 : 0};
+    const bool reuse = c->params_unchanged && c->pack_ok && c->pack_ws == (const void*)y.ARENA && memcmp(shape, c->pack_shape, sizeof(shape)) == 0 &&
+                       c->pack_train == (r.train != 0);      // the set of images depends on the mode (one-kernel tower layer)
+    c->pack_ok = false;
+    if (!reuse) {
+      pack_all(r);
+      if (r.rc) return;
+      c->pack_train = r.train != 0;
+    }
+    c->pack_ws = (const void*)y.ARENA;       // the layout is a pure function of the shape and the workspace base
+    memcpy(c->pack_shape, shape, sizeof(shape));
+    c->pack_ok = true;
+  }
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
   fork_streams(r, 3);
@@ -1410,6 +1427,10 @@ extern "C" void intel_destroy(IntelCtx* ctx) {
 }
 
 // on = 0: run every branch on the caller's stream (used while profiling single kernels); on = 1: default
+extern "C" void intel_set_params_unchanged(IntelCtx* ctx, int on) {
+  if (ctx) ctx->params_unchanged = on != 0;
+}
+
 extern "C" void intel_set_concurrency(IntelCtx* ctx, int on) {
   if (!ctx) return;
   if (!on) {

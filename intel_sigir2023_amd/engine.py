@@ -213,6 +213,7 @@ class IntELEngine(object):
         Returns (loss, ensemble_loss, intent_loss) as device tensors (no host sync).
         noise: optional [B,L,L] tie-breaking noise of the BPR loss (parity tests pass the reference's draw);
         noise_seed: optional explicit 64-bit seed of the in-kernel draw (default: the engine's generator)."""
+        self.model._opt_steps = getattr(self.model, '_opt_steps', 0) + 1      # parameters change behind torch's version counters
         model = self.model
         lib = L.lib()
         dev = self.device

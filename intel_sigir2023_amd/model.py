@@ -397,6 +397,11 @@ class IntEL(nn.Module):
             self._generation = getattr(self, '_generation', 0) + 1
         return {'weights': w, 'ens_score': e, 'intents': i}
 
+    def _params_key(self, param_tensors):
+        """Changes whenever a parameter may have changed: torch's version counters (in-place ops, load_state_dict), the
+        storage addresses, and the engine's own step counter (its fused optimizer writes through raw pointers)."""
+        return (getattr(self, '_opt_steps', 0), tuple(t._version for t in param_tensors), tuple(t.data_ptr() for t in param_tensors))
+
     def run_forward(self, batch, keep, param_tensors, train):
         items = self.slot_items()
         dev = keep['i_id_s'].device
@@ -420,6 +425,10 @@ class IntEL(nn.Module):
         intents = torch.empty(batch.B, I, dtype=torch.float32, device=dev)
         out = L.IntelOut(weights=weights.data_ptr(), ens_score=ens.data_ptr(), intents=intents.data_ptr())
         parr = self._param_array({s: t.contiguous() for (s, _, _), t in zip(items, param_tensors)})
+        # evaluation over a frozen model: the packed weight images of the previous forward are still valid
+        key = None if train else self._params_key(param_tensors)
+        lib.intel_set_params_unchanged(ctx, int(key is not None and key == getattr(self, '_packed_key', None)))
+        self._packed_key = key
         L.check(lib.intel_forward(ctx, parr, C.byref(batch), L.ptr(ws), ws.numel(), C.byref(out), int(train),
                                   L.stream_ptr(dev)), 'intel_forward')
         return weights, ens, intents

@@ -438,3 +438,49 @@ def test_out_of_range_ids_raise_when_checked(monkeypatch):
     with pytest.raises(_lib.IntelHipError):
         with torch.no_grad():
             model(bad)
+
+
+def test_packed_weight_reuse_never_serves_stale_parameters():
+    """Evaluation over a frozen model reuses the packed weight images of the previous forward (intel_set_params_unchanged);
+    every way the parameters can change -- the engine's fused Adam (raw pointers), an in-place torch op, load_state_dict --
+    must repack: each evaluation equals the one a fresh context computes from the same parameters."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    torch.manual_seed(3)
+    args = synth.make_args('tiny', dev)
+    corpus, _ = synth.make_corpus('tiny')
+    model = IntEL(args, corpus).to(dev)
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-2, l2=1e-4)
+    batch = synth.make_batch('tiny', 32, dev, seed=2, ragged=True)
+    other = synth.make_batch('tiny', 32, dev, seed=9, ragged=True)
+
+    def fresh():
+        torch.manual_seed(3)
+        m2 = IntEL(args, corpus).to(dev)
+        m2.load_state_dict(model.state_dict())
+        m2.eval()
+        with torch.no_grad():
+            return m2(batch)['ens_score'].clone()
+
+    model.eval()
+    a0 = eng.eval_step(batch)[0]['ens_score'].clone()
+    a1 = eng.eval_step(batch)[0]['ens_score'].clone()              # reuses the images
+    assert model._packed_key is not None and torch.equal(a0, a1) and torch.equal(a0, fresh())
+    eng.eval_step(other)                                            # same shape, other data: still reusable
+    assert torch.equal(eng.eval_step(batch)[0]['ens_score'], a0)
+    model.train()
+    eng.train_step(batch)                                           # fused Adam behind torch's version counters
+    model.eval()
+    b0 = eng.eval_step(batch)[0]['ens_score'].clone()
+    assert not torch.equal(b0, a0) and torch.equal(b0, fresh())
+    with torch.no_grad():
+        model.pred_layer.weight.mul_(1.5)                           # in-place torch op
+    c0 = eng.eval_step(batch)[0]['ens_score'].clone()
+    assert not torch.equal(c0, b0) and torch.equal(c0, fresh())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    sd['weight_embeddings.weight'] = sd['weight_embeddings.weight'] * 0.5
+    model.load_state_dict(sd)
+    d0 = eng.eval_step(batch)[0]['ens_score'].clone()
+    assert not torch.equal(d0, c0) and torch.equal(d0, fresh())
