@@ -116,7 +116,7 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
 // L <= 64, d in {64, 128}, head dim in {32, 64, 128}; INTEL_FUSE_TOWER=0 turns the fused path off
 bool tower_fused_supported(int L, int d, int heads);
 // the policy (INTEL_FUSE_TOWER unset): inference always, training in bf16 mode only (tower.hip)
-bool tower_fused_wanted(int train);
+bool tower_fused_wanted(int train, int d);
 // W*_b3: bf16 three-plane images (launch_pack_b3) of the packed [d -> 3d] / [d -> d] / [d -> d] weights.  out may be NULL
 // (x-hat / rstd only); train = 0: none of the stash pointers is written.
 int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,

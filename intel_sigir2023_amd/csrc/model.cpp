@@ -544,7 +544,7 @@ void pack_all(Run& r) {
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
-    if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train)) {
+    if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train, w.d)) {
       RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
       RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
       RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
@@ -631,7 +631,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
   // bf16-mode training: the one-kernel layer leaves its stashes as bf16 arrays, which needs the whole-sequence attention backward
   const bool h16_ok = attn_seq_h16_supported(L, d / D.heads) && (d == 64 || d == 128);
-  const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train) && !(r.train && r.ctx->drop_p > 0.f) &&
+  const bool fused = tower_fused_supported(L, d, D.heads) && tower_fused_wanted(r.train, w.d) && !(r.train && r.ctx->drop_p > 0.f) &&
                      !(r.train && gemm_planes() == 1 && !h16_ok);
   // bf16 mode: q/k/v (and, in the backward, their gradients) live in HBM as bf16 arrays -- every consumer rounds them to bf16
   // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)

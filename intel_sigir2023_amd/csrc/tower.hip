@@ -628,10 +628,11 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
 }
 
 // INTEL_FUSE_TOWER: 0 = never, 1 = always, unset / auto = where it is the faster path (measured on one box, same process):
-//   inference:              fused   (+4 % sessions/s in fp32, +22 % in bf16 mode)
-//   training, bf16 mode:    fused   (same step time, 1.1 GB less HBM traffic per step)
-//   training, fp32 mode:    kernel-per-op pipeline (the one-kernel layer saves the same 1.1 GB but its six-product MFMA work,
-//                           the L2 -> CU weight stream and one workgroup per CU make the step 3.5 % slower: DESIGN.md 6)
+//   inference:              fused   (+4 % sessions/s in fp32, +30 % in bf16 mode)
+//   training, bf16 mode:    fused   (two workgroups per CU at D = 128: -0.1 ms per step, 1.9 GB less HBM traffic)
+//   training, fp32 mode:    fused for the 64-wide tower (same step time, 0.4 GB less traffic), kernel-per-op pipeline for the
+//                           128-wide one (its six-product MFMA work, the L2 -> CU weight stream and one workgroup per CU
+//                           make the step 2.4 % slower: DESIGN.md 6)
 int fused_mode() {
   static const int m = [] { const char* e = getenv("INTEL_FUSE_TOWER"); return !e || !e[0] || e[0] == 'a' ? 2 : (e[0] == '0' ? 0 : 1); }();
   return m;
@@ -679,10 +680,13 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool tower_fused_wanted(int train) {
+bool tower_fused_wanted(int train, int d) {
   const int m = fused_mode();
   if (m != 2) return m == 1;
-  return !train || gemm_planes() == 1;
+  // fp32 training: the 64-wide tower only (80 KB of LDS: two workgroups per CU; same step time as the kernel-per-op pipeline,
+  // 0.4 GB less traffic); the 128-wide one (154 KB, one workgroup per CU) stays on the pipeline (-2.4 % otherwise)
+  static const int d64 = [] { const char* e = getenv("INTEL_FUSE_TOWER_D64"); return (e && e[0] == '0') ? 0 : 1; }();
+  return !train || gemm_planes() == 1 || (d64 && d == 64);
 }
 
 bool tower_fused_supported(int L, int d, int heads) {
