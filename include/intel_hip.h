@@ -168,6 +168,12 @@ void intel_destroy(IntelCtx* ctx);
  * the caller's stream (bench.py does this while it prices single kernels).  Default: on. */
 void intel_set_concurrency(IntelCtx* ctx, int on);
 
+/* stream (may be NULL = off): a stream that intel_backward (the one-call form) makes wait for the completion of
+ * grads[INTEL_P_IID_EMB] -- before its tail of shared-weight gradients and deferred reductions.  The caller enqueues the
+ * table's optimizer sweep there (HBM-bound, it then runs underneath that tail) and joins the streams before the next forward.
+ * The two-call form (intel_backward_phase) does not use it: there phase 1 returns at that point. */
+void intel_set_table_stream(IntelCtx* ctx, void* stream);
+
 /* A promise for the following intel_forward calls: the parameter VALUES equal those of the previous intel_forward on this
  * context.  The forward then reuses the packed weight images that call left in the workspace, provided the workspace
  * pointer, the batch shape and `train` are unchanged too (evaluation loops over a frozen model, helpers/BaseRunner.py:328-343:
@@ -368,6 +374,10 @@ int intel_feed_collate(const IntelFeedStore* store, const int* sess_idx, int shu
  * synchronises the device and returns a JSON object {"kernel": {"launches","ms","flops","bytes"}}. */
 void intel_prof_enable(int on);
 const char* intel_prof_collect(void);
+/* The same records as a timeline instead of per-kernel totals: a JSON array [{"name", "stream", "t0", "t1"}, ...] (ms from the
+ * first record, launch order).  With concurrency left on this is the step as its branches really overlap.  Synchronises and
+ * clears the records (call it INSTEAD of intel_prof_collect). */
+const char* intel_prof_timeline(void);
 
 /* ---- building blocks (exported for unit tests; see tests/test_ops_gpu.py) ------------------ */
 /* y[M,N] = x[M,K] @ w[N,K]^T (+bias) (relu) -- torch.nn.Linear. */

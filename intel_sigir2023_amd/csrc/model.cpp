@@ -79,7 +79,7 @@ struct Temps {
 
 struct Layout {
   int B, L, H, Hi, M;
-  Temps tmp[3];            // 0 / 1: tower-sized sets of the two concurrent branches; 2: encoder-sized (the third backward branch)
+  Temps tmp[4];            // 0 / 1: tower-sized sets of two concurrent branches; 2: session-history-encoder-sized; 3: score-tower-sized
   TowerBufs tw[2];          // 0 = item tower, 1 = score tower
   EncBufs enc[2];           // 0 = "encoder" (session history), 1 = "item_encoder"
   int F, Pin;               // width of the fusion feature / pred_layer input
@@ -110,6 +110,8 @@ struct IntelCtx {
   // concurrently -- MFMA-bound GEMMs of one branch overlap the HBM-bound row kernels of another
   hipStream_t side[3];
   hipEvent_t ev_fork, ev_join[3];
+  hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
+  hipStream_t table_stream = nullptr;      // intel_set_table_stream
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
   // weight-gradient / LayerNorm partial sums of a backward phase, reduced together when the phase ends
   ReduceQueue* rq;
@@ -326,10 +328,10 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   if (lnslab > slab) slab = lnslab;
   const int Tm = H > Hi ? H : Hi;
   const int Rm = I > Tm ? I : Tm;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < 4; ++i) {
     Temps& t = y.tmp[i];
-    // set 2 only ever holds the session-history encoder's backward (rows B*H, width dm0)
-    const size_t mds = i < 2 ? maxMD : rup_sz((size_t)B * H * dm0, 64);
+    // set 2 only ever holds the session-history encoder's backward (rows B*H, width dm0), set 3 the score tower's (rows M, width d_s)
+    const size_t mds = i < 2 ? maxMD : (i == 2 ? rup_sz((size_t)B * H * dm0, 64) : rup_sz((size_t)M * d_s, 64));
     t.dXa = ar.f(mds);
     t.dXb = ar.f(mds);
     t.dZ = ar.f(mds);
@@ -406,6 +408,7 @@ bool ensure_streams(IntelCtx* c) {
       ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 4; ++i) ok = ok && hipEventCreateWithFlags(&c->ev_x[i], hipEventDisableTiming) == hipSuccess;
     c->streams = ok ? 1 : -1;
   }
   return c->streams == 1;
@@ -1289,6 +1292,84 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     }
   };
 
+  // ===== the whole backward in one call (phase 0) with the branches on four streams: nothing heavy waits for a chain of small
+  // launches it does not depend on.
+  //   side 0:  cross-attention backward of the score tower -> [x1] -> score tower layers (set 3)
+  //   main:    cross-attention backward of the item tower -> [x0] -> wait x1 -> d(intent) chain -> [c] -> item-history encoder (set 1)
+  //   side 1:  wait x0 -> item tower layers + item-id / class table gradients (set 0)
+  //   side 2:  wait c -> session-history encoder (set 2)
+  //   main:    join; [iid] (the caller's table stream waits for it: intel_set_table_stream); shared intent-embedding gradients, reductions
+  // The two-call form (phases 1 and 2) keeps its order: there the caller overlaps the table's all-reduce with phase 2.
+  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
+  if (phase == 0 && wide_on && ensure_streams(r.ctx)) {
+    IntelCtx* c = r.ctx;
+    r.T = &y.tmp[0];
+    Run m = r;                                   // main stream, set 0 for the B-row temporaries of the chain
+    Run s0 = branch(r, 0, 1), s1 = branch(r, 1, 0), s2 = branch(r, 2, 2);
+    r.ok((int)hipEventRecord(c->ev_fork, r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
+    // score tower: cross-attention backward (B-row temporaries of set 1), then its layers with set 3
+    xatt_bwd(s0, 1, y.dXS, y.tmp[1].dINT);
+    r.ok((int)hipEventRecord(c->ev_x[1], s0.st));
+    {
+      Run t3 = s0;
+      t3.T = &y.tmp[3];
+      TowerBufs& w = y.tw[1];
+      float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
+      if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
+      r.ok(t3.rc);
+    }
+    r.ok(s0.rc);
+    // item tower: cross-attention backward on the main stream, layers on side 1
+    xatt_bwd(m, 0, y.tmp[0].dXa, y.tmp[0].dINT);
+    r.ok(m.rc);
+    if (r.rc) return;
+    r.ok((int)hipEventRecord(c->ev_x[0], r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[1], c->ev_x[0], 0));
+    item_tower_bwd(s1, y.tmp[0].dXa);
+    r.ok(s1.rc);
+    // d(intent) chain (needs both cross-attention backwards)
+    r.ok((int)hipStreamWaitEvent(r.st, c->ev_x[1], 0));
+    RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
+    RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
+    if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
+    RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
+    {
+      Run q = r;
+      q.T = &y.tmp[1];                           // (no temporaries used; set 1 is free until the encoder below)
+      wgrad(q, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+      lin(q, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+      r.ok(q.rc);
+    }
+    if (r.rc) return;
+    if (r.G(INTEL_P_CTX_EMB))
+      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
+    if (r.G(INTEL_P_UID_EMB))
+      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
+    r.ok((int)hipEventRecord(c->ev_x[2], r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_x[2], 0));
+    float *dE1 = nullptr, *dE0 = nullptr;
+    {
+      Run e1 = r;
+      e1.T = &y.tmp[1];
+      e1.rc = 0;
+      dE1 = encoder_branch(e1, 1);
+      dE0 = encoder_branch(s2, 0);
+      r.ok(e1.rc); r.ok(s2.rc);
+    }
+    join_streams(r, 3);
+    if (r.rc || !dE1 || !dE0) return;
+    if (c->table_stream) {                       // the item-id table gradient is complete: the caller's optimizer sweep may start
+      r.ok((int)hipEventRecord(c->ev_x[3], r.st));
+      r.ok((int)hipStreamWaitEvent(c->table_stream, c->ev_x[3], 0));
+    }
+    r.T = &y.tmp[0];
+    intent_wgrad(r, 1, dE1);
+    intent_wgrad(r, 0, dE0);
+    if (r.rc) return;
+    RUN(redq_flush(c->rq, r.st));
+    return;
+  }
   static const bool enc0_early = [] { const char* e = getenv("INTEL_ENC0_PHASE"); return !(e && e[0] == '2'); }();
   if (phase != 2) {
     // cross-attention backward of both towers first: d(intent) is then complete and the intent path can
@@ -1421,12 +1502,17 @@ extern "C" void intel_destroy(IntelCtx* ctx) {
       (void)hipEventDestroy(ctx->ev_join[i]);
     }
     (void)hipEventDestroy(ctx->ev_fork);
+    for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_x[i]);
   }
   redq_destroy(ctx->rq);
   delete ctx;
 }
 
 // on = 0: run every branch on the caller's stream (used while profiling single kernels); on = 1: default
+extern "C" void intel_set_table_stream(IntelCtx* ctx, void* stream) {
+  if (ctx) ctx->table_stream = (hipStream_t)stream;
+}
+
 extern "C" void intel_set_params_unchanged(IntelCtx* ctx, int on) {
   if (ctx) ctx->params_unchanged = on != 0;
 }

@@ -49,6 +49,9 @@ class IntELEngine(object):
         # two-phase backward + table all-reduce / Adam on a side stream (default); INTEL_OVERLAP_TABLE=0 runs the plain order
         import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
+        # one process (no gradient exchange): the one-call backward with its four branches on four streams and the table sweep
+        # underneath its tail; INTEL_BWD_SCHEDULE=phased keeps the two-call order data-parallel runs use
+        self.wide_backward = os.environ.get('INTEL_BWD_SCHEDULE', 'wide') != 'phased'
         self._side = None
         self._sort_side = None
         self._sorted_scatter = os.environ.get('INTEL_SCATTER_SORTED', 'auto')      # auto | 1 (always sort) | 0 (unsorted atomics)
@@ -292,7 +295,24 @@ class IntELEngine(object):
                 L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
                                             L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
                                             1, stream_ptr), 'intel_adam_step')
-        if self.overlap_table_update:
+        if self.overlap_table_update and not dp and self.wide_backward:
+            # one process: the whole backward in one call, its four branches (both towers, both encoders) on four streams.  The
+            # side stream is made to wait (inside intel_backward) for the item-id table gradient only, so the table's dense Adam
+            # sweep -- HBM-bound, 28 B per parameter -- runs underneath the backward's tail of small launches (shared
+            # intent-embedding gradients, deferred reductions) and the dense groups' Adam
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream()
+            lib.intel_set_table_stream(model._context(), C.c_void_p(side.cuda_stream))
+            try:
+                model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+            finally:
+                lib.intel_set_table_stream(model._context(), None)
+            with torch.cuda.stream(side):
+                adam('iid', self.l2, L.stream_ptr(dev))
+            adam('decay', self.l2, st)
+            adam('nodecay', 0.0, st)
+            cur.wait_stream(side)
+        elif self.overlap_table_update:
             # phase 1 completes the item-id table gradient (the 256 MB bucket).  Its all-reduce (data parallel) and its
             # dense Adam sweep -- HBM-bound, 28 B per parameter -- then run on a side stream underneath phase 2 (score-tower
             # layers, session-history encoder: matrix work that touches neither the table nor its gradient)
