@@ -429,6 +429,13 @@ void join_streams(Run& r, int n) {
     r.ok((int)hipStreamWaitEvent(r.st, c->ev_join[i], 0));
   }
 }
+// stream `to` waits for everything enqueued so far on side stream i (no-op when concurrency is off: one stream)
+void wait_side(Run& r, int i, hipStream_t to) {
+  IntelCtx* c = r.ctx;
+  if (c->streams != 1) return;
+  r.ok((int)hipEventRecord(c->ev_join[i], c->side[i]));
+  r.ok((int)hipStreamWaitEvent(to, c->ev_join[i], 0));
+}
 // a Run on side stream i (or on the main stream when concurrency is off) with temporaries set t
 Run branch(Run& r, int side, int t) {
   Run b = r;
@@ -1023,7 +1030,9 @@ void forward_impl(Run& r, const IntelOut* out) {
     }
     r.ok(b1.rc); r.ok(b2.rc); r.ok(b3.rc);
   }
-  join_streams(r, 3);
+  // the intent prediction needs the two encoders only (main + side 0): it and the intent-side projections of the pooling run
+  // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
+  wait_side(r, 0, r.st);
   if (r.rc) return;
   RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
@@ -1047,6 +1056,7 @@ void forward_impl(Run& r, const IntelOut* out) {
       lin(r, y.INTENTS, I, B, I, w.pXq, w.d, w.QV, w.d, e0);
       lin(r, w.QV, w.d, B, w.d, w.pXkT, w.d, w.QK, w.d, e0);
       if (r.rc) return;
+      wait_side(r, 1 + t, r.st);                 // tower t ran on side stream 1 + t
       if (tail_fusable(r.ctx, D, L, w.d, r.train)) {
         const int pb = w.pbase;
         RUN(launch_xatt_pool_fwd(w.layer[D.layers - 1].XH, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, r.st,
@@ -1063,6 +1073,7 @@ void forward_impl(Run& r, const IntelOut* out) {
       lin(r, y.INTENTS, I, B, I, w.pM0, D.q_size, w.MH, D.q_size, eh);
       lin(r, w.MH, D.q_size, B, D.q_size, w.pM2, w.d, w.MV, w.d, e0);
       if (r.rc) return;
+      wait_side(r, 1 + t, r.st);                 // tower t ran on side stream 1 + t
       if (D.pool_mean)      // aWELv_IntEL.py:195-198: (h * g(intent)).mean(dim=1), unmasked
         RUN(launch_gate_mean_fwd(Xf, w.d, w.MV, B, L, w.XBAR, y.FEAT, y.F, w.feat_off, r.st));
       else
@@ -1070,14 +1081,7 @@ void forward_impl(Run& r, const IntelOut* out) {
     }
   };
   fork_streams(r, 1);
-  {
-    Run b1 = branch(r, 0, 1);
-    pool_tower(b1, 1);
-    pool_tower(r, 0);
-    r.ok(b1.rc);
-  }
-  join_streams(r, 1);
-  if (r.rc) return;
+  // the user / intent columns of the fusion feature do not depend on the towers either
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.FEAT, y.F, off_u, 1, r.st));     // relu(h_u)
   {
     GemmEpilogue eh;
@@ -1086,6 +1090,14 @@ void forward_impl(Run& r, const IntelOut* out) {
     lin(r, y.INTENTS, I, B, I, y.pInt, D.d_int, y.FEAT + off_int, y.F, eh);                             // relu(h_intent)
     if (r.rc) return;
   }
+  {
+    Run b1 = branch(r, 0, 1);
+    pool_tower(b1, 1);
+    pool_tower(r, 0);
+    r.ok(b1.rc);
+  }
+  join_streams(r, 1);
+  if (r.rc) return;
   GemmEpilogue ew;
   ew.bias = r.P(INTEL_P_WE_B);
   if (per_session_weights(D)) {
