@@ -108,8 +108,8 @@ struct IntelCtx {
   unsigned char touched[INTEL_P_COUNT];
   // side streams: independent branches of the step (the two towers, the two sequence encoders) run
   // concurrently -- MFMA-bound GEMMs of one branch overlap the HBM-bound row kernels of another
-  hipStream_t side[3];
-  hipEvent_t ev_fork, ev_join[3];
+  hipStream_t side[4];         // 0, 3: the sequence encoders' branches; 1, 2: the item / score tower's (INTEL_CU_ENC: disjoint CU sets)
+  hipEvent_t ev_fork, ev_join[4];
   hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
   hipStream_t table_stream = nullptr;      // intel_set_table_stream
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
@@ -403,8 +403,26 @@ bool ensure_streams(IntelCtx* c) {
     const char* e = getenv("INTEL_STREAMS");
     if (e && e[0] == '0') { c->streams = -1; return false; }
     bool ok = true;
-    for (int i = 0; i < 3; ++i) {
-      ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
+    // INTEL_CU_ENC=n (experiment): the encoder branches' streams own n compute units, the tower branches' streams the others --
+    // a long chain of small launches then never queues behind a persistent kernel that holds every CU's LDS
+    int n_enc = 0, n_cu = 0;
+    { const char* q = getenv("INTEL_CU_ENC"); n_enc = q ? atoi(q) : 0; }
+    if (n_enc > 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+      if (n_enc >= n_cu) n_enc = 0;
+    }
+    for (int i = 0; i < 4; ++i) {
+      if (n_enc > 0) {
+        uint32_t mask[16] = {0};
+        const bool enc = (i == 0 || i == 3);
+        for (int cu = 0; cu < n_cu && cu < 512; ++cu)
+          if ((cu < n_enc) == enc) mask[cu >> 5] |= 1u << (cu & 31);
+        ok = ok && hipExtStreamCreateWithCUMask(&c->side[i], (uint32_t)((n_cu + 31) / 32), mask) == hipSuccess;
+      } else {
+        ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
+      }
       ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -975,7 +993,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   }
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
-  fork_streams(r, 3);
+  fork_streams(r, 4);
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = r.ctx->enc_rows[e], dm = n.dm;
@@ -1011,9 +1029,10 @@ void forward_impl(Run& r, const IntelOut* out) {
   TowerBufs& ti = y.tw[0];
   TowerBufs& ts = y.tw[1];
   {
-    Run b1 = branch(r, 0, 1), b2 = branch(r, 1, 0), b3 = branch(r, 2, 1);
-    encoder_branch(r, 0);
+    Run b0 = branch(r, 3, 0), b1 = branch(r, 0, 1), b2 = branch(r, 1, 0), b3 = branch(r, 2, 1);
+    encoder_branch(b0, 0);
     encoder_branch(b1, 1);
+    r.ok(b0.rc);
     // item tower
     if (b2.ok(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
         (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st))))
@@ -1033,6 +1052,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // the intent prediction needs the two encoders only (main + side 0): it and the intent-side projections of the pooling run
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
+  wait_side(r, 3, r.st);
   if (r.rc) return;
   RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
@@ -1306,10 +1326,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
 
   // ===== the whole backward in one call (phase 0) with the branches on four streams: nothing heavy waits for a chain of small
   // launches it does not depend on.
-  //   side 0:  cross-attention backward of the score tower -> [x1] -> score tower layers (set 3)
-  //   main:    cross-attention backward of the item tower -> [x0] -> wait x1 -> d(intent) chain -> [c] -> item-history encoder (set 1)
+  //   side 2:  cross-attention backward of the score tower -> [x1] -> score tower layers (set 3)
+  //   main:    cross-attention backward of the item tower -> [x0] -> wait x1 -> d(intent) chain -> [c]
   //   side 1:  wait x0 -> item tower layers + item-id / class table gradients (set 0)
-  //   side 2:  wait c -> session-history encoder (set 2)
+  //   side 3:  wait c -> item-history encoder (set 1);   side 0:  wait c -> session-history encoder (set 2)
   //   main:    join; [iid] (the caller's table stream waits for it: intel_set_table_stream); shared intent-embedding gradients, reductions
   // The two-call form (phases 1 and 2) keeps its order: there the caller overlaps the table's all-reduce with phase 2.
   static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
@@ -1317,21 +1337,21 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     IntelCtx* c = r.ctx;
     r.T = &y.tmp[0];
     Run m = r;                                   // main stream, set 0 for the B-row temporaries of the chain
-    Run s0 = branch(r, 0, 1), s1 = branch(r, 1, 0), s2 = branch(r, 2, 2);
+    Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2), s3 = branch(r, 3, 1);
     r.ok((int)hipEventRecord(c->ev_fork, r.st));
-    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
-    // score tower: cross-attention backward (B-row temporaries of set 1), then its layers with set 3
-    xatt_bwd(s0, 1, y.dXS, y.tmp[1].dINT);
-    r.ok((int)hipEventRecord(c->ev_x[1], s0.st));
+    r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
+    // score tower (side 2): cross-attention backward (B-row temporaries of set 1), then its layers with set 3
+    xatt_bwd(s2, 1, y.dXS, y.tmp[1].dINT);
+    r.ok((int)hipEventRecord(c->ev_x[1], s2.st));
     {
-      Run t3 = s0;
+      Run t3 = s2;
       t3.T = &y.tmp[3];
       TowerBufs& w = y.tw[1];
       float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
       if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
       r.ok(t3.rc);
     }
-    r.ok(s0.rc);
+    r.ok(s2.rc);
     // item tower: cross-attention backward on the main stream, layers on side 1
     xatt_bwd(m, 0, y.tmp[0].dXa, y.tmp[0].dINT);
     r.ok(m.rc);
@@ -1346,30 +1366,21 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
     if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
     RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
-    {
-      Run q = r;
-      q.T = &y.tmp[1];                           // (no temporaries used; set 1 is free until the encoder below)
-      wgrad(q, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
-      lin(q, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
-      r.ok(q.rc);
-    }
+    wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+    lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
     if (r.rc) return;
     if (r.G(INTEL_P_CTX_EMB))
       RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     if (r.G(INTEL_P_UID_EMB))
       RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
+    // the two encoders (side 3: item history, set 1; side 0: session history, set 2) need the chain's d(pred_layer input)
     r.ok((int)hipEventRecord(c->ev_x[2], r.st));
-    r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_x[2], 0));
-    float *dE1 = nullptr, *dE0 = nullptr;
-    {
-      Run e1 = r;
-      e1.T = &y.tmp[1];
-      e1.rc = 0;
-      dE1 = encoder_branch(e1, 1);
-      dE0 = encoder_branch(s2, 0);
-      r.ok(e1.rc); r.ok(s2.rc);
-    }
-    join_streams(r, 3);
+    r.ok((int)hipStreamWaitEvent(c->side[3], c->ev_x[2], 0));
+    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
+    float* dE1 = encoder_branch(s3, 1);
+    float* dE0 = encoder_branch(s0, 0);
+    r.ok(s3.rc); r.ok(s0.rc);
+    join_streams(r, 4);
     if (r.rc || !dE1 || !dE0) return;
     if (c->table_stream) {                       // the item-id table gradient is complete: the caller's optimizer sweep may start
       r.ok((int)hipEventRecord(c->ev_x[3], r.st));
@@ -1509,7 +1520,7 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
 extern "C" void intel_destroy(IntelCtx* ctx) {
   if (!ctx) return;
   if (ctx->streams == 1 || ctx->streams == 2) {
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
       (void)hipStreamDestroy(ctx->side[i]);
       (void)hipEventDestroy(ctx->ev_join[i]);
     }
