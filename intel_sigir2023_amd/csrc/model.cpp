@@ -108,7 +108,7 @@ struct IntelCtx {
   unsigned char touched[INTEL_P_COUNT];
   // side streams: independent branches of the step (the two towers, the two sequence encoders) run
   // concurrently -- MFMA-bound GEMMs of one branch overlap the HBM-bound row kernels of another
-  hipStream_t side[4];         // 0, 3: the sequence encoders' branches; 1, 2: the item / score tower's (INTEL_CU_ENC: disjoint CU sets)
+  hipStream_t side[4];         // 0, 3: the sequence encoders' branches; 1, 2: the item / score tower's
   hipEvent_t ev_fork, ev_join[4];
   hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
   hipStream_t table_stream = nullptr;      // intel_set_table_stream
@@ -403,26 +403,11 @@ bool ensure_streams(IntelCtx* c) {
     const char* e = getenv("INTEL_STREAMS");
     if (e && e[0] == '0') { c->streams = -1; return false; }
     bool ok = true;
-    // INTEL_CU_ENC=n (experiment): the encoder branches' streams own n compute units, the tower branches' streams the others --
-    // a long chain of small launches then never queues behind a persistent kernel that holds every CU's LDS
-    int n_enc = 0, n_cu = 0;
-    { const char* q = getenv("INTEL_CU_ENC"); n_enc = q ? atoi(q) : 0; }
-    if (n_enc > 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-      if (n_enc >= n_cu) n_enc = 0;
-    }
+    // (tried for the encoder / tower branches and dropped: streams restricted to disjoint CU sets with
+    // hipExtStreamCreateWithCUMask -- 3-4x slower at every split on this 8-XCD part; highest stream priority for the encoder
+    // branches, whose chains of small launches are the critical path -- 1.7x slower)
     for (int i = 0; i < 4; ++i) {
-      if (n_enc > 0) {
-        uint32_t mask[16] = {0};
-        const bool enc = (i == 0 || i == 3);
-        for (int cu = 0; cu < n_cu && cu < 512; ++cu)
-          if ((cu < n_enc) == enc) mask[cu >> 5] |= 1u << (cu & 31);
-        ok = ok && hipExtStreamCreateWithCUMask(&c->side[i], (uint32_t)((n_cu + 31) / 32), mask) == hipSuccess;
-      } else {
-        ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
-      }
+      ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
