@@ -1362,8 +1362,12 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ok((int)hipEventRecord(c->ev_x[2], r.st));
     r.ok((int)hipStreamWaitEvent(c->side[3], c->ev_x[2], 0));
     r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
+    // each encoder's share of the SHARED intent-embedding gradient follows on its own stream: the products only write slabs,
+    // the sums into the weight happen in the deferred reduction below, in the (fixed) order the jobs are pushed here
     float* dE1 = encoder_branch(s3, 1);
+    if (!s3.rc && dE1) intent_wgrad(s3, 1, dE1);
     float* dE0 = encoder_branch(s0, 0);
+    if (!s0.rc && dE0) intent_wgrad(s0, 0, dE0);
     r.ok(s3.rc); r.ok(s0.rc);
     join_streams(r, 4);
     if (r.rc || !dE1 || !dE0) return;
@@ -1371,10 +1375,6 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       r.ok((int)hipEventRecord(c->ev_x[3], r.st));
       r.ok((int)hipStreamWaitEvent(c->table_stream, c->ev_x[3], 0));
     }
-    r.T = &y.tmp[0];
-    intent_wgrad(r, 1, dE1);
-    intent_wgrad(r, 0, dE0);
-    if (r.rc) return;
     RUN(redq_flush(c->rq, r.st));
     return;
   }

@@ -277,6 +277,10 @@ class IntELEngine(object):
             L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label.contiguous()), self.kl_weight, self.kl_temp,
                                           self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws), nb, st),
                     'intel_intent_loss')
+        # (loss, ensemble_loss, intent_loss) like the reference's criterion: one tiny launch into a fresh 3-vector (the
+        # caller may keep every step's values: runner.fit averages them at the end of the epoch); enqueued before the backward
+        tot = torch.empty(3, dtype=torch.float64, device=dev)
+        L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), st), 'intel_loss_total')
         self.step_count += 1
         b1, b2 = self.betas
         if sort_ev is not None:
@@ -342,10 +346,6 @@ class IntELEngine(object):
                 parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
             for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
                 adam(gname, wd, st, dense_reduced=dp)
-        # (loss, ensemble_loss, intent_loss) like the reference's criterion: one tiny launch into a fresh 3-vector (the
-        # caller may keep every step's values: runner.fit averages them at the end of the epoch)
-        tot = torch.empty(3, dtype=torch.float64, device=dev)
-        L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), st), 'intel_loss_total')
         return tot[0], tot[1], tot[2]
 
     # ---- evaluation -----------------------------------------------------------------------------------
