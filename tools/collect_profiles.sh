@@ -16,6 +16,15 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ou
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -- python3 bench.py --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 4 $PMCARGS > $out/fetch_eval.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 4 $PMCARGS > $out/write_eval.log 2>&1 < /dev/null
+# bf16 mode: its own bench line, kernel stats and traffic passes
+timeout 600 python bench.py --dtype bf16 --no_cpu_baseline > $out/bench_bf16.json 2>/dev/null < /dev/null
+INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_bf16 -- python3 bench.py --dtype bf16 --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s_bf16.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_bf16 -- python3 bench.py --dtype bf16 --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch_bf16.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_bf16 -- python3 bench.py --dtype bf16 --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write_bf16.log 2>&1 < /dev/null
+# the step as it overlaps (HIP-event timeline, branches on their streams)
+timeout 300 python tools/step_timeline.py f32 train full > $out/timeline_f32_train.txt 2>&1 < /dev/null
+timeout 300 python tools/step_timeline.py bf16 train full > $out/timeline_bf16_train.txt 2>&1 < /dev/null
+timeout 300 python tools/step_timeline.py f32 eval full > $out/timeline_f32_eval.txt 2>&1 < /dev/null
 if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload lifedata --batch 2048 --no_cpu_baseline > $out/bench_lifedata.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 256 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
@@ -24,7 +33,9 @@ timeout 600 python bench.py --loss IntListloss --cal_diversity 1 --no_cpu_baseli
 timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline > $out/bench_gru4rec.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload tmall_pub --no_cpu_baseline > $out/bench_tmall_pub.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --zipf 1 --no_cpu_baseline > $out/bench_zipf.json 2>/dev/null < /dev/null
-INTEL_FUSE_TOWER=0 timeout 600 python bench.py --no_cpu_baseline > $out/bench_unfused.json 2>/dev/null < /dev/null
+INTEL_FUSE_TOWER=0 timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_unfused.json 2>/dev/null < /dev/null
+INTEL_BWD_SCHEDULE=phased timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_phased.json 2>/dev/null < /dev/null
+for b in 8192 16384 32768; do timeout 600 python bench.py --batch $b --steps 10 --no_cpu_baseline --no_roofline --no_feed --nbatches 4 > $out/bench_b$b.json 2>/dev/null < /dev/null; done
 fi
 # keep the merge small: only the summaries travel back
 find $out -name "*.csv" ! -name "*kernel_stats.csv" ! -name "*counter_collection.csv" -delete 2>/dev/null
