@@ -136,14 +136,20 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
                                                       stages['B4096']['full_step']['steps'], total)}
 
 
-def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_shape):
+def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_shape, planes=6.0):
     """`roofline` object for the kernel with the largest total time among the profiled launches: achieved = algorithmic bytes
     (or flops) / launch duration (HIP events on the launch stream), traffic = HBM bytes per launch from the committed PMC passes."""
-    prof = {}                       # aggregate the shape-tagged records by kernel
+    prof, split = {}, {}            # aggregate the shape-tagged records by kernel; per kernel also by row count (M of [MxNxK])
     for k, v in prof_shapes.items():
-        d = prof.setdefault(k.split('[')[0].strip('()').split('<')[0], {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+        base = k.split('[')[0].strip('()').split('<')[0]
+        d = prof.setdefault(base, {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
         for f in d:
             d[f] += v[f]
+        if '[' in k:
+            m = int(k.split('[')[1].split('x')[0])
+            part = split.setdefault(base, {}).setdefault('rows_ge_32768' if m >= 32768 else 'rows_lt_32768', {'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+            for f in part:
+                part[f] += v[f]
     tot = sum(v['ms'] for v in prof.values())
     name, dom = max(prof.items(), key=lambda kv: kv[1]['ms'])
     avg_ms = dom['ms'] / dom['launches']
@@ -152,8 +158,13 @@ def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_sh
         # far from its 2.5 PFLOP/s roof (reported as `bf16_mfma_frac`); the binding roof is HBM
         ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s', 'frac': round(ach / (HBM_PEAK / 1e9), 5),
-                'traffic': None, 'bf16_mfma_frac': round(6.0 * dom['flops'] / (dom['ms'] * 1e-3) / BF16_MFMA_PEAK, 5),
+                'traffic': None, 'bf16_mfma_frac': round(planes * dom['flops'] / (dom['ms'] * 1e-3) / BF16_MFMA_PEAK, 5),
                 'fp32_equivalent_TFLOPs': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2)}
+        # the same kernel serves the B*L-row products of the towers (HBM-bound) and the B-row products of the session head
+        # (one tile per workgroup, latency-bound): priced separately too
+        roof['by_rows'] = {kk: {'launches_per_step': vv['launches'] / psteps, 'avg_launch_ms': round(vv['ms'] / vv['launches'], 5),
+                                'achieved': round(vv['bytes'] / (vv['ms'] * 1e-3) / 1e9, 2), 'frac': round(vv['bytes'] / (vv['ms'] * 1e-3) / HBM_PEAK, 5)}
+                           for kk, vv in sorted(split.get(name, {}).items())}
     elif name in MFMA_KERNELS:
         ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 3), 'peak': F32_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
@@ -161,7 +172,7 @@ def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_sh
     elif name in FUSED_KERNELS:
         # the one-kernel tower layer: six bf16 plane products per linear + exact fp32-MFMA attention; priced against the
         # dense bf16 MFMA peak with the six-fold plane work counted (the HBM side is reported next to it)
-        eq = 6.0 * dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+        eq = planes * dom['flops'] / (dom['ms'] * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(eq, 2), 'peak': BF16_MFMA_PEAK / 1e12, 'unit': 'TFLOP/s',
                 'frac': round(eq / (BF16_MFMA_PEAK / 1e12), 5), 'traffic': None,
                 'fp32_equivalent_TFLOPs': round(dom['flops'] / (dom['ms'] * 1e-3) / 1e12, 2),
@@ -321,16 +332,17 @@ def main():
     if prof_shapes is not None:
         pmc, pmc_eval, src = None, None, None
         try:        # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
-            src = 'profiles/r02_pmc_traffic.json'
+            src = 'profiles/r02_pmc_traffic_bf16.json' if a.dtype == 'bf16' else 'profiles/r02_pmc_traffic.json'
             j = json.load(open(os.path.join(ROOT, src)))
             pmc, pmc_eval = j.get('kernels'), j.get('kernels_eval', j.get('kernels'))
             src += ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950), bytes per launch'
         except Exception:
             pass
-        exact = a.workload == 'tmall' and B == 4096 and not bf16
-        roof, prof = price_dominant_kernel(prof_shapes, psteps, pmc, src, exact)
+        exact = a.workload == 'tmall' and B == 4096
+        planes = 1.0 if bf16 else 6.0           # bf16 MFMA products per product of the path
+        roof, prof = price_dominant_kernel(prof_shapes, psteps, pmc, src, exact, planes)
         res['roofline'] = roof
-        eroof, eprof = price_dominant_kernel(prof_eval, psteps, pmc_eval, src, exact)
+        eroof, eprof = price_dominant_kernel(prof_eval, psteps, pmc_eval, src, exact and not bf16, planes)
         eroof['eval_bytes_per_session'] = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], False)
         eroof['gather_frac'] = round(eroof['eval_bytes_per_session'] * res['eval_sessions_per_s'] / world / HBM_PEAK, 6)
         res['eval_roofline'] = eroof
@@ -352,6 +364,12 @@ def main():
     if world == 1 and not bf16 and not a.no_bf16_line:
         # the same workload in the bf16 arithmetic mode (BASELINE.json configs[1] names it), measured in the same run on the same
         # resident batches: a second model + engine (own fp32 master weights and Adam state), same timing brackets
+        # (the fp32 model, its optimizer state and workspace are released first: two resident 1 GB tables + workspaces cost
+        # the second model 3-8 % -- measured)
+        del eng, model
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
         args_bf = synth.make_args(a.workload, dev, **dict(over, dtype='bf16'))
         torch.manual_seed(0)
         model_bf = IntEL(args_bf, corpus).to(dev)

@@ -49,8 +49,8 @@ def summarise(fetch_csv, write_csv, steps):
 def main():
     steps = int(sys.argv[3])
     out, per_step = summarise(sys.argv[1], sys.argv[2], steps)
-    res = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in its own run (--kernel-trace only) of `python3 bench.py --steps 3 --warmup 1 '
-                   '--eval_steps 0 --no_cpu_baseline --no_roofline --no_feed` (%d training steps, no evaluation steps); KiB units; '
+    res = {'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, each in its own run (--kernel-trace only) of `python3 bench.py [--dtype bf16] --steps 3 --warmup 1 '
+                   '--eval_steps 0 --no_cpu_baseline --no_roofline --no_feed --no_bf16_line` (%d training steps, no evaluation steps); KiB units; '
                    'FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B)' % steps,
            'train_steps': steps, 'hbm_GB_per_train_step': round(per_step / 1e9, 3), 'kernels': out}
     if len(sys.argv) > 7:

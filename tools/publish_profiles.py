@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Copy the summaries `tools/collect_profiles.sh <tag>` left under gpurun_out/<tag>/ into profiles/ under their round names
+(bench lines pretty-printed, kernel-stats CSVs, PMC traffic summaries, event timelines, the batch sweep as one array).
+usage: python tools/publish_profiles.py <tag> [round=r02]"""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+src = os.path.join('gpurun_out', tag)
+dst = 'profiles'
+
+
+def bench(name, out):
+    f = os.path.join(src, name)
+    if not os.path.exists(f):
+        print('missing', f)
+        return None
+    d = json.load(open(f))
+    json.dump(d, open(os.path.join(dst, out), 'w'), indent=1)
+    return d
+
+
+names = {'bench.json': 'bench_tmall', 'bench_bf16.json': 'bench_tmall_bf16', 'bench_lifedata.json': 'bench_lifedata', 'bench_stress.json': 'bench_stress',
+         'bench_stress_b1024.json': 'bench_stress_b1024', 'bench_pl_div.json': 'bench_pl_div', 'bench_gru4rec.json': 'bench_gru4rec',
+         'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased'}
+for k, v in names.items():
+    bench(k, '%s_%s.json' % (rnd, v))
+sweep = []
+for f in sorted(glob.glob(os.path.join(src, 'bench_b[0-9]*.json')), key=lambda p: int(os.path.basename(p)[7:-5])):
+    d = json.load(open(f))
+    sweep.append({'per_gpu_batch': d['config']['per_gpu_batch'], 'value': d['value'], 'ms_per_step': d['ms_per_step'],
+                  'eval_sessions_per_s': d['eval_sessions_per_s'], 'bf16_mode': d.get('bf16_mode', {}).get('value')})
+if sweep:
+    json.dump(sweep, open(os.path.join(dst, '%s_batch_sweep.json' % rnd), 'w'), indent=1)
+
+
+def one(pattern):
+    fs = glob.glob(os.path.join(src, pattern), recursive=True)
+    return fs[0] if fs else None
+
+
+for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'),
+                 ('stats_eval', 'bench_tmall_eval_kernel_stats.csv'), ('stats1s_bf16', 'bench_tmall_bf16_kernel_stats.csv')):
+    f = one('%s/**/*kernel_stats.csv' % sub)
+    if f:
+        shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, out)))
+    else:
+        print('missing', sub)
+f, w, fe, we = (one('%s/**/*counter_collection.csv' % s) for s in ('fetch', 'write', 'fetch_eval', 'write_eval'))
+if f and w:
+    cmd = [sys.executable, 'tools/pmc_summary.py', f, w, '4', os.path.join(dst, '%s_pmc_traffic.json' % rnd)]
+    if fe and we:
+        cmd += [fe, we, '4']
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+fb, wb = one('fetch_bf16/**/*counter_collection.csv'), one('write_bf16/**/*counter_collection.csv')
+if fb and wb:
+    subprocess.run([sys.executable, 'tools/pmc_summary.py', fb, wb, '4', os.path.join(dst, '%s_pmc_traffic_bf16.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
+for t in ('f32_train', 'bf16_train', 'f32_eval'):
+    f = os.path.join(src, 'timeline_%s.txt' % t)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, '%s_timeline_%s.txt' % (rnd, t)))
+for f in sorted(os.listdir(dst)):
+    if f.startswith(rnd):
+        print(f)
