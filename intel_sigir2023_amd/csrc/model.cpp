@@ -9,7 +9,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
 #include <new>
+#include <vector>
 
 #include "../../include/intel_hip.h"
 #include "kernels.h"
@@ -89,6 +91,7 @@ struct Layout {
   float *WVN[2], *WPADN[2], *WTN[2];
   float *pInt, *pIntT, *pScore, *pWe, *pWePad, *pWeT, *pWePadT, *pPred, *pPredT;
   float *dFEAT, *dWV, *dWPAD, *dWT, *dFEATFULL, *dINTENT, *dLOGITS, *dPREDIN;
+  float *dHINT, *dHB[2][3];   // B-row gradients of the session head kept until its (deferred) weight-gradient products have read them
   float *dXS;       // gradient w.r.t. the score tower output, parked between the two backward phases
   float *ONEHOT2;   // one-hot of the item-history intent indices (used on the main stream after a join)
   float *ARENA;     // slabs of the deferred reductions (ReduceQueue)
@@ -328,6 +331,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
   if (lnslab > slab) slab = lnslab;
   const int Tm = H > Hi ? H : Hi;
   const int Rm = I > Tm ? I : Tm;
+  y.dHINT = ar.f((size_t)B * vmax);
+  for (int t = 0; t < 2; ++t)
+    for (int j = 0; j < 3; ++j) y.dHB[t][j] = ar.f((size_t)B * vmax);
   for (int i = 0; i < 4; ++i) {
     Temps& t = y.tmp[i];
     // set 2 only ever holds the session-history encoder's backward (rows B*H, width dm0), set 3 the score tower's (rows M, width d_s)
@@ -1155,6 +1161,22 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   GemmEpilogue eacc;
   eacc.accumulate = 1;
   redq_reset(r.ctx->rq, y.ARENA, y.arena_floats);
+  // The weight-gradient products and table scatters of the session head are LEAVES of the dependency graph: nothing in this
+  // backward reads their results.  The one-call schedule keeps them off the critical chain (loss -> fusion weights -> cross
+  // attention backward -> d(intent) -> encoders): they are collected here and launched once the chain has been enqueued.
+  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
+  const bool wide = phase == 0 && wide_on && ensure_streams(r.ctx);
+  typedef std::function<void(Run&)> Leaf;
+  std::vector<Leaf> lv_main, lv_score;
+  std::vector<Leaf>* defer = wide ? &lv_main : nullptr;
+  auto leaf = [&](Run& q, Leaf f) {
+    if (defer) defer->push_back(f);
+    else f(q);
+  };
+  auto run_leaves = [&](Run& q, std::vector<Leaf>& v) {
+    for (Leaf& f : v) f(q);
+    v.clear();
+  };
   if (phase != 2) {
     memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
     // embedding tables accumulate with atomics into caller-zeroed buffers
@@ -1169,17 +1191,20 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         RUN(launch_softmax_rows_bwd(y.WVN[s], y.dWV, B, K, y.dWV, r.st));
         if (!D.pool_mean) RUN(launch_softmax_rows_bwd(y.WPADN[s], y.dWPAD, B, K, y.dWPAD, r.st));
       }
-      wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+      leaf(r, [=, &y](Run& r) {
+        wgrad(r, y.dWV, K, y.FEAT, y.F, B, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+        if (r.rc) return;
+        if (!r.D.pool_mean && r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
+          RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, nullptr, r.st, r.ctx->rq));
+        }
+      });
       if (r.rc) return;
-      if (!D.pool_mean && r.G(INTEL_P_WE_W)) {   // padded rows only see [h_u | h_intent]
-        RUN(launch_wgrad(y.dWPAD, K, y.FEAT + off_u, y.F, B, K, npad, r.G(INTEL_P_WE_W) + off_u, y.F, r.G(INTEL_P_WE_B), 1, nullptr, r.st, r.ctx->rq));
-      }
       lin(r, y.dWV, K, B, K, y.pWeT, y.F, y.dFEAT, y.F, e0);
       if (!D.pool_mean) lin(r, y.dWPAD, K, B, K, y.pWePadT, npad, y.dFEAT + off_u, y.F, eacc);
     } else {
       RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 1, nullptr, nullptr, y.dWT, r.st));
       for (int s = D.weight_norm - 1; s >= 0; --s) RUN(launch_softmax_rows_bwd(y.WTN[s], y.dWT, M, K, y.dWT, r.st));
-      wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B);
+      leaf(r, [=, &y](Run& r) { wgrad(r, y.dWT, K, y.FEATFULL, y.F, M, K, y.F, INTEL_P_WE_W, INTEL_P_WE_B); });
       lin(r, y.dWT, K, M, K, y.pWeT, y.F, y.dFEATFULL, y.F, e0);
       if (r.rc) return;
       // per-session parts of the feature: h_u, h_intent are broadcast over the list
@@ -1188,11 +1213,13 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     if (r.rc) return;
     // h_u = relu(uid_emb[u])
     if (r.G(INTEL_P_UID_EMB))
-      RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
-    // h_intent = relu(intent_embeddings(intent)): dpre -> dVB1 [B, d_int]
-    RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, r.T->dVB1, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
-    wgrad(r, r.T->dVB1, D.d_int, y.INTENTS, I, B, D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B);
-    lin(r, r.T->dVB1, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
+      leaf(r, [=, &y, &bt](Run& r) {
+        RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, r.D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
+      });
+    // h_intent = relu(intent_embeddings(intent)): dpre -> dHINT [B, d_int]
+    RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dHINT, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
+    leaf(r, [=, &y](Run& r) { wgrad(r, y.dHINT, r.D.d_int, y.INTENTS, I, B, r.D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B); });
+    lin(r, y.dHINT, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
     if (r.rc) return;
   }
 
@@ -1202,39 +1229,41 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     TowerBufs& w = y.tw[t];
     const int d = w.d;
     const float* Xf = D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0;
+    float *g1 = y.dHB[t][0], *g2 = y.dHB[t][1], *g3 = y.dHB[t][2];      // B-row gradients (kept for the deferred weight gradients)
     if (D.cross_attention) {
       const int xb = w.xbase;
       // pooled = xbar Wv^T
-      wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1);
-      lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, r.T->dVB1, d, e0);          // dxbar
+      leaf(r, [=, &y, &w](Run& r) { wgrad(r, y.dFEAT + w.feat_off, y.F, w.XBAR, d, B, d, d, xb + 2, -1); });
+      lin(r, y.dFEAT + w.feat_off, y.F, B, d, w.pXvT, d, g1, d, e0);          // dxbar
       if (r.rc) return;
       if (r.ctx->fused_tail[t]) {       // dXout receives dZ: the gradient BEHIND the last layer's LayerNorm
         const int pb = w.pbase;
         TowerLayerBufs& lb = w.layer[D.layers - 1];
         const int a = r.acc(pb + T_LNG);
         r.acc(pb + T_LNB);
-        RUN(launch_xatt_pool_ln_bwd(lb.XH, lb.RSTD, r.P(pb + T_LNG), r.P(pb + T_LNB), B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout,
-                                    r.T->dVB2, r.G(pb + T_LNG), r.G(pb + T_LNB), a, r.st, r.ctx->rq));
+        RUN(launch_xatt_pool_ln_bwd(lb.XH, lb.RSTD, r.P(pb + T_LNG), r.P(pb + T_LNB), B, L, d, w.QK, w.ATTW, g1, d, scale, dXout,
+                                    g2, r.G(pb + T_LNG), r.G(pb + T_LNB), a, r.st, r.ctx->rq));
       } else {
-        RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, r.T->dVB1, d, scale, dXout, r.T->dVB2, r.st));   // dX, dQK
+        RUN(launch_xatt_pool_bwd(Xf, B, L, d, w.QK, w.ATTW, g1, d, scale, dXout, g2, r.st));   // dX, dQK
       }
       // QK = QV Wk  (QK[b][j] = sum_i QV[b][i] Wk[i][j])
-      wgrad(r, w.QV, d, r.T->dVB2, d, B, d, d, xb + 1, -1);
-      lin(r, r.T->dVB2, d, B, d, w.pXk, d, r.T->dVB3, d, e0);                            // dQV
-      wgrad(r, r.T->dVB3, d, y.INTENTS, I, B, d, I, xb + 0, -1);
-      lin(r, r.T->dVB3, d, B, d, w.pXqT, I, dint, I, e0);
+      leaf(r, [=, &w](Run& r) { wgrad(r, w.QV, d, g2, d, B, d, d, xb + 1, -1); });
+      lin(r, g2, d, B, d, w.pXk, d, g3, d, e0);                            // dQV
+      leaf(r, [=, &y](Run& r) { wgrad(r, g3, d, y.INTENTS, I, B, d, I, xb + 0, -1); });
+      lin(r, g3, d, B, d, w.pXqT, I, dint, I, e0);
     } else {
       const int mb = t == 0 ? INTEL_P_MI_W0 : INTEL_P_MS_W0;
       if (D.pool_mean)
-        RUN(launch_gate_mean_bwd(y.dFEAT, y.F, w.feat_off, w.XBAR, d, w.MV, B, L, dXout, r.T->dVB1, r.st));   // dX (every row), dMV
+        RUN(launch_gate_mean_bwd(y.dFEAT, y.F, w.feat_off, w.XBAR, d, w.MV, B, L, dXout, g1, r.st));   // dX (every row), dMV
       else
-        RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dXout, r.T->dVB1, r.st));    // dX, dMV
-      wgrad(r, r.T->dVB1, d, w.MH, D.q_size, B, d, D.q_size, mb + 2, -1);
+        RUN(launch_gate_bwd(y.dFEATFULL, y.F, w.feat_off, Xf, d, w.MV, B, L, dXout, g1, r.st));    // dX, dMV
+      const int qs = D.q_size;
+      leaf(r, [=, &w](Run& r) { wgrad(r, g1, d, w.MH, qs, B, d, qs, mb + 2, -1); });
       GemmEpilogue em;
       em.mask = w.MH; em.ldmask = D.q_size;
-      lin(r, r.T->dVB1, d, B, d, w.pM2T, D.q_size, r.T->dVB2, D.q_size, em);            // d(pre-relu hidden)
-      wgrad(r, r.T->dVB2, D.q_size, y.INTENTS, I, B, D.q_size, I, mb + 0, mb + 1);
-      lin(r, r.T->dVB2, D.q_size, B, D.q_size, w.pM0T, I, dint, I, e0);
+      lin(r, g1, d, B, d, w.pM2T, D.q_size, g2, D.q_size, em);            // d(pre-relu hidden)
+      leaf(r, [=, &y](Run& r) { wgrad(r, g2, qs, y.INTENTS, I, B, qs, I, mb + 0, mb + 1); });
+      lin(r, g2, D.q_size, B, D.q_size, w.pM0T, I, dint, I, e0);
     }
   };
   // ===== tied self-attention layers of the item tower + its embedding-table gradients
@@ -1317,16 +1346,17 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   //   side 3:  wait c -> item-history encoder (set 1);   side 0:  wait c -> session-history encoder (set 2)
   //   main:    join; [iid] (the caller's table stream waits for it: intel_set_table_stream); shared intent-embedding gradients, reductions
   // The two-call form (phases 1 and 2) keeps its order: there the caller overlaps the table's all-reduce with phase 2.
-  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
-  if (phase == 0 && wide_on && ensure_streams(r.ctx)) {
+  if (wide) {
     IntelCtx* c = r.ctx;
     r.T = &y.tmp[0];
     Run m = r;                                   // main stream, set 0 for the B-row temporaries of the chain
     Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2), s3 = branch(r, 3, 1);
     r.ok((int)hipEventRecord(c->ev_fork, r.st));
     r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
-    // score tower (side 2): cross-attention backward (B-row temporaries of set 1), then its layers with set 3
+    // score tower (side 2): cross-attention backward, then its layers with set 3, then the pooling's weight gradients
+    defer = &lv_score;
     xatt_bwd(s2, 1, y.dXS, y.tmp[1].dINT);
+    defer = &lv_main;
     r.ok((int)hipEventRecord(c->ev_x[1], s2.st));
     {
       Run t3 = s2;
@@ -1334,6 +1364,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       TowerBufs& w = y.tw[1];
       float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
       if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
+      if (!t3.rc) run_leaves(t3, lv_score);
       r.ok(t3.rc);
     }
     r.ok(s2.rc);
@@ -1351,17 +1382,21 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
     if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
     RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
-    wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
     lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+    if (r.rc) return;
+    // the two encoders (side 3: item history, set 1; side 0: session history, set 2) need the chain's d(pred_layer input)
+    r.ok((int)hipEventRecord(c->ev_x[2], r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[3], c->ev_x[2], 0));
+    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
+    // the leaves of the session head, on the main stream behind the chain (host order = the order the shared slots accumulate in)
+    run_leaves(r, lv_main);
+    defer = nullptr;
+    wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
     if (r.rc) return;
     if (r.G(INTEL_P_CTX_EMB))
       RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
     if (r.G(INTEL_P_UID_EMB))
       RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
-    // the two encoders (side 3: item history, set 1; side 0: session history, set 2) need the chain's d(pred_layer input)
-    r.ok((int)hipEventRecord(c->ev_x[2], r.st));
-    r.ok((int)hipStreamWaitEvent(c->side[3], c->ev_x[2], 0));
-    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
     // each encoder's share of the SHARED intent-embedding gradient follows on its own stream: the products only write slabs,
     // the sums into the weight happen in the deferred reduction below, in the (fixed) order the jobs are pushed here
     float* dE1 = encoder_branch(s3, 1);
