@@ -174,6 +174,12 @@ void intel_set_concurrency(IntelCtx* ctx, int on);
  * The two-call form (intel_backward_phase) does not use it: there phase 1 returns at that point. */
 void intel_set_table_stream(IntelCtx* ctx, void* stream);
 
+/* One of the context's three internal side streams (i = 0..2; NULL when branch concurrency is off).  The runtime multiplexes
+ * streams onto four hardware queues by default, and a fifth ACTIVE stream shares a queue with one of the others: a caller that
+ * wants work next to the context's branches (the table's optimizer sweep after intel_backward, which leaves all three idle)
+ * should borrow one of these instead of creating its own.  Valid until intel_destroy. */
+void* intel_side_stream(IntelCtx* ctx, int i);
+
 /* A promise for the following intel_forward calls: the parameter VALUES equal those of the previous intel_forward on this
  * context.  The forward then reuses the packed weight images that call left in the workspace, provided the workspace
  * pointer, the batch shape and `train` are unchanged too (evaluation loops over a frozen model, helpers/BaseRunner.py:328-343:

@@ -111,8 +111,10 @@ struct IntelCtx {
   unsigned char touched[INTEL_P_COUNT];
   // side streams: independent branches of the step (the two towers, the two sequence encoders) run
   // concurrently -- MFMA-bound GEMMs of one branch overlap the HBM-bound row kernels of another
-  hipStream_t side[4];         // 0, 3: the sequence encoders' branches; 1, 2: the item / score tower's
-  hipEvent_t ev_fork, ev_join[4];
+  hipStream_t side[3];         // THREE side streams + the caller's = the four hardware queues the runtime multiplexes streams onto by default:
+                               // a fifth active stream shares a queue with another one (its launches then serialise behind that stream's), and
+                               // GPU_MAX_HW_QUEUES > 4 makes the whole step 1.5x slower (measured)
+  hipEvent_t ev_fork, ev_join[3];
   hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
   hipStream_t table_stream = nullptr;      // intel_set_table_stream
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
@@ -410,9 +412,9 @@ bool ensure_streams(IntelCtx* c) {
     if (e && e[0] == '0') { c->streams = -1; return false; }
     bool ok = true;
     // (tried for the encoder / tower branches and dropped: streams restricted to disjoint CU sets with
-    // hipExtStreamCreateWithCUMask -- 3-4x slower at every split on this 8-XCD part; highest stream priority for the encoder
-    // branches, whose chains of small launches are the critical path -- 1.7x slower)
-    for (int i = 0; i < 4; ++i) {
+    // hipExtStreamCreateWithCUMask and a higher stream priority for the encoder branches -- both open extra hardware queues,
+    // and more than four active queues cost 1.5-4x)
+    for (int i = 0; i < 3; ++i) {
       ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;
     }
@@ -984,7 +986,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   }
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
-  fork_streams(r, 4);
+  fork_streams(r, 3);
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = r.ctx->enc_rows[e], dm = n.dm;
@@ -1020,10 +1022,9 @@ void forward_impl(Run& r, const IntelOut* out) {
   TowerBufs& ti = y.tw[0];
   TowerBufs& ts = y.tw[1];
   {
-    Run b0 = branch(r, 3, 0), b1 = branch(r, 0, 1), b2 = branch(r, 1, 0), b3 = branch(r, 2, 1);
-    encoder_branch(b0, 0);
+    Run b1 = branch(r, 0, 1), b2 = branch(r, 1, 0), b3 = branch(r, 2, 1);
+    encoder_branch(r, 0);                        // session-history encoder on the caller's stream
     encoder_branch(b1, 1);
-    r.ok(b0.rc);
     // item tower
     if (b2.ok(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
         (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st))))
@@ -1043,7 +1044,6 @@ void forward_impl(Run& r, const IntelOut* out) {
   // the intent prediction needs the two encoders only (main + side 0): it and the intent-side projections of the pooling run
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
-  wait_side(r, 3, r.st);
   if (r.rc) return;
   RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
@@ -1340,17 +1340,17 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
 
   // ===== the whole backward in one call (phase 0) with the branches on four streams: nothing heavy waits for a chain of small
   // launches it does not depend on.
-  //   side 2:  cross-attention backward of the score tower -> [x1] -> score tower layers (set 3)
-  //   main:    cross-attention backward of the item tower -> [x0] -> wait x1 -> d(intent) chain -> [c]
+  //   side 2:  cross-attention backward of the score tower -> [x1] -> score tower layers (set 3) -> wait c -> the head's leaves
+  //   main:    cross-attention backward of the item tower -> [x0] -> wait x1 -> d(intent) chain -> [c] -> item-history encoder (set 1)
   //   side 1:  wait x0 -> item tower layers + item-id / class table gradients (set 0)
-  //   side 3:  wait c -> item-history encoder (set 1);   side 0:  wait c -> session-history encoder (set 2)
+  //   side 0:  wait c -> session-history encoder (set 2)
   //   main:    join; [iid] (the caller's table stream waits for it: intel_set_table_stream); shared intent-embedding gradients, reductions
   // The two-call form (phases 1 and 2) keeps its order: there the caller overlaps the table's all-reduce with phase 2.
   if (wide) {
     IntelCtx* c = r.ctx;
     r.T = &y.tmp[0];
     Run m = r;                                   // main stream, set 0 for the B-row temporaries of the chain
-    Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2), s3 = branch(r, 3, 1);
+    Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2);
     r.ok((int)hipEventRecord(c->ev_fork, r.st));
     r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
     // score tower (side 2): cross-attention backward, then its layers with set 3, then the pooling's weight gradients
@@ -1384,27 +1384,34 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
     lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
     if (r.rc) return;
-    // the two encoders (side 3: item history, set 1; side 0: session history, set 2) need the chain's d(pred_layer input)
+    // the two encoders need the chain's d(pred_layer input): session history on side 0 (set 2), item history on the main
+    // stream (set 1).  The leaves of the session head go to side 2 behind the score tower (the shortest branch): off the
+    // critical chain, and in the same host order as before (ahead of the encoders' shares of the shared intent-embedding slot).
     r.ok((int)hipEventRecord(c->ev_x[2], r.st));
-    r.ok((int)hipStreamWaitEvent(c->side[3], c->ev_x[2], 0));
     r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
-    // the leaves of the session head, on the main stream behind the chain (host order = the order the shared slots accumulate in)
-    run_leaves(r, lv_main);
+    r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_x[2], 0));
     defer = nullptr;
-    wgrad(r, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+    {
+      Run lf = s2;
+      lf.rc = 0;
+      run_leaves(lf, lv_main);
+      wgrad(lf, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+      if (!lf.rc && r.G(INTEL_P_CTX_EMB))
+        lf.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, lf.st));
+      if (!lf.rc && r.G(INTEL_P_UID_EMB))
+        lf.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, lf.st));
+      r.ok(lf.rc);
+    }
     if (r.rc) return;
-    if (r.G(INTEL_P_CTX_EMB))
-      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, r.st));
-    if (r.G(INTEL_P_UID_EMB))
-      RUN(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, r.st));
-    // each encoder's share of the SHARED intent-embedding gradient follows on its own stream: the products only write slabs,
-    // the sums into the weight happen in the deferred reduction below, in the (fixed) order the jobs are pushed here
-    float* dE1 = encoder_branch(s3, 1);
-    if (!s3.rc && dE1) intent_wgrad(s3, 1, dE1);
     float* dE0 = encoder_branch(s0, 0);
     if (!s0.rc && dE0) intent_wgrad(s0, 0, dE0);
-    r.ok(s3.rc); r.ok(s0.rc);
-    join_streams(r, 4);
+    Run e1 = r;
+    e1.T = &y.tmp[1];
+    e1.rc = 0;
+    float* dE1 = encoder_branch(e1, 1);
+    if (!e1.rc && dE1) intent_wgrad(e1, 1, dE1);
+    r.ok(e1.rc); r.ok(s0.rc);
+    join_streams(r, 3);
     if (r.rc || !dE1 || !dE0) return;
     if (c->table_stream) {                       // the item-id table gradient is complete: the caller's optimizer sweep may start
       r.ok((int)hipEventRecord(c->ev_x[3], r.st));
@@ -1540,7 +1547,7 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
 extern "C" void intel_destroy(IntelCtx* ctx) {
   if (!ctx) return;
   if (ctx->streams == 1 || ctx->streams == 2) {
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {
       (void)hipStreamDestroy(ctx->side[i]);
       (void)hipEventDestroy(ctx->ev_join[i]);
     }
@@ -1552,6 +1559,11 @@ extern "C" void intel_destroy(IntelCtx* ctx) {
 }
 
 // on = 0: run every branch on the caller's stream (used while profiling single kernels); on = 1: default
+extern "C" void* intel_side_stream(IntelCtx* ctx, int i) {
+  if (!ctx || i < 0 || i > 2 || !ensure_streams(ctx)) return nullptr;
+  return (void*)ctx->side[i];
+}
+
 extern "C" void intel_set_table_stream(IntelCtx* ctx, void* stream) {
   if (ctx) ctx->table_stream = (hipStream_t)stream;
 }

@@ -142,6 +142,14 @@ class IntELEngine(object):
             ev.record(side)
         return ev
 
+    def _table_stream(self):
+        """The stream of the item-id table's Adam sweep next to the one-call backward's tail: one of the context's own side
+        streams (idle by then) -- a stream of our own would be a fifth active one and share a hardware queue."""
+        if getattr(self, '_table', None) is None:
+            ptr = L.lib().intel_side_stream(self.model._context(), 1)
+            self._table = torch.cuda.ExternalStream(ptr, device=self.device) if ptr else self._side_stream()
+        return self._table
+
     def _side_stream(self):
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
@@ -305,7 +313,7 @@ class IntELEngine(object):
             # sweep -- HBM-bound, 28 B per parameter -- runs underneath the backward's tail of small launches (shared
             # intent-embedding gradients, deferred reductions) and the dense groups' Adam
             cur = torch.cuda.current_stream(dev)
-            side = self._side_stream()
+            side = self._table_stream()
             lib.intel_set_table_stream(model._context(), C.c_void_p(side.cuda_stream))
             try:
                 model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
