@@ -145,7 +145,8 @@ def _declare(l):
     sig('intel_destroy', None, [vp])
     sig('intel_set_concurrency', None, [vp, i])
     sig('intel_set_params_unchanged', None, [vp, i])
-    sig('intel_set_table_stream', 'intel_side_stream', None, [vp, vp])
+    sig('intel_set_table_stream', None, [vp, vp])
+    sig('intel_side_stream', vp, [vp, i])
     sig('intel_set_dropout', i, [vp, f, C.c_ulonglong, vp])
     sig('intel_set_iid_grad_row_flags', i, [vp, vp])
     sig('intel_workspace_bytes', sz, [vp, i, i, i, i, i])
