@@ -2455,6 +2455,8 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(RedJobs jobs) {
 
 struct ReduceQueue {
   std::vector<RedJob> jobs;
+  std::vector<int> tags;          // per job: the branch that pushed it (redq_set_tag); 0 = untagged
+  int cur_tag = 0;
   float* arena = nullptr;
   size_t cap = 0, used = 0;
   int max_round = -1;
@@ -2463,8 +2465,11 @@ ReduceQueue* redq_create() { return new (std::nothrow) ReduceQueue(); }
 void redq_destroy(ReduceQueue* q) { delete q; }
 void redq_reset(ReduceQueue* q, float* arena, size_t arena_floats) {
   q->jobs.clear();
+  q->tags.clear();
+  q->cur_tag = 0;
   q->arena = arena; q->cap = arena_floats; q->used = 0; q->max_round = -1;
 }
+void redq_set_tag(ReduceQueue* q, int tag) { q->cur_tag = tag; }
 float* redq_alloc(ReduceQueue* q, size_t floats) {
   const size_t need = (floats + 63) & ~(size_t)63;
   if (!q->arena || q->used + need > q->cap) return nullptr;
@@ -2492,8 +2497,11 @@ void redq_push(ReduceQueue* q, const float* slabs, size_t stride, int S, int row
   j.round = round;
   if (round > q->max_round) q->max_round = round;
   q->jobs.push_back(j);
+  q->tags.push_back(q->cur_tag);
 }
-int redq_flush(ReduceQueue* q, hipStream_t st) {
+// tag < 0: every job, then the arena is free again; tag >= 0: the jobs pushed under that tag only (a branch reduces its own weight
+// gradients on its own stream as soon as it has produced them; destinations shared between branches must stay untagged)
+static int redq_flush_impl(ReduceQueue* q, int tag, hipStream_t st) {
   for (int rnd = 0; rnd <= q->max_round; ++rnd) {
     RedJobs jb;
     jb.n = 0; jb.pad = 0;
@@ -2506,8 +2514,9 @@ int redq_flush(ReduceQueue* q, hipStream_t st) {
       jb.n = 0; blocks = 0; bytes = 0.0;
       return 0;
     };
-    for (const RedJob& e : q->jobs) {
-      if (e.round != rnd) continue;
+    for (size_t ji = 0; ji < q->jobs.size(); ++ji) {
+      const RedJob& e = q->jobs[ji];
+      if (e.round != rnd || (tag >= 0 && q->tags[ji] != tag)) continue;
       if (jb.n == RED_MAX_JOBS) {
         int rc = fire();
         if (rc) return rc;
@@ -2521,10 +2530,21 @@ int redq_flush(ReduceQueue* q, hipStream_t st) {
     int rc = fire();
     if (rc) return rc;
   }
-  q->jobs.clear();
-  q->used = 0; q->max_round = -1;
+  if (tag < 0) {
+    q->jobs.clear();
+    q->tags.clear();
+    q->used = 0; q->max_round = -1;
+    return 0;
+  }
+  size_t w = 0;
+  for (size_t ji = 0; ji < q->jobs.size(); ++ji)
+    if (q->tags[ji] != tag) { q->jobs[w] = q->jobs[ji]; q->tags[w] = q->tags[ji]; ++w; }
+  q->jobs.resize(w);
+  q->tags.resize(w);
   return 0;
 }
+int redq_flush(ReduceQueue* q, hipStream_t st) { return redq_flush_impl(q, -1, st); }
+int redq_flush_tag(ReduceQueue* q, int tag, hipStream_t st) { return redq_flush_impl(q, tag, st); }
 
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
                  float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q, const WgradSplit* split, int io16) {

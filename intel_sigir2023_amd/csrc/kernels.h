@@ -73,6 +73,10 @@ float* redq_alloc(ReduceQueue* q, size_t floats);
 void redq_push(ReduceQueue* q, const float* slabs, size_t stride, int S, int rows, int cols, float* out, int ldo,
                int accumulate);
 int redq_flush(ReduceQueue* q, hipStream_t st);
+// branch-local reductions: jobs pushed after redq_set_tag(q, t > 0) can be reduced ahead of the rest by redq_flush_tag(q, t, stream)
+// (their slabs stay allocated until redq_flush); destinations shared between branches must be pushed under tag 0
+void redq_set_tag(ReduceQueue* q, int tag);
+int redq_flush_tag(ReduceQueue* q, int tag, hipStream_t st);
 
 // with q == nullptr the reduction is launched immediately and `slabs` is used; with a queue the
 // partials go to the queue's arena and dW / db are valid only after redq_flush

@@ -1354,7 +1354,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ok((int)hipEventRecord(c->ev_fork, r.st));
     r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
     // score tower (side 2): cross-attention backward, then its layers with set 3, then the pooling's weight gradients
+    // (every branch reduces the slabs of ITS weights on its own stream when it is done -- tags 1..4 -- instead of leaving
+    // 0.5 GB of reduction to the tail; the shared intent-embedding slot and the session head stay in the final flush)
     defer = &lv_score;
+    redq_set_tag(c->rq, 1);
     xatt_bwd(s2, 1, y.dXS, y.tmp[1].dINT);
     defer = &lv_main;
     r.ok((int)hipEventRecord(c->ev_x[1], s2.st));
@@ -1365,8 +1368,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
       if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
       if (!t3.rc) run_leaves(t3, lv_score);
+      if (!t3.rc) t3.ok(redq_flush_tag(c->rq, 1, t3.st));
       r.ok(t3.rc);
     }
+    redq_set_tag(c->rq, 2);
     r.ok(s2.rc);
     // item tower: cross-attention backward on the main stream, layers on side 1
     xatt_bwd(m, 0, y.tmp[0].dXa, y.tmp[0].dINT);
@@ -1375,7 +1380,9 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ok((int)hipEventRecord(c->ev_x[0], r.st));
     r.ok((int)hipStreamWaitEvent(c->side[1], c->ev_x[0], 0));
     item_tower_bwd(s1, y.tmp[0].dXa);
+    if (!s1.rc) s1.ok(redq_flush_tag(c->rq, 2, s1.st));
     r.ok(s1.rc);
+    redq_set_tag(c->rq, 0);
     // d(intent) chain (needs both cross-attention backwards)
     r.ok((int)hipStreamWaitEvent(r.st, c->ev_x[1], 0));
     RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
@@ -1403,12 +1410,18 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       r.ok(lf.rc);
     }
     if (r.rc) return;
+    redq_set_tag(c->rq, 3);
     float* dE0 = encoder_branch(s0, 0);
+    if (!s0.rc) s0.ok(redq_flush_tag(c->rq, 3, s0.st));
+    redq_set_tag(c->rq, 0);
     if (!s0.rc && dE0) intent_wgrad(s0, 0, dE0);
     Run e1 = r;
     e1.T = &y.tmp[1];
     e1.rc = 0;
+    redq_set_tag(c->rq, 4);
     float* dE1 = encoder_branch(e1, 1);
+    if (!e1.rc) e1.ok(redq_flush_tag(c->rq, 4, e1.st));
+    redq_set_tag(c->rq, 0);
     if (!e1.rc && dE1) intent_wgrad(e1, 1, dE1);
     r.ok(e1.rc); r.ok(s0.rc);
     join_streams(r, 3);
