@@ -329,7 +329,7 @@ class IntELEngine(object):
             # dense Adam sweep -- HBM-bound, 28 B per parameter -- then run on a side stream underneath phase 2 (score-tower
             # layers, session-history encoder: matrix work that touches neither the table nor its gradient)
             cur = torch.cuda.current_stream(dev)
-            side = self._side_stream()
+            side = self._table_stream()         # a context stream (idle in phase 2), not a fifth stream of our own
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
             sparse = dp and self._sparse_exchange(keep, world)
             work = parallel.allreduce_sum_async(self.gflat['iid']) if (dp and not sparse) else None
