@@ -1166,15 +1166,20 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   // attention backward -> d(intent) -> encoders): they are collected here and launched once the chain has been enqueued.
   static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
   const bool wide = phase == 0 && wide_on && ensure_streams(r.ctx);
-  typedef std::function<void(Run&)> Leaf;
+  struct Leaf { std::function<void(Run&)> f; bool shared; };      // shared: writes a slot other branches write too
   std::vector<Leaf> lv_main, lv_score;
   std::vector<Leaf>* defer = wide ? &lv_main : nullptr;
-  auto leaf = [&](Run& q, Leaf f) {
-    if (defer) defer->push_back(f);
+  auto leaf = [&](Run& q, std::function<void(Run&)> f, bool shared = false) {
+    if (defer) defer->push_back(Leaf{f, shared});
     else f(q);
   };
-  auto run_leaves = [&](Run& q, std::vector<Leaf>& v) {
-    for (Leaf& f : v) f(q);
+  // tag > 0: the leaves' reduction jobs are pushed under it (the caller reduces them right away), shared slots stay untagged
+  auto run_leaves = [&](Run& q, std::vector<Leaf>& v, int tag) {
+    for (Leaf& l : v) {
+      redq_set_tag(r.ctx->rq, l.shared ? 0 : tag);
+      l.f(q);
+    }
+    redq_set_tag(r.ctx->rq, tag);
     v.clear();
   };
   if (phase != 2) {
@@ -1218,7 +1223,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       });
     // h_intent = relu(intent_embeddings(intent)): dpre -> dHINT [B, d_int]
     RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dHINT, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
-    leaf(r, [=, &y](Run& r) { wgrad(r, y.dHINT, r.D.d_int, y.INTENTS, I, B, r.D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B); });
+    leaf(r, [=, &y](Run& r) { wgrad(r, y.dHINT, r.D.d_int, y.INTENTS, I, B, r.D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B); }, true);
     lin(r, y.dHINT, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
     if (r.rc) return;
   }
@@ -1367,7 +1372,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       TowerBufs& w = y.tw[1];
       float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
       if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
-      if (!t3.rc) run_leaves(t3, lv_score);
+      if (!t3.rc) run_leaves(t3, lv_score, 1);
       if (!t3.rc) t3.ok(redq_flush_tag(c->rq, 1, t3.st));
       r.ok(t3.rc);
     }
@@ -1401,8 +1406,12 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     {
       Run lf = s2;
       lf.rc = 0;
-      run_leaves(lf, lv_main);
+      // the leaves' own slots (fusion weights, pooling projections, pred_layer) are reduced right here (tag 5); the
+      // intent-embedding slot, shared with the encoders, stays untagged for the final flush
+      run_leaves(lf, lv_main, 5);
       wgrad(lf, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+      if (!lf.rc) lf.ok(redq_flush_tag(c->rq, 5, lf.st));
+      redq_set_tag(c->rq, 0);
       if (!lf.rc && r.G(INTEL_P_CTX_EMB))
         lf.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, lf.st));
       if (!lf.rc && r.G(INTEL_P_UID_EMB))
@@ -1424,12 +1433,15 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     redq_set_tag(c->rq, 0);
     if (!e1.rc && dE1) intent_wgrad(e1, 1, dE1);
     r.ok(e1.rc); r.ok(s0.rc);
-    join_streams(r, 3);
-    if (r.rc || !dE1 || !dE0) return;
-    if (c->table_stream) {                       // the item-id table gradient is complete: the caller's optimizer sweep may start
+    if (c->table_stream) {
+      // the item-id table gradient is complete once the item tower (side 1) and the item-history encoder (main stream, up to
+      // here) are: the caller's optimizer sweep of the table may start without waiting for the other two branches
       r.ok((int)hipEventRecord(c->ev_x[3], r.st));
       r.ok((int)hipStreamWaitEvent(c->table_stream, c->ev_x[3], 0));
+      if (c->table_stream != c->side[1]) wait_side(r, 1, c->table_stream);
     }
+    join_streams(r, 3);
+    if (r.rc || !dE1 || !dE0) return;
     RUN(redq_flush(c->rq, r.st));
     return;
   }
