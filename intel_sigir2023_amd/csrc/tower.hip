@@ -256,18 +256,19 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
       const __bf16* frag = planes + p * LDP + 8 * j;
 #pragma unroll 1
       for (int c = 0; c < 3; ++c) {
-        uint4 bw[KB];
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) bw[kb] = Bimg[((size_t)(c * KBT + kb) * 3) * 64];
+        uint4 bw[2];                               // weight fragments one k block ahead (register budget)
+        bw[0] = Bimg[((size_t)(c * KBT) * 3) * 64];
         f32x4 acc[4];
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb)
+        for (int kb = 0; kb < KB; ++kb) {
+          if (kb + 1 < KB) bw[(kb + 1) & 1] = Bimg[((size_t)(c * KBT + kb + 1) * 3) * 64];
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[kb]),
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[kb & 1]),
                                                               *reinterpret_cast<const bf16x8*>(frag + rt * 16 * LDP + kb * 32), acc[rt], 0, 0, 0);
+        }
         const int n = (3 * wave + c) * 16 + 4 * j;           // column of [q | k | v]
         const int which = n / D, col = n - which * D;
         __bf16* dst16 = Q16 + which * PLANE + col;
@@ -397,6 +398,7 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
       ps = gsum16(ps);
       const float inv = 1.f / ps;                            // L >= 1: at least one live key
       const int q = tile * 16 + p;
+      if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);     // (before P V: mx / ps die here)
       if constexpr (DK >= 64) {
         // V read as one b128 along the head dim: lane p takes dims 4p .. 4p+3 of its key row and feeds four MFMAs whose
         // output row i means dim 4 i + t
@@ -426,8 +428,13 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
               for (int t = 0; t < 4; ++t)
                 o4[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, pb[kt], o4[t], 0, 0, 0);
             }
+            // this 64-dim block of the output row goes straight into the plane of the W1 product
 #pragma unroll
-            for (int t = 0; t < 4; ++t) oT[dq * 4 + t] = o4[t];
+            for (int r = 0; r < 4; ++r) {
+              const f32x4 o = f32x4{o4[0][r], o4[1][r], o4[2][r], o4[3][r]} * inv;
+              const int col = h * DK + dq * 64 + 16 * j + 4 * r;
+              *reinterpret_cast<bf16x4*>(planes + q * LDP + col) = bf16x4{(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
@@ -443,6 +450,7 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
               oT[dq * 4 + t] = mma4<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, st[kt], oT[dq * 4 + t]);
           }
         }
+        if constexpr (NP != 1) {
 #pragma unroll
         for (int dq = 0; dq < DQ; ++dq)
 #pragma unroll
@@ -453,8 +461,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
             split4(o, hh, mm, ll);
             const int off = q * LDP + col;
             store_planes<NP, PLANE>(planes + off, hh, mm, ll);
-            if (NP != 1 && TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
+            if (TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
           }
+        }
       } else {
         // narrow heads (dk = 32): two output tiles of 16 dims, V read as scalars (lane p = dim, j = key of the k-step)
         f32x4 oT[2];
@@ -483,7 +492,6 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
           if (NP != 1 && TRAIN && a.A && q < L) stash4<NP>(a.A, ((size_t)b * L + q) * D + col, o, a.qkv16);
         }
       }
-      if (TRAIN && a.LSE && j == 0 && q < L) a.LSE[((size_t)b * HEADS + h) * L + q] = mx * scale + __logf(ps);
     }
     // query tiles of padding only were skipped above: their planes still hold X (rows >= L are zero there already)
     mark(2);
@@ -541,15 +549,20 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     if constexpr (NP == 1 && TRAIN) {
       if (a.R1) stash_rows16<D, LDP, PLANE, NT>(r1planes, 1, reinterpret_cast<__bf16*>(a.R1) + (size_t)b * L * D, D, L, tid);
     }
-    // the residual rows of phase 5 come back from L2 while the W2 product runs
+    // the residual rows of phase 5 come back from L2 while the W2 product runs (bf16 mode: loaded in phase 5 -- the 128-register
+    // budget of its four waves per SIMD has no room for them here, and a spilling kernel's occupancy depends on the scratch the
+    // runtime happens to have allocated: 2-4x run-to-run differences were measured)
     constexpr int RPW = 64 / NW, CPL = D / 64;
     float res[RPW][CPL];
+    auto load_res = [&]() {
 #pragma unroll
-    for (int rr = 0; rr < RPW; ++rr) {
-      const int row = min(wave * RPW + rr, L - 1);
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int row = min(wave * RPW + rr, L - 1);
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
-    }
+        for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
+      }
+    };
+    if (NP != 1) load_res();
     // ---- phase 4: Z = R1 W2^T + b2 -> fp32 tile
     if constexpr (NP == 1) {
       const uint4* Bimg = per_session(a.W2) + ((size_t)wave * KBT * 3) * 64 + lane;
@@ -581,6 +594,7 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     mark(4);
     // ---- phase 5: LayerNorm(Z + X) over the D columns; wave = 64 / NW rows, lane = columns lane (and lane + 64)
     {
+      if (NP == 1) load_res();
       float g[CPL], be[CPL];
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) { g[cc] = a.gamma[lane + 64 * cc]; be[cc] = a.beta[lane + 64 * cc]; }
