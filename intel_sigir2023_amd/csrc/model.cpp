@@ -969,6 +969,10 @@ void forward_impl(Run& r, const IntelOut* out) {
   Layout& y = r.y;
   const IntelBatch& bt = *r.bt;
   const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
+  // the side branches start with work that needs no packed weights (history packing, embedding gathers): they fork BEFORE the
+  // packing launches of the main stream and wait for them (ev_pack) in front of their first matrix product
+  fork_streams(r, 3);
+  hipEvent_t ev_pack = r.ctx->ev_x[0];
   {
     IntelCtx* c = r.ctx;
     const int shape[5] = {y.B, y.L, y.H, y.Hi, (r.train && c->drop_p > 0.f) ? 1 : 0};
@@ -983,10 +987,14 @@ void forward_impl(Run& r, const IntelOut* out) {
     c->pack_ws = (const void*)y.ARENA;       // the layout is a pure function of the shape and the workspace base
     memcpy(c->pack_shape, shape, sizeof(shape));
     c->pack_ok = true;
+    if (c->streams == 1) r.ok((int)hipEventRecord(ev_pack, r.st));
   }
+  hipStream_t main_st = r.st;
+  auto wait_pack = [&](Run& b) {
+    if (r.ctx->streams == 1 && b.st != main_st) b.ok((int)hipStreamWaitEvent(b.st, ev_pack, 0));
+  };
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
-  fork_streams(r, 3);
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = r.ctx->enc_rows[e], dm = n.dm;
@@ -1005,6 +1013,7 @@ void forward_impl(Run& r, const IntelOut* out) {
       if (pk) RUN(launch_his_pack(bt.history_item_len, bt.hisitem_off, B, n.T, bt.his_item_id, n.pkIds, bt.his_item_idx, n.pkIdx2,
                                   bt.his_item_idx ? nullptr : bt.his_item_int, I, n.pkVec, n.rowT, r.st));
       RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
+      wait_pack(r);
       if (bt.his_item_idx)
         RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, pk ? n.pkIdx2 : bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st));
       else
@@ -1027,16 +1036,21 @@ void forward_impl(Run& r, const IntelOut* out) {
     encoder_branch(b1, 1);
     // item tower
     if (b2.ok(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
-        (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st))))
+        (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st)))) {
+      wait_pack(b2);
       tower_fwd(b2, ti);
+    }
     // score tower
     {
       GemmEpilogue es;
       es.bias = r.P(INTEL_P_SCORE_B);
-      if (smallk_supported(D.d_s, K))
+      if (smallk_supported(D.d_s, K)) {
         b3.ok(launch_linear_smallk(bt.scores, K, M, K, r.P(INTEL_P_SCORE_W), es.bias, D.d_s, ts.X0, D.d_s, 0, b3.st));
-      else
+        wait_pack(b3);
+      } else {
+        wait_pack(b3);
         lin(b3, bt.scores, K, M, K, y.pScore, D.d_s, ts.X0, D.d_s, es);
+      }
       if (!b3.rc) tower_fwd(b3, ts);
     }
     r.ok(b1.rc); r.ok(b2.rc); r.ok(b3.rc);
