@@ -252,6 +252,24 @@ class IntELEngine(object):
         sc64 = sc.contiguous() if sc.dtype == torch.float64 else None
         sc32 = keep['scores']
         gs_e = self.ensemble_weight / world
+        # the intent loss (three small launches) does not depend on the ensemble loss: it runs next to it on the context stream
+        # the table sweep will use later (idle now), with its own scratch
+        d_int, out3, iside = None, None, None
+        if self.with_intent:
+            out3 = self._buf('out3', (3,), torch.float64)
+            d_int = self._buf('d_int', (B, I), torch.float32)
+            ws_i = self._buf('loss_ws_intent', (int(nb),), torch.uint8)
+            label = batch['intents']
+            label = label if label.dtype == torch.float64 else label.double()
+            label = label.contiguous()
+            cur0 = torch.cuda.current_stream(dev)
+            iside = self._table_stream() if (self.overlap_table_update and self.wide_backward and not dp) else None
+            if iside is not None:
+                iside.wait_stream(cur0)
+            with torch.cuda.stream(iside if iside is not None else cur0):
+                L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label), self.kl_weight, self.kl_temp,
+                                              self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws_i), nb, L.stream_ptr(dev)),
+                        'intel_intent_loss')
         if self.kind == 'bpr':
             select = self._buf('select', (B, Lmax), torch.int32)
             if noise is None and self._noise_tensor:
@@ -276,19 +294,18 @@ class IntELEngine(object):
             L.check(lib.intel_list_loss(B, Lmax, K, L.ptr(ens), L.ptr(ranking), L.ptr(slen), L.ptr(sc64), L.ptr(sc32),
                                         L.ptr(weights), self.cal_diversity, self.alpha, gs_e, L.ptr(loss_e), L.ptr(d_ens),
                                         L.ptr(d_w), L.ptr(ws), nb, st), 'intel_list_loss')
-        d_int, out3 = None, None
-        if self.with_intent:
-            out3 = self._buf('out3', (3,), torch.float64)
-            d_int = self._buf('d_int', (B, I), torch.float32)
-            label = batch['intents']
-            label = label if label.dtype == torch.float64 else label.double()
-            L.check(lib.intel_intent_loss(B, I, L.ptr(intents), L.ptr(label.contiguous()), self.kl_weight, self.kl_temp,
-                                          self.intent_weight / world, L.ptr(out3), L.ptr(d_int), L.ptr(ws), nb, st),
-                    'intel_intent_loss')
+        if iside is not None:
+            torch.cuda.current_stream(dev).wait_stream(iside)
         # (loss, ensemble_loss, intent_loss) like the reference's criterion: one tiny launch into a fresh 3-vector (the
-        # caller may keep every step's values: runner.fit averages them at the end of the epoch); enqueued before the backward
+        # caller may keep every step's values: runner.fit averages them at the end of the epoch).  One-call backward: it rides on
+        # the table stream behind the sweep (off both the head and the tail of the step); otherwise here, before the backward
         tot = torch.empty(3, dtype=torch.float64, device=dev)
-        L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), st), 'intel_loss_total')
+
+        def loss_total(stream_ptr):
+            L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), stream_ptr), 'intel_loss_total')
+        wide = self.overlap_table_update and not dp and self.wide_backward
+        if not wide:
+            loss_total(st)
         self.step_count += 1
         b1, b2 = self.betas
         if sort_ev is not None:
@@ -307,7 +324,7 @@ class IntELEngine(object):
                 L.check(lib.intel_adam_step(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
                                             L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
                                             1, stream_ptr), 'intel_adam_step')
-        if self.overlap_table_update and not dp and self.wide_backward:
+        if wide:
             # one process: the whole backward in one call, its four branches (both towers, both encoders) on four streams.  The
             # side stream is made to wait (inside intel_backward) for the item-id table gradient only, so the table's dense Adam
             # sweep -- HBM-bound, 28 B per parameter -- runs underneath the backward's tail of small launches (shared
@@ -321,6 +338,7 @@ class IntELEngine(object):
                 lib.intel_set_table_stream(model._context(), None)
             with torch.cuda.stream(side):
                 adam('iid', self.l2, L.stream_ptr(dev))
+                loss_total(L.stream_ptr(dev))
             adam('decay', self.l2, st)
             adam('nodecay', 0.0, st)
             cur.wait_stream(side)
