@@ -484,3 +484,34 @@ def test_packed_weight_reuse_never_serves_stale_parameters():
     model.load_state_dict(sd)
     d0 = eng.eval_step(batch)[0]['ens_score'].clone()
     assert not torch.equal(d0, c0) and torch.equal(d0, fresh())
+
+
+def test_timeline_records_and_borrowed_stream():
+    """intel_prof_timeline returns one record per launch with start <= end and the streams of the concurrent branches;
+    intel_side_stream hands out the context's streams (the engine's table sweep borrows one instead of creating a fifth)."""
+    import json
+    from intel_sigir2023_amd import _lib, synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    torch.manual_seed(0)
+    args = synth.make_args('tiny', dev)
+    corpus, _ = synth.make_corpus('tiny')
+    model = IntEL(args, corpus).to(dev)
+    eng = IntELEngine(model, 'IntBPRloss', args)
+    batch = synth.make_batch('tiny', 32, dev, seed=4, ragged=True)
+    eng.train_step(batch)
+    torch.cuda.synchronize()
+    lib = _lib.lib()
+    ptrs = [lib.intel_side_stream(model._context(), i) for i in range(3)]
+    assert all(ptrs) and len(set(ptrs)) == 3 and lib.intel_side_stream(model._context(), 3) is None
+    assert eng._table_stream().cuda_stream == ptrs[1]
+    lib.intel_prof_enable(1)
+    eng.train_step(batch)
+    tl = json.loads(lib.intel_prof_timeline().decode())
+    lib.intel_prof_enable(0)
+    assert len(tl) > 100 and all(r['t1'] >= r['t0'] for r in tl)
+    assert len({r['stream'] for r in tl}) >= 4                 # the caller's stream + three branches
+    names = {r['name'].split('[')[0].strip('()').split('<')[0] for r in tl}
+    assert {'bpr_loss_kernel', 'adam_rows_kernel', 'slab_reduce_batch_kernel'} <= names
+    assert json.loads(lib.intel_prof_timeline().decode()) == []      # cleared
