@@ -54,10 +54,12 @@ seg = tl[lo:hi]
 t0 = seg[0]['t0']
 wall = tl[hi]['t0'] - t0
 ev = []
-for r in seg:
-    ev.append((r['t0'], 1, short(r['name'])))
-    ev.append((min(r['t1'], tl[hi]['t0']), -1, short(r['name'])))
-ev.sort(key=lambda x: (x[0], x[1]))
+end = tl[hi]['t0']
+for r in seg:        # (launch order is enqueue order: a launch of this step may run past the next step's first kernel -- clipped)
+    a0 = min(r['t0'], end)
+    ev.append((a0, 1, short(r['name'])))
+    ev.append((max(a0, min(r['t1'], end)), -1, short(r['name'])))
+ev.sort(key=lambda x: (x[0], -x[1]))
 live, last, busy = [], t0, 0.0
 conc, alone, gaps = Counter(), Counter(), Counter()
 prev = seg[0]['name']
@@ -76,7 +78,7 @@ for t, k, n in ev:
         prev = n
     last = t
 print('%s %s step: wall %.3f ms, busy (union) %.3f ms, summed %.3f ms, idle %.3f ms' %
-      (dtype, mode, wall, busy, sum(min(r['t1'], tl[hi]['t0']) - r['t0'] for r in seg), wall - busy))
+      (dtype, mode, wall, busy, sum(max(0.0, min(r['t1'], end) - min(r['t0'], end)) for r in seg), wall - busy))
 print('ms with k launches in flight:', {k: round(v, 3) for k, v in sorted(conc.items())})
 print('alone:', [(k, round(v, 3)) for k, v in alone.most_common(14)])
 print('idle after:', [(k, round(v, 3)) for k, v in gaps.most_common(8)])
