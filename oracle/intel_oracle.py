@@ -54,17 +54,37 @@ class Config(object):
             setattr(self, k, v)
 
 
+# bf16-mode emulation (forward_bf16 below): the HIP build's `--dtype bf16` rounds BOTH operands of a product to bf16 exactly where the
+# product runs on the bf16 matrix pipe -- every linear with 64 or 128 input features and an output width that is a multiple of 4
+# (csrc/gemm.hip: launch_gemm_rows), the attention products of the whole-sequence kernels -- and nowhere else (odd widths, the pooling
+# scores, the pruned last encoder block's one-row attention, LayerNorm, softmax, losses stay fp32).  fp32 accumulation in both.
+_EMU = {'on': False}
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def _on_bf16_pipe(w):
+    return _EMU['on'] and w.shape[1] in (64, 128) and w.shape[0] % 4 == 0
+
+
 def _lin(x, sd, name, bias=True):
     b = sd.get(name + '.bias') if bias else None
-    return F.linear(x, sd[name + '.weight'], b)
+    w = sd[name + '.weight']
+    if _on_bf16_pipe(w):
+        x, w = _bf(x), _bf(w)
+    return F.linear(x, w, b)
 
 
 # ----------------------------------------------------------------------------------------
 # attention blocks
 # ----------------------------------------------------------------------------------------
-def mha(x, sd, prefix, heads, key_mask=None):
+def mha(x, sd, prefix, heads, key_mask=None, bf16_products=True):
     """modules/layers.py:31-60.  No output projection; softmax over keys after subtracting the
-    tensor-global max (a no-op unless a row sits ~88 below it); all-masked rows -> 0."""
+    tensor-global max (a no-op unless a row sits ~88 below it); all-masked rows -> 0.
+    bf16_products: under forward_bf16 only -- whether THIS attention runs on the bf16 pipe (q, k, v and the unnormalised
+    probabilities rounded to bf16, row sums and the normalisation in fp32, as csrc/attn_seq.hip / tower.hip do)."""
     B, T, D = x.shape
     dk = D // heads
 
@@ -73,6 +93,16 @@ def mha(x, sd, prefix, heads, key_mask=None):
     q = split(_lin(x, sd, prefix + '.q_linear'))
     k = split(_lin(x, sd, prefix + '.k_linear'))
     v = split(_lin(x, sd, prefix + '.v_linear'))
+    if _EMU['on'] and bf16_products:
+        s = torch.matmul(_bf(q), _bf(k).transpose(-1, -2)) / dk ** 0.5
+        if key_mask is not None:
+            s = s.masked_fill(~key_mask[:, None, None, :], float('-inf'))
+        m = s.max(dim=-1, keepdim=True)[0]
+        e = torch.exp(s - torch.where(torch.isinf(m), torch.zeros_like(m), m))
+        e = torch.where(torch.isnan(e), torch.zeros_like(e), e)
+        den = e.sum(-1, keepdim=True)
+        o = torch.matmul(_bf(e), _bf(v)) / torch.where(den > 0, den, torch.ones_like(den))
+        return o.transpose(1, 2).reshape(B, T, D)
     s = torch.matmul(q, k.transpose(-1, -2)) / dk ** 0.5
     if key_mask is not None:
         s = s.masked_fill(~key_mask[:, None, None, :], float('-inf'))
@@ -109,7 +139,8 @@ def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2, taps=None):
     x = seq + sd[prefix + '.p_embeddings.weight'][pos]
     for l in range(layers):
         p = '%s.transformer_block.%d' % (prefix, l)
-        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid)
+        # (bf16 emulation: the LAST block is run pruned by the HIP build -- one query row per session in an fp32 kernel)
+        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid, bf16_products=l + 1 < layers)
         ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
         pre = _lin(ctx, sd, p + '.linear1')
         if taps is not None:
@@ -146,6 +177,19 @@ def single_query_pool(intent, h, valid, sd, prefix, scale):
     padded row receives 0.  The row max is taken over ALL L positions before
     masking (attention.py:57)."""
     q = F.linear(intent, sd[prefix + '.query_layer.weight'])            # [B,a]
+    if _EMU['on']:
+        # the HIP build's algebra (csrc/session.hip: xatt_pool): att_l = scale * <Wk^T q, h_l>, pooled = Wv (sum_l w_l h_l); the two
+        # d x d products run on the bf16 pipe, the scores and the weighted sum in fp32
+        wk, wv = sd[prefix + '.key_layer.weight'], sd[prefix + '.value_layer.weight']
+        qk = torch.matmul(_bf(q), _bf(wk)) if _on_bf16_pipe(wk.t()) else torch.matmul(q, wk)                  # [B,d]
+        att = torch.einsum('bd,bld->bl', qk, h) * scale
+        att = att - att.max(dim=-1, keepdim=True)[0]
+        att = att.masked_fill(~valid, float('-inf'))
+        w = torch.softmax(att, dim=-1)
+        w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
+        xbar = torch.einsum('bl,bld->bd', w, h)
+        pooled = F.linear(_bf(xbar), _bf(wv)) if _on_bf16_pipe(wv) else F.linear(xbar, wv)
+        return pooled[:, None, :] * valid[:, :, None].float()
     k = F.linear(h, sd[prefix + '.key_layer.weight'])                    # [B,L,a]
     v = F.linear(h, sd[prefix + '.value_layer.weight'])                  # [B,L,v]
     att = torch.einsum('ba,bla->bl', q, k) * scale
@@ -231,6 +275,16 @@ def forward(sd, data, cfg, dropout_keep=None, taps=None):
     intent = predict_intent(sd, data, cfg, taps)
     weights, ens = predict_ensemble(sd, data, intent, cfg, dropout_keep, taps)
     return {'weights': weights, 'ens_score': ens, 'intents': intent}
+
+
+def forward_bf16(sd, data, cfg):
+    """`forward` with the rounding points of the HIP build's `--dtype bf16` mode (see _EMU above): an independent CPU
+    restatement of WHAT that mode computes, for tests/test_bf16_gpu.py.  BERT4Rec encoders, evaluation mode."""
+    _EMU['on'] = True
+    try:
+        return forward(sd, data, cfg)
+    finally:
+        _EMU['on'] = False
 
 
 # ----------------------------------------------------------------------------------------

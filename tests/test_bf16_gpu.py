@@ -52,6 +52,38 @@ def test_bf16_forward_and_gradients_track_fp32(name):
     assert worst < 0.15, (wk, worst)                          # every gradient tensor within 15 % in norm
 
 
+@pytest.mark.parametrize('name', ['tmall64', 'default'])
+def test_bf16_forward_matches_the_emulating_oracle(name):
+    """oracle.forward_bf16 restates WHAT the mode computes: the reference's forward with both operands of a product rounded
+    to bf16 exactly where the HIP build runs it on the bf16 pipe (64- / 128-wide linears, whole-sequence attention products)
+    and fp32 everywhere else.  The HIP outputs must sit an order of magnitude closer to it than to the fp32 forward: what is
+    left is summation order and the rare value that rounds the other way."""
+    from oracle import intel_oracle as O
+    from intel_sigir2023_amd.model import IntEL
+    fx = Fixture(name)
+    dev = _dev()
+    a = dict(fx.args)
+    a['dtype'] = 'bf16'
+    args = make_args(a, dev)
+    model = IntEL(args, make_corpus(fx.shape))
+    model.load_state_dict(fx.state_dict(), strict=True)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        got = {k: v.cpu() for k, v in model(fx.batch(dev)).items()}
+    cfg = O.Config(**fx.args)
+    sd, batch = fx.state_dict(), fx.batch()
+    with torch.no_grad():
+        emu = O.forward_bf16(sd, batch, cfg)
+        f32 = O.forward(sd, batch, cfg)
+    for k in ('weights', 'ens_score', 'intents'):
+        scale = max(1.0, float(f32[k].abs().max()))
+        e_emu = float((got[k] - emu[k]).abs().max()) / scale
+        e_f32 = float((got[k] - f32[k]).abs().max()) / scale
+        d_emu = float((emu[k] - f32[k]).abs().max()) / scale
+        assert d_emu > 1e-5, (k, d_emu)                      # the mode is engaged: the emulation differs from fp32
+        assert e_emu <= 2e-3 and e_emu <= 0.25 * e_f32 + 1e-5, (k, e_emu, e_f32)
+
+
 def test_bf16_training_reaches_the_fp32_ndcg():
     """The gate of the mode: 300 fused training steps on a planted ranking signal (labels = top items of base ranker 0) with
     identical data, initialisation and BPR tie-breaks; held-out NDCG@3 of the bf16 build within 1e-3 of the fp32 build's and
