@@ -119,7 +119,9 @@ def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0, taps=No
     taps: optional dict; receives the pre-ReLU activations of every layer under the key ``w1`` (tests only)."""
     for l in range(layers):
         res = h
-        h = mha(h, sd, attn, heads)
+        # (bf16 emulation, evaluation: the one-kernel tower layer takes lists of up to 64 rows, widths 64 / 128, head dims 32 / 64 / 128)
+        D_, dk_ = h.shape[-1], h.shape[-1] // heads
+        h = mha(h, sd, attn, heads, bf16_products=h.shape[1] <= 64 and D_ in (64, 128) and dk_ in (32, 64, 128))
         h = _lin(h, sd, w1)
         if taps is not None:
             taps.setdefault(w1, []).append(h.detach())
@@ -140,7 +142,8 @@ def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2, taps=None):
     for l in range(layers):
         p = '%s.transformer_block.%d' % (prefix, l)
         # (bf16 emulation: the LAST block is run pruned by the HIP build -- one query row per session in an fp32 kernel)
-        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid, bf16_products=l + 1 < layers)
+        # and the whole-sequence attention kernels take histories of up to 64 rows with head dims 64 / 128)
+        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid, bf16_products=l + 1 < layers and T <= 64 and D // heads in (64, 128))
         ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
         pre = _lin(ctx, sd, p + '.linear1')
         if taps is not None:

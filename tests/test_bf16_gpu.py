@@ -52,7 +52,7 @@ def test_bf16_forward_and_gradients_track_fp32(name):
     assert worst < 0.15, (wk, worst)                          # every gradient tensor within 15 % in norm
 
 
-@pytest.mark.parametrize('name', ['tmall64', 'default'])
+@pytest.mark.parametrize('name', ['tmall64', 'stress', 'lifedata', 'default'])
 def test_bf16_forward_matches_the_emulating_oracle(name):
     """oracle.forward_bf16 restates WHAT the mode computes: the reference's forward with both operands of a product rounded
     to bf16 exactly where the HIP build runs it on the bf16 pipe (64- / 128-wide linears, whole-sequence attention products)
@@ -80,8 +80,11 @@ def test_bf16_forward_matches_the_emulating_oracle(name):
         e_emu = float((got[k] - emu[k]).abs().max()) / scale
         e_f32 = float((got[k] - f32[k]).abs().max()) / scale
         d_emu = float((emu[k] - f32[k]).abs().max()) / scale
-        assert d_emu > 1e-5, (k, d_emu)                      # the mode is engaged: the emulation differs from fp32
-        assert e_emu <= 2e-3 and e_emu <= 0.25 * e_f32 + 1e-5, (k, e_emu, e_f32)
+        if name != 'default':
+            assert d_emu > 1e-5, (k, d_emu)                  # the mode is engaged: the emulation differs from fp32
+        else:
+            assert d_emu == 0.0, (k, d_emu)                  # 16/32-wide model: nothing runs on the bf16 pipe, in either
+        assert e_emu <= 2e-3 and e_emu <= 0.25 * e_f32 + 3e-5, (k, e_emu, e_f32)
 
 
 def test_bf16_training_reaches_the_fp32_ndcg():
