@@ -265,6 +265,14 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None, taps=None):
     h_int = torch.relu(_lin(intent, sd, 'intent_embeddings'))[:, None, :].expand(B, L, -1)
     feat = torch.cat([item_x, score_x, h_u, h_int], dim=-1)
     weights = _lin(feat, sd, 'weight_embeddings')            # NO softmax (IntEL.py:214)
+    if _EMU['on'] and cfg.cross_attention:
+        # the HIP build computes the PAD rows' weights as their own product over [h_u | h_intent] (the pooled columns are zero
+        # there): d_u + d_int input features -- on the bf16 pipe when that is 64 or 128 and K is a multiple of 4
+        w_all, npad = sd['weight_embeddings.weight'], h_u.shape[-1] + h_int.shape[-1]
+        w_pad = w_all[:, w_all.shape[1] - npad:]
+        if _on_bf16_pipe(w_pad):
+            pad = F.linear(_bf(torch.cat([h_u, h_int], dim=-1)), _bf(w_pad), sd['weight_embeddings.bias'])
+            weights = torch.where(valid[:, :, None], weights, pad)
     if getattr(cfg, 'weight_norm', 'none') == 'softmax':      # the build's optional K-way normalisation
         weights = torch.softmax(weights, dim=-1)
     ens = (weights * scores).sum(-1)

@@ -56,8 +56,8 @@ def test_bf16_forward_and_gradients_track_fp32(name):
 def test_bf16_forward_matches_the_emulating_oracle(name):
     """oracle.forward_bf16 restates WHAT the mode computes: the reference's forward with both operands of a product rounded
     to bf16 exactly where the HIP build runs it on the bf16 pipe (64- / 128-wide linears, whole-sequence attention products)
-    and fp32 everywhere else.  The HIP outputs must sit an order of magnitude closer to it than to the fp32 forward: what is
-    left is summation order and the rare value that rounds the other way."""
+    and fp32 everywhere else.  The HIP outputs equal it to summation order (measured 5e-8 .. 3e-6 of the output scale, where the
+    fp32 forward is 1e-4 .. 1e-3 away): the mode is the reference's arithmetic with those rounding points, nothing else."""
     from oracle import intel_oracle as O
     from intel_sigir2023_amd.model import IntEL
     fx = Fixture(name)
@@ -84,7 +84,7 @@ def test_bf16_forward_matches_the_emulating_oracle(name):
             assert d_emu > 1e-5, (k, d_emu)                  # the mode is engaged: the emulation differs from fp32
         else:
             assert d_emu == 0.0, (k, d_emu)                  # 16/32-wide model: nothing runs on the bf16 pipe, in either
-        assert e_emu <= 2e-3 and e_emu <= 0.25 * e_f32 + 3e-5, (k, e_emu, e_f32)
+        assert e_emu <= 2e-5, (k, e_emu, e_f32)              # measured: 5e-8 .. 3e-6 (summation order) against 1e-4 .. 1e-3 to fp32
 
 
 def test_bf16_training_reaches_the_fp32_ndcg():
