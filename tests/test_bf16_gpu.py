@@ -83,7 +83,8 @@ def test_bf16_forward_matches_the_emulating_oracle(name):
         if name != 'default':
             assert d_emu > 1e-5, (k, d_emu)                  # the mode is engaged: the emulation differs from fp32
         else:
-            assert d_emu == 0.0, (k, d_emu)                  # 16/32-wide model: nothing runs on the bf16 pipe, in either
+            assert d_emu < 1e-6, (k, d_emu)                  # 16/32-wide model: nothing runs on the bf16 pipe, in either (the pooling's
+                                                             # algebraic form differs: fp32 rounding only)
         assert e_emu <= 2e-5, (k, e_emu, e_f32)              # measured: 5e-8 .. 3e-6 (summation order) against 1e-4 .. 1e-3 to fp32
 
 
