@@ -90,7 +90,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 // ---- tiny input width (smallk.hip): K <= 32, N <= 128, raw (unpacked) weights W[N, K] ---------------------
 bool smallk_supported(int N, int K);
 int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
-                         int relu, hipStream_t st);
+                         int relu, hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr)      // pos: Y[m, n] += pos[row_t[m] * ldy + n];
 int smallk_wgrad_slabs(int M);
 int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,
                         int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
@@ -130,7 +130,7 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu
 int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,
-                       hipStream_t st);
+                       hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr);
 // dst[b*T+t, col0:col0+d] = src[b, :]  broadcast of a per-session vector
 int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst, int ldd, int col0, hipStream_t st);
 // grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics

@@ -67,6 +67,7 @@ struct EncBufs {
   // packed history (IntelBatch.his_off): ids / intent indices / intent rows of the valid positions only, position of each row
   int *pkIds, *pkIdx2, *rowT;
   float* pkVec;
+  bool pos_done;            // this forward folded the position embedding into the kernels that produce the input rows
   EncBlockBufs blk[INTEL_ENC_MAX_BLOCKS];
   EncLastBufs last;
   GruBufs gru;
@@ -767,7 +768,9 @@ void bert_fwd(Run& r, int e) {
   const int B = r.y.B, T = n.T, dm = n.dm, rows = r.ctx->enc_rows[e];
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
   const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
-  if (off)
+  if (off && n.pos_done)
+    ;                                            // added by the gather / intent-embedding kernels (forward_impl)
+  else if (off)
     RUN(launch_add_pos_rows(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), n.rowT, rows, r.st));
   else
     RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
@@ -1004,18 +1007,23 @@ void forward_impl(Run& r, const IntelOut* out) {
     if (e == 0) {
       if (pk) RUN(launch_his_pack(bt.history_len, bt.his_off, B, n.T, bt.his_context_mh, n.pkIds, nullptr, nullptr, bt.his_intents, I, n.pkVec, n.rowT, r.st));
       const float* hint = pk ? n.pkVec : bt.his_intents;
-      RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, pk ? n.pkIds : bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st));
+      // packed BERT4Rec rows: the position embedding rides on the kernels that write the input row (one [rows, dm] round trip less)
+      n.pos_done = pk && D.encoder == INTEL_ENC_BERT4REC && smallk_supported(D.d_int, I);
+      const float* pos = n.pos_done ? r.P(enc_slot(e, INTEL_ENC_POS)) : nullptr;
+      RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, pk ? n.pkIds : bt.his_context_mh, rows, n.E0, dm, 0, 0, r.st, pos, n.rowT));
       if (smallk_supported(D.d_int, I))
-        RUN(launch_linear_smallk(hint, I, rows, I, r.P(INTEL_P_INTENT_W), eb.bias, D.d_int, n.E0 + D.d_c, dm, 0, r.st));
+        RUN(launch_linear_smallk(hint, I, rows, I, r.P(INTEL_P_INTENT_W), eb.bias, D.d_int, n.E0 + D.d_c, dm, 0, r.st, pos ? pos + D.d_c : nullptr, n.rowT));
       else
         lin(r, hint, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_c, dm, eb);
     } else {
       if (pk) RUN(launch_his_pack(bt.history_item_len, bt.hisitem_off, B, n.T, bt.his_item_id, n.pkIds, bt.his_item_idx, n.pkIdx2,
                                   bt.his_item_idx ? nullptr : bt.his_item_int, I, n.pkVec, n.rowT, r.st));
-      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st));
+      n.pos_done = pk && D.encoder == INTEL_ENC_BERT4REC && bt.his_item_idx != nullptr;
+      const float* pos = n.pos_done ? r.P(enc_slot(e, INTEL_ENC_POS)) : nullptr;
+      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st, pos, n.rowT));
       wait_pack(r);
       if (bt.his_item_idx)
-        RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, pk ? n.pkIdx2 : bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st));
+        RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, pk ? n.pkIdx2 : bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st, pos, n.rowT));
       else
         lin(r, pk ? n.pkVec : bt.his_item_int, I, rows, I, y.pInt, D.d_int, n.E0 + D.d_id, dm, eb);
     }

@@ -11,8 +11,11 @@ int launch_slab_reduce(const float* slabs, size_t stride, int S, int rows, int c
 // gather: dst[m, col0:col0+d] = table[idx[m]]   (nn.Embedding forward, IntEL.py:135,141,147-148,170-172)
 // A row of d floats is read by d/4 consecutive lanes with 16-byte loads (d=64 -> 256 B per row).
 // ------------------------------------------------------------------------------------------
+// pos / row_t (optional): dst[m, col0 + c] += pos[row_t[m] * ldd + col0 + c] -- the BERT4Rec position embedding of packed history
+// rows folded into the gather (pos rows have the width of dst rows)
 __global__ void gather_rows_kernel(const float* __restrict__ table, int d, const int* __restrict__ idx, int M,
-                                   float* __restrict__ dst, int ldd, int col0, int relu) {
+                                   float* __restrict__ dst, int ldd, int col0, int relu, const float* __restrict__ pos,
+                                   const int* __restrict__ row_t) {
   const int d4 = d >> 2;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * d4) return;
@@ -24,30 +27,34 @@ __global__ void gather_rows_kernel(const float* __restrict__ table, int d, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
   }
+  if (pos) v += *reinterpret_cast<const f32x4*>(pos + (size_t)row_t[m] * ldd + col0 + c * 4);
   *reinterpret_cast<f32x4*>(dst + (size_t)m * ldd + col0 + c * 4) = v;
 }
 __global__ void gather_rows_scalar_kernel(const float* __restrict__ table, int d, const int* __restrict__ idx, int M,
-                                          float* __restrict__ dst, int ldd, int col0, int relu) {
+                                          float* __restrict__ dst, int ldd, int col0, int relu, const float* __restrict__ pos,
+                                          const int* __restrict__ row_t) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * d) return;
   const int m = (int)(i / d), c = (int)(i - (long long)m * d);
   const int row = idx[m];
   float v = row >= 0 ? table[(size_t)row * d + c] : 0.f;
   if (relu) v = fmaxf(v, 0.f);
+  if (pos) v += pos[(size_t)row_t[m] * ldd + col0 + c];
   dst[(size_t)m * ldd + col0 + c] = v;
 }
 
 int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,
-                       hipStream_t st) {
+                       hipStream_t st, const float* pos, const int* row_t) {
+  if (!row_t) pos = nullptr;
   if (M <= 0 || d <= 0) return 0;
   const bool vec = (d % 4 == 0) && (ldd % 4 == 0) && (col0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
-                   ((reinterpret_cast<uintptr_t>(table) & 15) == 0);
+                   ((reinterpret_cast<uintptr_t>(table) & 15) == 0) && ((reinterpret_cast<uintptr_t>(pos) & 15) == 0);
   if (vec) {
     long long n = (long long)M * (d / 4);
-    LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+    LAUNCH_W(0.0, 8.0 * (double)M * d + 4.0 * M, gather_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu, pos, row_t);
   } else {
     long long n = (long long)M * d;
-    LAUNCH(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu);
+    LAUNCH(gather_rows_scalar_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, table, d, idx, M, dst, ldd, col0, relu, pos, row_t);
   }
   INTEL_CHECK_LAUNCH();
   return 0;

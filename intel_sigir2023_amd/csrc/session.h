@@ -29,7 +29,7 @@ int launch_session_colsum(const float* src, int lds, int col0, int d, int B, int
                           int accumulate, hipStream_t st);
 int launch_add_pos(float* E, int dm, const float* pos, const int* len, int B, int T, hipStream_t st);
 int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
-                         int col0, hipStream_t st);
+                         int col0, hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr);
 int launch_make_onehot(const int* idx, const int* len, int T, int M, int R, float* oh, hipStream_t st);
 // row_off (optional, [B]): packed history rows (kernels.h)
 int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,

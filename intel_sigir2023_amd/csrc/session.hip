@@ -811,7 +811,8 @@ int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, i
 // one-hot intent rows of the item history (IntEL.py:142 with his_item_int one-hot):
 // E[m, col0:col0+d_int] = Wint[:, idx[m]] + bint   (idx < 0: bias only)
 __global__ void onehot_linear_kernel(const float* __restrict__ W, const float* __restrict__ bias, int d_int, int I,
-                                     const int* __restrict__ idx, int M, float* __restrict__ E, int lde, int col0) {
+                                     const int* __restrict__ idx, int M, float* __restrict__ E, int lde, int col0,
+                                     const float* __restrict__ pos, const int* __restrict__ row_t) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)M * d_int) return;
   const int c = (int)(i % d_int);
@@ -819,13 +820,15 @@ __global__ void onehot_linear_kernel(const float* __restrict__ W, const float* _
   const int j = idx[m];
   float v = bias[c];
   if (j >= 0) v += W[(size_t)c * I + j];
+  if (pos) v += pos[(size_t)row_t[m] * lde + col0 + c];        // position embedding of a packed history row
   E[(size_t)m * lde + col0 + c] = v;
 }
 int launch_onehot_linear(const float* W, const float* bias, int d_int, int I, const int* idx, int M, float* E, int lde,
-                         int col0, hipStream_t st) {
+                         int col0, hipStream_t st, const float* pos, const int* row_t) {
+  if (!row_t) pos = nullptr;
   long long n = (long long)M * d_int;
   if (n <= 0) return 0;
-  LAUNCH(onehot_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, bias, d_int, I, idx, M, E, lde, col0);
+  LAUNCH(onehot_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, bias, d_int, I, idx, M, E, lde, col0, pos, row_t);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -14,7 +14,8 @@ namespace {
 
 // y[m, col0 + n] = act(b[n] + sum_k x[m, k] W[n, k])
 __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restrict__ X, int ldx, int M, int K, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int relu) {
+                                                            const float* __restrict__ bias, int N, float* __restrict__ Y, int ldy, int relu,
+                                                            const float* __restrict__ pos, const int* __restrict__ row_t) {
   __shared__ float wT[SK_MAXK * SK_MAXN];        // [k][n]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < N * K; i += 256) {
@@ -49,6 +50,11 @@ __global__ __launch_bounds__(256) void linear_smallk_kernel(const float* __restr
       if (m0 + i >= M) break;
       float v0 = a0[i], v1 = a1[i];
       if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      if (pos) {             // position embedding of a packed history row (pos is offset like Y)
+        const float* pr = pos + (size_t)row_t[m0 + i] * ldy;
+        if (n0 < N) v0 += pr[n0];
+        if (n1 < N) v1 += pr[n1];
+      }
       if (n0 < N) Y[(size_t)(m0 + i) * ldy + n0] = v0;
       if (n1 < N) Y[(size_t)(m0 + i) * ldy + n1] = v1;
     }
@@ -136,12 +142,13 @@ __global__ __launch_bounds__(256) void wgrad_smallk_kernel(const float* __restri
 bool smallk_supported(int N, int K) { return K >= 1 && K <= SK_MAXK && N >= 1 && N <= SK_MAXN; }
 
 int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
-                         int relu, hipStream_t st) {
+                         int relu, hipStream_t st, const float* pos, const int* row_t) {
+  if (!row_t) pos = nullptr;
   if (M <= 0) return 0;
   INTEL_CHECK_ARG(smallk_supported(N, K), "linear_smallk: N=%d K=%d unsupported", N, K);
   const int grid = min(cdiv(M, 4), 8 * num_cus());
   LAUNCH_W(2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N), linear_smallk_kernel, dim3(grid), dim3(256), 0, st, X, ldx, M, K, W, bias, N, Y, ldy,
-           relu);
+           relu, pos, row_t);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
