@@ -90,7 +90,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
 // ---- tiny input width (smallk.hip): K <= 32, N <= 128, raw (unpacked) weights W[N, K] ---------------------
 bool smallk_supported(int N, int K);
 int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
-                         int relu, hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr)      // pos: Y[m, n] += pos[row_t[m] * ldy + n];
+                         int relu, hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr);      // pos: Y[m, n] += pos[row_t[m] * ldy + n]
 int smallk_wgrad_slabs(int M);
 int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,
                         int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
