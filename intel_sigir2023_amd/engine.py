@@ -49,8 +49,8 @@ class IntELEngine(object):
         # two-phase backward + table all-reduce / Adam on a side stream (default); INTEL_OVERLAP_TABLE=0 runs the plain order
         import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
-        # one process (no gradient exchange): the one-call backward with its four branches on four streams and the table sweep
-        # underneath its tail; INTEL_BWD_SCHEDULE=phased keeps the two-call order data-parallel runs use
+        # the one-call backward with its four branches on four streams, the table exchange (data parallel) and sweep underneath
+        # its tail; INTEL_BWD_SCHEDULE=phased: the two-call order (table gradient first, its exchange under the second call)
         self.wide_backward = os.environ.get('INTEL_BWD_SCHEDULE', 'wide') != 'phased'
         self._side = None
         self._sort_side = None
@@ -90,15 +90,8 @@ class IntELEngine(object):
         lib = L.lib()
         table = self.model.iid_embeddings.weight.grad
         d = table.shape[1]
-        # unique touched rows at a static shape (torch.unique would synchronise the host to size its result, which
-        # stalls the enqueueing of the second backward phase): sort, keep the first of every run, -1 elsewhere
-        ids = torch.cat([keep['i_id_s'].reshape(-1), keep['his_item_id'].reshape(-1)])
-        cap = ids.numel()
-        srt = ids.sort().values
-        prev = torch.empty_like(srt)
-        prev[0] = -1
-        prev[1:] = srt[:-1]
-        idx = torch.where(srt != prev, srt, torch.full_like(srt, -1)).to(torch.int32).contiguous()
+        idx = self._touched_idx(keep)
+        cap = idx.numel()
         rows = self._buf('xch_rows', (cap, d), torch.float32)
         L.check(lib.intel_rows_take(L.ptr(table), d, L.ptr(idx), cap, L.ptr(rows), 1, stream_ptr), 'intel_rows_take')
         all_idx = parallel.allgather(idx)
@@ -108,6 +101,21 @@ class IntELEngine(object):
         if self._iid_flags is not None:                   # rows of the other ranks (row 0 for the -1 padding: harmless)
             self._iid_flags.index_fill_(0, all_idx.reshape(-1).clamp_min(0).long(), 1)
         self._bufs['xch_keep'] = (all_idx, all_rows)      # alive until the kernels have run
+
+    @staticmethod
+    def _touched_idx(keep):
+        """Unique touched item-id rows of the batch at a static shape (torch.unique would synchronise the host to size its
+        result, which stalls the enqueueing of the backward): sort, keep the first of every run, -1 elsewhere.  Depends on the
+        batch only: computed once per prepared batch, ahead of the forward pass."""
+        idx = keep.get('xch_idx')
+        if idx is None:
+            ids = torch.cat([keep['i_id_s'].reshape(-1), keep['his_item_id'].reshape(-1)])
+            srt = ids.sort().values
+            prev = torch.empty_like(srt)
+            prev[0] = -1
+            prev[1:] = srt[:-1]
+            idx = keep['xch_idx'] = torch.where(srt != prev, srt, torch.full_like(srt, -1)).to(torch.int32).contiguous()
+        return idx
 
     def _sort_scatter_ids(self, ib, keep):
         """The batch's item / class / history-item ids sorted with their row indices, on a side stream under the forward pass
@@ -233,6 +241,8 @@ class IntELEngine(object):
         ib, keep = model.prepare_batch(batch)
         if dp:
             self._check_global_shape(ib)
+            if self._sparse_exchange(keep, world):
+                self._touched_idx(keep)
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
         sort_ev = self._sort_scatter_ids(ib, keep)
@@ -263,7 +273,7 @@ class IntELEngine(object):
             label = label if label.dtype == torch.float64 else label.double()
             label = label.contiguous()
             cur0 = torch.cuda.current_stream(dev)
-            iside = self._table_stream() if (self.overlap_table_update and self.wide_backward and not dp) else None
+            iside = self._table_stream() if (self.overlap_table_update and self.wide_backward) else None
             if iside is not None:
                 iside.wait_stream(cur0)
             with torch.cuda.stream(iside if iside is not None else cur0):
@@ -303,7 +313,7 @@ class IntELEngine(object):
 
         def loss_total(stream_ptr):
             L.check(lib.intel_loss_total(L.ptr(loss_e), L.ptr(out3), self.ensemble_weight, self.intent_weight, L.ptr(tot), stream_ptr), 'intel_loss_total')
-        wide = self.overlap_table_update and not dp and self.wide_backward
+        wide = self.overlap_table_update and self.wide_backward
         if not wide:
             loss_total(st)
         self.step_count += 1
@@ -325,10 +335,11 @@ class IntELEngine(object):
                                             L.ptr(self.v[gname]), n, self.lr, b1, b2, self.eps, wd, self.step_count, 1.0,
                                             1, stream_ptr), 'intel_adam_step')
         if wide:
-            # one process: the whole backward in one call, its four branches (both towers, both encoders) on four streams.  The
-            # side stream is made to wait (inside intel_backward) for the item-id table gradient only, so the table's dense Adam
-            # sweep -- HBM-bound, 28 B per parameter -- runs underneath the backward's tail of small launches (shared
-            # intent-embedding gradients, deferred reductions) and the dense groups' Adam
+            # the whole backward in one call, its four branches (both towers, both encoders) on four streams.  The side stream is
+            # made to wait (inside intel_backward) for the item-id table gradient only, so the table's exchange (data parallel:
+            # touched rows all-gathered, or the dense all-reduce) and its dense Adam sweep -- HBM-bound, 28 B per parameter -- run
+            # underneath the backward's tail of small launches (shared intent-embedding gradients, deferred reductions), the
+            # dense buckets' all-reduce and the dense groups' Adam
             cur = torch.cuda.current_stream(dev)
             side = self._table_stream()
             lib.intel_set_table_stream(model._context(), C.c_void_p(side.cuda_stream))
@@ -337,8 +348,15 @@ class IntELEngine(object):
             finally:
                 lib.intel_set_table_stream(model._context(), None)
             with torch.cuda.stream(side):
-                adam('iid', self.l2, L.stream_ptr(dev))
+                sparse = dp and self._sparse_exchange(keep, world)
+                if sparse:
+                    self._exchange_touched_rows(keep, L.stream_ptr(dev))
+                elif dp:
+                    parallel.allreduce_sum_([self.gflat['iid']])
+                adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=dp and not sparse)
                 loss_total(L.stream_ptr(dev))
+            if dp:
+                parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
             adam('decay', self.l2, st)
             adam('nodecay', 0.0, st)
             cur.wait_stream(side)

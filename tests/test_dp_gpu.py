@@ -22,13 +22,14 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=False, overlap='1', tag=''):
+def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=False, overlap='1', tag='', schedule='wide'):
     """One rank of a 2-step training run on its shard of the 'default' fixture batch.  backend='nccl' with world 1 builds
     a REAL one-rank RCCL group (INTEL_DP_FORCE=1) so that every collective branch of the engine runs through RCCL.
     seeded: the BPR tie-breaking noise is drawn inside the loss kernel (common seed, counter keyed by the global session
     index) instead of passed as a tensor."""
     os.environ['INTEL_DP_EXCHANGE'] = exchange
     os.environ['INTEL_OVERLAP_TABLE'] = overlap
+    os.environ['INTEL_BWD_SCHEDULE'] = schedule       # wide: the one-call backward, the exchange under its tail; phased: two calls
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), INTEL_DIST_BACKEND=backend, INTEL_SINGLE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     if backend == 'nccl':
@@ -67,14 +68,16 @@ def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=Fal
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse')])
-def test_n_rank_engine_equals_single_process(world, exchange):
+@pytest.mark.parametrize('world,exchange,schedule', [(2, 'dense', 'wide'), (2, 'sparse', 'wide'), (4, 'sparse', 'wide'),
+                                                     (2, 'dense', 'phased'), (2, 'sparse', 'phased')])
+def test_n_rank_engine_equals_single_process(world, exchange, schedule):
     """exchange: dense all-reduce of the item-id table gradient, or the touched-rows all-gather.
+    schedule: the one-call backward with the exchange under its tail (default), or the two-call order.
     world 4 = one session per rank of the 4-session fixture batch."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
-        mp.spawn(_run, args=(world, _free_port(), d, exchange), nprocs=world, join=True)
+        mp.spawn(_run, args=(world, _free_port(), d, exchange, 'gloo', False, '1', '', schedule), nprocs=world, join=True)
         one = torch.load(os.path.join(d, 'w1_r0.pt'))
         ranks = [torch.load(os.path.join(d, 'w%d_r%d.pt' % (world, r))) for r in range(world)]
     for s in range(2):
@@ -109,10 +112,11 @@ def test_seeded_bpr_noise_is_keyed_by_global_session():
         assert float((ranks[0]['sd'][k] - v).abs().max()) < 5e-5, k
 
 
-@pytest.mark.parametrize('exchange,overlap', [('dense', '1'), ('sparse', '1'), ('dense', '0')])
-def test_rccl_world1_runs_every_collective_branch(exchange, overlap):
+@pytest.mark.parametrize('exchange,overlap,schedule', [('dense', '1', 'wide'), ('sparse', '1', 'wide'), ('dense', '1', 'phased'),
+                                                       ('sparse', '1', 'phased'), ('dense', '0', 'wide')])
+def test_rccl_world1_runs_every_collective_branch(exchange, overlap, schedule):
     """RCCL itself: a one-rank `nccl` process group on the test GPU with the engine forced onto its data-parallel branches
-    (INTEL_DP_FORCE=1) -- the asynchronous all-reduce waited for on the side stream, the uint8 MAX all-reduce of the row
+    (INTEL_DP_FORCE=1), in both backward schedules -- the (phased: asynchronous) all-reduce on the side stream, the uint8 MAX all-reduce of the row
     marks, all_gather_into_tensor of the touched rows, the bucket all-reduces, broadcast and barrier all execute through
     RCCL (identities at world 1), and the result must equal the plain single-process run (two steps; the embedding
     rows are accumulated with float atomics, whose order varies from run to run, so step 2 is compared to 1e-6, not bit
@@ -120,7 +124,7 @@ def test_rccl_world1_runs_every_collective_branch(exchange, overlap):
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', False, overlap), nprocs=1, join=True)
-        mp.spawn(_run, args=(1, _free_port(), d, exchange, 'nccl', False, overlap, '_nccl'), nprocs=1, join=True)
+        mp.spawn(_run, args=(1, _free_port(), d, exchange, 'nccl', False, overlap, '_nccl', schedule), nprocs=1, join=True)
         one = torch.load(os.path.join(d, 'w1_r0.pt'))
         got = torch.load(os.path.join(d, 'w1_r0_nccl.pt'))
     assert one['losses'][0] == got['losses'][0]
