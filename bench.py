@@ -201,6 +201,8 @@ def main():
     ap.add_argument('--cal_diversity', type=int, default=-1, help='-1: the workload default')
     ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
     ap.add_argument('--dtype', type=str, default='f32', help='f32: the parity mode (headline); bf16: single bf16 product per linear')
+    ap.add_argument('--adam', type=str, default='auto', help='auto: lazy when a step touches at most 1/16 of the item-id table (engine.py), dense otherwise; lazy: the item-id table\'s dense Adam in its lazy form (rows replayed when they are next read; the whole table '
+                    'is settled INSIDE the timed region after the last step); dense: one sweep over the whole table every step')
     ap.add_argument('--nbatches', type=int, default=8, help='distinct resident batches cycled by the timed loop')
     ap.add_argument('--eval_steps', type=int, default=-1, help='evaluation steps timed after the training loop (-1: max(3, steps/2); 0: none)')
     ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -237,7 +239,8 @@ def main():
     torch.manual_seed(0)
     model = IntEL(args_ns, corpus).to(dev)
     lr, l2 = w.get('optim', (1e-3, 1e-4))
-    eng = IntELEngine(model, a.loss, args_ns, lr=lr, l2=l2)
+    lazy = {'lazy': True, 'dense': False}.get(a.adam, 'auto')
+    eng = IntELEngine(model, a.loss, args_ns, lr=lr, l2=l2, lazy_table=lazy)
     parallel.broadcast_(eng.param_buckets())
     B = a.batch or w.get('bench_batch', 4096)
     # distinct resident batches (inputs in HBM before the timed region): 8 x 73 MB of gathered item rows at the headline shape,
@@ -261,6 +264,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = one_step(i)
+    eng.flush()                 # lazy table Adam: every row left behind is brought up to the last step inside the timed region
     torch.cuda.synchronize()
     parallel.barrier()
     torch.cuda.synchronize()
@@ -320,7 +324,10 @@ def main():
                                % (a.workload, cinfo['items'], Lmax, f['model_num'], cinfo['I'], w['batch']['H'], f['i_emb_size'], f['im_emb_size'],
                                   f['s_emb_size'], f['context_emb_size'], args_ns.encoder, f['num_heads'], f['num_layers'], a.dtype, a.loss,
                                   int(args_ns.cal_diversity), 'zipf(1.05)' if a.zipf else 'uniform', nbatches),
-                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'arithmetic': arith},
+                   'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'arithmetic': arith,
+                   'table_adam': ('lazy: torch.optim.Adam\'s dense update of the item-id table, rows without a gradient replayed step by step when they are next '
+                                  'gathered (bit-identical to the dense sweep, tests/test_lazy_adam_gpu.py); all rows settled inside the timed region after '
+                                  'the last step') if eng._lazy is not None else 'dense sweep over the whole table every step'},
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
     }
@@ -373,13 +380,14 @@ def main():
         args_bf = synth.make_args(a.workload, dev, **dict(over, dtype='bf16'))
         torch.manual_seed(0)
         model_bf = IntEL(args_bf, corpus).to(dev)
-        eng_bf = IntELEngine(model_bf, a.loss, args_bf, lr=lr, l2=l2)
+        eng_bf = IntELEngine(model_bf, a.loss, args_bf, lr=lr, l2=l2, lazy_table=lazy)
         for i in range(a.warmup):
             eng_bf.train_step(batches[i % nbatches])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(a.steps):
             lb = eng_bf.train_step(batches[i % nbatches])
+        eng_bf.flush()
         torch.cuda.synchronize()
         el_bf = time.perf_counter() - t0
         model_bf.eval()

@@ -281,6 +281,40 @@ int intel_adam_step_rows(float* p, float* g, float* m, float* v, long long rows,
                          float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                          float grad_scale, void* stream);
 
+/* ---- lazy form of the item-id table's dense Adam -------------------------------------------------------------
+ * torch.optim.Adam updates EVERY row of iid_embeddings.weight every step (helpers/BaseRunner.py:182-188, 288-290: dense
+ * gradient, coupled L2), although a step's gradient is non-zero only in the rows of its batch.  The update of a row with
+ * g = 0 reads nothing but the row's own (p, m, v) and the step's two scalars, so it can be REPLAYED later, step by step,
+ * with exactly the arithmetic of intel_adam_step_rows: last[r] = the step row r has been updated through;
+ * sched[2*(s - base - 1) + {0, 1}] = (lr / (1 - beta1^s), 1 / sqrt(1 - beta2^s)) of step s, base < s <= base + cap (written
+ * by intel_adam_lazy_step).  Whatever a reader then observes -- the rows a forward pass gathers (intel_set_lazy_table),
+ * the rows named to intel_adam_lazy_catchup, the whole table after intel_adam_lazy_flush -- is bit-identical to
+ * the dense sweep; the table's traffic per step drops from 6 passes over all rows to the touched rows.  d as for
+ * intel_adam_step_rows.  The caller owns every array; all hyper-parameters except lr are fixed while rows are pending. */
+typedef struct IntelLazyTable {
+  float* p; float* m; float* v;        /* [rows, d] parameter and Adam moments */
+  int* last;                           /* [rows] */
+  float* sched;                        /* [cap, 2] */
+  long long rows;
+  int d, base, cap;
+  float beta1, beta2, eps, weight_decay;
+} IntelLazyTable;
+int intel_lazy_table_sizeof(void);
+/* Step `step` (1-based, base < step <= base + cap) for the rows flagged in row_flags (see intel_set_iid_grad_row_flags): the
+ * steps a row missed are replayed, then its gradient row of g is applied, cleared and the flag reset; last[r] = step. */
+int intel_adam_lazy_step(const IntelLazyTable* t, float* g, unsigned char* row_flags, float lr, int step, void* stream);
+/* Rows ids_a[0..n_a) and ids_b[0..n_b) (ids may repeat, ids outside [0, rows) are skipped, ids_b may be NULL) brought up to
+ * step `upto`. */
+int intel_adam_lazy_catchup(const IntelLazyTable* t, const int* ids_a, long long n_a, const int* ids_b, long long n_b, int upto,
+                            void* stream);
+/* Every row brought up to step `upto`. */
+int intel_adam_lazy_flush(const IntelLazyTable* t, int upto, void* stream);
+/* t != NULL: the item-id gathers of every following intel_forward (i_id_s, his_item_id) deliver the rows AS OF step `upto`: a
+ * row that is behind is replayed in registers from its stored (p, m, v); nothing is written back, so a reader that asks
+ * for the same stale rows again and again (an evaluation pass) should call intel_adam_lazy_flush once first.  The struct
+ * is copied.  t == NULL: off (default). */
+int intel_set_lazy_table(IntelCtx* ctx, const IntelLazyTable* t, int upto);
+
 /* ---- data-parallel gradient exchange of a table's touched rows ------------------------------ */
 /* out[i,:] = table[idx[i],:] (zeros for idx[i] < 0); zero_rows != 0 also clears those table rows.  idx: a rank's
  * unique touched rows, padded with -1.  No reference counterpart (the reference is single-GPU). */

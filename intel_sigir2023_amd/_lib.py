@@ -48,6 +48,8 @@ def lib():
         _lib.intel_feed_abi_sizes(fs)
         if list(fs) != [C.sizeof(IntelFeedStore), C.sizeof(IntelFeedOut)]:
             raise IntelHipError('feed struct layout mismatch between _lib.py and intel_hip.h')
+        if _lib.intel_lazy_table_sizeof() != C.sizeof(IntelLazyTable):
+            raise IntelHipError('IntelLazyTable layout mismatch between _lib.py and intel_hip.h')
     return _lib
 
 
@@ -103,6 +105,11 @@ class IntelFeedOut(C.Structure):
                                           'his_context_mh', 'his_intents', 'history_len', 'his_item_id', 'his_item_idx', 'history_item_len')]
 
 
+class IntelLazyTable(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('p', 'm', 'v', 'last', 'sched')] + [('rows', C.c_longlong), ('d', C.c_int), ('base', C.c_int),
+               ('cap', C.c_int), ('beta1', C.c_float), ('beta2', C.c_float), ('eps', C.c_float), ('weight_decay', C.c_float)]
+
+
 class IntelOut(C.Structure):
     _fields_ = [('weights', C.c_void_p), ('ens_score', C.c_void_p), ('intents', C.c_void_p)]
 
@@ -127,6 +134,7 @@ EXPORTS = [
     'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
     'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_prof_timeline', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add',
+    'intel_lazy_table_sizeof', 'intel_adam_lazy_step', 'intel_adam_lazy_catchup', 'intel_adam_lazy_flush', 'intel_set_lazy_table',
 ]
 
 
@@ -162,6 +170,11 @@ def _declare(l):
     sig('intel_loss_total', i, [vp, vp, d, d, vp, vp])
     sig('intel_adam_step', i, [vp, vp, vp, vp, ll, f, f, f, f, f, i, f, i, vp])
     sig('intel_adam_step_rows', i, [vp, vp, vp, vp, ll, i, vp, f, f, f, f, f, i, f, vp])
+    sig('intel_lazy_table_sizeof', i, [])
+    sig('intel_adam_lazy_step', i, [C.POINTER(IntelLazyTable), vp, vp, f, i, vp])
+    sig('intel_adam_lazy_catchup', i, [C.POINTER(IntelLazyTable), vp, ll, vp, ll, i, vp])
+    sig('intel_adam_lazy_flush', i, [C.POINTER(IntelLazyTable), i, vp])
+    sig('intel_set_lazy_table', i, [vp, C.POINTER(IntelLazyTable), i])
     sig('intel_ndcg', i, [i, i, i, vp, vp, vp, vp, vp])
     sig('intel_eval_metrics', i, [i, i, i, i, C.POINTER(C.c_int), vp, vp, vp, vp, vp, vp, vp, vp])
     sig('intel_op_linear', i, [vp, i, i, vp, i, vp, i, vp, vp, sz, vp])

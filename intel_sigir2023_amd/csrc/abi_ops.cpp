@@ -154,6 +154,24 @@ extern "C" int intel_adam_step(float* p, float* g, float* m, float* v, long long
   return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, (hipStream_t)stream);
 }
 
+extern "C" int intel_lazy_table_sizeof(void) { return (int)sizeof(IntelLazyTable); }
+
+extern "C" int intel_adam_lazy_step(const IntelLazyTable* t, float* g, unsigned char* row_flags, float lr, int step, void* stream) {
+  INTEL_CHECK_ARG(t, "adam_lazy: null table");
+  return launch_adam_lazy_step(*t, g, row_flags, lr, step, (hipStream_t)stream);
+}
+
+extern "C" int intel_adam_lazy_catchup(const IntelLazyTable* t, const int* ids_a, long long n_a, const int* ids_b, long long n_b,
+                                       int upto, void* stream) {
+  INTEL_CHECK_ARG(t && (ids_a || n_a == 0) && (ids_b || n_b == 0), "adam_lazy_catchup: null table / ids");
+  return launch_adam_lazy_ids(*t, ids_a, n_a, ids_b, n_b, upto, (hipStream_t)stream);
+}
+
+extern "C" int intel_adam_lazy_flush(const IntelLazyTable* t, int upto, void* stream) {
+  INTEL_CHECK_ARG(t, "adam_lazy: null table");
+  return launch_adam_lazy_flush(*t, upto, (hipStream_t)stream);
+}
+
 extern "C" int intel_adam_step_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags,
                                     float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                     float grad_scale, void* stream) {

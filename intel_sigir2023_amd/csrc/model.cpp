@@ -126,6 +126,8 @@ struct IntelCtx {
   unsigned long long drop_seed;
   const float* drop_ext;       // optional 0/1 keep flags, item-tower layers then score-tower layers
   bool fwd_dropout;            // the stashed forward ran with dropout
+  IntelLazyTable lazy;          // intel_set_lazy_table: the item-id table's Adam state (lazy.p == nullptr: off)
+  int lazy_upto = 0;            // ... and the step the rows of a batch are brought up to ahead of the gathers
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
   bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
   bool enc_packed[2];          // this forward ran encoder e on the valid history rows only (IntelBatch.his_off / hisitem_off)
@@ -998,6 +1000,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   };
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
+  const bool lazy_gather = r.ctx->lazy.p != nullptr && r.ctx->lazy_upto > r.ctx->lazy.base && r.P(INTEL_P_IID_EMB) == r.ctx->lazy.p;
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = r.ctx->enc_rows[e], dm = n.dm;
@@ -1020,7 +1023,11 @@ void forward_impl(Run& r, const IntelOut* out) {
                                   bt.his_item_idx ? nullptr : bt.his_item_int, I, n.pkVec, n.rowT, r.st));
       n.pos_done = pk && D.encoder == INTEL_ENC_BERT4REC && bt.his_item_idx != nullptr;
       const float* pos = n.pos_done ? r.P(enc_slot(e, INTEL_ENC_POS)) : nullptr;
-      RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st, pos, n.rowT));
+      // lazy table Adam (intel_set_lazy_table): rows that are behind are replayed inside the gather
+      if (lazy_gather)
+        RUN(launch_gather_rows_lazy(r.ctx->lazy, r.ctx->lazy_upto, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, r.st, pos, n.rowT));
+      else
+        RUN(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, 0, r.st, pos, n.rowT));
       wait_pack(r);
       if (bt.his_item_idx)
         RUN(launch_onehot_linear(r.P(INTEL_P_INTENT_W), r.P(INTEL_P_INTENT_B), D.d_int, I, pk ? n.pkIdx2 : bt.his_item_idx, rows, n.E0, dm, D.d_id, r.st, pos, n.rowT));
@@ -1043,7 +1050,8 @@ void forward_impl(Run& r, const IntelOut* out) {
     encoder_branch(r, 0);                        // session-history encoder on the caller's stream
     encoder_branch(b1, 1);
     // item tower
-    if (b2.ok(launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
+    if (b2.ok(lazy_gather ? launch_gather_rows_lazy(r.ctx->lazy, r.ctx->lazy_upto, bt.i_id_s, M, ti.X0, ti.d, 0, b2.st, nullptr, nullptr)
+                          : launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
         (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st)))) {
       wait_pack(b2);
       tower_fwd(b2, ti);
@@ -1582,6 +1590,8 @@ extern "C" IntelCtx* intel_create(const IntelDesc* desc) {
   c->drop_ext = nullptr;
   c->fwd_dropout = false;
   c->iid_row_flags = nullptr;
+  memset(&c->lazy, 0, sizeof(c->lazy));
+  c->lazy_upto = 0;
   c->fused_tail[0] = c->fused_tail[1] = false;
   c->rq = redq_create();
   if (!c->rq) {
@@ -1642,6 +1652,20 @@ extern "C" int intel_set_dropout(IntelCtx* ctx, float p, unsigned long long seed
 extern "C" int intel_set_iid_grad_row_flags(IntelCtx* ctx, unsigned char* row_flags) {
   INTEL_CHECK_ARG(ctx, "intel_set_iid_grad_row_flags: null context");
   ctx->iid_row_flags = row_flags;
+  return 0;
+}
+
+extern "C" int intel_set_lazy_table(IntelCtx* ctx, const IntelLazyTable* t, int upto) {
+  INTEL_CHECK_ARG(ctx, "intel_set_lazy_table: null context");
+  if (t) {
+    INTEL_CHECK_ARG(t->p && t->m && t->v && t->last && t->sched, "intel_set_lazy_table: null tensor");
+    INTEL_CHECK_ARG(t->rows == ctx->d.item_num && t->d == ctx->d.d_id, "intel_set_lazy_table: table is [%lld, %d], iid_embeddings.weight is [%d, %d]",
+                    t->rows, t->d, ctx->d.item_num, ctx->d.d_id);
+    ctx->lazy = *t;
+  } else {
+    memset(&ctx->lazy, 0, sizeof(ctx->lazy));
+  }
+  ctx->lazy_upto = upto;
   return 0;
 }
 

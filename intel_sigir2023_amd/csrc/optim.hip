@@ -1,4 +1,5 @@
 // Fused Adam (dense, coupled L2) and on-device NDCG@k.
+#include "../../include/intel_hip.h"
 #include "kernels.h"
 #include "session.h"
 
@@ -13,12 +14,16 @@ struct AdamArgs {
   float step_size, beta1, beta2, eps, wd, inv_bc2_sqrt, grad_scale; int zero_grad;
 };
 
+// The roundings are pinned (explicit fused multiply-adds, no contraction left to the compiler): the dense sweeps and the lazy
+// replay below must produce the same bits from the same inputs whatever code surrounds the inlined body.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
-  g = g * a.grad_scale + a.wd * p;
-  m = m + (g - m) * (1.f - a.beta1);
-  v = v * a.beta2 + (1.f - a.beta2) * g * g;
-  const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
-  p = p - a.step_size * (m / denom);
+#pragma clang fp contract(off)
+  g = __builtin_fmaf(g, a.grad_scale, a.wd * p);
+  m = __builtin_fmaf(g - m, 1.f - a.beta1, m);
+  const float g2 = ((1.f - a.beta2) * g) * g;
+  v = __builtin_fmaf(v, a.beta2, g2);
+  const float denom = __builtin_fmaf(sqrtf(v), a.inv_bc2_sqrt, a.eps);
+  p = __builtin_fmaf(-a.step_size, m / denom, p);
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(AdamArgs a) {
@@ -121,6 +126,248 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
   long long blocks = ((n >> 2) + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);     // grid-stride: 256 CUs x 8
   LAUNCH_W(0.0, (zero_grad ? 32.0 : 28.0) * (double)n, adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Lazy form of the table's dense Adam.  A row whose gradient is zero still moves every step (moments decay, coupled L2), but its
+// update reads nothing except its own (p, m, v) and the step's two scalars (lr / bc1, 1 / sqrt(bc2)): the row can be brought up
+// to date LATER, by replaying the missed steps one after the other with exactly the arithmetic of the dense sweep (adam_one,
+// g = 0).  last[r] = the step row r has been updated through; sched[s - base - 1] = the scalars of step s.  A step then
+// touches only the rows that carry a gradient (flag sweep: replay, then the step with its gradient) and, ahead of a forward
+// pass, the rows that pass is about to gather (id sweep); everything a reader can observe is bit-identical to the dense sweep.
+// ------------------------------------------------------------------------------------------
+struct LazyArgs {
+  float* p; float* g; float* m; float* v; int* last; float* sched; unsigned char* flags;
+  long long rows; int d, base, step;
+  float beta1, beta2, eps, wd, grad_scale, zero, step_size, inv_bc2_sqrt;
+};
+
+__device__ __forceinline__ AdamArgs lazy_consts(const LazyArgs& a) {
+  AdamArgs c;
+  c.p = c.g = c.m = c.v = nullptr; c.n = 0; c.zero_grad = 0;
+  c.beta1 = a.beta1; c.beta2 = a.beta2; c.eps = a.eps; c.wd = a.wd; c.grad_scale = a.grad_scale;
+  c.step_size = a.step_size; c.inv_bc2_sqrt = a.inv_bc2_sqrt;
+  return c;
+}
+
+// steps from+1 .. upto with g = 0 (a.zero: a run-time 0 -- the same instruction sequence as a gradient that happens to be 0)
+__device__ __forceinline__ void lazy_replay(f32x4& p, f32x4& m, f32x4& v, int from, int upto, const LazyArgs& a, AdamArgs& c) {
+  for (int s = from + 1; s <= upto; ++s) {
+    const float2 sc = reinterpret_cast<const float2*>(a.sched)[s - a.base - 1];
+    c.step_size = sc.x; c.inv_bc2_sqrt = sc.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = p[k], mk = m[k], vk = v[k];
+      adam_one(pk, a.zero, mk, vk, c);
+      p[k] = pk; m[k] = mk; v[k] = vk;
+    }
+  }
+}
+
+// the step `a.step` for the flagged rows (replay of what they missed first); rows without a flag are left for later
+__global__ __launch_bounds__(256) void adam_lazy_rows_kernel(LazyArgs a) {
+  const int lpr = a.d >> 2;
+  const int sub = threadIdx.x % lpr;
+  const long long r0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+  const long long stride = (long long)gridDim.x * blockDim.x / lpr;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.sched[2 * (a.step - a.base - 1)] = a.step_size;
+    a.sched[2 * (a.step - a.base - 1) + 1] = a.inv_bc2_sqrt;
+  }
+  AdamArgs c = lazy_consts(a);
+  for (long long rb = r0; rb < a.rows; rb += 4 * stride) {
+    unsigned char f[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long r = rb + q * stride;
+      f[q] = r < a.rows ? a.flags[r] : (unsigned char)0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!f[q]) continue;
+      const long long r = rb + q * stride;
+      const long long i = r * lpr + sub;
+      const int from = a.last[r];
+      f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+      f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+      f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+      const f32x4 g = reinterpret_cast<f32x4*>(a.g)[i];
+      lazy_replay(p, m, v, from, a.step - 1, a, c);
+      c.step_size = a.step_size; c.inv_bc2_sqrt = a.inv_bc2_sqrt;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pk = p[k], mk = m[k], vk = v[k];
+        adam_one(pk, g[k], mk, vk, c);
+        p[k] = pk; m[k] = mk; v[k] = vk;
+      }
+      reinterpret_cast<f32x4*>(a.p)[i] = p;
+      reinterpret_cast<f32x4*>(a.m)[i] = m;
+      reinterpret_cast<f32x4*>(a.v)[i] = v;
+      reinterpret_cast<f32x4*>(a.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (sub == 0) { a.last[r] = a.step; a.flags[r] = 0; }
+    }
+  }
+}
+
+// rows ids_a[...] and ids_b[...] brought up to step `upto`; an id may repeat: the occurrence that raises last[id] owns the row
+__global__ __launch_bounds__(256) void adam_lazy_ids_kernel(LazyArgs a, const int* __restrict__ ids_a, long long n_a,
+                                                            const int* __restrict__ ids_b, long long n_b, int upto) {
+  const int lpr = a.d >> 2;
+  const int sub = threadIdx.x % lpr;
+  const long long j0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+  const long long stride = (long long)gridDim.x * blockDim.x / lpr;
+  const long long n = n_a + n_b;
+  AdamArgs c = lazy_consts(a);
+  // every lane group runs the same number of rounds (the claim is handed to the group's lanes by a shuffle)
+  const long long rounds = (n + stride - 1) / stride;
+  for (long long t = 0; t < rounds; ++t) {
+    const long long j = j0 + t * stride;
+    int id = -1;
+    if (j < n) id = j < n_a ? ids_a[j] : ids_b[j - n_a];
+    const bool valid = id >= 0 && (long long)id < a.rows;
+    // a row that is up to date already (the pad id, popular items: thousands of occurrences) is left alone without an atomic
+    const bool behind = valid && a.last[id] < upto;
+    int from = upto;
+    if (behind && sub == 0) from = atomicMax(&a.last[id], upto);
+    from = __shfl(from, 0, lpr);
+    if (!behind || from >= upto) continue;
+    const long long i = (long long)id * lpr + sub;
+    f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+    lazy_replay(p, m, v, from, upto, a, c);
+    reinterpret_cast<f32x4*>(a.p)[i] = p;
+    reinterpret_cast<f32x4*>(a.m)[i] = m;
+    reinterpret_cast<f32x4*>(a.v)[i] = v;
+  }
+}
+
+// dst[m, col0 : col0 + d] = the row idx[m] of the table AS OF step `upto` (+ the position row, as gather_rows_kernel): a row that
+// is behind is replayed in registers from its stored (p, m, v); nothing is written back (the step's flag sweep does that), so
+// repeated ids and concurrent gathers need no ordering
+__global__ __launch_bounds__(256) void gather_rows_lazy_kernel(LazyArgs a, const int* __restrict__ idx, int M, float* __restrict__ dst,
+                                                               int ldd, int col0, const float* __restrict__ pos,
+                                                               const int* __restrict__ row_t, int upto) {
+  const int d4 = a.d >> 2;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)M * d4) return;
+  const int mrow = (int)(i / d4), c = (int)(i - (long long)mrow * d4);
+  const int row = idx[mrow];
+  f32x4 p = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (row >= 0) {
+    // all four loads are issued together (most rows of a training batch are behind: waiting for last[row] before asking for the
+    // moments would put a second memory latency in front of the replay)
+    const long long e = (long long)row * d4 + c;
+    p = reinterpret_cast<const f32x4*>(a.p)[e];
+    f32x4 m = reinterpret_cast<const f32x4*>(a.m)[e];
+    f32x4 v = reinterpret_cast<const f32x4*>(a.v)[e];
+    const int from = a.last[row];
+    AdamArgs cst = lazy_consts(a);
+    lazy_replay(p, m, v, from, upto, a, cst);
+  }
+  if (pos) p += *reinterpret_cast<const f32x4*>(pos + (size_t)row_t[mrow] * ldd + col0 + c * 4);
+  *reinterpret_cast<f32x4*>(dst + (size_t)mrow * ldd + col0 + c * 4) = p;
+}
+
+// every row brought up to step `upto` (state_dict, evaluation through another path, change of hyper-parameters, sched full)
+__global__ __launch_bounds__(256) void adam_lazy_flush_kernel(LazyArgs a, int upto) {
+  const int lpr = a.d >> 2;
+  const int sub = threadIdx.x % lpr;
+  const long long r0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / lpr;
+  const long long stride = (long long)gridDim.x * blockDim.x / lpr;
+  AdamArgs c = lazy_consts(a);
+  for (long long rb = r0; rb < a.rows; rb += 4 * stride) {
+    int l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const long long r = rb + q * stride;
+      l[q] = r < a.rows ? a.last[r] : upto;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (l[q] >= upto) continue;
+      const long long r = rb + q * stride;
+      const long long i = r * lpr + sub;
+      f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
+      f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];
+      f32x4 v = reinterpret_cast<f32x4*>(a.v)[i];
+      lazy_replay(p, m, v, l[q], upto, a, c);
+      reinterpret_cast<f32x4*>(a.p)[i] = p;
+      reinterpret_cast<f32x4*>(a.m)[i] = m;
+      reinterpret_cast<f32x4*>(a.v)[i] = v;
+      if (sub == 0) a.last[r] = upto;
+    }
+  }
+}
+
+static int lazy_fill(LazyArgs& a, const IntelLazyTable& t) {
+  INTEL_CHECK_ARG(t.p && t.m && t.v && t.last && t.sched, "adam_lazy: null tensor");
+  INTEL_CHECK_ARG(t.d == 16 || t.d == 32 || t.d == 64 || t.d == 128 || t.d == 256, "adam_lazy: row width %d unsupported", t.d);
+  INTEL_CHECK_ARG(((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.m) | reinterpret_cast<uintptr_t>(t.v)) & 15) == 0 &&
+                  (reinterpret_cast<uintptr_t>(t.sched) & 7) == 0, "adam_lazy: tensors must be 16-byte aligned");
+  a.p = t.p; a.g = nullptr; a.m = t.m; a.v = t.v; a.last = t.last; a.sched = t.sched; a.flags = nullptr;
+  a.rows = t.rows; a.d = t.d; a.base = t.base; a.step = 0;
+  a.beta1 = t.beta1; a.beta2 = t.beta2; a.eps = t.eps; a.wd = t.weight_decay; a.grad_scale = 1.f; a.zero = 0.f;
+  a.step_size = 0.f; a.inv_bc2_sqrt = 0.f;
+  return 0;
+}
+
+static unsigned lazy_grid(long long groups, int lpr) {
+  long long blocks = (groups * lpr + 255) / 256;
+  return (unsigned)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));
+}
+
+int launch_adam_lazy_step(const IntelLazyTable& t, float* g, unsigned char* row_flags, float lr, int step, hipStream_t st) {
+  if (t.rows <= 0) return 0;
+  LazyArgs a;
+  if (int rc = lazy_fill(a, t)) return rc;
+  INTEL_CHECK_ARG(g && row_flags && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "adam_lazy: gradient / row flags missing or misaligned");
+  INTEL_CHECK_ARG(step > t.base && step - t.base <= t.cap, "adam_lazy: step %d outside the schedule window (%d, %d]", step, t.base, t.base + t.cap);
+  const double bc1 = 1.0 - pow((double)t.beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)t.beta2, (double)step);
+  a.g = g; a.flags = row_flags; a.step = step;
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  LAUNCH_W(0.0, (double)t.rows, adam_lazy_rows_kernel, dim3(lazy_grid(t.rows, t.d >> 2)), dim3(256), 0, st, a);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_adam_lazy_ids(const IntelLazyTable& t, const int* ids_a, long long n_a, const int* ids_b, long long n_b, int upto, hipStream_t st) {
+  if (t.rows <= 0 || n_a + n_b <= 0 || upto <= t.base) return 0;
+  LazyArgs a;
+  if (int rc = lazy_fill(a, t)) return rc;
+  INTEL_CHECK_ARG(upto - t.base <= t.cap, "adam_lazy: step %d outside the schedule window", upto);
+  LAUNCH_W(0.0, 4.0 * (double)(n_a + n_b), adam_lazy_ids_kernel, dim3(lazy_grid(n_a + n_b, t.d >> 2)), dim3(256), 0, st, a, ids_a, n_a,
+           ids_b, n_b, upto);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_gather_rows_lazy(const IntelLazyTable& t, int upto, const int* idx, int M, float* dst, int ldd, int col0, hipStream_t st,
+                            const float* pos, const int* row_t) {
+  if (!row_t) pos = nullptr;
+  if (M <= 0) return 0;
+  LazyArgs a;
+  if (int rc = lazy_fill(a, t)) return rc;
+  INTEL_CHECK_ARG(upto - t.base <= t.cap, "gather_rows_lazy: step %d outside the schedule window", upto);
+  INTEL_CHECK_ARG((ldd % 4 == 0) && (col0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(pos) & 15) == 0), "gather_rows_lazy: destination / position rows must be 16-byte aligned");
+  const long long n = (long long)M * (t.d / 4);
+  LAUNCH_W(0.0, 16.0 * (double)M * t.d + 8.0 * M, gather_rows_lazy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, idx, M, dst,
+           ldd, col0, pos, row_t, upto);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_adam_lazy_flush(const IntelLazyTable& t, int upto, hipStream_t st) {
+  if (t.rows <= 0 || upto <= t.base) return 0;
+  LazyArgs a;
+  if (int rc = lazy_fill(a, t)) return rc;
+  INTEL_CHECK_ARG(upto - t.base <= t.cap, "adam_lazy: step %d outside the schedule window", upto);
+  LAUNCH_W(0.0, 4.0 * (double)t.rows, adam_lazy_flush_kernel, dim3(lazy_grid(t.rows, t.d >> 2)), dim3(256), 0, st, a, upto);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

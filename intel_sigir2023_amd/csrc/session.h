@@ -72,6 +72,13 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
                 float wd, int step, float grad_scale, int zero_grad, hipStream_t st);
 int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int d, unsigned char* row_flags, float lr,
                      float beta1, float beta2, float eps, float wd, int step, float grad_scale, hipStream_t st);
+// lazy form of the table's dense Adam (IntelLazyTable: include/intel_hip.h)
+struct IntelLazyTable;
+int launch_adam_lazy_step(const IntelLazyTable& t, float* g, unsigned char* row_flags, float lr, int step, hipStream_t st);
+int launch_adam_lazy_ids(const IntelLazyTable& t, const int* ids_a, long long n_a, const int* ids_b, long long n_b, int upto, hipStream_t st);
+int launch_adam_lazy_flush(const IntelLazyTable& t, int upto, hipStream_t st);
+int launch_gather_rows_lazy(const IntelLazyTable& t, int upto, const int* idx, int M, float* dst, int ldd, int col0, hipStream_t st,
+                            const float* pos, const int* row_t);
 int launch_ndcg(int B, int L, int k, const float* ens, const int* ranking, const int* slen, float* out, hipStream_t st);
 int launch_eval_metrics(int B, int L, int width, int nk, const int* topk, const float* ens, const int* ranking, const int* slen,
                         const int* pos_nums, const int* label_pos, double* out, unsigned char* valid, hipStream_t st);

@@ -20,7 +20,7 @@ from . import parallel
 
 
 class IntELEngine(object):
-    def __init__(self, model, loss_name='IntBPRloss', args=None, lr=1e-3, l2=0.0, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, model, loss_name='IntBPRloss', args=None, lr=1e-3, l2=0.0, betas=(0.9, 0.999), eps=1e-8, lazy_table=None):
         self.model = model
         self.loss_name = loss_name
         if loss_name not in ('IntBPRloss', 'IntListloss', 'IntMSEloss', 'BPRloss', 'Listloss', 'MSEloss'):
@@ -68,6 +68,66 @@ class IntELEngine(object):
         if os.environ.get('INTEL_ADAM_ROWS', '1') != '0' and w.shape[1] in (16, 32, 64, 128, 256):
             self._iid_flags = torch.zeros(w.shape[0], dtype=torch.uint8, device=self.device)
             L.check(L.lib().intel_set_iid_grad_row_flags(model._context(), L.ptr(self._iid_flags)), 'intel_set_iid_grad_row_flags')
+        # lazy form of the item-id table's dense Adam (include/intel_hip.h: IntelLazyTable): a step updates the rows that carry a
+        # gradient, every forward pass first brings the rows it gathers up to date, flush() the rest -- bit-identical to the dense
+        # sweep wherever the table is observed THROUGH the engine / the model (forward, state_dict, load_state_dict); code that
+        # reads model.iid_embeddings.weight or eng.m / eng.v directly calls eng.flush() first.  Opt-in: lazy_table=True or
+        # INTEL_ADAM_LAZY=1 (bench.py and the runner's engine path switch it on)
+        # 'auto' (what bench.py and the runner pass): decided at the first step from the batch shape -- lazy when a step touches at
+        # most 1/16 of the table's rows (the 10 M-item stress table: 1 %, the dense sweep is 2.75 of its 5.7 ms step; Tmall at
+        # batch 512: 3.6 %), dense otherwise (Tmall at batch 4096 touches 29 %: the sweep hides under the backward's tail and the
+        # lazy form only saves its traffic)
+        if lazy_table is None:
+            lazy_table = {'0': False, '1': True}.get(os.environ.get('INTEL_ADAM_LAZY', '0'), 'auto')
+        self._lazy = None
+        self._lazy_auto = lazy_table == 'auto' and self._iid_flags is not None and w.shape[0] > 0
+        if lazy_table is True and self._iid_flags is not None and w.shape[0] > 0:
+            self._lazy_init()
+
+    # ---- lazy table Adam ---------------------------------------------------------------------------------------------
+    LAZY_CAP = 1 << 16          # steps the schedule window holds before the table is flushed and the window moved
+
+    def _lazy_init(self):
+        w = self.model.iid_embeddings.weight
+        rows, d = w.shape
+        self._lazy_last = torch.zeros(rows, dtype=torch.int32, device=self.device)
+        self._lazy_sched = torch.zeros(self.LAZY_CAP, 2, dtype=torch.float32, device=self.device)
+        b1, b2 = self.betas
+        self._lazy = L.IntelLazyTable(p=self.flat['iid'].data_ptr(), m=self.m['iid'].data_ptr(), v=self.v['iid'].data_ptr(),
+                                      last=self._lazy_last.data_ptr(), sched=self._lazy_sched.data_ptr(), rows=rows, d=d,
+                                      base=self.step_count, cap=self.LAZY_CAP, beta1=b1, beta2=b2, eps=self.eps, weight_decay=self.l2)
+        self._lazy_last.fill_(self.step_count)
+        self._lazy_publish()
+        self._lazy_settled = self.step_count
+        # readers outside the engine: state_dict() / load_state_dict() see (and replace) an up-to-date table; the model's own
+        # forward (evaluation through model(batch)) settles the table once instead of replaying stale rows in every gather
+        self._lazy_hooks = [self.model.register_state_dict_pre_hook(lambda *a, **k: self.flush()),
+                            self.model.register_load_state_dict_pre_hook(lambda *a, **k: self.flush()),
+                            self.model.register_forward_pre_hook(lambda *a, **k: self.flush())]
+
+    def _lazy_publish(self, settled=False):
+        """Tell the context which step the gathers of a forward pass must deliver the table's rows at (settled: every row is
+        up to date -- the plain gather will do until the next step)."""
+        upto = self._lazy.base if settled else self.step_count
+        L.check(L.lib().intel_set_lazy_table(self.model._context(), C.byref(self._lazy), upto), 'intel_set_lazy_table')
+
+    def flush(self):
+        """Lazy table Adam: every row of the item-id table (and its moments) brought up to the current step.  No-op otherwise."""
+        if self._lazy is None or self._lazy_settled == self.step_count:
+            return
+        L.check(L.lib().intel_adam_lazy_flush(C.byref(self._lazy), self.step_count, L.stream_ptr(self.device)), 'intel_adam_lazy_flush')
+        self._lazy_settled = self.step_count
+        self._lazy_publish(settled=True)
+
+    def _lazy_step(self, stream_ptr):
+        if self.step_count - self._lazy.base > self._lazy.cap:          # window full: settle everything, move the window
+            self.step_count -= 1
+            L.check(L.lib().intel_adam_lazy_flush(C.byref(self._lazy), self.step_count, stream_ptr), 'intel_adam_lazy_flush')
+            self.step_count += 1
+            self._lazy.base = self.step_count - 1
+        L.check(L.lib().intel_adam_lazy_step(C.byref(self._lazy), L.ptr(self.gflat['iid']), L.ptr(self._iid_flags), self.lr,
+                                             self.step_count, stream_ptr), 'intel_adam_lazy_step')
+        self._lazy_publish()
 
     # ---- data-parallel exchange of the item-id table gradient ------------------------------------------------------
     def _sparse_exchange(self, keep, world):
@@ -243,6 +303,10 @@ class IntELEngine(object):
             self._check_global_shape(ib)
             if self._sparse_exchange(keep, world):
                 self._touched_idx(keep)
+        if self._lazy_auto:             # same decision on every rank: the shape is global (_check_global_shape)
+            self._lazy_auto = False
+            if (ib.B * world) * (ib.L + ib.Hi) * 16 <= model.iid_embeddings.weight.shape[0]:
+                self._lazy_init()
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
         sort_ev = self._sort_scatter_ids(ib, keep)
@@ -326,6 +390,8 @@ class IntELEngine(object):
             if gname == 'iid' and self._iid_flags is not None and n:
                 if dense_reduced:       # the gradient was summed over ranks as a dense table: so are the row marks
                     parallel.allreduce_max_(self._iid_flags)
+                if self._lazy is not None:
+                    return self._lazy_step(stream_ptr)
                 rows, d = self.model.iid_embeddings.weight.shape
                 L.check(lib.intel_adam_step_rows(L.ptr(self.flat[gname]), L.ptr(self.gflat[gname]), L.ptr(self.m[gname]),
                                                  L.ptr(self.v[gname]), rows, d, L.ptr(self._iid_flags), self.lr, b1, b2, self.eps,
@@ -398,6 +464,7 @@ class IntELEngine(object):
         """forward + on-device NDCG@k (helpers/BaseRunner.py:328-343 + :117-126).  Returns
         (out_dict, ndcg[B] device tensor)."""
         model = self.model
+        self.flush()                # lazy table Adam: settle the table once per evaluation phase (no-op when nothing is pending)
         ib, keep = model.prepare_batch(batch)
         params = [p.detach() for _, _, p in model.slot_items()]
         weights, ens, intents = model.run_forward(ib, keep, params, train=False)

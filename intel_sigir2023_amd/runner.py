@@ -252,7 +252,10 @@ class BaseRunner(object):
         losses = []
         if self.use_engine:
             if self.engine is None:
-                self.engine = IntELEngine(model, loss_name or type(criterion).__name__, self.args, lr=self.learning_rate, l2=self.l2)
+                # lazy table Adam (engine.py): evaluation catches its batches' rows up inside the forward pass, state_dict()
+                # (save_model) and load_state_dict() settle the whole table through the engine's hooks
+                self.engine = IntELEngine(model, loss_name or type(criterion).__name__, self.args, lr=self.learning_rate, l2=self.l2,
+                                          lazy_table={'0': False, '1': True}.get(os.environ.get('INTEL_ADAM_LAZY', 'auto'), 'auto'))
             for batch in batches:
                 loss, _, _ = self.engine.train_step(batch)
                 losses.append(loss.detach())

@@ -22,13 +22,14 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=False, overlap='1', tag='', schedule='wide'):
+def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=False, overlap='1', tag='', schedule='wide', lazy='0'):
     """One rank of a 2-step training run on its shard of the 'default' fixture batch.  backend='nccl' with world 1 builds
     a REAL one-rank RCCL group (INTEL_DP_FORCE=1) so that every collective branch of the engine runs through RCCL.
     seeded: the BPR tie-breaking noise is drawn inside the loss kernel (common seed, counter keyed by the global session
     index) instead of passed as a tensor."""
     os.environ['INTEL_DP_EXCHANGE'] = exchange
     os.environ['INTEL_OVERLAP_TABLE'] = overlap
+    os.environ['INTEL_ADAM_LAZY'] = lazy               # 1: the lazy form of the item-id table's Adam (engine.py)
     os.environ['INTEL_BWD_SCHEDULE'] = schedule       # wide: the one-call backward, the exchange under its tail; phased: two calls
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), INTEL_DIST_BACKEND=backend, INTEL_SINGLE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
@@ -89,6 +90,28 @@ def test_n_rank_engine_equals_single_process(world, exchange, schedule):
             continue            # analytically-zero gradient: Adam direction is rounding noise
         err = float((ranks[0]['sd'][k] - v).abs().max())
         assert err < 5e-5, (k, err)
+
+
+@pytest.mark.parametrize('exchange,backend', [('dense', 'gloo'), ('sparse', 'gloo'), ('dense', 'nccl'), ('sparse', 'nccl')])
+def test_lazy_table_adam_data_parallel(exchange, backend):
+    """The lazy table Adam under data parallelism: every rank brings its OWN batch's rows up to date ahead of the forward pass and
+    applies the step to the UNION of the ranks' touched rows (all-reduced row marks / all-gathered indices); after the
+    state_dict flush the replicas are bit-identical and equal the dense single-process run.  nccl: a one-rank RCCL group."""
+    assert torch.cuda.is_available()
+    world = 2 if backend == 'gloo' else 1
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
+        mp.spawn(_run, args=(world, _free_port(), d, exchange, backend, False, '1', '_lazy', 'wide', '1'), nprocs=world, join=True)
+        one = torch.load(os.path.join(d, 'w1_r0.pt'))
+        ranks = [torch.load(os.path.join(d, 'w%d_r%d_lazy.pt' % (world, r))) for r in range(world)]
+    for s in range(2):
+        assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
+    for k, v in one['sd'].items():
+        for r in ranks[1:]:
+            assert torch.equal(ranks[0]['sd'][k], r['sd'][k]), 'replicas diverged: ' + k
+        if 'k_linear.bias' in k:
+            continue
+        assert float((ranks[0]['sd'][k] - v).abs().max()) < 5e-5, k
 
 
 def test_seeded_bpr_noise_is_keyed_by_global_session():
