@@ -74,9 +74,9 @@ class IntELEngine(object):
         # reads model.iid_embeddings.weight or eng.m / eng.v directly calls eng.flush() first.  Opt-in: lazy_table=True or
         # INTEL_ADAM_LAZY=1 (bench.py and the runner's engine path switch it on)
         # 'auto' (what bench.py and the runner pass): decided at the first step from the batch shape -- lazy when a step touches at
-        # most 1/16 of the table's rows (the 10 M-item stress table: 1 %, the dense sweep is 2.75 of its 5.7 ms step; Tmall at
-        # batch 512: 3.6 %), dense otherwise (Tmall at batch 4096 touches 29 %: the sweep hides under the backward's tail and the
-        # lazy form only saves its traffic)
+        # most 1/8 of the table's rows (the 10 M-item stress table at batch 256: 1 %, the dense sweep is 2.75 of its 5.7 ms step,
+        # 43 k -> 69 k sessions/s; Tmall at batch 1024: 7 %, +7 %), dense otherwise (Tmall at batch 4096 touches 29 %: the sweep
+        # hides under the backward's tail and the lazy form only saves its traffic -- measured equal within 1 %, fp32 and bf16)
         if lazy_table is None:
             lazy_table = {'0': False, '1': True}.get(os.environ.get('INTEL_ADAM_LAZY', '0'), 'auto')
         self._lazy = None
@@ -305,7 +305,7 @@ class IntELEngine(object):
                 self._touched_idx(keep)
         if self._lazy_auto:             # same decision on every rank: the shape is global (_check_global_shape)
             self._lazy_auto = False
-            if (ib.B * world) * (ib.L + ib.Hi) * 16 <= model.iid_embeddings.weight.shape[0]:
+            if (ib.B * world) * (ib.L + ib.Hi) * 8 <= model.iid_embeddings.weight.shape[0]:
                 self._lazy_init()
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
