@@ -120,11 +120,16 @@ class IntELEngine(object):
         self._lazy_publish(settled=True)
 
     def _lazy_step(self, stream_ptr):
-        if self.step_count - self._lazy.base > self._lazy.cap:          # window full: settle everything, move the window
+        b1, b2 = self.betas
+        hyper = (C.c_float(b1).value, C.c_float(b2).value, C.c_float(self.eps).value, C.c_float(self.l2).value)
+        changed = hyper != (self._lazy.beta1, self._lazy.beta2, self._lazy.eps, self._lazy.weight_decay)
+        if changed or self.step_count - self._lazy.base > self._lazy.cap:
+            # window full, or a hyper-parameter other than lr changed (the replay uses ONE set): settle everything, move the window
             self.step_count -= 1
             L.check(L.lib().intel_adam_lazy_flush(C.byref(self._lazy), self.step_count, stream_ptr), 'intel_adam_lazy_flush')
             self.step_count += 1
             self._lazy.base = self.step_count - 1
+            self._lazy.beta1, self._lazy.beta2, self._lazy.eps, self._lazy.weight_decay = hyper
         L.check(L.lib().intel_adam_lazy_step(C.byref(self._lazy), L.ptr(self.gflat['iid']), L.ptr(self._iid_flags), self.lr,
                                              self.step_count, stream_ptr), 'intel_adam_lazy_step')
         self._lazy_publish()

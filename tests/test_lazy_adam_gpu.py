@@ -90,8 +90,8 @@ def _engines(monkeypatch, workload='tiny', cap=None, **engine_kw):
 
 @pytest.mark.parametrize('cap', [None, 4])
 def test_lazy_engine_equals_dense_engine(cap, monkeypatch):
-    """Nine fused steps over three alternating batches (rows come back after being left behind), a learning-rate change and an
-    evaluation in between: every loss, the evaluation outputs and the final state_dict of the lazy engine equal the dense
+    """Nine fused steps over three alternating batches (rows come back after being left behind), a learning-rate change, a
+    weight-decay change and an evaluation in between: every loss, the evaluation outputs and the final state_dict of the lazy engine equal the dense
     engine's (up to the order of the embedding scatter's float atomics); before the flush the lazy table really differs.
     cap = 4: the schedule window is moved twice on the way."""
     from intel_sigir2023_amd import synth
@@ -102,6 +102,8 @@ def test_lazy_engine_equals_dense_engine(cap, monkeypatch):
     for step in range(9):
         if step == 5:
             e0.set_lr(5e-4), e1.set_lr(5e-4)
+        if step == 7:
+            e0.l2 = e1.l2 = 5e-4          # another hyper-parameter: the lazy engine settles the table first (one set per replay)
         b = batches[step % 3]
         l0 = e0.train_step(b, noise_seed=100 + step)
         l1 = e1.train_step(b, noise_seed=100 + step)

@@ -21,6 +21,9 @@ timeout 600 python bench.py --dtype bf16 --no_cpu_baseline > $out/bench_bf16.jso
 INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_bf16 -- python3 bench.py --dtype bf16 --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s_bf16.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_bf16 -- python3 bench.py --dtype bf16 --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch_bf16.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_bf16 -- python3 bench.py --dtype bf16 --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write_bf16.log 2>&1 < /dev/null
+# the lazy form of the table's Adam forced onto the headline shape (auto keeps the dense sweep there): traffic passes
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_lazy -- python3 bench.py --adam lazy --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch_lazy.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_lazy -- python3 bench.py --adam lazy --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write_lazy.log 2>&1 < /dev/null
 # the step as it overlaps (HIP-event timeline, branches on their streams)
 timeout 300 python tools/step_timeline.py f32 train full > $out/timeline_f32_train.txt 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py bf16 train full > $out/timeline_bf16_train.txt 2>&1 < /dev/null
@@ -29,6 +32,11 @@ if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload lifedata --batch 2048 --no_cpu_baseline > $out/bench_lifedata.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 256 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 1024 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress_b1024.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 256 --adam dense --steps 5 --warmup 2 --no_cpu_baseline --no_bf16_line > $out/bench_stress_dense.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 1024 --adam dense --steps 5 --warmup 2 --no_cpu_baseline --no_bf16_line > $out/bench_stress_b1024_dense.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --batch 1024 --adam dense --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_b1024_dense.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --batch 1024 --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_b1024.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --adam lazy --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_lazy.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --loss IntListloss --cal_diversity 1 --no_cpu_baseline > $out/bench_pl_div.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline > $out/bench_gru4rec.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload tmall_pub --no_cpu_baseline > $out/bench_tmall_pub.json 2>/dev/null < /dev/null

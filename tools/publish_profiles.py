@@ -27,7 +27,8 @@ def bench(name, out):
 
 names = {'bench.json': 'bench_tmall', 'bench_bf16.json': 'bench_tmall_bf16', 'bench_lifedata.json': 'bench_lifedata', 'bench_stress.json': 'bench_stress',
          'bench_stress_b1024.json': 'bench_stress_b1024', 'bench_pl_div.json': 'bench_pl_div', 'bench_gru4rec.json': 'bench_gru4rec',
-         'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased'}
+         'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_stress_dense.json': 'bench_stress_dense_adam', 'bench_stress_b1024_dense.json': 'bench_stress_b1024_dense_adam',
+         'bench_tmall_b1024_dense.json': 'bench_tmall_b1024_dense_adam', 'bench_tmall_b1024.json': 'bench_tmall_b1024', 'bench_tmall_lazy.json': 'bench_tmall_lazy_adam', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased'}
 for k, v in names.items():
     bench(k, '%s_%s.json' % (rnd, v))
 sweep = []
@@ -60,6 +61,9 @@ if f and w:
 fb, wb = one('fetch_bf16/**/*counter_collection.csv'), one('write_bf16/**/*counter_collection.csv')
 if fb and wb:
     subprocess.run([sys.executable, 'tools/pmc_summary.py', fb, wb, '4', os.path.join(dst, '%s_pmc_traffic_bf16.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
+fl, wl = one('fetch_lazy/**/*counter_collection.csv'), one('write_lazy/**/*counter_collection.csv')
+if fl and wl:
+    subprocess.run([sys.executable, 'tools/pmc_summary.py', fl, wl, '4', os.path.join(dst, '%s_pmc_traffic_lazy_adam.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
 for t in ('f32_train', 'bf16_train', 'f32_eval'):
     f = os.path.join(src, 'timeline_%s.txt' % t)
     if os.path.exists(f):
