@@ -2033,6 +2033,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // CU), the next tile is prefetched into registers under the MFMAs.  db = column sums of dY is accumulated by the
 // staging threads in registers (a thread always owns the same four columns).
 // ------------------------------------------------------------------------------------------
+#ifndef WB_ABLATE          // tools/wgrad_ablate.sh: 1 no MFMAs, 2 no LDS staging stores (the loaded registers are only waited for), 4 only the first tile is loaded
+#define WB_ABLATE 0
+#endif
 #define WB_LDT 40          // 80-byte column pitch: four columns = 2.5 bank rows -> the 8-byte stores of a 16-lane group (two column
                            // blocks x eight row blocks) fall into disjoint bank halves; the b128 fragment reads are 2-way on 3 of 16 slots
 // TAIL: M is not a multiple of 32 (zero-padded last tile); Y16 / X16 (bf16 mode, NP = 1): dY / X is stored as a bf16 array
@@ -2121,6 +2124,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     }
   };
   auto store_tile = [&]() {
+    if (WB_ABLATE & 2) {
+#pragma unroll
+      for (int u = 0; u < YPT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(py[u][r]));
+#pragma unroll
+      for (int u = 0; u < XPT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" ::"v"(px[u][r]));
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < YPT; ++u) {
       const int b = tid + 256 * u;
@@ -2153,7 +2167,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   for (; t < ntiles; t += S) {
     store_tile();
     __syncthreads();
-    if (t + S < ntiles) load_tile(t + S);
+    if (!(WB_ABLATE & 4) && t + S < ntiles) load_tile(t + S);
+    if (WB_ABLATE & 1) { __syncthreads(); continue; }
     bf16x8 xh[KTW], xm[KTW], xl[KTW];
 #pragma unroll
     for (int j = 0; j < KTW; ++j) {
