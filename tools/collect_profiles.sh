@@ -30,10 +30,10 @@ timeout 300 python tools/step_timeline.py bf16 train full > $out/timeline_bf16_t
 timeout 300 python tools/step_timeline.py f32 eval full > $out/timeline_f32_eval.txt 2>&1 < /dev/null
 if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload lifedata --batch 2048 --no_cpu_baseline > $out/bench_lifedata.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --workload stress --batch 256 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --workload stress --batch 1024 --steps 5 --warmup 2 --no_cpu_baseline > $out/bench_stress_b1024.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --workload stress --batch 256 --adam dense --steps 5 --warmup 2 --no_cpu_baseline --no_bf16_line > $out/bench_stress_dense.json 2>/dev/null < /dev/null
-timeout 600 python bench.py --workload stress --batch 1024 --adam dense --steps 5 --warmup 2 --no_cpu_baseline --no_bf16_line > $out/bench_stress_b1024_dense.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 256 --steps 20 --warmup 3 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 1024 --steps 20 --warmup 3 --no_cpu_baseline > $out/bench_stress_b1024.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 256 --adam dense --steps 20 --warmup 3 --no_cpu_baseline --no_bf16_line > $out/bench_stress_dense.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload stress --batch 1024 --adam dense --steps 20 --warmup 3 --no_cpu_baseline --no_bf16_line > $out/bench_stress_b1024_dense.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --batch 1024 --adam dense --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_b1024_dense.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --batch 1024 --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_b1024.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --adam lazy --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_lazy.json 2>/dev/null < /dev/null
