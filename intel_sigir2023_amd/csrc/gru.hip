@@ -6,6 +6,9 @@
 #include "kernels.h"
 #include "session.h"
 
+int gru_fwd_steps(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
+                  float* out, int ldo, int col0, hipStream_t st);
+
 static float* carve(char* base, size_t& off, size_t n) {
   off = rup_sz(off, 256);
   float* p = reinterpret_cast<float*>(base + off);
@@ -105,8 +108,220 @@ __global__ void gru_gate_bwd_kernel(const float* __restrict__ dH, const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The recurrence as ONE kernel per direction (hidden size 128, the reference's constant: IntEL.py:105-106).  Sessions are
+// independent, so a workgroup owns 16 of them for the whole time loop: no launch, no [B, 3H] round trip through HBM and no
+// grid-wide dependency per step (the per-step form is two launches per step and direction: 80 dependent launches per encoder
+// and training step -- at batch 512 the whole step was that chain).
+//   * 512 threads = 8 waves; wave w owns hidden units 16w .. 16w+15 and, forward, their three gate columns (r, z, n tiles of
+//     h W_hh^T): its B fragments -- 3 x 128 x 16 floats of W_hh -- stay in 96 registers for the whole loop; backward, the
+//     16 columns of dGH W_hh (K = 384): again 96 registers;
+//   * the A operand (h_{t-1} [16, 128], resp. dGH_t [16, 384]) lives in LDS, rewritten by the gate phase of every step (row
+//     pitch +4 floats: the 16-byte fragment reads of 16 rows fall into disjoint banks);
+//   * exact fp32 MFMAs (v_mfma_f32_16x16x4_f32: lane (i, j) supplies k = 16 g + 4 j + s to MFMA s of group g); the accumulator
+//     tile puts rows 4j .. 4j+3 of unit i on lane (i, j), so the gate arithmetic is lane-local and the new state goes back to
+//     LDS with one 4-byte store per row;
+//   * the loop runs to the longest history of the workgroup's 16 sessions; shorter ones keep their state (forward) / pass the
+//     gradient through and write zero gate gradients (backward), as the per-step kernels do.
+// The same stashes as the per-step form (HP, GATES, GHN, HCUR; dGI, dGH), so the two forms mix freely (INTEL_GRU_SEQ=0: per step).
+// ------------------------------------------------------------------------------------------
+#define GS_ROWS 16
+#define GS_H 128
+#define GS_LDH (GS_H + 4)
+#define GS_LDG (3 * GS_H + 4)
+
+__device__ __forceinline__ f32x4 gs_mma4(const f32x4& a, const f32x4& b, f32x4 c) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) c = mfma16(a[s], b[s], c);
+  return c;
+}
+
+__global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
+                                                             const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
+                                                             float* __restrict__ HP, float* __restrict__ HCUR,
+                                                             float* __restrict__ GATES, float* __restrict__ GHN) {
+  __shared__ __attribute__((aligned(16))) float hs[GS_ROWS * GS_LDH];
+  __shared__ int slen[GS_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * GS_ROWS;
+  const int unit = 16 * w + p;
+  for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;          // h_0 = 0
+  if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
+  // B fragments: gate q, k group j: W_hh[q*128 + unit][16 j + 4 g .. + 3]
+  f32x4 wb[3][8];
+  float bh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    bh[q] = bhh[q * GS_H + unit];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wb[q][j] = *reinterpret_cast<const f32x4*>(Whh + (size_t)(q * GS_H + unit) * GS_H + 16 * j + 4 * g);
+  }
+  __syncthreads();
+  int tmax = 0, lr[4];
+#pragma unroll
+  for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) lr[r] = slen[4 * g + r];
+  float h[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < tmax; ++t) {
+    // gate inputs of this step: in flight under the MFMAs
+    float gi[4][3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = (size_t)(b0 + 4 * g + r) * T + t;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) gi[r][q] = (t < lr[r]) ? GI[row * (3 * GS_H) + q * GS_H + unit] : 0.f;
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) acc[q] = f32x4{bh[q], bh[q], bh[q], bh[q]};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(hs + p * GS_LDH + 16 * j + 4 * g);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = gs_mma4(a, wb[q][j], acc[q]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + 4 * g + r;
+      const size_t row = (size_t)b * T + t;
+      if (t < lr[r]) {
+        const float rg = sigm(gi[r][0] + acc[0][r]);
+        const float zg = sigm(gi[r][1] + acc[1][r]);
+        const float ghn = acc[2][r];
+        const float ng = tanhf(gi[r][2] + rg * ghn);
+        h[r] = (1.f - zg) * ng + zg * h[r];
+        float* ga = GATES + row * (3 * GS_H);
+        ga[unit] = rg; ga[GS_H + unit] = zg; ga[2 * GS_H + unit] = ng;
+        GHN[row * GS_H + unit] = ghn;
+      }
+      if (b < B && t + 1 < T) HP[(row + 1) * GS_H + unit] = h[r];
+    }
+    __syncthreads();                      // every wave has read h_{t-1}
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * GS_LDH + unit] = h[r];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * g + r;
+    if (b < B) {
+      HCUR[(size_t)b * GS_H + unit] = h[r];
+      // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
+      for (int t = max(tmax, 0); t + 1 < T; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
+                                                             const float* __restrict__ GATES, const float* __restrict__ GHN,
+                                                             const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
+                                                             float* __restrict__ dGI, float* __restrict__ dGH) {
+  __shared__ __attribute__((aligned(16))) float ds[GS_ROWS * GS_LDG];
+  __shared__ int slen[GS_ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * GS_ROWS;
+  const int unit = 16 * w + p;
+  if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
+  // B fragments of dh_{t-1} += dGH_t W_hh: k group j (of 24): W_hh[16 j + 4 g + s][unit]
+  f32x4 wb[24];
+#pragma unroll
+  for (int j = 0; j < 24; ++j)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) wb[j][s] = Whh[(size_t)(16 * j + 4 * g + s) * GS_H + unit];
+  __syncthreads();
+  int tmax = 0, lr[4];
+#pragma unroll
+  for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
+  float dh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    lr[r] = slen[4 * g + r];
+    const int b = b0 + 4 * g + r;
+    dh[r] = b < B ? dH0[(size_t)b * GS_H + unit] : 0.f;
+  }
+  // steps nobody in this workgroup reached: zero gate gradients (they feed the weight-gradient products over all B*T rows)
+  for (int t = T - 1; t >= tmax; --t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + 4 * g + r;
+      if (b < B) {
+        const size_t row = (size_t)b * T + t;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          dGI[row * (3 * GS_H) + q * GS_H + unit] = 0.f;
+          dGH[row * (3 * GS_H) + q * GS_H + unit] = 0.f;
+        }
+      }
+    }
+  for (int t = tmax - 1; t >= 0; --t) {
+    float dprev[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = b0 + 4 * g + r;
+      const size_t row = (size_t)b * T + t;
+      float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f;
+      dprev[r] = dh[r];
+      if (t < lr[r]) {
+        const float* ga = GATES + row * (3 * GS_H);
+        const float rg = ga[unit], zg = ga[GS_H + unit], ng = ga[2 * GS_H + unit];
+        const float hp = HP[row * GS_H + unit];
+        const float dn = dh[r] * (1.f - zg);
+        const float dz = dh[r] * (hp - ng);
+        dnp = dn * (1.f - ng * ng);
+        dzp = dz * zg * (1.f - zg);
+        const float dr = dnp * GHN[row * GS_H + unit];
+        drp = dr * rg * (1.f - rg);
+        dnr = dnp * rg;
+        dprev[r] = dh[r] * zg;
+      }
+      if (b < B) {
+        float* dgi = dGI + row * (3 * GS_H);
+        float* dgh = dGH + row * (3 * GS_H);
+        dgi[unit] = drp; dgi[GS_H + unit] = dzp; dgi[2 * GS_H + unit] = dnp;
+        dgh[unit] = drp; dgh[GS_H + unit] = dzp; dgh[2 * GS_H + unit] = dnr;
+      }
+      float* dl = ds + (4 * g + r) * GS_LDG;
+      dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
+    }
+    __syncthreads();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 24; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ds + p * GS_LDG + 16 * j + 4 * g);
+      acc = gs_mma4(a, wb[j], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dh[r] = dprev[r] + acc[r];
+    __syncthreads();                      // the next step rewrites ds
+  }
+}
+
+static bool gru_seq_on(int Hd, const float* Whh) {
+  static const bool on = [] { const char* e = getenv("INTEL_GRU_SEQ"); return !(e && e[0] == '0'); }();
+  return on && Hd == GS_H && Whh != nullptr && (reinterpret_cast<uintptr_t>(Whh) & 15) == 0;
+}
+
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
-            float* out, int ldo, int col0, hipStream_t st) {
+            float* out, int ldo, int col0, hipStream_t st, const float* Whh) {
+  if (gru_seq_on(Hd, Whh)) {
+    int rc;
+    GemmEpilogue ei;
+    ei.bias = bih;
+    if ((rc = launch_gemm_rows(E0, dm, B * T, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
+    if ((rc = launch_fill(g.HP, (long long)B * T * Hd, 0.f, st))) return rc;       // h_0 = 0 (HP[:, 0]); rows past B*T never read
+    LAUNCH(gru_seq_fwd_kernel, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
+    INTEL_CHECK_LAUNCH();
+    GemmEpilogue e0;
+    return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);
+  }
+  return gru_fwd_steps(g, E0, B, T, dm, Hd, len, bih, bhh, out, ldo, col0, st);
+}
+
+int gru_fwd_steps(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
+                  float* out, int ldo, int col0, hipStream_t st) {
   int rc;
   GemmEpilogue ei;
   ei.bias = bih;
@@ -131,14 +346,19 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,
             const float* dout, int ldo, int col0, const GruGrads& gg, float* dE0, float* scratch, float* slabs,
             hipStream_t st) {
-  (void)Whh; (void)bhh; (void)scratch;
+  (void)bhh; (void)scratch;
   int rc;
   // vec = HCUR Wout^T
   if (gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st))) return rc;
   GemmEpilogue e0;
   float *dH = g.dHa, *dHn = g.dHb;
   if ((rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
-  for (int t = T - 1; t >= 0; --t) {
+  const bool seq = gru_seq_on(Hd, Whh);
+  if (seq) {
+    LAUNCH(gru_seq_bwd_kernel, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
+    INTEL_CHECK_LAUNCH();
+  }
+  for (int t = T - 1; t >= 0 && !seq; --t) {
     LAUNCH(gru_gate_bwd_kernel, dim3(cdiv(B * Hd, 256)), dim3(256), 0, st, dH, g.HP, g.GATES, g.GHN, len, B, T, Hd, t,
                        g.dGI, g.dGH, dHn);
     INTEL_CHECK_LAUNCH();

@@ -1040,7 +1040,7 @@ void forward_impl(Run& r, const IntelOut* out) {
     } else {
       const int* len = e == 0 ? bt.history_len : bt.history_item_len;
       RUN(gru_fwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_BIH)),
-                  r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st));
+                  r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st, r.P(enc_slot(e, INTEL_ENC_GRU_WHH))));
     }
   };
   TowerBufs& ti = y.tw[0];

@@ -1,5 +1,7 @@
 """Experiment: capture one fused training step (all launches of the C ABI on torch's stream + the library's forked side
-streams) in a HIP graph through torch.cuda.CUDAGraph and replay it."""
+streams) in a HIP graph through torch.cuda.CUDAGraph and replay it.  (A replay repeats the captured step's scalars -- Adam's
+bias corrections, the noise seed -- so this times the launch path only.)
+usage: python tools/graph_probe.py [workload=tmall] [batch=4096]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch
@@ -7,12 +9,16 @@ from intel_sigir2023_amd import synth
 from intel_sigir2023_amd.engine import IntELEngine
 from intel_sigir2023_amd.model import IntEL
 dev = torch.device('cuda:0')
-args = synth.make_args('tmall', dev)
-corpus, _ = synth.make_corpus('tmall')
+wl = sys.argv[1] if len(sys.argv) > 1 else 'tmall'
+BS = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+args = synth.make_args(wl, dev)
+corpus, _ = synth.make_corpus(wl)
 torch.manual_seed(0)
 m = IntEL(args, corpus).to(dev)
 e = IntELEngine(m, 'IntBPRloss', args)
-b = synth.make_batch('tmall', 4096, dev, seed=1)
+b = synth.make_batch(wl, BS, dev, seed=1)
+b['_intel'] = m.prepare_batch(b)
+b['_intel'][1]['ranking_i32'] = b['ranking']
 B, Lm = b['i_id_s'].shape
 noise = torch.rand(B, Lm, Lm, device=dev)
 
