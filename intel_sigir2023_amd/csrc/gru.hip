@@ -136,26 +136,79 @@ __device__ __forceinline__ f32x4 gs_mma4(const f32x4& a, const f32x4& b, f32x4 c
   return c;
 }
 
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
+#define GS_LDP (GS_H + 8)            // bf16 plane pitch of the state rows (272 B: 16 rows' 16-byte fragments fall into disjoint banks)
+#define GS_LDQ (3 * GS_H + 8)        // ... of the gate-gradient rows
+
+__device__ __forceinline__ void gs_split(float x, __bf16& h, __bf16& m, __bf16& l) {
+  h = (__bf16)x;
+  const float r1 = x - (float)h;
+  m = (__bf16)r1;
+  l = (__bf16)(r1 - (float)m);
+}
+// eight consecutive floats -> three bf16 planes
+__device__ __forceinline__ void gs_split8(const float (&x)[8], gs_bf16x8& h, gs_bf16x8& m, gs_bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    __bf16 a, b, c;
+    gs_split(x[i], a, b, c);
+    h[i] = a; m[i] = b; l[i] = c;
+  }
+}
+// the six plane products of weight >= 2^-16, smallest first (as gemm_rows_b3 / tower.hip): fp32 accuracy on the bf16 pipe
+__device__ __forceinline__ f32x4 gs_mma6(const gs_bf16x8& ah, const gs_bf16x8& am, const gs_bf16x8& al, const gs_bf16x8& bh,
+                                         const gs_bf16x8& bm, const gs_bf16x8& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+  return c;
+}
+
+// PL: the step's product on the bf16 pipe as three-plane splits (six plane products: 72 MFMAs of 16 cycles per wave and step
+// instead of 96 of 32; the state / gate-gradient rows are kept in LDS as three bf16 planes, W_hh is split once into registers)
+template <bool PL>
 __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
                                                              const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
                                                              float* __restrict__ HP, float* __restrict__ HCUR,
                                                              float* __restrict__ GATES, float* __restrict__ GHN) {
-  __shared__ __attribute__((aligned(16))) float hs[GS_ROWS * GS_LDH];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDP * 2 : GS_ROWS * GS_LDH * 4];
+  float* hs = reinterpret_cast<float*>(smem_raw);
+  __bf16* hp3 = reinterpret_cast<__bf16*>(smem_raw);
+  constexpr int PLANE = GS_ROWS * GS_LDP;
   __shared__ int slen[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GS_ROWS;
   const int unit = 16 * w + p;
-  for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;          // h_0 = 0
+  if (PL) {
+    for (int i = tid; i < 3 * PLANE; i += 512) hp3[i] = (__bf16)0.f;      // h_0 = 0
+  } else {
+    for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;
+  }
   if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
-  // B fragments: gate q, k group j: W_hh[q*128 + unit][16 j + 4 g .. + 3]
-  f32x4 wb[3][8];
+  // B fragments: gate q, W_hh[q*128 + unit][k]: fp32 MFMAs take k = 16 j + 4 g + s, the bf16 ones k = 32 j + 8 g + s
+  f32x4 wb[PL ? 1 : 3][PL ? 1 : 8];
+  gs_bf16x8 wq[PL ? 3 : 1][PL ? 4 : 1][3];
   float bh[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     bh[q] = bhh[q * GS_H + unit];
+    const float* wrow = Whh + (size_t)(q * GS_H + unit) * GS_H;
+    if (PL) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wb[q][j] = *reinterpret_cast<const f32x4*>(Whh + (size_t)(q * GS_H + unit) * GS_H + 16 * j + 4 * g);
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g + 4);
+        const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        gs_split8(x, wq[PL ? q : 0][PL ? j : 0][0], wq[PL ? q : 0][PL ? j : 0][1], wq[PL ? q : 0][PL ? j : 0][2]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wb[PL ? 0 : q][PL ? 0 : j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j + 4 * g);
+    }
   }
   __syncthreads();
   int tmax = 0, lr[4];
@@ -176,11 +229,24 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     f32x4 acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = f32x4{bh[q], bh[q], bh[q], bh[q]};
+    if (PL) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(hs + p * GS_LDH + 16 * j + 4 * g);
+      for (int j = 0; j < 4; ++j) {
+        const __bf16* ap = hp3 + p * GS_LDP + 32 * j + 8 * g;
+        const gs_bf16x8 ah = *reinterpret_cast<const gs_bf16x8*>(ap);
+        const gs_bf16x8 am = *reinterpret_cast<const gs_bf16x8*>(ap + PLANE);
+        const gs_bf16x8 al = *reinterpret_cast<const gs_bf16x8*>(ap + 2 * PLANE);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) acc[q] = gs_mma4(a, wb[q][j], acc[q]);
+        for (int q = 0; q < 3; ++q)
+          acc[q] = gs_mma6(ah, am, al, wq[PL ? q : 0][PL ? j : 0][0], wq[PL ? q : 0][PL ? j : 0][1], wq[PL ? q : 0][PL ? j : 0][2], acc[q]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(hs + p * GS_LDH + 16 * j + 4 * g);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) acc[q] = gs_mma4(a, wb[PL ? 0 : q][PL ? 0 : j], acc[q]);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -200,7 +266,16 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     }
     __syncthreads();                      // every wave has read h_{t-1}
 #pragma unroll
-    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * GS_LDH + unit] = h[r];
+    for (int r = 0; r < 4; ++r) {
+      if (PL) {
+        __bf16 a, bq, c;
+        gs_split(h[r], a, bq, c);
+        __bf16* d = hp3 + (4 * g + r) * GS_LDP + unit;
+        d[0] = a; d[PLANE] = bq; d[2 * PLANE] = c;
+      } else {
+        hs[(4 * g + r) * GS_LDH + unit] = h[r];
+      }
+    }
     __syncthreads();
   }
 #pragma unroll
@@ -214,23 +289,41 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   }
 }
 
+template <bool PL>
 __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
                                                              const float* __restrict__ GATES, const float* __restrict__ GHN,
                                                              const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
                                                              float* __restrict__ dGI, float* __restrict__ dGH) {
-  __shared__ __attribute__((aligned(16))) float ds[GS_ROWS * GS_LDG];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDQ * 2 : GS_ROWS * GS_LDG * 4];
+  float* ds = reinterpret_cast<float*>(smem_raw);
+  __bf16* dq3 = reinterpret_cast<__bf16*>(smem_raw);
+  constexpr int PLANE = GS_ROWS * GS_LDQ;
   __shared__ int slen[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GS_ROWS;
   const int unit = 16 * w + p;
   if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
-  // B fragments of dh_{t-1} += dGH_t W_hh: k group j (of 24): W_hh[16 j + 4 g + s][unit]
-  f32x4 wb[24];
+  if (PL) {
+    for (int i = tid; i < 3 * PLANE; i += 512) dq3[i] = (__bf16)0.f;      // the pad columns are never written again
+  }
+  // B fragments of dh_{t-1} += dGH_t W_hh: W_hh[k][unit], k = 16 j + 4 g + s (fp32 MFMAs) / 32 j + 8 g + s (bf16 ones)
+  f32x4 wb[PL ? 1 : 24];
+  gs_bf16x8 wq[PL ? 12 : 1][3];
+  if (PL) {
 #pragma unroll
-  for (int j = 0; j < 24; ++j)
+    for (int j = 0; j < 12; ++j) {
+      float x[8];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) wb[j][s] = Whh[(size_t)(16 * j + 4 * g + s) * GS_H + unit];
+      for (int s = 0; s < 8; ++s) x[s] = Whh[(size_t)(32 * j + 8 * g + s) * GS_H + unit];
+      gs_split8(x, wq[PL ? j : 0][0], wq[PL ? j : 0][1], wq[PL ? j : 0][2]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 24; ++j)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wb[PL ? 0 : j][s] = Whh[(size_t)(16 * j + 4 * g + s) * GS_H + unit];
+  }
   __syncthreads();
   int tmax = 0, lr[4];
 #pragma unroll
@@ -283,25 +376,51 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         dgi[unit] = drp; dgi[GS_H + unit] = dzp; dgi[2 * GS_H + unit] = dnp;
         dgh[unit] = drp; dgh[GS_H + unit] = dzp; dgh[2 * GS_H + unit] = dnr;
       }
-      float* dl = ds + (4 * g + r) * GS_LDG;
-      dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
+      if (PL) {
+        const float v3[3] = {drp, dzp, dnr};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          __bf16 a, bq, c;
+          gs_split(v3[q], a, bq, c);
+          __bf16* d = dq3 + (4 * g + r) * GS_LDQ + q * GS_H + unit;
+          d[0] = a; d[PLANE] = bq; d[2 * PLANE] = c;
+        }
+      } else {
+        float* dl = ds + (4 * g + r) * GS_LDG;
+        dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
+      }
     }
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (PL) {
 #pragma unroll
-    for (int j = 0; j < 24; ++j) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(ds + p * GS_LDG + 16 * j + 4 * g);
-      acc = gs_mma4(a, wb[j], acc);
+      for (int j = 0; j < 12; ++j) {
+        const __bf16* ap = dq3 + p * GS_LDQ + 32 * j + 8 * g;
+        const gs_bf16x8 ah = *reinterpret_cast<const gs_bf16x8*>(ap);
+        const gs_bf16x8 am = *reinterpret_cast<const gs_bf16x8*>(ap + PLANE);
+        const gs_bf16x8 al = *reinterpret_cast<const gs_bf16x8*>(ap + 2 * PLANE);
+        acc = gs_mma6(ah, am, al, wq[PL ? j : 0][0], wq[PL ? j : 0][1], wq[PL ? j : 0][2], acc);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 24; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(ds + p * GS_LDG + 16 * j + 4 * g);
+        acc = gs_mma4(a, wb[PL ? 0 : j], acc);
+      }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh[r] = dprev[r] + acc[r];
-    __syncthreads();                      // the next step rewrites ds
+    __syncthreads();                      // the next step rewrites the gate-gradient rows
   }
 }
 
+// INTEL_GRU_SEQ: 0 the per-step form, 1 the one-kernel recurrence with exact fp32 MFMAs, 2 (default) with three-plane bf16 products
+static int gru_seq_mode() {
+  static const int m = [] { const char* e = getenv("INTEL_GRU_SEQ"); return e ? atoi(e) : 2; }();
+  return m;
+}
 static bool gru_seq_on(int Hd, const float* Whh) {
-  static const bool on = [] { const char* e = getenv("INTEL_GRU_SEQ"); return !(e && e[0] == '0'); }();
-  return on && Hd == GS_H && Whh != nullptr && (reinterpret_cast<uintptr_t>(Whh) & 15) == 0;
+  return gru_seq_mode() != 0 && Hd == GS_H && Whh != nullptr && (reinterpret_cast<uintptr_t>(Whh) & 15) == 0;
 }
 
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
@@ -312,7 +431,10 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     ei.bias = bih;
     if ((rc = launch_gemm_rows(E0, dm, B * T, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
     if ((rc = launch_fill(g.HP, (long long)B * T * Hd, 0.f, st))) return rc;       // h_0 = 0 (HP[:, 0]); rows past B*T never read
-    LAUNCH(gru_seq_fwd_kernel, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
+    if (gru_seq_mode() == 1)
+      LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
+    else
+      LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
     INTEL_CHECK_LAUNCH();
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);
@@ -355,7 +477,10 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
   if ((rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
   const bool seq = gru_seq_on(Hd, Whh);
   if (seq) {
-    LAUNCH(gru_seq_bwd_kernel, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
+    if (gru_seq_mode() == 1)
+      LAUNCH(gru_seq_bwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
+    else
+      LAUNCH(gru_seq_bwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
     INTEL_CHECK_LAUNCH();
   }
   for (int t = T - 1; t >= 0 && !seq; --t) {

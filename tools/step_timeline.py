@@ -1,7 +1,7 @@
 """The training (or evaluation) step as it really overlaps: every launch bracketed by two HIP events on its own stream
 (intel_prof_enable + intel_prof_timeline), branches left on their streams.  Far less intrusive than a tracing profiler, whose
 per-launch host cost makes the step host-bound.
-usage (GPU box): python tools/step_timeline.py [f32|bf16] [train|eval] [full]"""
+usage (GPU box): python tools/step_timeline.py [f32|bf16] [train|eval] [full] [workload=tmall] [batch=4096]"""
 import json
 import re
 import sys
@@ -16,14 +16,16 @@ from intel_sigir2023_amd.model import IntEL
 
 dtype = sys.argv[1] if len(sys.argv) > 1 else 'f32'
 mode = sys.argv[2] if len(sys.argv) > 2 else 'train'
-full = len(sys.argv) > 3
+full = len(sys.argv) > 3 and sys.argv[3] == 'full'
+wl = sys.argv[4] if len(sys.argv) > 4 else 'tmall'
+BS = int(sys.argv[5]) if len(sys.argv) > 5 else 4096
 dev = torch.device('cuda:0')
-args = synth.make_args('tmall', dev, dtype=dtype)
-corpus, _ = synth.make_corpus('tmall')
+args = synth.make_args(wl, dev, dtype=dtype)
+corpus, _ = synth.make_corpus(wl)
 torch.manual_seed(0)
 model = IntEL(args, corpus).to(dev)
 eng = IntELEngine(model, 'IntBPRloss', args)
-bs = [synth.make_batch('tmall', 4096, dev, seed=i) for i in range(4)]
+bs = [synth.make_batch(wl, BS, dev, seed=i) for i in range(4)]
 for b in bs:
     b['_intel'] = model.prepare_batch(b)
     b['_intel'][1]['ranking_i32'] = b['ranking']
