@@ -136,6 +136,10 @@ __device__ __forceinline__ f32x4 gs_mma4(const f32x4& a, const f32x4& b, f32x4 c
   return c;
 }
 
+// Workgroup barrier over the LDS rows only: __syncthreads() also waits for every global access of the wave (s_waitcnt vmcnt(0)),
+// i.e. for the step's stash stores to be acknowledged by HBM -- microseconds per step of a 20-step loop
+__device__ __forceinline__ void gs_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
 #define GS_LDP (GS_H + 8)            // bf16 plane pitch of the state rows (272 B: 16 rows' 16-byte fragments fall into disjoint banks)
 #define GS_LDQ (3 * GS_H + 8)        // ... of the gate-gradient rows
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
       }
       if (b < B && t + 1 < T) HP[(row + 1) * GS_H + unit] = h[r];
     }
-    __syncthreads();                      // every wave has read h_{t-1}
+    gs_lds_barrier();                     // every wave has read h_{t-1}
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       if (PL) {
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         hs[(4 * g + r) * GS_LDH + unit] = h[r];
       }
     }
-    __syncthreads();
+    gs_lds_barrier();
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
       }
     }
-    __syncthreads();
+    gs_lds_barrier();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (PL) {
 #pragma unroll
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh[r] = dprev[r] + acc[r];
-    __syncthreads();                      // the next step rewrites the gate-gradient rows
+    gs_lds_barrier();                     // the next step rewrites the gate-gradient rows
   }
 }
 

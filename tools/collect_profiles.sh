@@ -40,6 +40,8 @@ timeout 600 python bench.py --adam lazy --no_cpu_baseline --no_bf16_line --no_fe
 timeout 600 python bench.py --loss IntListloss --cal_diversity 1 --no_cpu_baseline > $out/bench_pl_div.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline > $out/bench_gru4rec.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload tmall_pub --no_cpu_baseline > $out/bench_tmall_pub.json 2>/dev/null < /dev/null
+INTEL_GRU_SEQ=0 timeout 600 python bench.py --encoder GRU4Rec --no_cpu_baseline --no_feed > $out/bench_gru4rec_steps.json 2>/dev/null < /dev/null
+INTEL_GRU_SEQ=0 timeout 600 python bench.py --workload tmall_pub --no_cpu_baseline --no_feed > $out/bench_tmall_pub_steps.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --zipf 1 --no_cpu_baseline > $out/bench_zipf.json 2>/dev/null < /dev/null
 INTEL_FUSE_TOWER=0 timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_unfused.json 2>/dev/null < /dev/null
 INTEL_BWD_SCHEDULE=phased timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_phased.json 2>/dev/null < /dev/null

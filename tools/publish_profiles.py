@@ -27,7 +27,7 @@ def bench(name, out):
 
 names = {'bench.json': 'bench_tmall', 'bench_bf16.json': 'bench_tmall_bf16', 'bench_lifedata.json': 'bench_lifedata', 'bench_stress.json': 'bench_stress',
          'bench_stress_b1024.json': 'bench_stress_b1024', 'bench_pl_div.json': 'bench_pl_div', 'bench_gru4rec.json': 'bench_gru4rec',
-         'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_stress_dense.json': 'bench_stress_dense_adam', 'bench_stress_b1024_dense.json': 'bench_stress_b1024_dense_adam',
+         'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_gru4rec_steps.json': 'bench_gru4rec_per_step', 'bench_tmall_pub_steps.json': 'bench_tmall_pub_per_step', 'bench_stress_dense.json': 'bench_stress_dense_adam', 'bench_stress_b1024_dense.json': 'bench_stress_b1024_dense_adam',
          'bench_tmall_b1024_dense.json': 'bench_tmall_b1024_dense_adam', 'bench_tmall_b1024.json': 'bench_tmall_b1024', 'bench_tmall_lazy.json': 'bench_tmall_lazy_adam', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased'}
 for k, v in names.items():
     bench(k, '%s_%s.json' % (rnd, v))
