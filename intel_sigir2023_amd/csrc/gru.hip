@@ -49,7 +49,17 @@ int gru_pack(GruBufs& g, const float* Wih, const float* Whh, const float* Wout, 
   return launch_pack_b(Wout, Hd, dm, Hd, 1, g.pWoutT, 0, st);
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+// Gate non-linearities on the hardware exp / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each) instead of libm's expf / tanhf, whose
+// range reductions and branches were most of a recurrence step's instructions (absolute error <= 2e-7, both forms of the recurrence)
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float gtanh(float x) {
+  const float ax = fabsf(x);
+  const float e = __expf(-2.f * ax);                                   // (0, 1]
+  const float big = (1.f - e) * __builtin_amdgcn_rcpf(1.f + e);
+  const float x2 = ax * ax;                                            // |x| < 0.1: odd series (the quotient cancels there)
+  const float small = ax * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  return copysignf(ax < 0.1f ? small : big, x);
+}
 
 // step t: gates from GI[:,t] + GH, new state -> HCUR and HP[:,t+1]
 __global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ GH, float* __restrict__ HP,
@@ -67,7 +77,7 @@ __global__ void gru_gate_fwd_kernel(const float* __restrict__ GI, const float* _
     const float r = sigm(gi[c] + gh[c]);
     const float z = sigm(gi[Hd + c] + gh[Hd + c]);
     const float ghn = gh[2 * Hd + c];
-    const float n = tanhf(gi[2 * Hd + c] + r * ghn);
+    const float n = gtanh(gi[2 * Hd + c] + r * ghn);
     hn = (1.f - z) * n + z * hp;
     float* ga = GATES + row * 3 * Hd;
     ga[c] = r; ga[Hd + c] = z; ga[2 * Hd + c] = n;
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         const float rg = sigm(gi[r][0] + acc[0][r]);
         const float zg = sigm(gi[r][1] + acc[1][r]);
         const float ghn = acc[2][r];
-        const float ng = tanhf(gi[r][2] + rg * ghn);
+        const float ng = gtanh(gi[r][2] + rg * ghn);
         h[r] = (1.f - zg) * ng + zg * h[r];
         float* ga = GATES + row * (3 * GS_H);
         ga[unit] = rg; ga[GS_H + unit] = zg; ga[2 * GS_H + unit] = ng;
@@ -353,6 +363,22 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         }
       }
     }
+  // the step's stash values (r, z, n, h_{t-1}, gh_n of four rows): loaded one step ahead, under the previous step's MFMAs
+  float sv[4][5];
+  auto load_stash = [&](int t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t row = (size_t)(b0 + 4 * g + r) * T + t;
+      const bool on = t >= 0 && t < lr[r];
+      const float* ga = GATES + row * (3 * GS_H);
+      sv[r][0] = on ? ga[unit] : 0.f;
+      sv[r][1] = on ? ga[GS_H + unit] : 0.f;
+      sv[r][2] = on ? ga[2 * GS_H + unit] : 0.f;
+      sv[r][3] = on ? HP[row * GS_H + unit] : 0.f;
+      sv[r][4] = on ? GHN[row * GS_H + unit] : 0.f;
+    }
+  };
+  load_stash(tmax - 1);
   for (int t = tmax - 1; t >= 0; --t) {
     float dprev[4];
 #pragma unroll
@@ -362,14 +388,13 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
       float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f;
       dprev[r] = dh[r];
       if (t < lr[r]) {
-        const float* ga = GATES + row * (3 * GS_H);
-        const float rg = ga[unit], zg = ga[GS_H + unit], ng = ga[2 * GS_H + unit];
-        const float hp = HP[row * GS_H + unit];
+        const float rg = sv[r][0], zg = sv[r][1], ng = sv[r][2];
+        const float hp = sv[r][3];
         const float dn = dh[r] * (1.f - zg);
         const float dz = dh[r] * (hp - ng);
         dnp = dn * (1.f - ng * ng);
         dzp = dz * zg * (1.f - zg);
-        const float dr = dnp * GHN[row * GS_H + unit];
+        const float dr = dnp * sv[r][4];
         drp = dr * rg * (1.f - rg);
         dnr = dnp * rg;
         dprev[r] = dh[r] * zg;
@@ -395,6 +420,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
       }
     }
     gs_lds_barrier();
+    load_stash(t - 1);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (PL) {
 #pragma unroll
