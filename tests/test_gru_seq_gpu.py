@@ -1,0 +1,65 @@
+"""The GRU4Rec recurrence (csrc/gru.hip) in its three forms.  The default is the one-kernel recurrence with three-plane bf16
+products (INTEL_GRU_SEQ=2), which the fixture / fuzz parity suites exercise in this process; the switch is read once per
+process, so the same suites are re-run in child processes with the exact-fp32-MFMA recurrence kernel (1) and with the per-step
+form (0: hidden GEMM + gate kernel per step, the round-1 path): forward outputs, losses and every parameter gradient against
+the reference fixtures (gru_bpr: models/GeneralSeq.py:58-78 through torch.nn.GRU) and the oracle's autograd, unchanged
+tolerances.  A direct comparison of the three forms on one batch with ragged histories (lengths 0 .. T, a batch that is not a
+multiple of the 16-session workgroup tile) follows."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('mode', ['0', '1'])
+def test_parity_suites_in_the_other_recurrence_forms(mode):
+    env = dict(os.environ, INTEL_GRU_SEQ=mode)
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_model_gpu.py', 'tests/test_fuzz_gpu.py', '-m', 'gpu', '-x', '-q',
+                        '-p', 'no:cacheprovider', '-k', 'gru or fuzz'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+
+
+_CHILD = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from intel_sigir2023_amd import synth
+from intel_sigir2023_amd.model import IntEL
+dev = torch.device('cuda:0')
+torch.manual_seed(11)
+args = synth.make_args('tiny', dev, encoder='GRU4Rec', cal_diversity=0)
+corpus, _ = synth.make_corpus('tiny')
+model = IntEL(args, corpus).to(dev)
+batch = synth.make_batch('tiny', 37, dev, seed=5, ragged=True)
+batch['history_len'][:3] = 0                     # sessions without history keep h = 0
+batch['history_item_len'][3:6] = 0
+model.train()
+out = model(batch)
+loss = (out['ens_score'] * torch.linspace(0.5, 1.5, out['ens_score'].numel(), device=dev).view_as(out['ens_score'])).sum() + out['intents'].square().sum()
+loss.backward()
+torch.save({'out': {k: v.detach().cpu() for k, v in out.items()},
+            'grads': {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}}, sys.argv[1])
+'''
+
+
+def test_three_forms_agree_on_ragged_histories(tmp_path):
+    import torch
+    res = {}
+    for mode in ('0', '1', '2'):
+        f = str(tmp_path / ('gru%s.pt' % mode))
+        r = subprocess.run([sys.executable, '-c', _CHILD % ROOT, f], cwd=ROOT, env=dict(os.environ, INTEL_GRU_SEQ=mode),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-3000:]
+        res[mode] = torch.load(f)
+    ref = res['0']
+    assert any('rnn' in k for k in ref['grads']), 'GRU parameters carry no gradient'
+    for mode in ('1', '2'):
+        for k, v in ref['out'].items():
+            assert float((res[mode]['out'][k] - v).abs().max()) <= 2e-6 * max(1.0, float(v.abs().max())), (mode, k)
+        for k, v in ref['grads'].items():
+            err = float((res[mode]['grads'][k] - v).abs().max())
+            assert err <= 2e-5 * max(1e-3, float(v.abs().max())), (mode, k, err, float(v.abs().max()))
