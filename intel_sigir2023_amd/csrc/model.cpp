@@ -957,7 +957,7 @@ float* bert_bwd(Run& r, int e) {
     const int ps = enc_slot(e, INTEL_ENC_POS);
     if (D.history_max + 1 > T && !r.ok(launch_fill(r.G(ps) + (size_t)T * dm, (long long)(D.history_max + 1 - T) * dm, 0.f, r.st))) return nullptr;
     r.acc(ps);
-    if (!r.ok(launch_pos_grad(dX, dm, off ? n.rowT : nullptr, len, T, rows, r.G(ps), r.st, r.ctx->rq))) return nullptr;
+    if (!r.ok(launch_pos_grad(dX, dm, off ? n.rowT : nullptr, len, T, rows, r.G(ps), r.st, r.ctx->rq, off, r.y.B))) return nullptr;
   } else if (r.G(enc_slot(e, INTEL_ENC_POS))) {      // table too large for LDS: onehot^T dE through the weight-gradient kernel
     const int ps = enc_slot(e, INTEL_ENC_POS);
     if (!r.ok(launch_make_onehot(off ? n.rowT : nullptr, len, T, rows, T, r.T->ONEHOT, r.st))) return nullptr;

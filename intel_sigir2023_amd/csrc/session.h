@@ -43,7 +43,8 @@ int launch_select_last(const float* E, int dm, const int* len, int B, int T, flo
 int launch_add_pos_rows(float* E, int dm, const float* pos, const int* row_t, int rows, hipStream_t st);
 bool pos_grad_supported(int T, int dm);
 int pos_grad_slabs(int rows);
-int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st, ReduceQueue* q);
+int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st, ReduceQueue* q,
+                    const int* off = nullptr, int B = 0);      // off (packed rows: first row of every session): the atomic-free form
 int launch_his_pack(const int* len, const int* off, int B, int T, const int* ids, int* ids_out, const int* idx2, int* idx2_out,
                     const float* vec, int w, float* vec_out, int* row_t, hipStream_t st);
 int launch_copy_cols(const float* src, int lds, int scol0, int d, long long M, float* dst, int ldd, int dcol0,

@@ -784,6 +784,38 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
   float* slab = slabs + (size_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += 256) slab[i] = s_tab[i];
 }
+// Packed rows (off[b] = first row of session b, len[b] rows, position = row - off[b]): no atomics at all.  A thread keeps one
+// column; it visits the rows at ITS positions (t = tsub, tsub + 256/dm, ...) of the workgroup's sessions and sums them in a
+// register -- every row is read once, by the dm lanes of one position group, and the slab is written directly.  The LDS-atomic
+// form above spends its time in ds_add_f32 (5.5 M of them per encoder at Tmall shape: 34 us; deeper load unrolling and a
+// division-free index did not move it).
+#define PGP_SESS 8            // sessions whose rows are in flight together
+__global__ __launch_bounds__(256) void pos_grad_packed_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ off,
+                                                              const int* __restrict__ len, int B, int T, float* __restrict__ slabs) {
+  const int c = threadIdx.x % dm, tsub = threadIdx.x / dm, tpp = 256 / dm;
+  const int per = (B + gridDim.x - 1) / gridDim.x;
+  const int b_begin = blockIdx.x * per, b_end = min(B, b_begin + per);
+  float* slab = slabs + (size_t)blockIdx.x * T * dm;
+  for (int t = tsub; t < T; t += tpp) {
+    float acc = 0.f;
+    for (int b0 = b_begin; b0 < b_end; b0 += PGP_SESS) {
+      int o[PGP_SESS], l[PGP_SESS];
+#pragma unroll
+      for (int u = 0; u < PGP_SESS; ++u) {
+        const int b = min(b0 + u, b_end - 1);
+        o[u] = off[b];
+        l[u] = (b0 + u < b_end) ? min(len[b], T) : 0;
+      }
+      float v[PGP_SESS];
+#pragma unroll
+      for (int u = 0; u < PGP_SESS; ++u) v[u] = (t < l[u]) ? dE[(size_t)(o[u] + t) * dm + c] : 0.f;
+#pragma unroll
+      for (int u = 0; u < PGP_SESS; ++u) acc += v[u];
+    }
+    slab[(size_t)t * dm + c] = acc;
+  }
+}
+
 int pos_grad_slabs(int rows) {
   int s = cdiv(rows, 64);
   return s < 1 ? 1 : (s > 512 ? 512 : s);
@@ -791,8 +823,21 @@ int pos_grad_slabs(int rows) {
 bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * sizeof(float) <= 150 * 1024; }
 // dpos[0:T, :] = the sum (valid after redq_flush); needs pos_grad_slabs(rows) * T * dm floats of the queue's arena
 int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st,
-                    ReduceQueue* q) {
+                    ReduceQueue* q, const int* off, int B) {
   if (rows <= 0) return 0;
+  static const bool packed_on = [] { const char* e = getenv("INTEL_POS_GRAD_PACKED"); return !(e && e[0] == '0'); }();
+  if (packed_on && off && row_t && B > 0 && dm <= 256 && 256 % dm == 0 && q) {
+    const int S = (B + 7) / 8 < 1 ? 1 : ((B + 7) / 8 > 512 ? 512 : (B + 7) / 8);
+    float* slabs = redq_alloc(q, (size_t)S * T * dm);
+    if (!slabs) {
+      intel_set_error("pos_grad: reduction arena exhausted");
+      return -2;
+    }
+    LAUNCH_W(0.0, 4.0 * (double)rows * dm, pos_grad_packed_kernel, dim3(S), dim3(256), 0, st, dE, dm, off, len, B, T, slabs);
+    INTEL_CHECK_LAUNCH();
+    redq_push(q, slabs, (size_t)T * dm, S, T, dm, dpos, dm, 0);
+    return 0;
+  }
   INTEL_CHECK_ARG(pos_grad_supported(T, dm) && q, "pos_grad: table %d x %d does not fit LDS", T, dm);
   const size_t smem = (size_t)T * dm * sizeof(float);
   allow_lds(pos_grad_kernel, smem);
