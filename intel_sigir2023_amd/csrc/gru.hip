@@ -187,7 +187,8 @@ template <bool PL>
 __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
                                                              const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
                                                              float* __restrict__ HP, float* __restrict__ HCUR,
-                                                             float* __restrict__ GATES, float* __restrict__ GHN) {
+                                                             float* __restrict__ GATES, float* __restrict__ GHN,
+                                                             const int* __restrict__ off) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDP * 2 : GS_ROWS * GS_LDH * 4];
   float* hs = reinterpret_cast<float*>(smem_raw);
   __bf16* hp3 = reinterpret_cast<__bf16*>(smem_raw);
@@ -226,17 +227,22 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   }
   __syncthreads();
   int tmax = 0, lr[4];
+  size_t rb[4];           // first row of the session: b*T (padded [B, T] rows) or off[b] (packed: only the len[b] valid rows exist)
 #pragma unroll
   for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) lr[r] = slen[4 * g + r];
+  for (int r = 0; r < 4; ++r) {
+    lr[r] = slen[4 * g + r];
+    const int b = b0 + 4 * g + r;
+    rb[r] = b < B ? (off ? (size_t)off[b] : (size_t)b * T) : 0;
+  }
   float h[4] = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < tmax; ++t) {
     // gate inputs of this step: in flight under the MFMAs
     float gi[4][3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t row = (size_t)(b0 + 4 * g + r) * T + t;
+      const size_t row = rb[r] + t;
 #pragma unroll
       for (int q = 0; q < 3; ++q) gi[r][q] = (t < lr[r]) ? GI[row * (3 * GS_H) + q * GS_H + unit] : 0.f;
     }
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + 4 * g + r;
-      const size_t row = (size_t)b * T + t;
+      const size_t row = rb[r] + t;
       if (t < lr[r]) {
         const float rg = sigm(gi[r][0] + acc[0][r]);
         const float zg = sigm(gi[r][1] + acc[1][r]);
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         ga[unit] = rg; ga[GS_H + unit] = zg; ga[2 * GS_H + unit] = ng;
         GHN[row * GS_H + unit] = ghn;
       }
-      if (b < B && t + 1 < T) HP[(row + 1) * GS_H + unit] = h[r];
+      if (b < B && t + 1 < (off ? lr[r] : T)) HP[(row + 1) * GS_H + unit] = h[r];      // packed: row t+1 exists only below len
     }
     gs_lds_barrier();                     // every wave has read h_{t-1}
 #pragma unroll
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     if (b < B) {
       HCUR[(size_t)b * GS_H + unit] = h[r];
       // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
-      for (int t = max(tmax, 0); t + 1 < T; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
+      // (padded rows only: packed histories have no rows past len)
+      for (int t = max(tmax, 0); t + 1 < T && !off; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
     }
   }
 }
@@ -307,7 +314,7 @@ template <bool PL>
 __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
                                                              const float* __restrict__ GATES, const float* __restrict__ GHN,
                                                              const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
-                                                             float* __restrict__ dGI, float* __restrict__ dGH) {
+                                                             float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDQ * 2 : GS_ROWS * GS_LDG * 4];
   float* ds = reinterpret_cast<float*>(smem_raw);
   __bf16* dq3 = reinterpret_cast<__bf16*>(smem_raw);
@@ -343,14 +350,17 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
   float dh[4];
+  size_t rb[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     lr[r] = slen[4 * g + r];
     const int b = b0 + 4 * g + r;
     dh[r] = b < B ? dH0[(size_t)b * GS_H + unit] : 0.f;
+    rb[r] = b < B ? (off ? (size_t)off[b] : (size_t)b * T) : 0;
   }
-  // steps nobody in this workgroup reached: zero gate gradients (they feed the weight-gradient products over all B*T rows)
-  for (int t = T - 1; t >= tmax; --t)
+  // steps nobody in this workgroup reached: zero gate gradients (they feed the weight-gradient products over all B*T rows;
+  // packed histories have no such rows)
+  for (int t = T - 1; t >= tmax && !off; --t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + 4 * g + r;
@@ -368,7 +378,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
   auto load_stash = [&](int t) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const size_t row = (size_t)(b0 + 4 * g + r) * T + t;
+      const size_t row = rb[r] + t;
       const bool on = t >= 0 && t < lr[r];
       const float* ga = GATES + row * (3 * GS_H);
       sv[r][0] = on ? ga[unit] : 0.f;
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int b = b0 + 4 * g + r;
-      const size_t row = (size_t)b * T + t;
+      const size_t row = rb[r] + t;
       float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f;
       dprev[r] = dh[r];
       if (t < lr[r]) {
@@ -399,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         dnr = dnp * rg;
         dprev[r] = dh[r] * zg;
       }
-      if (b < B) {
+      if (b < B && (!off || t < lr[r])) {       // packed: the row exists only below len
         float* dgi = dGI + row * (3 * GS_H);
         float* dgh = dGH + row * (3 * GS_H);
         dgi[unit] = drp; dgi[GS_H + unit] = dzp; dgi[2 * GS_H + unit] = dnp;
@@ -453,18 +463,22 @@ static bool gru_seq_on(int Hd, const float* Whh) {
   return gru_seq_mode() != 0 && Hd == GS_H && Whh != nullptr && (reinterpret_cast<uintptr_t>(Whh) & 15) == 0;
 }
 
+bool gru_packed_supported(int Hd) { return gru_seq_mode() != 0 && Hd == GS_H; }
+
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
-            float* out, int ldo, int col0, hipStream_t st, const float* Whh) {
+            float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows) {
+  if (!off) rows = B * T;
+  INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   if (gru_seq_on(Hd, Whh)) {
     int rc;
     GemmEpilogue ei;
     ei.bias = bih;
-    if ((rc = launch_gemm_rows(E0, dm, B * T, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
-    if ((rc = launch_fill(g.HP, (long long)B * T * Hd, 0.f, st))) return rc;       // h_0 = 0 (HP[:, 0]); rows past B*T never read
+    if ((rc = launch_gemm_rows(E0, dm, rows, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
+    if ((rc = launch_fill(g.HP, (long long)rows * Hd, 0.f, st))) return rc;       // h_0 = 0 (the first row of every session)
     if (gru_seq_mode() == 1)
-      LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
+      LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off);
     else
-      LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN);
+      LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off);
     INTEL_CHECK_LAUNCH();
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);
@@ -497,8 +511,9 @@ int gru_fwd_steps(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, con
 
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,
             const float* dout, int ldo, int col0, const GruGrads& gg, float* dE0, float* scratch, float* slabs,
-            hipStream_t st) {
+            hipStream_t st, const int* off, int prows) {
   (void)bhh; (void)scratch;
+  INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   int rc;
   // vec = HCUR Wout^T
   if (gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st))) return rc;
@@ -508,9 +523,9 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
   const bool seq = gru_seq_on(Hd, Whh);
   if (seq) {
     if (gru_seq_mode() == 1)
-      LAUNCH(gru_seq_bwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
+      LAUNCH(gru_seq_bwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off);
     else
-      LAUNCH(gru_seq_bwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH);
+      LAUNCH(gru_seq_bwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off);
     INTEL_CHECK_LAUNCH();
   }
   for (int t = T - 1; t >= 0 && !seq; --t) {
@@ -523,7 +538,7 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     if ((rc = launch_gemm_rows(g.dGH + (size_t)t * 3 * Hd, T * 3 * Hd, B, 3 * Hd, g.pWhhT, Hd, dHn, Hd, ea, st))) return rc;
     float* tmp = dH; dH = dHn; dHn = tmp;
   }
-  const int rows = B * T;
+  const int rows = off ? prows : B * T;
   if (gg.dWih && (rc = launch_wgrad(g.dGI, 3 * Hd, E0, dm, rows, 3 * Hd, dm, gg.dWih, dm, gg.dbih, 0, slabs, st))) return rc;
   if (gg.dWhh && (rc = launch_wgrad(g.dGH, 3 * Hd, g.HP, Hd, rows, 3 * Hd, Hd, gg.dWhh, Hd, gg.dbhh, 0, slabs, st))) return rc;
   return launch_gemm_rows(g.dGI, 3 * Hd, rows, 3 * Hd, g.pWihT, dm, dE0, dm, e0, st);

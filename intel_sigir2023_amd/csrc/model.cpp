@@ -1040,7 +1040,8 @@ void forward_impl(Run& r, const IntelOut* out) {
     } else {
       const int* len = e == 0 ? bt.history_len : bt.history_item_len;
       RUN(gru_fwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_BIH)),
-                  r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st, r.P(enc_slot(e, INTEL_ENC_GRU_WHH))));
+                  r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
+                  pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows));
     }
   };
   TowerBufs& ti = y.tw[0];
@@ -1338,7 +1339,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       gg.dWout = r.G(enc_slot(e, INTEL_ENC_GRU_OUT));
       dE = r.T->dXa;
       r.ok(gru_bwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
-                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, r.T->dXb, r.T->SLABS, r.st));
+                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, r.T->dXb, r.T->SLABS, r.st,
+                   pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows));
     }
     if (r.rc || !dE) return nullptr;
     if (e == 0) {
@@ -1696,15 +1698,16 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   const bool dropout = train && ctx->drop_p > 0.f;
   make_layout(ctx->d, batch->B, batch->L, batch->H, batch->Hi, static_cast<char*>(workspace), ctx->lay, dropout);
   ctx->fwd_dropout = dropout;
-  {   // run the BERT4Rec encoders on the valid history rows only when the caller supplied the row offsets (INTEL_PACK_HISTORY=0: never)
+  {   // run the encoders on the valid history rows only when the caller supplied the row offsets (INTEL_PACK_HISTORY=0: never)
     static const int pack_on = [] { const char* e = getenv("INTEL_PACK_HISTORY"); return (e && e[0] == '0') ? 0 : 1; }();
     const IntelDesc& D = ctx->d;
     for (int e = 0; e < 2; ++e) {
       const int T = e == 0 ? batch->H : batch->Hi, dm = e == 0 ? D.d_c + D.d_int : D.d_id + D.d_int;
       const int* off = e == 0 ? batch->his_off : batch->hisitem_off;
       const int nrows = e == 0 ? batch->n_his_rows : batch->n_hisitem_rows;
-      const bool pk = pack_on && off && nrows > 0 && nrows <= batch->B * T && D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 1 &&
-                      attn_seq_packed_supported(T, dm / D.enc_heads);
+      const bool pk = pack_on && off && nrows > 0 && nrows <= batch->B * T &&
+                      ((D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 1 && attn_seq_packed_supported(T, dm / D.enc_heads)) ||
+                       (D.encoder == INTEL_ENC_GRU4REC && gru_packed_supported(D.gru_hidden)));
       ctx->enc_packed[e] = pk;
       ctx->enc_rows[e] = pk ? nrows : batch->B * T;
     }

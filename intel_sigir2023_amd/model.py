@@ -364,9 +364,9 @@ class IntEL(nn.Module):
                     raise L.IntelHipError('batch[%r] holds ids outside [0, %d)' % (key, hi))
         b = L.IntelBatch(B=Bsz, L=Lmax, H=H, Hi=Hi)
         # packed histories: when the producer of the batch knows the total number of valid history rows on the HOST (the device
-        # feed, the synthetic generator and data.collate_batch do: 'his_rows' / 'hisitem_rows'), the BERT4Rec encoders run on those
+        # feed, the synthetic generator and data.collate_batch do: 'his_rows' / 'hisitem_rows'), the sequence encoders run on those
         # rows only.  The offsets are two small prefix sums; nothing here synchronises with the device
-        if 'his_rows' in data and 'hisitem_rows' in data and self.encoder_name == 'BERT4Rec':
+        if 'his_rows' in data and 'hisitem_rows' in data:
             for key, lens, total in (('his_off', keep['history_len'], data['his_rows']), ('hisitem_off', keep['history_item_len'], data['hisitem_rows'])):
                 c = torch.cumsum(lens, 0, dtype=torch.int32)
                 keep[key] = (c - lens).contiguous()
