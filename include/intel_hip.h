@@ -143,6 +143,11 @@ typedef struct IntelBatch {
   const int* iid_sort_ids;     const int* iid_sort_rows;
   const int* cls_sort_ids;     const int* cls_sort_rows;
   const int* hisitem_sort_ids; const int* hisitem_sort_rows;
+  /* optional (GRU4Rec encoders): the sessions ordered by history_len / history_item_len (device int [B], a permutation of
+   * 0 .. B-1; NULL = batch order).  The one-kernel recurrence gives 16 consecutive sessions of this order to a workgroup, whose
+   * time loop runs to the longest of them: with sessions of similar length together a workgroup stops at its own length instead
+   * of (almost always) the maximum.  Results do not depend on the order. */
+  const int* his_order; const int* hisitem_order;
 } IntelBatch;
 
 /* Outputs of IntEL.forward (IntEL.py:117-124). */

@@ -89,7 +89,7 @@ class IntelBatch(C.Structure):
         'i_id_s', 'i_class_c', 'scores', 'session_len', 'u_id_c', 'context_mh', 'his_context_mh',
         'his_intents', 'history_len', 'his_item_id', 'his_item_idx', 'his_item_int', 'history_item_len', 'his_off', 'hisitem_off')] + \
         [('n_his_rows', C.c_int), ('n_hisitem_rows', C.c_int)] + \
-        [(n, C.c_void_p) for n in ('iid_sort_ids', 'iid_sort_rows', 'cls_sort_ids', 'cls_sort_rows', 'hisitem_sort_ids', 'hisitem_sort_rows')]
+        [(n, C.c_void_p) for n in ('iid_sort_ids', 'iid_sort_rows', 'cls_sort_ids', 'cls_sort_rows', 'hisitem_sort_ids', 'hisitem_sort_rows', 'his_order', 'hisitem_order')]
 
 
 class IntelFeedStore(C.Structure):

@@ -188,12 +188,12 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
                                                              const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
                                                              float* __restrict__ HP, float* __restrict__ HCUR,
                                                              float* __restrict__ GATES, float* __restrict__ GHN,
-                                                             const int* __restrict__ off) {
+                                                             const int* __restrict__ off, const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDP * 2 : GS_ROWS * GS_LDH * 4];
   float* hs = reinterpret_cast<float*>(smem_raw);
   __bf16* hp3 = reinterpret_cast<__bf16*>(smem_raw);
   constexpr int PLANE = GS_ROWS * GS_LDP;
-  __shared__ int slen[GS_ROWS];
+  __shared__ int slen[GS_ROWS], sses[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GS_ROWS;
@@ -203,7 +203,12 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   } else {
     for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;
   }
-  if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
+  // workgroup slot i is session order[b0 + i] (sessions of similar length together) or b0 + i
+  if (tid < GS_ROWS) {
+    const int bsess = (b0 + tid < B) ? (order ? order[b0 + tid] : b0 + tid) : -1;
+    sses[tid] = bsess;
+    slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
+  }
   // B fragments: gate q, W_hh[q*128 + unit][k]: fp32 MFMAs take k = 16 j + 4 g + s, the bf16 ones k = 32 j + 8 g + s
   f32x4 wb[PL ? 1 : 3][PL ? 1 : 8];
   gs_bf16x8 wq[PL ? 3 : 1][PL ? 4 : 1][3];
@@ -230,11 +235,12 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   size_t rb[4];           // first row of the session: b*T (padded [B, T] rows) or off[b] (packed: only the len[b] valid rows exist)
 #pragma unroll
   for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
+  int bs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     lr[r] = slen[4 * g + r];
-    const int b = b0 + 4 * g + r;
-    rb[r] = b < B ? (off ? (size_t)off[b] : (size_t)b * T) : 0;
+    bs[r] = sses[4 * g + r];
+    rb[r] = bs[r] >= 0 ? (off ? (size_t)off[bs[r]] : (size_t)bs[r] * T) : 0;
   }
   float h[4] = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < tmax; ++t) {
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int b = b0 + 4 * g + r;
+      const int b = bs[r] >= 0 ? bs[r] : B;
       const size_t row = rb[r] + t;
       if (t < lr[r]) {
         const float rg = sigm(gi[r][0] + acc[0][r]);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int b = b0 + 4 * g + r;
+    const int b = bs[r] >= 0 ? bs[r] : B;
     if (b < B) {
       HCUR[(size_t)b * GS_H + unit] = h[r];
       // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
@@ -314,17 +320,22 @@ template <bool PL>
 __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
                                                              const float* __restrict__ GATES, const float* __restrict__ GHN,
                                                              const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
-                                                             float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off) {
+                                                             float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off,
+                                                             const int* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDQ * 2 : GS_ROWS * GS_LDG * 4];
   float* ds = reinterpret_cast<float*>(smem_raw);
   __bf16* dq3 = reinterpret_cast<__bf16*>(smem_raw);
   constexpr int PLANE = GS_ROWS * GS_LDQ;
-  __shared__ int slen[GS_ROWS];
+  __shared__ int slen[GS_ROWS], sses[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GS_ROWS;
   const int unit = 16 * w + p;
-  if (tid < GS_ROWS) slen[tid] = (b0 + tid < B) ? min(len[b0 + tid], T) : 0;
+  if (tid < GS_ROWS) {
+    const int bsess = (b0 + tid < B) ? (order ? order[b0 + tid] : b0 + tid) : -1;
+    sses[tid] = bsess;
+    slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
+  }
   if (PL) {
     for (int i = tid; i < 3 * PLANE; i += 512) dq3[i] = (__bf16)0.f;      // the pad columns are never written again
   }
@@ -351,10 +362,12 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
   for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
   float dh[4];
   size_t rb[4];
+  int bs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     lr[r] = slen[4 * g + r];
-    const int b = b0 + 4 * g + r;
+    bs[r] = sses[4 * g + r];
+    const int b = bs[r] >= 0 ? bs[r] : B;
     dh[r] = b < B ? dH0[(size_t)b * GS_H + unit] : 0.f;
     rb[r] = b < B ? (off ? (size_t)off[b] : (size_t)b * T) : 0;
   }
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
   for (int t = T - 1; t >= tmax && !off; --t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int b = b0 + 4 * g + r;
+      const int b = bs[r] >= 0 ? bs[r] : B;
       if (b < B) {
         const size_t row = (size_t)b * T + t;
 #pragma unroll
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
     float dprev[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int b = b0 + 4 * g + r;
+      const int b = bs[r] >= 0 ? bs[r] : B;
       const size_t row = rb[r] + t;
       float drp = 0.f, dzp = 0.f, dnp = 0.f, dnr = 0.f;
       dprev[r] = dh[r];
@@ -466,7 +479,7 @@ static bool gru_seq_on(int Hd, const float* Whh) {
 bool gru_packed_supported(int Hd) { return gru_seq_mode() != 0 && Hd == GS_H; }
 
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
-            float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows) {
+            float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows, const int* order) {
   if (!off) rows = B * T;
   INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   if (gru_seq_on(Hd, Whh)) {
@@ -476,9 +489,9 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     if ((rc = launch_gemm_rows(E0, dm, rows, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
     if ((rc = launch_fill(g.HP, (long long)rows * Hd, 0.f, st))) return rc;       // h_0 = 0 (the first row of every session)
     if (gru_seq_mode() == 1)
-      LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off);
+      LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     else
-      LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off);
+      LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     INTEL_CHECK_LAUNCH();
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);
@@ -511,7 +524,7 @@ int gru_fwd_steps(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, con
 
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,
             const float* dout, int ldo, int col0, const GruGrads& gg, float* dE0, float* scratch, float* slabs,
-            hipStream_t st, const int* off, int prows) {
+            hipStream_t st, const int* off, int prows, const int* order) {
   (void)bhh; (void)scratch;
   INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   int rc;
@@ -523,9 +536,9 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
   const bool seq = gru_seq_on(Hd, Whh);
   if (seq) {
     if (gru_seq_mode() == 1)
-      LAUNCH(gru_seq_bwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off);
+      LAUNCH(gru_seq_bwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off, order);
     else
-      LAUNCH(gru_seq_bwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off);
+      LAUNCH(gru_seq_bwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, dH, g.HP, g.GATES, g.GHN, Whh, len, B, T, g.dGI, g.dGH, off, order);
     INTEL_CHECK_LAUNCH();
   }
   for (int t = T - 1; t >= 0 && !seq; --t) {

@@ -371,6 +371,11 @@ class IntEL(nn.Module):
                 c = torch.cumsum(lens, 0, dtype=torch.int32)
                 keep[key] = (c - lens).contiguous()
             b.n_his_rows, b.n_hisitem_rows = int(data['his_rows']), int(data['hisitem_rows'])
+        if self.encoder_name == 'GRU4Rec' and os.environ.get('INTEL_GRU_ORDER', '1') != '0':
+            # sessions ordered by history length for the one-kernel recurrence (a workgroup's time loop runs to the longest of its 16
+            # sessions): depends on the batch only, like the row offsets above
+            keep['his_order'] = torch.argsort(keep['history_len'], stable=True).to(torch.int32).contiguous()
+            keep['hisitem_order'] = torch.argsort(keep['history_item_len'], stable=True).to(torch.int32).contiguous()
         for k, v in keep.items():
             setattr(b, k, v.data_ptr())
         prepared = (b, keep)
