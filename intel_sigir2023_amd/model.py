@@ -374,8 +374,9 @@ class IntEL(nn.Module):
         if self.encoder_name == 'GRU4Rec' and os.environ.get('INTEL_GRU_ORDER', '1') != '0':
             # sessions ordered by history length for the one-kernel recurrence (a workgroup's time loop runs to the longest of its 16
             # sessions): depends on the batch only, like the row offsets above
-            keep['his_order'] = torch.argsort(keep['history_len'], stable=True).to(torch.int32).contiguous()
-            keep['hisitem_order'] = torch.argsort(keep['history_item_len'], stable=True).to(torch.int32).contiguous()
+            desc = os.environ.get('INTEL_GRU_ORDER', '1') == '2'          # 2: longest first (training equal, evaluation 4.1 M against 4.3 M sessions/s)
+            keep['his_order'] = torch.argsort(keep['history_len'], descending=desc, stable=True).to(torch.int32).contiguous()
+            keep['hisitem_order'] = torch.argsort(keep['history_item_len'], descending=desc, stable=True).to(torch.int32).contiguous()
         for k, v in keep.items():
             setattr(b, k, v.data_ptr())
         prepared = (b, keep)
