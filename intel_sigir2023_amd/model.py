@@ -371,7 +371,7 @@ class IntEL(nn.Module):
                 c = torch.cumsum(lens, 0, dtype=torch.int32)
                 keep[key] = (c - lens).contiguous()
             b.n_his_rows, b.n_hisitem_rows = int(data['his_rows']), int(data['hisitem_rows'])
-        if self.encoder_name == 'GRU4Rec' and os.environ.get('INTEL_GRU_ORDER', '1') != '0' and Bsz >= 1024:      # fewer workgroups than CUs: nothing to free
+        if self.encoder_name == 'GRU4Rec' and os.environ.get('INTEL_GRU_ORDER', '1') != '0' and Bsz >= int(os.environ.get('INTEL_GRU_ORDER_MIN_B', '1024')):      # fewer workgroups than CUs: nothing to free
             # sessions ordered by history length for the one-kernel recurrence (a workgroup's time loop runs to the longest of its 16
             # sessions): depends on the batch only, like the row offsets above
             desc = os.environ.get('INTEL_GRU_ORDER', '1') == '2'          # 2: longest first (training equal, evaluation 4.1 M against 4.3 M sessions/s)

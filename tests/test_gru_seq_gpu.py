@@ -51,7 +51,7 @@ def test_three_forms_agree_on_ragged_histories(tmp_path):
     res = {}
     for mode in ('0', '1', '2'):
         f = str(tmp_path / ('gru%s.pt' % mode))
-        r = subprocess.run([sys.executable, '-c', _CHILD % ROOT, f], cwd=ROOT, env=dict(os.environ, INTEL_GRU_SEQ=mode),
+        r = subprocess.run([sys.executable, '-c', _CHILD % ROOT, f], cwd=ROOT, env=dict(os.environ, INTEL_GRU_SEQ=mode, INTEL_GRU_ORDER_MIN_B='1'),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         assert r.returncode == 0, r.stdout[-3000:]
         res[mode] = torch.load(f)
@@ -65,7 +65,7 @@ def test_three_forms_agree_on_ragged_histories(tmp_path):
             assert err <= 2e-5 * max(1e-3, float(v.abs().max())), (mode, k, err, float(v.abs().max()))
 
 
-def test_packed_gru_histories_equal_padded_histories():
+def test_packed_gru_histories_equal_padded_histories(monkeypatch):
     """GRU4Rec encoders on the valid history rows only (the batch carries 'his_rows' / 'hisitem_rows': input projection, recurrence
     stashes and the weight / input gradient products run on the packed rows) == on the padded [B, T] rows: forward outputs and
     every parameter gradient, ragged histories including empty ones."""
@@ -74,7 +74,9 @@ def test_packed_gru_histories_equal_padded_histories():
     from intel_sigir2023_amd.model import IntEL
     dev = torch.device('cuda:0')
     res = []
+    # packed: sessions ordered by length too (the default from 1024 sessions on); padded: batch order
     for packed in (True, False):
+        monkeypatch.setenv('INTEL_GRU_ORDER_MIN_B', '1' if packed else '100000')
         torch.manual_seed(12)
         args = synth.make_args('tiny', dev, encoder='GRU4Rec', cal_diversity=0)
         corpus, _ = synth.make_corpus('tiny')
@@ -86,6 +88,7 @@ def test_packed_gru_histories_equal_padded_histories():
         model.train()
         out = model(batch)
         assert bool(model._ctx) and (batch['history_len'] < batch['his_context_mh'].shape[1]).any()
+        assert ('his_order' in model.prepare_batch(batch)[1]) == packed
         loss = (out['ens_score'] * torch.linspace(0.5, 1.5, out['ens_score'].numel(), device=dev).view_as(out['ens_score'])).sum() + out['intents'].square().sum()
         loss.backward()
         res.append(({k: v.detach().cpu() for k, v in out.items()}, {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None}))
