@@ -1,5 +1,5 @@
 """Every kernel of a training step, one at a time on one stream (intel_prof): launches, time, time per launch and the bytes the
-launcher declares per second -- the whole list, not the top 16 of the bench line.  usage: python tools/full_profile.py [--shapes]"""
+launcher declares per second -- the whole list, not the top 16 of the bench line.  usage: python tools/full_profile.py [--shapes] [workload batch]"""
 import json, sys
 sys.path.insert(0, '.')
 import torch
@@ -7,12 +7,15 @@ from intel_sigir2023_amd import _lib, synth
 from intel_sigir2023_amd.engine import IntELEngine
 from intel_sigir2023_amd.model import IntEL
 dev = torch.device('cuda:0')
-args = synth.make_args('tmall', dev)
-corpus, _ = synth.make_corpus('tmall')
+pos = [a for a in sys.argv[1:] if not a.startswith('--')]
+wl = pos[0] if pos else 'tmall'
+BS = int(pos[1]) if len(pos) > 1 else 4096
+args = synth.make_args(wl, dev)
+corpus, _ = synth.make_corpus(wl)
 torch.manual_seed(0)
 m = IntEL(args, corpus).to(dev)
 e = IntELEngine(m, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
-bs = [synth.make_batch('tmall', 4096, dev, seed=i) for i in range(4)]
+bs = [synth.make_batch(wl, BS, dev, seed=i) for i in range(4)]
 for b in bs:
     b['_intel'] = m.prepare_batch(b); b['_intel'][1]['ranking_i32'] = b['ranking']
 for i in range(5): e.train_step(bs[i % 4])
