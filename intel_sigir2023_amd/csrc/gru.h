@@ -20,7 +20,8 @@ int gru_pack(GruBufs& g, const float* Wih, const float* Whh, const float* Wout, 
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
             float* out, int ldo, int col0, hipStream_t st, const float* Whh = nullptr,       // Whh (raw [3H, H]): the one-kernel recurrence
             const int* off = nullptr, int rows = 0,      // off / rows: E0 holds only the valid history rows (session b: rows off[b] .. off[b] + len[b])
-            const int* order = nullptr);                 // sessions ordered by length (IntelBatch.his_order)
+            const int* order = nullptr,                  // sessions ordered by length (IntelBatch.his_order)
+            bool stash = true);                          // false (inference): the recurrence keeps no gate / state stash
 bool gru_packed_supported(int Hd);
 // dvec = dout[b, col0:col0+dm]; writes parameter grads (overwrite) and dE0 [B*T, dm]
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,

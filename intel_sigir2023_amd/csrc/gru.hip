@@ -183,7 +183,8 @@ __device__ __forceinline__ f32x4 gs_mma6(const gs_bf16x8& ah, const gs_bf16x8& a
 
 // PL: the step's product on the bf16 pipe as three-plane splits (six plane products: 72 MFMAs of 16 cycles per wave and step
 // instead of 96 of 32; the state / gate-gradient rows are kept in LDS as three bf16 planes, W_hh is split once into registers)
-template <bool PL>
+// STASH: training (the backward reads GATES, GHN, HP); inference keeps only the final state
+template <bool PL, bool STASH = true>
 __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
                                                              const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
                                                              float* __restrict__ HP, float* __restrict__ HCUR,
@@ -284,11 +285,13 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         const float ghn = acc[2][r];
         const float ng = gtanh(gi[r][2] + rg * ghn);
         h[r] = (1.f - zg) * ng + zg * h[r];
-        float* ga = GATES + row * (3 * GS_H);
-        ga[unit] = rg; ga[GS_H + unit] = zg; ga[2 * GS_H + unit] = ng;
-        GHN[row * GS_H + unit] = ghn;
+        if (STASH) {
+          float* ga = GATES + row * (3 * GS_H);
+          ga[unit] = rg; ga[GS_H + unit] = zg; ga[2 * GS_H + unit] = ng;
+          GHN[row * GS_H + unit] = ghn;
+        }
       }
-      if (b < B && t + 1 < (off ? lr[r] : T)) HP[(row + 1) * GS_H + unit] = h[r];      // packed: row t+1 exists only below len
+      if (STASH && b < B && t + 1 < (off ? lr[r] : T)) HP[(row + 1) * GS_H + unit] = h[r];      // packed: row t+1 exists only below len
     }
     gs_lds_barrier();                     // every wave has read h_{t-1}
 #pragma unroll
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
       HCUR[(size_t)b * GS_H + unit] = h[r];
       // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
       // (padded rows only: packed histories have no rows past len)
-      for (int t = max(tmax, 0); t + 1 < T && !off; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
+      for (int t = max(tmax, 0); t + 1 < T && !off && STASH; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
     }
   }
 }
@@ -479,7 +482,7 @@ static bool gru_seq_on(int Hd, const float* Whh) {
 bool gru_packed_supported(int Hd) { return gru_seq_mode() != 0 && Hd == GS_H; }
 
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
-            float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows, const int* order) {
+            float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows, const int* order, bool stash) {
   if (!off) rows = B * T;
   INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   if (gru_seq_on(Hd, Whh)) {
@@ -487,11 +490,13 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     GemmEpilogue ei;
     ei.bias = bih;
     if ((rc = launch_gemm_rows(E0, dm, rows, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
-    if ((rc = launch_fill(g.HP, (long long)rows * Hd, 0.f, st))) return rc;       // h_0 = 0 (the first row of every session)
+    if (stash && (rc = launch_fill(g.HP, (long long)rows * Hd, 0.f, st))) return rc;       // h_0 = 0 (the first row of every session)
     if (gru_seq_mode() == 1)
       LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
-    else
+    else if (stash)
       LAUNCH(gru_seq_fwd_kernel<true>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
+    else
+      LAUNCH((gru_seq_fwd_kernel<true, false>), dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     INTEL_CHECK_LAUNCH();
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);

@@ -1041,7 +1041,7 @@ void forward_impl(Run& r, const IntelOut* out) {
       const int* len = e == 0 ? bt.history_len : bt.history_item_len;
       RUN(gru_fwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_BIH)),
                   r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.PREDIN, y.Pin, n.predin_off, r.st, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
-                  pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows, e == 0 ? bt.his_order : bt.hisitem_order));
+                  pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows, e == 0 ? bt.his_order : bt.hisitem_order, r.train != 0));
     }
   };
   TowerBufs& ti = y.tw[0];
