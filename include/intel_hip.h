@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define INTEL_ABI_VERSION 2
+#define INTEL_ABI_VERSION 3
 
 enum {
   INTEL_OK = 0,

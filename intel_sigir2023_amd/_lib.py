@@ -37,7 +37,7 @@ def lib():
         except OSError as e:
             raise IntelHipError('cannot load %s: %s' % (LIB_PATH, e))
         _declare(_lib)
-        if _lib.intel_abi_version() != 2:
+        if _lib.intel_abi_version() != 3:
             raise IntelHipError('ABI version mismatch')
         sizes = (C.c_int * 4)()
         _lib.intel_abi_sizes(sizes)
