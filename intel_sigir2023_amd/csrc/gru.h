@@ -26,4 +26,5 @@ bool gru_packed_supported(int Hd);
 // dvec = dout[b, col0:col0+dm]; writes parameter grads (overwrite) and dE0 [B*T, dm]
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,
             const float* dout, int ldo, int col0, const GruGrads& gg, float* dE0, float* scratch, float* slabs,
-            hipStream_t st, const int* off = nullptr, int rows = 0, const int* order = nullptr);
+            hipStream_t st, const int* off = nullptr, int rows = 0, const int* order = nullptr,
+            struct ReduceQueue* q = nullptr);      // q: the weight gradients' slabs join the backward's batched reduction instead of three immediate ones

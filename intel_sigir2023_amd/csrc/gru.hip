@@ -529,12 +529,12 @@ int gru_fwd_steps(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, con
 
 int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* Whh, const float* bhh,
             const float* dout, int ldo, int col0, const GruGrads& gg, float* dE0, float* scratch, float* slabs,
-            hipStream_t st, const int* off, int prows, const int* order) {
+            hipStream_t st, const int* off, int prows, const int* order, ReduceQueue* q) {
   (void)bhh; (void)scratch;
   INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   int rc;
   // vec = HCUR Wout^T
-  if (gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st))) return rc;
+  if (gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st, q))) return rc;
   GemmEpilogue e0;
   float *dH = g.dHa, *dHn = g.dHb;
   if ((rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
@@ -557,7 +557,7 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     float* tmp = dH; dH = dHn; dHn = tmp;
   }
   const int rows = off ? prows : B * T;
-  if (gg.dWih && (rc = launch_wgrad(g.dGI, 3 * Hd, E0, dm, rows, 3 * Hd, dm, gg.dWih, dm, gg.dbih, 0, slabs, st))) return rc;
-  if (gg.dWhh && (rc = launch_wgrad(g.dGH, 3 * Hd, g.HP, Hd, rows, 3 * Hd, Hd, gg.dWhh, Hd, gg.dbhh, 0, slabs, st))) return rc;
+  if (gg.dWih && (rc = launch_wgrad(g.dGI, 3 * Hd, E0, dm, rows, 3 * Hd, dm, gg.dWih, dm, gg.dbih, 0, slabs, st, q))) return rc;
+  if (gg.dWhh && (rc = launch_wgrad(g.dGH, 3 * Hd, g.HP, Hd, rows, 3 * Hd, Hd, gg.dWhh, Hd, gg.dbhh, 0, slabs, st, q))) return rc;
   return launch_gemm_rows(g.dGI, 3 * Hd, rows, 3 * Hd, g.pWihT, dm, dE0, dm, e0, st);
 }

@@ -371,6 +371,10 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
       a += rup_sz((size_t)512 * H * dm0, 64) + rup_sz((size_t)512 * Hi * dm1, 64);      // position-embedding gradient tables
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
     }
+    if (D.encoder == INTEL_ENC_GRU4REC) {       // the three weight gradients of each GRU encoder (input, hidden, output projection)
+      a += Wf((size_t)B * H, 3 * (size_t)gh, dm0) + Wf((size_t)B * H, 3 * (size_t)gh, gh) + Wf(B, dm0, gh);
+      a += Wf((size_t)B * Hi, 3 * (size_t)gh, dm1) + Wf((size_t)B * Hi, 3 * (size_t)gh, gh) + Wf(B, dm1, gh);
+    }
     a += 2 * Wf(psw ? B : M, K, y.F);                                     // fusion weights (+ pad rows)
     a += Wf(B, D.d_int, I) + Wf(B, I, y.Pin) + Wf(M, d_s, K);             // intent embedding, predictor, score embedding
     a += Wf((size_t)B * H, D.d_int, I) + Wf((size_t)B * Hi, D.d_int, I);  // shared intent embedding from the histories
@@ -1340,7 +1344,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       dE = r.T->dXa;
       r.ok(gru_bwd(n.gru, n.E0, B, n.T, dm, D.gru_hidden, len, r.P(enc_slot(e, INTEL_ENC_GRU_WHH)),
                    r.P(enc_slot(e, INTEL_ENC_GRU_BHH)), y.dPREDIN, y.Pin, n.predin_off, gg, dE, r.T->dXb, r.T->SLABS, r.st,
-                   pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows, e == 0 ? bt.his_order : bt.hisitem_order));
+                   pk ? (e == 0 ? bt.his_off : bt.hisitem_off) : nullptr, rows, e == 0 ? bt.his_order : bt.hisitem_order, r.ctx->rq));
     }
     if (r.rc || !dE) return nullptr;
     if (e == 0) {
