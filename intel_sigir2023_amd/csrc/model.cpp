@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "session.h"
 #include "gru.h"
+#include "enc.h"
 
 #define MAX_TOWER_LAYERS 8
 
@@ -53,6 +54,7 @@ struct EncBlockBufs {
   float *QKV, *A, *LSE, *C, *XH1, *RSTD1, *F1, *Eout, *XH2, *RSTD2;
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T, *bQKV;
   float* b3WqkvT;
+  float *b3Wqkv, *b3W1, *b3W2;     // images of the forward weights for the fused encoder kernels (enc.hip)
 };
 // the LAST BERT4Rec block only feeds row len-1 of its output forward (GeneralSeq.py:103-105): it is run
 // "pruned" -- K/V for all rows, everything else for one row per session
@@ -66,6 +68,7 @@ struct EncBufs {
   float* E0;
   // packed history (IntelBatch.his_off): ids / intent indices / intent rows of the valid positions only, position of each row
   int *pkIds, *pkIdx2, *rowT;
+  int* tileS;               // fused encoder kernels: first session of every row tile (launch_enc_tiles)
   float* pkVec;
   bool pos_done;            // this forward folded the position embedding into the kernels that produce the input rows
   EncBlockBufs blk[INTEL_ENC_MAX_BLOCKS];
@@ -131,6 +134,7 @@ struct IntelCtx {
   unsigned char* iid_row_flags; // optional [item_num]: set to 1 for every item-id gradient row the backward adds into
   bool fused_tail[2];          // the stashed forward folded the last LayerNorm of tower t into the cross-attention pooling
   bool enc_packed[2];          // this forward ran encoder e on the valid history rows only (IntelBatch.his_off / hisitem_off)
+  bool enc_fused[2];           // ... through the fused BERT4Rec kernels (enc.hip): packed rows, history <= 32, width 128
   // intel_set_params_unchanged: the packed weight images of the previous forward (same workspace, same batch shape) are reused
   bool params_unchanged = false, pack_ok = false, pack_train = false;
   const void* pack_ws = nullptr;
@@ -215,6 +219,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
         k.pW1T = ar.f(packed_floats(dm, dm));
         k.pW2T = ar.f(packed_floats(dm, dm));
         k.bQKV = ar.f(3 * dm);
+        k.b3Wqkv = ar.f(packed_b3_bytes(dm, 3 * dm) / 4);
+        k.b3W1 = ar.f(packed_b3_bytes(dm, dm) / 4);
+        k.b3W2 = ar.f(packed_b3_bytes(dm, dm) / 4);
       }
       n.last.pWkvT = ar.f(packed_floats(2 * rup(dm, 16), dm));
       n.last.b3WkvT = ar.f(packed_b3_bytes(2 * rup(dm, 16), dm) / 4);
@@ -274,6 +281,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     n.pkIds = reinterpret_cast<int*>(ar.f(rows));
     n.pkIdx2 = reinterpret_cast<int*>(ar.f(rows));
     n.rowT = reinterpret_cast<int*>(ar.f(rows));
+    n.tileS = reinterpret_cast<int*>(ar.f(rows + 2));
     n.pkVec = ar.f(rows * I);
     if (md > maxMD) maxMD = md;
     if (D.encoder == INTEL_ENC_BERT4REC) {
@@ -583,6 +591,13 @@ void pack_all(Run& r) {
       EncBufs& n = y.enc[e];
       for (int l = 0; l + 1 < D.enc_layers; ++l) RUN(launch_pack_b3(n.blk[l].pWqkvT, 3 * rup(n.dm, 16), n.dm, n.blk[l].b3WqkvT, r.st));
       RUN(launch_pack_b3(n.last.pWkvT, 2 * rup(n.dm, 16), n.dm, n.last.b3WkvT, r.st));
+      if (D.enc_layers >= 2 && enc_fused_supported(n.T, n.dm, D.enc_heads)) {      // the fused encoder kernels stream the forward weights as images
+        for (int l = 0; l < D.enc_layers; ++l) {
+          RUN(launch_pack_b3(n.blk[l].pWqkv, n.dm, 3 * n.dm, n.blk[l].b3Wqkv, r.st));
+          RUN(launch_pack_b3(n.blk[l].pW1, n.dm, n.dm, n.blk[l].b3W1, r.st));
+          RUN(launch_pack_b3(n.blk[l].pW2, n.dm, n.dm, n.blk[l].b3W2, r.st));
+        }
+      }
     }
   }
   RUN(pack_b3_flush(r.st));
@@ -781,6 +796,50 @@ void bert_fwd(Run& r, int e) {
   else
     RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
   const float* X = n.E0;
+  if (r.ctx->enc_fused[e]) {
+    // two kernels for the whole encoder (enc.hip): every full block as one kernel over tiles of whole sessions -- the last full
+    // block also projects the pruned last block's keys / values --, then the pruned last block, 16 sessions per workgroup
+    const int L = D.enc_layers;
+    RUN(launch_enc_tiles(off, B, T, rows, n.tileS, r.st));
+    for (int l = 0; l + 1 < L; ++l) {
+      EncBlockBufs& k = n.blk[l];
+      EncBlockFwd f;
+      f.X = X; f.rows = rows; f.B = B; f.T = T; f.dm = dm; f.heads = D.enc_heads; f.train = r.train;
+      f.off = off; f.tile_s = n.tileS;
+      f.Wqkv = k.b3Wqkv; f.W1 = k.b3W1; f.W2 = k.b3W2;
+      f.bqkv = k.bQKV; f.b1 = r.P(enc_blk_slot(e, l, INTEL_ENC_B1)); f.b2 = r.P(enc_blk_slot(e, l, INTEL_ENC_B2));
+      f.g1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)); f.be1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B));
+      f.g2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)); f.be2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B));
+      f.C = k.C;
+      f.QKV = k.QKV; f.LSE = k.LSE; f.XH1 = k.XH1; f.RSTD1 = k.RSTD1; f.F1 = k.F1; f.XH2 = k.XH2; f.RSTD2 = k.RSTD2;
+      const bool feeds_last = l + 2 == L;
+      f.out = (r.train || !feeds_last) ? k.Eout : nullptr;      // inference: the last full block's output lives on as K' / V' and x_last only
+      if (feeds_last) {
+        const size_t kv_off = (size_t)(dm / 16) * 4 * 3 * 64 * 4;      // floats: the image's column tiles dm/16 .. are [k | v]
+        f.Wkv = n.blk[L - 1].b3Wqkv + kv_off;
+        f.bkv = n.blk[L - 1].bQKV + dm;
+        f.KV = n.last.KV;
+        f.xlast = n.last.XLAST;
+      }
+      RUN(launch_enc_block_fwd(f, r.st));
+      X = k.Eout;
+    }
+    {
+      const int l = L - 1;
+      EncBlockBufs& k = n.blk[l];
+      EncLastBufs& q = n.last;
+      EncLastFwd f;
+      f.xlast = q.XLAST; f.KV = q.KV; f.off = off; f.len = len; f.B = B; f.T = T; f.dm = dm; f.heads = D.enc_heads; f.train = r.train;
+      f.Wq = k.b3Wqkv; f.W1 = k.b3W1; f.W2 = k.b3W2;
+      f.bq = k.bQKV; f.b1 = r.P(enc_blk_slot(e, l, INTEL_ENC_B1)); f.b2 = r.P(enc_blk_slot(e, l, INTEL_ENC_B2));
+      f.g1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)); f.be1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1B));
+      f.g2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G)); f.be2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2B));
+      f.out = r.y.PREDIN + n.predin_off; f.ldo = r.y.Pin;
+      f.QL = q.QLAST; f.PL = q.PL; f.CL = q.CL; f.XH1 = q.XH1; f.RSTD1 = q.RSTD1; f.F1 = q.F1; f.XH2 = q.XH2; f.RSTD2 = q.RSTD2;
+      RUN(launch_enc_last_fwd(f, r.st));
+    }
+    return;
+  }
   for (int l = 0; l + 1 < D.enc_layers; ++l) {
     EncBlockBufs& k = n.blk[l];
     {   // fused q/k/v projection (bias=True in TransformerLayer, layers.py:70)
@@ -1714,6 +1773,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
                        (D.encoder == INTEL_ENC_GRU4REC && gru_packed_supported(D.gru_hidden)));
       ctx->enc_packed[e] = pk;
       ctx->enc_rows[e] = pk ? nrows : batch->B * T;
+      ctx->enc_fused[e] = pk && D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 2 && enc_fused_supported(T, dm, D.enc_heads);
     }
   }
   ctx->fused_tail[0] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[0].d, train != 0);

@@ -1,0 +1,111 @@
+"""The fused BERT4Rec encoder kernels (csrc/enc.hip, csrc/enc_bwd.hip): models/GeneralSeq.py:89-106 on packed history rows as
+tiles of whole sessions.  Through the model (C ABI) against the oracle: outputs, the IntBPRloss value and every parameter gradient
+(the oracle's autograd), on batches with enough sessions for many row tiles -- histories of 1 .. history_max rows, sessions of exactly
+16 / 17 rows (one / two query tiles), the longest history at a tile boundary, history_max 7 / 20 / 32 (tile windows of 58 / 45 / 33
+rows).  The switch INTEL_ENC_FUSED is read once per process: the kernel-per-op encoder is re-checked in a child process."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def _case(history_max, B, seed, train):
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.model import IntEL
+    from oracle import intel_oracle as O
+    dev = _dev()
+    name = 'enc%d' % history_max
+    w = dict(synth.WORKLOADS['tmall'])
+    w['flags'] = dict(w['flags'], history_max=history_max)
+    w['corpus'] = dict(items=5000, users=500, classes=60, ctx=100, I=30)
+    w['batch'] = dict(L=12, H=history_max)
+    synth.WORKLOADS[name] = w
+    torch.manual_seed(seed)
+    args = synth.make_args(name, dev, cal_diversity=0)
+    corpus, c = synth.make_corpus(name)
+    model = IntEL(args, corpus).to(dev)
+    sd = {k: v.detach().cpu().clone().requires_grad_(train) for k, v in model.state_dict().items()}
+    batch = synth.make_batch(name, B, dev, seed=seed, ragged=True)
+    # pin the interesting lengths
+    H = history_max
+    for key in ('history_len', 'history_item_len'):
+        ln = batch[key]
+        for i, v in ((0, H), (1, 1), (2, min(H, 16)), (3, min(H, 17)), (B - 1, H)):
+            if 0 <= i < B:
+                ln[i] = v
+    hv = torch.arange(H, device=dev)[None, :] < batch['history_len'][:, None]
+    hiv = torch.arange(H, device=dev)[None, :] < batch['history_item_len'][:, None]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    batch['his_intents'] = torch.softmax(torch.rand(B, H, 30, generator=g, device=dev), dim=-1) * hv[:, :, None]
+    batch['his_context_mh'] = (torch.randint(0, 100, (B, H), generator=g, device=dev) * hv).int()
+    batch['his_item_id'] = (torch.randint(1, 5000, (B, H), generator=g, device=dev) * hiv).int()
+    batch['his_item_idx'] = torch.where(hiv, torch.randint(0, 30, (B, H), generator=g, device=dev), torch.full((B, H), -1, device=dev)).int()
+    batch['his_rows'], batch['hisitem_rows'] = int(batch['history_len'].sum()), int(batch['history_item_len'].sum())
+    ref_batch = synth.to_reference_layout(batch, c['I'])
+    cfg = O.Config(**{k: v for k, v in vars(args).items() if k != 'device'})
+    L = batch['i_id_s'].shape[1]
+    noise = torch.rand(B, L, L, device=dev)
+    batch['bpr_noise'] = noise
+    if train:
+        model.train()
+        out = model(batch)
+        assert 'his_off' in model.prepare_batch(batch)[1]          # the encoders do run packed
+        loss, _, _ = LS.IntBPRloss(args)(out, batch)
+        loss.backward()
+        ref = O.forward(sd, ref_batch, cfg)
+        rl = O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
+        rl[0].backward()
+        assert abs(float(loss) - float(rl[0])) < 1e-5
+    else:
+        model.eval()
+        with torch.no_grad():
+            out = model(batch)
+            ref = O.forward(sd, ref_batch, cfg)
+    for k in ('weights', 'ens_score', 'intents'):
+        err = float((out[k].detach().cpu() - ref[k].detach()).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref[k].abs().max())), (k, err)
+    if train:
+        worst = 0.0
+        for k, p in model.named_parameters():
+            gr = sd[k].grad
+            if gr is None:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            tol = 2e-4 * max(float(gr.abs().max()), 1e-6) + 1e-7
+            err = float((p.grad.detach().cpu() - gr).abs().max())
+            if any(k.endswith(s) for s in ('linear1.weight', 'linear1.bias', '_W1.weight', '_W1.bias')):
+                tol *= 50                                            # one flipped relu moves one row (tools/fuzz_parity.py)
+            worst = max(worst, err / tol)
+            assert err <= tol, (k, err, tol)
+        return worst
+    return 0.0
+
+
+@pytest.mark.parametrize('history_max,B,seed', [(20, 257, 0), (32, 130, 1), (7, 300, 2), (20, 16, 3), (20, 1, 4), (17, 64, 5)])
+def test_fused_encoder_inference_matches_oracle(history_max, B, seed):
+    _case(history_max, B, seed, train=False)
+
+
+@pytest.mark.parametrize('history_max,B,seed', [(20, 257, 10), (32, 130, 11), (7, 200, 12), (20, 5, 13)])
+def test_fused_encoder_training_step_matches_oracle_autograd(history_max, B, seed):
+    _case(history_max, B, seed, train=True)
+
+
+def test_kernel_per_op_encoder_when_forced_off():
+    env = dict(os.environ, INTEL_ENC_FUSED='0')
+    r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_enc_gpu.py', 'tests/test_pack_gpu.py', '-m', 'gpu', '-x', '-q', '-p', 'no:cacheprovider',
+                        '-k', 'not forced_off'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]

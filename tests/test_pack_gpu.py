@@ -2,6 +2,8 @@
 padded positions never reach a valid row in the reference (masked keys, row-wise blocks, `seq * valid`, GeneralSeq.py:95-105),
 so the packed run must reproduce the padded run: outputs bit for bit (every row's products are computed identically),
 gradients up to the summation order of the weight gradients (their row tiles differ)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -39,11 +41,17 @@ def test_packed_histories_equal_padded_histories(name):
         assert bool(model._ctx) and packed == ('his_off' in model.prepare_batch(batch)[1])
         res[packed] = ({k: v.detach().cpu() for k, v in out.items()}, float(loss),
                        {k: p.grad.detach().cpu() for k, p in model.named_parameters() if p.grad is not None})
+    # the fused encoder kernels (csrc/enc.hip: packed rows, width 128, history <= 32) tile the rows differently from the
+    # kernel-per-op pipeline the padded run takes: equal to summation order there, bit for bit everywhere else
+    fused = name == 'tmall64' and os.environ.get('INTEL_ENC_FUSED', '1') != '0'
     for k in ('weights', 'ens_score', 'intents'):
-        assert torch.equal(res[True][0][k], res[False][0][k]), k
-    assert res[True][1] == res[False][1]
+        if fused:
+            assert float((res[True][0][k] - res[False][0][k]).abs().max()) <= 3e-6 * max(1.0, float(res[False][0][k].abs().max())), k
+        else:
+            assert torch.equal(res[True][0][k], res[False][0][k]), k
+    assert res[True][1] == res[False][1] or (fused and abs(res[True][1] - res[False][1]) < 1e-6)
     for k, g in res[False][2].items():
-        tol = 1e-7 + 2e-6 * float(g.abs().max())
+        tol = 1e-7 + (2e-5 if fused else 2e-6) * float(g.abs().max())
         assert float((res[True][2][k] - g).abs().max()) <= tol, k
 
 
