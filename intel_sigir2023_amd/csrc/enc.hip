@@ -81,6 +81,43 @@ __device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img
   }
 }
 
+// the weight fragments of k block kb of column tiles ct0 .. ct0 + CT - 1
+template <int NP, int CT>
+__device__ __forceinline__ void load_w(uint4 (&bw)[CT][NP], const uint4* img, int ct0, int kb) {
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) bw[c][pl] = img[((size_t)((ct0 + c) * 4 + kb) * 3 + pl) * 64];
+}
+// gemm_planes with the fragments of k block 0 already in bw[0] (loaded ahead of the barrier in front of the product)
+// `tail_loads` runs right behind the product's last fragment loads: global loads of the NEXT phase issued there do not delay this
+// product (vmcnt retires in order: anything issued earlier would have to land before the fragments behind it count as arrived)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int D, int NP, int CT, int RT, int ROWS, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_planes_pre(const __bf16* frag, const uint4* img, int ct0, f32x4 (&acc)[CT][RT], uint4 (&bw)[2][CT][NP],
+                                                Hook tail_loads = Hook()) {
+  constexpr int KB = D / 32, LDP = D + 8, PLANE = ROWS * LDP;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) load_w<NP, CT>(bw[(kb + 1) & 1], img, ct0, kb + 1);
+    if (kb == (KB >= 2 ? KB - 2 : 0)) tail_loads();
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+      bf16x8 am = ah, al = ah;
+      if (NP == 3) {
+        am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+        al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        acc[c][rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][NP == 3 ? 1 : 0]),
+                             __builtin_bit_cast(bf16x8, bw[kb & 1][c][NP == 3 ? 2 : 0]), ah, am, al, acc[c][rt]);
+    }
+  }
+}
+
 struct EncBlockArgs {
   const float* X;            // [rows, D] packed block input
   int rows, B, T, ntiles;
@@ -100,13 +137,14 @@ struct EncBlockArgs {
   float* XH1; float* RSTD1;  // LayerNorm1 x-hat [rows, D], 1/std [rows]
   float* F1;                 // [rows, D] relu(W1 C + b1)
   float* XH2; float* RSTD2;
+  unsigned long long* dbg;   // INTEL_ENC_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
 };
 
 // ---- attention + LayerNorm1 for one (session, 16-query tile): both heads by one wave, so that every row of the tile is complete in
 // the wave's registers and LayerNorm1 needs no LDS round trip.  KT = key tiles of 16 (the session's length decides).
 template <int D, int DK, int NP, int KT, bool TRAIN>
-__device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsigned char* rbase, __bf16* cplanes, int base, int len, int qt,
-                                              int r0, int sess, int lane) {
+__device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsigned char* rbase, __bf16* cplanes, const float* s_par, int base, int len,
+                                              int qt, int r0, int sess, int lane) {
   using C = EncCfg<D, NP>;
   constexpr int LQ = C::LQ, LDP = C::LDP, PLANE = C::PLANE, HEADS = D / DK;
   static_assert(DK == 64, "the b128 V read feeds four 16-dim output tiles: head dim 64");
@@ -122,6 +160,16 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
     krow[kt] = min(base + kt * 16 + p, 63);
 #pragma unroll
     for (int r = 0; r < 4; ++r) vrow[kt][r] = min(base + kt * 16 + 4 * j + r, 63);
+  }
+  // the residual rows of LayerNorm1 (the block input) travel while the attention is computed
+  const size_t grow = (size_t)r0 + min(base + q, base + len - 1);       // clamped for the lanes without a query (loads only)
+  constexpr bool HOIST = NP == 3;                  // (the bf16 mode's 128-register budget: loaded where they are used)
+  f32x4 xres[HOIST ? HEADS : 1][4];
+  if constexpr (HOIST) {
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xres[h][r] = *reinterpret_cast<const f32x4*>(a.X + grow * D + h * DK + 16 * j + 4 * r);
   }
   f32x4 o[HEADS][4];                               // o[h][r] = columns h*DK + 16j + 4r .. +3 of query q
 #pragma unroll
@@ -146,15 +194,21 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
       const float* Qs = reinterpret_cast<const float*>(rbase);
       const float* Ks = Qs + 64 * LQ;
       const float* Qp = Qs + qrow * LQ + h * DK + 4 * j;
+      f32x4 sb[KT];                                 // second partial sum: two independent MFMA chains per key tile
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) sb[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < DK / 16; ++g) {
         const f32x4 qf = *reinterpret_cast<const f32x4*>(Qp + 16 * g);
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
           const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow[kt] * LQ + h * DK + 4 * j + 16 * g);
-          st[kt] = mma4(kf, qf, st[kt]);
+          if (g & 1) sb[kt] = mma4(kf, qf, sb[kt]);
+          else st[kt] = mma4(kf, qf, st[kt]);
         }
       }
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) st[kt] += sb[kt];
     }
     // accumulator register r of tile kt at lane (j, p) = key kt*16 + 4j + r, query q
     float mx = -INFINITY;
@@ -211,14 +265,13 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
     for (int r = 0; r < 4; ++r) o[h][r] = f32x4{oT[0][r], oT[1][r], oT[2][r], oT[3][r]} * inv;
   }
   // ---- LayerNorm1(A + X): lane (p, j) holds 8 * HEADS column quads of query q, the other quads sit in the lanes p + 16 j'
-  const size_t grow = (size_t)r0 + min(base + q, base + len - 1);       // clamped for the lanes without a query (loads only)
   float s = 0.f;
 #pragma unroll
   for (int h = 0; h < HEADS; ++h)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(a.X + grow * D + h * DK + 16 * j + 4 * r);
-      o[h][r] += x;
+      if constexpr (HOIST) o[h][r] += xres[h][r];
+      else o[h][r] += *reinterpret_cast<const f32x4*>(a.X + grow * D + h * DK + 16 * j + 4 * r);
       s += (o[h][r][0] + o[h][r][1]) + (o[h][r][2] + o[h][r][3]);
     }
   const float mean = gsum16(s) * (1.f / (float)D);
@@ -239,7 +292,7 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
       for (int r = 0; r < 4; ++r) {
         const int col = h * DK + 16 * j + 4 * r;
         const f32x4 xh = o[h][r] * rs;
-        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g1 + col), be = *reinterpret_cast<const f32x4*>(a.be1 + col);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(s_par + col), be = *reinterpret_cast<const f32x4*>(s_par + D + col);
         const f32x4 c = xh * g + be;
         if (TRAIN && a.XH1) *reinterpret_cast<f32x4*>(a.XH1 + grow * D + col) = xh;
         *reinterpret_cast<f32x4*>(a.C + grow * D + col) = c;
@@ -248,16 +301,24 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
   }
 }
 
+// parameter vectors of a block staged once per workgroup in LDS (the attention / LayerNorm code reads them per tile)
+template <int D>
+struct EncPar {
+  static constexpr int G1 = 0, BE1 = D, G2 = 2 * D, BE2 = 3 * D, B1 = 4 * D, B2 = 5 * D, BQKV = 6 * D, BKV = 9 * D, N = 11 * D;
+};
+
 template <int D, int DK, bool TRAIN, int NP>
 __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc_block_fwd_kernel(EncBlockArgs a) {
   using C = EncCfg<D, NP>;
+  using PR = EncPar<D>;
   constexpr int NW = C::NW, NT = C::NT, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ, KBT = C::KBT;
-  constexpr int HEADS = D / DK;
+  constexpr bool PF = NP == 3;          // cross-phase prefetch of weight fragments / residual rows (the bf16 mode's 128-register budget has no room)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_start[65];        // first row (inside the tile) of every session of the tile, then the tile's row count
   __shared__ int s_rowlast[64];      // session whose last row this is, or -1
   __shared__ int s_items[128];       // attention work items: session | query tile << 8
   __shared__ int s_nitems;
+  __shared__ __attribute__((aligned(16))) float s_par[PR::N];
   __bf16* planes = reinterpret_cast<__bf16*>(smem_raw);                  // P
   unsigned char* rbase = smem_raw + C::P_BYTES;                           // R
   float* Qs = reinterpret_cast<float*>(rbase);
@@ -266,6 +327,18 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
   float* Es = reinterpret_cast<float*>(rbase + C::R1_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < PR::N; i += NT) {
+    float v = 0.f;
+    if (i < PR::BE1) v = a.g1[i];
+    else if (i < PR::G2) v = a.be1[i - PR::BE1];
+    else if (i < PR::BE2) v = a.g2[i - PR::G2];
+    else if (i < PR::B1) v = a.be2[i - PR::BE2];
+    else if (i < PR::B2) v = a.b1[i - PR::B1];
+    else if (i < PR::BQKV) v = a.b2[i - PR::B2];
+    else if (i < PR::BKV) v = a.bqkv[i - PR::BQKV];
+    else if (a.bkv) v = a.bkv[i - PR::BKV];
+    s_par[i] = v;
+  }
   int trow[NJ], tcol[NJ];
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) {
@@ -273,19 +346,58 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
     trow[jj] = i / (D / 4);
     tcol[jj] = (i - trow[jj] * (D / 4)) * 4;
   }
+  unsigned long long tstamp = 0;
+  const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int ph) {
+    if (probe) {
+      const unsigned long long now = clock64();
+      if (ph >= 0) a.dbg[ph] += now - tstamp;
+      tstamp = now;
+    }
+  };
+  // tile bookkeeping is read one tile ahead: the X rows of the next tile travel (into `pre`) while this one is computed
+  struct Tile { int s_lo, ns, r0, nrows; };
+  auto tile_meta = [&](int t) {
+    Tile tl{0, 0, 0, 0};
+    if (t < a.ntiles) {
+      const int s_lo = a.tile_s[t], s_hi = a.tile_s[t + 1];
+      tl.s_lo = s_lo;
+      tl.ns = s_hi - s_lo;
+      if (tl.ns > 0) {
+        tl.r0 = a.off[s_lo];
+        tl.nrows = (s_hi < a.B ? a.off[s_hi] : a.rows) - tl.r0;
+      }
+    }
+    return tl;
+  };
+  f32x4 pre[NJ];
+  int w_st = 0, w_en = 0;                                      // wave 0: first row / end row of session s_lo + lane
+  auto load_tile = [&](const Tile& tl) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int row = min(trow[jj], max(tl.nrows - 1, 0));
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)tl.r0 + row) * D + tcol[jj]);
+      pre[jj] = trow[jj] < tl.nrows ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (wave == 0 && lane < tl.ns) {
+      w_st = a.off[tl.s_lo + lane];
+      w_en = tl.s_lo + lane + 1 < a.B ? a.off[tl.s_lo + lane + 1] : a.rows;
+    }
+  };
+  Tile cur = tile_meta(blockIdx.x);
+  if constexpr (PF) load_tile(cur);
+  mark(-1);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
-    const int s_lo = a.tile_s[t], s_hi = a.tile_s[t + 1];
-    const int ns = s_hi - s_lo;
-    if (ns <= 0) continue;                                   // no session starts in this window (workgroup-uniform)
-    const int r0 = a.off[s_lo];
-    const int nrows = (s_hi < a.B ? a.off[s_hi] : a.rows) - r0;
+    if (cur.ns <= 0) break;            // only the last window can be without a session start (a window holds 65 - T > T rows)
+    const int s_lo = cur.s_lo, ns = cur.ns, r0 = cur.r0, nrows = cur.nrows;
+    if constexpr (!PF) load_tile(cur);
     // ---- tile bookkeeping (wave 0) + X rows -> planes
     if (wave == 0) {
       s_rowlast[lane] = -1;
-      int start = 0, ln = 0;
+      int ln = 0;
       if (lane < ns) {
-        start = a.off[s_lo + lane] - r0;
-        ln = (s_lo + lane + 1 < a.B ? a.off[s_lo + lane + 1] : a.rows) - r0 - start;
+        const int start = w_st - r0;
+        ln = w_en - w_st;
         s_start[lane] = start;
         s_rowlast[start + ln - 1] = s_lo + lane;
         s_items[lane] = lane;
@@ -303,18 +415,18 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
       if (lane == 63) s_nitems = ns + incl;
     }
 #pragma unroll
-    for (int jj = 0; jj < NJ; ++jj) {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (trow[jj] < nrows) v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)r0 + trow[jj]) * D + tcol[jj]);
-      store4<NP, PLANE>(planes + trow[jj] * LDP + tcol[jj], v);
-    }
+    for (int jj = 0; jj < NJ; ++jj) store4<NP, PLANE>(planes + trow[jj] * LDP + tcol[jj], pre[jj]);
+    uint4 bwq[2][PF ? 3 : 1][NP];
+    if constexpr (PF) load_w<NP, 3>(bwq[0], launder(a.Wqkv) + lane, 3 * wave, 0);
+    mark(0);
     lds_barrier();
+    mark(1);
     // ---- [Q | K | V] = X Wqkv^T + b; wave = column tiles 3 wave .. 3 wave + 2, all four row tiles
     {
       const uint4* img = launder(a.Wqkv) + lane;
       const __bf16* frag = planes + p * LDP + 8 * j;
       auto epilogue = [&](int n, const f32x4 (&acc)[4]) {      // n = column of [q | k | v]
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bqkv + n);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::BQKV + n);
         const int which = n / D, col = n - which * D;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
@@ -340,12 +452,17 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_planes<D, NP, 3, 4, 64>(frag, img, 3 * wave, acc);
+        gemm_planes_pre<D, NP, 3, 4, 64>(frag, img, 3 * wave, acc, bwq);
 #pragma unroll
         for (int c = 0; c < 3; ++c) epilogue((3 * wave + c) * 16 + 4 * j, acc[c]);
       }
     }
+    // the next tile's bookkeeping and rows travel from here on
+    const Tile nxt = tile_meta(t + gridDim.x);
+    if constexpr (PF) { if (nxt.ns > 0) load_tile(nxt); }
+    mark(2);
     lds_barrier();
+    mark(3);
     // ---- attention + LayerNorm1 -> C planes (over the dead X planes), C rows to HBM
     {
       const int nitems = s_nitems;
@@ -353,19 +470,28 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         const int item = s_items[it];
         const int s = item & 255, qt = item >> 8;
         const int base = s_start[s], len = s_start[s + 1] - base;
-        if (len > 16) attn_ln1_item<D, DK, NP, 2, TRAIN>(a, rbase, planes, base, len, qt, r0, s_lo + s, lane);
-        else attn_ln1_item<D, DK, NP, 1, TRAIN>(a, rbase, planes, base, len, qt, r0, s_lo + s, lane);
+        if (len > 16) attn_ln1_item<D, DK, NP, 2, TRAIN>(a, rbase, planes, s_par, base, len, qt, r0, s_lo + s, lane);
+        else attn_ln1_item<D, DK, NP, 1, TRAIN>(a, rbase, planes, s_par, base, len, qt, r0, s_lo + s, lane);
       }
     }
+    uint4 bw1[2][1][NP], bw2[2][1][NP];
+    if constexpr (PF) load_w<NP, 1>(bw1[0], launder(a.W1) + lane, wave, 0);
+    mark(4);
     __syncthreads();       // C planes in LDS and the C rows in HBM (read back as the LayerNorm2 residual) are complete
+    mark(5);
+    // the LayerNorm2 residual rows of this thread come back while the two feed-forward products run
+    constexpr int CPL = D / 64;                      // float4 per lane per row (16 lanes per row)
+    constexpr int ROUNDS = 64 / (NW * 4);
+    f32x4 cres[PF ? ROUNDS : 1][CPL];
     // ---- R1 = relu(C W1^T + b1) -> planes over the dead q / k / v rows; wave = one column tile
     {
       f32x4 acc[1][4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gemm_planes<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc);
+      if (PF) gemm_planes_pre<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc, bw1);
+      else gemm_planes<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc);
       const int col = wave * 16 + 4 * j;
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + col);
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B1 + col);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int row = rt * 16 + p;
@@ -376,23 +502,37 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         if (TRAIN && a.F1 && row < nrows) *reinterpret_cast<f32x4*>(a.F1 + ((size_t)r0 + row) * D + col) = x;
       }
     }
+    if constexpr (PF) load_w<NP, 1>(bw2[0], launder(a.W2) + lane, wave, 0);
+    mark(6);
     lds_barrier();
-    // ---- Z = R1 W2^T + b2 -> fp32 tile
+    mark(7);
+    // ---- Z = R1 W2^T + b2 -> fp32 tile; the LayerNorm2 residual rows of this thread are requested behind the product's loads
     {
       f32x4 acc[1][4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gemm_planes<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc);
+      auto res_loads = [&]() {
+#pragma unroll
+        for (int rnd = 0; rnd < (PF ? ROUNDS : 1); ++rnd) {
+          const int row = min((rnd * NW + wave) * 4 + j, nrows - 1);
+#pragma unroll
+          for (int cc = 0; cc < CPL; ++cc) cres[rnd][cc] = *reinterpret_cast<const f32x4*>(a.C + ((size_t)r0 + row) * D + (D / 16) * p + 4 * cc);
+        }
+      };
+      if (PF) gemm_planes_pre<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc, bw2, res_loads);
+      else gemm_planes<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc);
       const int col = wave * 16 + 4 * j;
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b2 + col);
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B2 + col);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[0][rt] + bias;
     }
+    uint4 bwk[2][PF ? 2 : 1][NP];
+    if constexpr (PF) { if (a.Wkv) load_w<NP, 2>(bwk[0], launder(a.Wkv) + lane, 2 * wave, 0); }
+    mark(8);
     lds_barrier();
+    mark(9);
     // ---- E = LayerNorm2(Z + C): 16 lanes per row (lane p = columns (D/16) p ..), four rows per wave at a time
     {
-      constexpr int CPL = D / 64;                    // float4 per lane per row
-      constexpr int ROUNDS = 64 / (NW * 4);
       const float inv_n = 1.f / (float)D;
 #pragma unroll
       for (int rnd = 0; rnd < ROUNDS; ++rnd) {
@@ -404,7 +544,8 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
           const int col = (D / 16) * p + 4 * cc;
-          v[cc] = *reinterpret_cast<const f32x4*>(Es + row * LQ + col) + *reinterpret_cast<const f32x4*>(a.C + grow * D + col);
+          const f32x4 res = PF ? cres[PF ? rnd : 0][cc] : *reinterpret_cast<const f32x4*>(a.C + grow * D + col);
+          v[cc] = *reinterpret_cast<const f32x4*>(Es + row * LQ + col) + res;
           s += (v[cc][0] + v[cc][1]) + (v[cc][2] + v[cc][3]);
         }
         const float mean = row16_sum(s) * inv_n;
@@ -420,7 +561,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         for (int cc = 0; cc < CPL; ++cc) {
           const int col = (D / 16) * p + 4 * cc;
           const f32x4 xh = v[cc] * rs;
-          const f32x4 e = xh * *reinterpret_cast<const f32x4*>(a.g2 + col) + *reinterpret_cast<const f32x4*>(a.be2 + col);
+          const f32x4 e = xh * *reinterpret_cast<const f32x4*>(s_par + PR::G2 + col) + *reinterpret_cast<const f32x4*>(s_par + PR::BE2 + col);
           if (a.Wkv) store4<NP, PLANE>(planes + row * LDP + col, rok ? e : f32x4{0.f, 0.f, 0.f, 0.f});
           if (rok) {
             if (TRAIN && a.XH2) *reinterpret_cast<f32x4*>(a.XH2 + grow * D + col) = xh;
@@ -431,13 +572,15 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         if (TRAIN && a.RSTD2 && rok && p == 0) a.RSTD2[grow] = rs;
       }
     }
+    mark(10);
     lds_barrier();
+    mark(11);
     // ---- the next (last) block's [K' | V'] = E Wkv'^T + b' straight to HBM; wave = column tiles 2 wave, 2 wave + 1 of 2D
     if (a.Wkv) {
       const uint4* img = launder(a.Wkv) + lane;
       const __bf16* frag = planes + p * LDP + 8 * j;
       auto epilogue = [&](int n, const f32x4 (&acc)[4]) {
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bkv + n);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::BKV + n);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           const int row = rt * 16 + p;
@@ -459,13 +602,16 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_planes<D, NP, 2, 4, 64>(frag, img, 2 * wave, acc);
+        gemm_planes_pre<D, NP, 2, 4, 64>(frag, img, 2 * wave, acc, bwk);
 #pragma unroll
         for (int c = 0; c < 2; ++c) epilogue((2 * wave + c) * 16 + 4 * j, acc[c]);
       }
+      mark(12);
       lds_barrier();       // the next tile's X planes go over the E planes
+      mark(13);
     }
-    (void)KBT; (void)HEADS;
+    cur = nxt;
+    (void)KBT;
   }
 }
 
@@ -666,8 +812,25 @@ int launch_block(const EncBlockArgs& a, hipStream_t st) {
   const double flops = 2.0 * M * D * D * (5 + (a.Wkv ? 2 : 0)) + 4.0 * M * a.T * D * 0.5;
   double bytes = 4.0 * M * D * (2.0 + (a.out ? 1.0 : 0.0) + (a.KV ? 2.0 : 0.0));
   if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? 3.0 : 0.0) + (a.XH1 ? 1.0 : 0.0) + (a.F1 ? 1.0 : 0.0) + (a.XH2 ? 1.0 : 0.0));
-  LAUNCH_S(a.rows, D, DK, flops, bytes, (enc_block_fwd_kernel<D, DK, TRAIN, NP>), dim3(grid), dim3(C::NT), smem, st, a);
+  static const int dbg_on = [] { const char* e = getenv("INTEL_ENC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  EncBlockArgs aa = a;
+  static unsigned long long* dbg_buf = nullptr;
+  if (dbg_on) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_buf, 0, 16 * sizeof(unsigned long long), st);
+    aa.dbg = dbg_buf;
+  }
+  LAUNCH_S(a.rows, D, DK, flops, bytes, (enc_block_fwd_kernel<D, DK, TRAIN, NP>), dim3(grid), dim3(C::NT), smem, st, aa);
   INTEL_CHECK_LAUNCH();
+  if (dbg_on) {          // per-phase cycles of workgroup 0 (synchronises)
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const int iters = (a.ntiles + grid - 1) / grid;
+    fprintf(stderr, "enc_block_fwd train=%d NP=%d grid=%d iters=%d cycles/tile: stage %llu (+bar %llu) qkv %llu (+bar %llu) attn %llu (+bar %llu) w1 %llu (+bar %llu) w2 %llu (+bar %llu) ln2 %llu (+bar %llu) kv %llu (+bar %llu)\n",
+            (int)TRAIN, NP, grid, iters, h[0] / iters, h[1] / iters, h[2] / iters, h[3] / iters, h[4] / iters, h[5] / iters, h[6] / iters, h[7] / iters,
+            h[8] / iters, h[9] / iters, h[10] / iters, h[11] / iters, h[12] / iters, h[13] / iters);
+  }
   return 0;
 }
 
@@ -715,6 +878,7 @@ int launch_enc_block_fwd(const EncBlockFwd& f, hipStream_t st) {
   const bool tr = f.train != 0;
   a.QKV = tr ? f.QKV : nullptr; a.LSE = tr ? f.LSE : nullptr; a.XH1 = tr ? f.XH1 : nullptr; a.RSTD1 = tr ? f.RSTD1 : nullptr;
   a.F1 = tr ? f.F1 : nullptr; a.XH2 = tr ? f.XH2 : nullptr; a.RSTD2 = tr ? f.RSTD2 : nullptr;
+  a.dbg = nullptr;
   if (gemm_planes() == 1) return tr ? launch_block<128, 64, true, 1>(a, st) : launch_block<128, 64, false, 1>(a, st);
   return tr ? launch_block<128, 64, true, 3>(a, st) : launch_block<128, 64, false, 3>(a, st);
 }
