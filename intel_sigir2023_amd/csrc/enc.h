@@ -41,3 +41,35 @@ struct EncLastFwd {
   float *QL = nullptr, *PL = nullptr, *CL = nullptr, *XH1 = nullptr, *RSTD1 = nullptr, *F1 = nullptr, *XH2 = nullptr, *RSTD2 = nullptr;
 };
 int launch_enc_last_fwd(const EncLastFwd& f, hipStream_t st);
+
+// ---- backward (enc_bwd.hip; fp32 mode) -------------------------------------------------------------------------------------
+// the pruned last block: d(output vector) -> B-row gradients for the weight-gradient products, d(x_last), d[K' | V']
+struct EncLastBwd {
+  const float* dvec = nullptr; int ldv = 0;      // [B, ldv]
+  const float* KV = nullptr; const int* off = nullptr; const int* len = nullptr;
+  int B = 0, T = 0, dm = 0, heads = 0;
+  const void *W2T = nullptr, *W1T = nullptr, *WqT = nullptr;      // images of the TRANSPOSED weights (dX = dY W)
+  const float *g1 = nullptr, *g2 = nullptr;
+  const float *XH2 = nullptr, *RSTD2 = nullptr, *F1 = nullptr, *XH1 = nullptr, *RSTD1 = nullptr, *PL = nullptr, *QL = nullptr;   // forward stash
+  float *DZ2 = nullptr, *DF1 = nullptr, *DQ = nullptr, *DXL = nullptr;      // [B, dm]
+  float* DKV = nullptr;                                                        // [rows, 2 dm]
+  float *dg2 = nullptr, *db2 = nullptr, *dg1 = nullptr, *db1 = nullptr;      // LayerNorm parameter gradients (through the reduce queue)
+  int acc_g2 = 0, acc_b2 = 0, acc_g1 = 0, acc_b1 = 0;
+};
+int launch_enc_last_bwd(const EncLastBwd& f, hipStream_t st, ReduceQueue* q);
+
+// one full block: d(block output) (+ d(x_last) at the last rows) -> dZ2, dF1, dZ1, dQKV
+struct EncBlockBwd {
+  const float* dE = nullptr; const float* dxl = nullptr;
+  int rows = 0, B = 0, T = 0, dm = 0, heads = 0;
+  const int* off = nullptr; const int* tile_s = nullptr;
+  const void *W2T = nullptr, *W1T = nullptr;
+  const float *g1 = nullptr, *g2 = nullptr;
+  const float *XH2 = nullptr, *RSTD2 = nullptr, *F1 = nullptr, *XH1 = nullptr, *RSTD1 = nullptr, *QKV = nullptr;
+  float *DZ2 = nullptr, *DF1 = nullptr, *DZ1 = nullptr, *DQKV = nullptr;
+  float *dg2 = nullptr, *db2 = nullptr, *dg1 = nullptr, *db1 = nullptr;
+  int acc_g2 = 0, acc_b2 = 0, acc_g1 = 0, acc_b1 = 0;
+};
+int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q);
+// floats of reduction arena the two launches of one encoder take (LayerNorm partials)
+size_t enc_bwd_slab_floats(int rows, int B, int T, int dm);

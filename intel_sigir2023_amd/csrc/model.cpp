@@ -55,6 +55,7 @@ struct EncBlockBufs {
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T, *bQKV;
   float* b3WqkvT;
   float *b3Wqkv, *b3W1, *b3W2;     // images of the forward weights for the fused encoder kernels (enc.hip)
+  float *b3W1T, *b3W2T;            // ... and of the transposed feed-forward weights for their backward (enc_bwd.hip)
 };
 // the LAST BERT4Rec block only feeds row len-1 of its output forward (GeneralSeq.py:103-105): it is run
 // "pruned" -- K/V for all rows, everything else for one row per session
@@ -62,6 +63,7 @@ struct EncLastBufs {
   float *KV, *XLAST, *QLAST, *PL, *OL, *CL, *XH1, *RSTD1, *F1, *XH2, *RSTD2;
   float *pWkvT, *pWqT;
   float* b3WkvT;
+  float* b3WqT;
 };
 struct EncBufs {
   int T, dm, d_tab, pbase, predin_off;
@@ -222,10 +224,13 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
         k.b3Wqkv = ar.f(packed_b3_bytes(dm, 3 * dm) / 4);
         k.b3W1 = ar.f(packed_b3_bytes(dm, dm) / 4);
         k.b3W2 = ar.f(packed_b3_bytes(dm, dm) / 4);
+        k.b3W1T = ar.f(packed_b3_bytes(dm, dm) / 4);
+        k.b3W2T = ar.f(packed_b3_bytes(dm, dm) / 4);
       }
       n.last.pWkvT = ar.f(packed_floats(2 * rup(dm, 16), dm));
       n.last.b3WkvT = ar.f(packed_b3_bytes(2 * rup(dm, 16), dm) / 4);
       n.last.pWqT = ar.f(packed_floats(dm, dm));
+      n.last.b3WqT = ar.f(packed_b3_bytes(dm, dm) / 4);
     } else {
       gru_layout_packed(n.gru, dm, D.gru_hidden, ar.base, ar.off);
     }
@@ -377,6 +382,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     if (D.encoder == INTEL_ENC_BERT4REC) {
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * H, dm0, dm0) + Lf((size_t)B * H, dm0)) + Lf((size_t)B * H, dm0) + Wf((size_t)B * H, H, dm0);
       a += rup_sz((size_t)512 * H * dm0, 64) + rup_sz((size_t)512 * Hi * dm1, 64);      // position-embedding gradient tables
+      a += 2 * D.enc_layers * (rup_sz(enc_bwd_slab_floats(B * H, B, H > 32 ? 32 : H, dm0), 64) + rup_sz(enc_bwd_slab_floats(B * Hi, B, Hi > 32 ? 32 : Hi, dm1), 64));   // fused encoder backward: LayerNorm partials
       a += (size_t)D.enc_layers * (6 * Wf((size_t)B * Hi, dm1, dm1) + Lf((size_t)B * Hi, dm1)) + Lf((size_t)B * Hi, dm1) + Wf((size_t)B * Hi, Hi, dm1);
     }
     if (D.encoder == INTEL_ENC_GRU4REC) {       // the three weight gradients of each GRU encoder (input, hidden, output projection)
@@ -596,7 +602,12 @@ void pack_all(Run& r) {
           RUN(launch_pack_b3(n.blk[l].pWqkv, n.dm, 3 * n.dm, n.blk[l].b3Wqkv, r.st));
           RUN(launch_pack_b3(n.blk[l].pW1, n.dm, n.dm, n.blk[l].b3W1, r.st));
           RUN(launch_pack_b3(n.blk[l].pW2, n.dm, n.dm, n.blk[l].b3W2, r.st));
+          if (r.train) {
+            RUN(launch_pack_b3(n.blk[l].pW1T, n.dm, n.dm, n.blk[l].b3W1T, r.st));
+            RUN(launch_pack_b3(n.blk[l].pW2T, n.dm, n.dm, n.blk[l].b3W2T, r.st));
+          }
         }
+        if (r.train) RUN(launch_pack_b3(n.last.pWqT, n.dm, n.dm, n.last.b3WqT, r.st));
       }
     }
   }
@@ -924,7 +935,80 @@ float* bert_bwd(Run& r, int e) {
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
   const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
   float *dX = r.T->dXa, *dXalt = r.T->dXb;
-  {   // ---- last block, pruned (see bert_fwd): gradient of one output row per session
+  static const bool fused_bwd_on = [] { const char* e = getenv("INTEL_ENC_FUSED_BWD"); return !(e && e[0] == '0'); }();      // 0: kernel-per-op backward on the fused forward's stash
+  const bool fused_bwd = fused_bwd_on && r.ctx->enc_fused[e] && gemm_planes() == 3;
+  if (fused_bwd) {
+    // the data-gradient chain of every block as one kernel (enc_bwd.hip); the weight gradients (reductions over all rows) and
+    // the two K > 128 data-gradient products stay on the GEMM kernels
+    const int L = D.enc_layers;
+    float *dZl = r.T->dLB[0], *dF1l = r.T->dLB[1], *dXl = r.T->dLB[2], *dQl = r.T->dLB[4];
+    auto ln_slots = [&](int l, float** outs, int* accs) {
+      const int sl[4] = {enc_blk_slot(e, l, INTEL_ENC_LN2G), enc_blk_slot(e, l, INTEL_ENC_LN2B), enc_blk_slot(e, l, INTEL_ENC_LN1G), enc_blk_slot(e, l, INTEL_ENC_LN1B)};
+      for (int i = 0; i < 4; ++i) {
+        outs[i] = r.G(sl[i]);
+        accs[i] = outs[i] ? r.acc(sl[i]) : 0;
+      }
+    };
+    {
+      const int l = L - 1;
+      EncBlockBufs& k = n.blk[l];
+      EncLastBufs& q = n.last;
+      const float* Xin = n.blk[l - 1].Eout;
+      EncLastBwd f;
+      f.dvec = y.dPREDIN + n.predin_off; f.ldv = y.Pin; f.KV = q.KV; f.off = off; f.len = len; f.B = B; f.T = T; f.dm = dm; f.heads = D.enc_heads;
+      f.W2T = k.b3W2T; f.W1T = k.b3W1T; f.WqT = q.b3WqT;
+      f.g1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)); f.g2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G));
+      f.XH2 = q.XH2; f.RSTD2 = q.RSTD2; f.F1 = q.F1; f.XH1 = q.XH1; f.RSTD1 = q.RSTD1; f.PL = q.PL; f.QL = q.QLAST;
+      f.DZ2 = dZl; f.DF1 = dF1l; f.DQ = dQl; f.DXL = dXl; f.DKV = r.T->dQKV;
+      float* outs[4]; int accs[4];
+      ln_slots(l, outs, accs);
+      f.dg2 = outs[0]; f.db2 = outs[1]; f.dg1 = outs[2]; f.db1 = outs[3];
+      f.acc_g2 = accs[0]; f.acc_b2 = accs[1]; f.acc_g1 = accs[2]; f.acc_b1 = accs[3];
+      if (!r.ok(launch_enc_last_bwd(f, r.st, r.ctx->rq))) return nullptr;
+      wgrad(r, dZl, dm, q.F1, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
+      wgrad(r, dF1l, dm, q.CL, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
+      wgrad(r, dQl, dm, q.XLAST, dm, B, dm, dm, enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_BQ));
+      {
+        const int ws[2] = {enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
+        const int bs[2] = {enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
+        wgrad_split(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, 2, ws, bs);
+      }
+      GemmEpilogue e0;
+      e0.b3 = q.b3WkvT;
+      lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dE = dKV [Wk;Wv]; d(x_last) joins inside the block kernel
+      if (r.rc) return nullptr;
+    }
+    for (int l = L - 2; l >= 0; --l) {
+      EncBlockBufs& k = n.blk[l];
+      const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
+      EncBlockBwd f;
+      f.dE = dX; f.dxl = l == L - 2 ? dXl : nullptr;
+      f.rows = rows; f.B = B; f.T = T; f.dm = dm; f.heads = D.enc_heads; f.off = off; f.tile_s = n.tileS;
+      f.W2T = k.b3W2T; f.W1T = k.b3W1T;
+      f.g1 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN1G)); f.g2 = r.P(enc_blk_slot(e, l, INTEL_ENC_LN2G));
+      f.XH2 = k.XH2; f.RSTD2 = k.RSTD2; f.F1 = k.F1; f.XH1 = k.XH1; f.RSTD1 = k.RSTD1; f.QKV = k.QKV;
+      f.DZ2 = r.T->dZ; f.DF1 = r.T->dF1; f.DZ1 = r.T->dA; f.DQKV = r.T->dQKV;
+      float* outs[4]; int accs[4];
+      ln_slots(l, outs, accs);
+      f.dg2 = outs[0]; f.db2 = outs[1]; f.dg1 = outs[2]; f.db1 = outs[3];
+      f.acc_g2 = accs[0]; f.acc_b2 = accs[1]; f.acc_g1 = accs[2]; f.acc_b1 = accs[3];
+      if (!r.ok(launch_enc_block_bwd(f, r.st, r.ctx->rq))) return nullptr;
+      wgrad(r, r.T->dZ, dm, k.F1, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W2), enc_blk_slot(e, l, INTEL_ENC_B2));
+      wgrad(r, r.T->dF1, dm, k.C, dm, rows, dm, dm, enc_blk_slot(e, l, INTEL_ENC_W1), enc_blk_slot(e, l, INTEL_ENC_B1));
+      {
+        const int ws[3] = {enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
+        const int bs[3] = {enc_blk_slot(e, l, INTEL_ENC_BQ), enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
+        wgrad_split(r, r.T->dQKV, 3 * dm, Xin, dm, rows, dm, dm, 3, ws, bs);
+      }
+      GemmEpilogue er;
+      er.res = r.T->dA; er.ldres = dm;          // dZ1: the residual into the block input
+      er.b3 = k.b3WqkvT;
+      lin(r, r.T->dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);
+      if (r.rc) return nullptr;
+      float* t = dX; dX = dXalt; dXalt = t;
+    }
+  }
+  if (!fused_bwd) {   // ---- last block, pruned (see bert_fwd): gradient of one output row per session
     const int l = D.enc_layers - 1;
     EncBlockBufs& k = n.blk[l];
     EncLastBufs& q = n.last;
@@ -971,7 +1055,7 @@ float* bert_bwd(Run& r, int e) {
     if (r.rc) return nullptr;
     if (!r.ok(launch_add_at_last(dZl, dm, dm, len, B, T, dX, r.st, off))) return nullptr;
   }
-  for (int l = D.enc_layers - 2; l >= 0; --l) {
+  for (int l = D.enc_layers - 2; l >= 0 && !fused_bwd; --l) {
     EncBlockBufs& k = n.blk[l];
     const float* Xin = l == 0 ? n.E0 : n.blk[l - 1].Eout;
     // LN2: Eout = LN2(F2 + C)
