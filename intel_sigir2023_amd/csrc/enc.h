@@ -28,7 +28,9 @@ struct EncBlockFwd {
 };
 int launch_enc_block_fwd(const EncBlockFwd& f, hipStream_t st);
 
-// the pruned last block: one query row per session
+// the pruned last block: one query row per session.  A workgroup takes ENC_LAST_SPB sessions: its chain of small dependent steps is
+// latency-bound, so two half-filled 16-row tiles per CU beat one full one (B / 8 workgroups instead of B / 16)
+#define ENC_LAST_SPB 8
 struct EncLastFwd {
   const float* xlast = nullptr;        // [B, dm]
   const float* KV = nullptr;           // [rows, 2 dm]

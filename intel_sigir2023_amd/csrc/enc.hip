@@ -615,7 +615,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
   }
 }
 
-// ---- the pruned last block: 16 sessions per workgroup ----------------------------------------------------------------
+// ---- the pruned last block: ENC_LAST_SPB sessions per workgroup (enc.h) in a 16-row MFMA tile ---------------------------
 struct EncLastArgs {
   const float* xlast;        // [B, D] block input at row len-1 of every session
   const float* KV;           // [rows, 2D] this block's [k | v] rows (packed)
@@ -642,7 +642,8 @@ struct EncLastCfg {
 template <int D, int DK, bool TRAIN, int NP>
 __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(EncLastArgs a) {
   using C = EncLastCfg<D, NP>;
-  constexpr int LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK, SPW = 16 / C::NW;     // sessions per wave
+  constexpr int LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK, NW = C::NW, SPB = ENC_LAST_SPB;
+  constexpr int SLOTS = 16 / NW;                     // tile rows per wave: row s = ss * NW + wave holds session b0 + s when s < SPB
   static_assert(HEADS == 2 && DK == 64, "one-row attention: lane = (head, key), 32 keys per head");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* xpl = reinterpret_cast<__bf16*>(smem_raw);
@@ -653,18 +654,18 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
   float* Es = CLs + 16 * LQ;
   const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b0 = blockIdx.x * 16;
+  const int b0 = blockIdx.x * SPB;
   const float scale = 1.0f / sqrtf((float)DK);
   // ---- x_last rows -> planes
   for (int i = tid; i < 16 * (D / 4); i += C::NT) {
     const int row = i / (D / 4), col = (i - row * (D / 4)) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (b0 + row < a.B) v = *reinterpret_cast<const f32x4*>(a.xlast + (size_t)(b0 + row) * D + col);
+    if (row < SPB && b0 + row < a.B) v = *reinterpret_cast<const f32x4*>(a.xlast + (size_t)(b0 + row) * D + col);
     store4<NP, PLANE>(xpl + row * LDP + col, v);
   }
   lds_barrier();
   const int col = wave * 16 + 4 * j;                 // this lane's four output columns of every D -> D product
-  const bool rowok = b0 + p < a.B;
+  const bool rowok = p < SPB && b0 + p < a.B;
   const size_t growp = (size_t)(b0 + p);
   // ---- q = x_last Wq^T + bq
   {
@@ -678,9 +679,18 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
   lds_barrier();
   // ---- attention of the one query row (fp32 on the vector unit) + LayerNorm1; a wave owns whole sessions
 #pragma unroll 1
-  for (int ss = 0; ss < SPW; ++ss) {
-    const int s = wave * SPW + ss, b = b0 + s;
-    if (b >= a.B) break;                              // wave-uniform
+  for (int ss = 0; ss < SLOTS; ++ss) {
+    const int s = ss * NW + wave, b = b0 + s;
+    if (s >= SPB || b >= a.B) {                       // wave-uniform: no session in this tile row -- finite values for the tile products
+      CLs[s * LQ + lane] = 0.f;
+      CLs[s * LQ + 64 + lane] = 0.f;
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+        cpl[pl * PLANE + s * LDP + lane] = (__bf16)0.f;
+        cpl[pl * PLANE + s * LDP + 64 + lane] = (__bf16)0.f;
+      }
+      continue;
+    }
     const int n = a.len[b];
     const size_t rb = (size_t)a.off[b];
     const int h = lane >> 5, t = lane & 31;
@@ -737,17 +747,6 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
       if (a.RSTD1 && lane == 0) a.RSTD1[b] = rs;
     }
   }
-  // sessions past the batch: their plane rows must hold finite values for the tile products
-  if (b0 + 16 > a.B) {
-    for (int i = tid; i < 16 * D; i += C::NT) {
-      const int row = i / D, c = i - row * D;
-      if (b0 + row >= a.B) {
-        cpl[row * LDP + c] = (__bf16)0.f;
-        if (NP == 3) { cpl[PLANE + row * LDP + c] = (__bf16)0.f; cpl[2 * PLANE + row * LDP + c] = (__bf16)0.f; }
-        CLs[row * LQ + c] = 0.f;
-      }
-    }
-  }
   lds_barrier();
   // ---- f = relu(c W1^T + b1)
   {
@@ -771,9 +770,9 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
   lds_barrier();
   // ---- out = LayerNorm2(z + c)
 #pragma unroll 1
-  for (int ss = 0; ss < SPW; ++ss) {
-    const int s = wave * SPW + ss, b = b0 + s;
-    if (b >= a.B) break;
+  for (int ss = 0; ss < SLOTS; ++ss) {
+    const int s = ss * NW + wave, b = b0 + s;
+    if (s >= SPB || b >= a.B) continue;
     float z0 = Es[s * LQ + lane] + CLs[s * LQ + lane], z1 = Es[s * LQ + 64 + lane] + CLs[s * LQ + 64 + lane];
     const float mean = wave_sum(z0 + z1) * (1.f / (float)D);
     z0 -= mean; z1 -= mean;
@@ -841,7 +840,7 @@ int launch_last(const EncLastArgs& a, hipStream_t st) {
   allow_lds((enc_last_fwd_kernel<D, DK, TRAIN, NP>), smem);
   const double flops = 2.0 * a.B * (double)D * D * 3 + 4.0 * a.B * (double)a.T * D * 0.5;
   const double bytes = 4.0 * a.B * (double)D * (2.0 + a.T);
-  LAUNCH_S(a.B, D, DK, flops, bytes, (enc_last_fwd_kernel<D, DK, TRAIN, NP>), dim3(cdiv(a.B, 16)), dim3(C::NT), smem, st, a);
+  LAUNCH_S(a.B, D, DK, flops, bytes, (enc_last_fwd_kernel<D, DK, TRAIN, NP>), dim3(cdiv(a.B, ENC_LAST_SPB)), dim3(C::NT), smem, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
 }

@@ -25,8 +25,11 @@ namespace {
 using namespace planes;
 
 // self-contained plane product (as enc.hip: gemm_planes)
-template <int D, int CT, int RT, int ROWS>
-__device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img, int ct0, f32x4 (&acc)[CT][RT]) {
+// `tail_loads` runs right behind the product's last fragment loads (vmcnt retires in order: global loads for a LATER phase issued
+// there delay nothing of this product)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int D, int CT, int RT, int ROWS, typename Hook = NoHook>
+__device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img, int ct0, f32x4 (&acc)[CT][RT], Hook tail_loads = Hook()) {
   constexpr int KB = D / 32, KBT = 4, LDP = D + 8, PLANE = ROWS * LDP;
   uint4 bw[2][CT][3];
 #pragma unroll
@@ -41,6 +44,7 @@ __device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bw[(kb + 1) & 1][c][pl] = img[((size_t)((ct0 + c) * KBT + kb + 1) * 3 + pl) * 64];
     }
+    if (kb == (KB >= 2 ? KB - 2 : 0)) tail_loads();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
@@ -69,6 +73,7 @@ struct EncBlockBwdArgs {
   float* DZ2; float* DF1; float* DZ1;      // [rows, D]
   float* DQKV;                             // [rows, 3D]
   float* slab;                             // [gridDim.x][4][D]: partial d(gamma2), d(beta2), d(gamma1), d(beta1)
+  unsigned long long* dbg;                 // INTEL_ENC_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0
 };
 
 template <int D>
@@ -81,12 +86,27 @@ struct EncBwdCfg {
   static constexpr size_t SMEM = ES_BYTES + U_BYTES;
 };
 
-// attention backward of one (session, head): KT = tiles of 16 rows the session spans.  `stat` = this wave's LDS scratch [3][32]:
-// the per-query softmax statistics of pass 1 for pass 2 (which holds the queries on the accumulator rows instead of the lanes).
-// The tile loops are NOT unrolled for KT = 2: with all four score tiles in flight the kernel spills.
+// Attention backward of one (session, head) as TWO independent work items (different waves take them):
+//   pass Q   transposed score tiles (keys on the accumulator rows, the query on the lane): softmax statistics by lane-group
+//            shuffles, dS^T straight from the accumulators into dQ = dS K;
+//   pass KV  straight tiles (operands swapped: queries on the accumulator rows, the key on the lane): the same statistics by 16-lane
+//            DPP reductions, P and dS from the accumulators into dV = P^T dO and dK = dS^T Q.
+// Recomputing the score tiles in both layouts (7 tile products instead of 5) needs no transposition through LDS and no hand-over
+// between the two halves.  KT = tiles of 16 rows the session spans.  The tile loops are not unrolled for KT = 2 (registers).
+template <int CTRL>
+__device__ __forceinline__ float dpp_max_step(float v) {
+  return fmaxf(v, dpp_mov<CTRL>(v));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = dpp_max_step<0xB1>(v);
+  v = dpp_max_step<0x4E>(v);
+  v = dpp_max_step<0x141>(v);
+  v = dpp_max_step<0x140>(v);
+  return v;
+}
+
 template <int D, int DK, int KT>
-__device__ __forceinline__ void attn_bwd_item(const EncBlockBwdArgs& a, const float* Qs, const float* Es, float* stat, int base, int len, int h, int r0,
-                                              int lane) {
+__device__ __forceinline__ void attn_bwd_q(const EncBlockBwdArgs& a, const float* Qs, const float* Es, int base, int len, int h, int r0, int lane) {
   constexpr int LQ = D + 4;
   static_assert(DK == 64, "head dim 64");
   const int j = lane >> 4, p = lane & 15;
@@ -98,7 +118,7 @@ __device__ __forceinline__ void attn_bwd_item(const EncBlockBwdArgs& a, const fl
   // tile rows by lane index p / by 4j + r, clamped into the tile (masked where they lie past the session)
   auto rowp = [&](int t) { return min(base + t * 16 + p, 63); };
   auto row4 = [&](int t, int r) { return min(base + t * 16 + 4 * j + r, 63); };
-  // ---- pass 1, transposed tiles: register r of key tile kb at lane (p, j) = key 16 kb + 4j + r, query 16 qa + p
+  // register r of key tile kb at lane (p, j) = key 16 kb + 4j + r, query 16 qa + p
 #pragma unroll 1
   for (int qa = 0; qa < KT; ++qa) {
     f32x4 st[KT], dpt[KT];
@@ -150,11 +170,6 @@ __device__ __forceinline__ void attn_bwd_item(const EncBlockBwdArgs& a, const fl
         dl += st[kb][r] * dpt[kb][r];
       }
     dl = gsum16(dl);
-    if (j == 0) {
-      stat[qa * 16 + p] = moff;
-      stat[32 + qa * 16 + p] = inv;
-      stat[64 + qa * 16 + p] = dl;
-    }
 #pragma unroll
     for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
@@ -179,66 +194,102 @@ __device__ __forceinline__ void attn_bwd_item(const EncBlockBwdArgs& a, const fl
       if (q < len) *reinterpret_cast<f32x4*>(a.DQKV + ((size_t)r0 + base + q) * (3 * D) + hc + 4 * p) = f32x4{dq[0][r], dq[1][r], dq[2][r], dq[3][r]};
     }
   }
-  // ---- pass 2, straight tiles (the operands swapped): register r of query tile qa at lane (p, j) = query 16 qa + 4j + r, key 16 kb + p
+}
+
+template <int D, int DK, int KT>
+__device__ __forceinline__ void attn_bwd_kv(const EncBlockBwdArgs& a, const float* Qs, const float* Es, int base, int len, int h, int r0, int lane) {
+  constexpr int LQ = D + 4;
+  const int j = lane >> 4, p = lane & 15;
+  const float* Ks = Qs + 64 * LQ;
+  const float* Vs = Ks + 64 * LQ;
+  const float scale = 1.0f / sqrtf((float)DK);
+  const float c2 = scale * 1.4426950408889634f;
+  const int hc = h * DK;
+  auto rowp = [&](int t) { return min(base + t * 16 + p, 63); };
+  auto row4 = [&](int t, int r) { return min(base + t * 16 + 4 * j + r, 63); };
+  f32x4 dk[KT][4], dv[KT][4];
+#pragma unroll
+  for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dk[kb][t] = dv[kb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // register r of key tile kb at lane (p, j) = query 16 qa + 4j + r, key 16 kb + p
 #pragma unroll 1
-  for (int kb = 0; kb < KT; ++kb) {
+  for (int qa = 0; qa < KT; ++qa) {
     f32x4 s2[KT], dp2[KT];
 #pragma unroll
-    for (int qa = 0; qa < KT; ++qa) s2[qa] = dp2[qa] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int krow = rowp(kb);
+    for (int kb = 0; kb < KT; ++kb) s2[kb] = dp2[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int qrow = rowp(qa);
 #pragma unroll
     for (int g = 0; g < DK / 16; ++g) {
-      const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow * LQ + hc + 4 * j + 16 * g);
-      const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + krow * LQ + hc + 4 * j + 16 * g);
+      const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + qrow * LQ + hc + 4 * j + 16 * g);
+      const f32x4 of = *reinterpret_cast<const f32x4*>(Es + qrow * LQ + hc + 4 * j + 16 * g);
 #pragma unroll
-      for (int qa = 0; qa < KT; ++qa) {
-        const int qrow = rowp(qa);
-        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + qrow * LQ + hc + 4 * j + 16 * g);
-        const f32x4 of = *reinterpret_cast<const f32x4*>(Es + qrow * LQ + hc + 4 * j + 16 * g);
-        s2[qa] = mma4(qf, kf, s2[qa]);
-        dp2[qa] = mma4(of, vf, dp2[qa]);
+      for (int kb = 0; kb < KT; ++kb) {
+        const int krow = rowp(kb);
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow * LQ + hc + 4 * j + 16 * g);
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + krow * LQ + hc + 4 * j + 16 * g);
+        s2[kb] = mma4(qf, kf, s2[kb]);
+        dp2[kb] = mma4(of, vf, dp2[kb]);
       }
       if (KT > 1) __builtin_amdgcn_sched_barrier(0);
     }
-    const bool kok = (kb * 16 + p) < len;
+    // per query (accumulator row r of this lane group): max / sum / rowsum(P dP) over the keys = over the 16 lanes and the key tiles
 #pragma unroll
-    for (int qa = 0; qa < KT; ++qa)
+    for (int r = 0; r < 4; ++r) {
+      const bool qok = (qa * 16 + 4 * j + r) < len;
+      float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = qa * 16 + 4 * j + r;
-        const bool ok = kok && q < len;
-        const float pr = ok ? __builtin_amdgcn_exp2f(__builtin_fmaf(s2[qa][r], c2, stat[q])) * stat[32 + q] : 0.f;
-        s2[qa][r] = pr;                                                          // P
-        dp2[qa][r] = ok ? pr * (dp2[qa][r] - stat[64 + q]) * scale : 0.f;         // dS
+      for (int kb = 0; kb < KT; ++kb) {
+        const float v = (kb * 16 + p) < len ? s2[kb][r] : -INFINITY;
+        s2[kb][r] = v;
+        mx = fmaxf(mx, v);
       }
-    // dK[key][dim] = sum_query dS[query][key] Q[query][dim], dV[key][dim] = sum_query P[query][key] dO[query][dim]
-    f32x4 dk[4], dv[4];
+      mx = row16_max(mx);                      // key 0 is live for every query
+      const float moff = -mx * c2;
+      float ps = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) dk[t] = dv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int qa = 0; qa < KT; ++qa) {
-      f32x4 qv[4], ov[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        qv[s] = *reinterpret_cast<const f32x4*>(Qs + row4(qa, s) * LQ + hc + 4 * p);
-        ov[s] = *reinterpret_cast<const f32x4*>(Es + row4(qa, s) * LQ + hc + 4 * p);
+      for (int kb = 0; kb < KT; ++kb) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s2[kb][r], c2, moff));
+        s2[kb][r] = e;
+        ps += e;
       }
+      const float inv = qok ? 1.f / row16_sum(ps) : 0.f;      // rows past the session are other sessions' rows: no contribution
+      float dl = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < KT; ++kb) {
+        s2[kb][r] *= inv;                                      // P
+        dl += s2[kb][r] * dp2[kb][r];
+      }
+      dl = row16_sum(dl);
+#pragma unroll
+      for (int kb = 0; kb < KT; ++kb) dp2[kb][r] = s2[kb][r] * (dp2[kb][r] - dl) * scale;      // dS
+    }
+    // dK[key][dim] += sum_query dS[query][key] Q[query][dim], dV[key][dim] += sum_query P[query][key] dO[query][dim]
+    f32x4 qv[4], ov[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qv[s] = *reinterpret_cast<const f32x4*>(Qs + row4(qa, s) * LQ + hc + 4 * p);
+      ov[s] = *reinterpret_cast<const f32x4*>(Es + row4(qa, s) * LQ + hc + 4 * p);
+    }
+#pragma unroll
+    for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        dk[t] = mma4(dp2[qa], f32x4{qv[0][t], qv[1][t], qv[2][t], qv[3][t]}, dk[t]);
-        dv[t] = mma4(s2[qa], f32x4{ov[0][t], ov[1][t], ov[2][t], ov[3][t]}, dv[t]);
+        dk[kb][t] = mma4(dp2[kb], f32x4{qv[0][t], qv[1][t], qv[2][t], qv[3][t]}, dk[kb][t]);
+        dv[kb][t] = mma4(s2[kb], f32x4{ov[0][t], ov[1][t], ov[2][t], ov[3][t]}, dv[kb][t]);
       }
-    }
+  }
+#pragma unroll
+  for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = kb * 16 + 4 * j + r;
       if (k < len) {
         float* dst = a.DQKV + ((size_t)r0 + base + k) * (3 * D) + hc + 4 * p;
-        *reinterpret_cast<f32x4*>(dst + D) = f32x4{dk[0][r], dk[1][r], dk[2][r], dk[3][r]};
-        *reinterpret_cast<f32x4*>(dst + 2 * D) = f32x4{dv[0][r], dv[1][r], dv[2][r], dv[3][r]};
+        *reinterpret_cast<f32x4*>(dst + D) = f32x4{dk[kb][0][r], dk[kb][1][r], dk[kb][2][r], dk[kb][3][r]};
+        *reinterpret_cast<f32x4*>(dst + 2 * D) = f32x4{dv[kb][0][r], dv[kb][1][r], dv[kb][2][r], dv[kb][3][r]};
       }
     }
-  }
 }
 
 template <int D, int DK>
@@ -250,7 +301,6 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
   __shared__ int s_start[65];
   __shared__ int s_rowlast[64];
   __shared__ __attribute__((aligned(16))) float s_g[2 * D];                  // gamma2 | gamma1
-  __shared__ float s_stat[NW][96];                                            // attention backward: per-wave query statistics
   float* Es = reinterpret_cast<float*>(smem_raw);
   __bf16* zplanes = reinterpret_cast<__bf16*>(smem_raw + C::ES_BYTES);                  // dZ2 planes
   __bf16* fplanes = reinterpret_cast<__bf16*>(smem_raw + C::ES_BYTES + C::P_BYTES);     // dF1 planes
@@ -261,6 +311,16 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
   f32x4 pg2[CPL], pb2[CPL], pg1[CPL], pb1[CPL];      // this lane's partial d(gamma) / d(beta) of its columns (D/16) p + 4 cc ..
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) pg2[cc] = pb2[cc] = pg1[cc] = pb1[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned long long tstamp = 0;
+  const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int ph) {
+    if (probe) {
+      const unsigned long long now = clock64();
+      if (ph >= 0) a.dbg[ph] += now - tstamp;
+      tstamp = now;
+    }
+  };
+  mark(-1);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     const int s_lo = a.tile_s[t], s_hi = a.tile_s[t + 1];
     const int ns = s_hi - s_lo;
@@ -278,6 +338,7 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
       if (lane == 0) s_start[ns] = nrows;
     }
     __syncthreads();      // bookkeeping visible; also: everybody is done with the previous tile's LDS
+    mark(0);
     // ---- dE (+ d(x_last)) -> LayerNorm2 backward -> dZ2: fp32 rows, planes, HBM.  16 lanes per row, four rows per wave at a time
     const float inv_n = 1.f / (float)D;
 #pragma unroll
@@ -314,7 +375,10 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
         store4<3, PLANE>(zplanes + row * LDP + col, dz);
       }
     }
+    mark(1);
     lds_barrier();
+    mark(2);
+    float warm[2];
     // ---- dF1 = (dZ2 W2) * [F1 > 0]; wave = one column tile, four row tiles
     {
       f32x4 acc[1][4];
@@ -324,7 +388,18 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
       f32x4 mk[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) mk[rt] = *reinterpret_cast<const f32x4*>(a.F1 + ((size_t)r0 + min(rt * 16 + p, nrows - 1)) * D + col);
-      gemm_planes<D, 1, 4, 64>(zplanes + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc);
+      // the stashed q / k / v and LayerNorm1 x-hat rows of this tile have not been touched since the forward pass: one 4-byte read per
+      // 128-byte line now pulls them from HBM into L2 while the two products run (they are staged / read two phases from here)
+      auto touch = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = tid + NT * u;                       // 64 rows x (12 q/k/v + 4 x-hat) lines
+          const int row = min(i >> 4, nrows - 1), seg = i & 15;
+          const float* src = seg < 12 ? a.QKV + ((size_t)r0 + row) * (3 * D) + seg * 32 : a.XH1 + ((size_t)r0 + row) * D + (seg - 12) * 32;
+          warm[u] = *src;
+        }
+      };
+      gemm_planes<D, 1, 4, 64>(zplanes + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc, touch);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int row = rt * 16 + p;
@@ -335,7 +410,9 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
         if (row < nrows) *reinterpret_cast<f32x4*>(a.DF1 + ((size_t)r0 + row) * D + col) = x;
       }
     }
+    mark(3);
     lds_barrier();
+    mark(4);
     // ---- dC = dF1 W1 + dZ2, in place over the dZ2 rows (every element is read and rewritten by the same lane)
     {
       f32x4 acc[1][4];
@@ -349,9 +426,12 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
         *reinterpret_cast<f32x4*>(e) = *reinterpret_cast<const f32x4*>(e) + acc[0][rt];
       }
     }
+    mark(5);
     lds_barrier();
+    mark(6);
     // ---- LayerNorm1 backward -> dZ1 (= the attention output's gradient and the residual into dX), in place; the stashed q / k / v
     // rows of the tile come in over the dead planes
+    asm volatile("" ::"v"(warm[0]), "v"(warm[1]));         // (the L2 warm-up reads end here)
     for (int i = tid; i < 64 * (3 * D / 4); i += NT) {
       const int row = i / (3 * D / 4), c4 = i - row * (3 * D / 4);
       const int which = c4 / (D / 4), col = (c4 - which * (D / 4)) * 4;
@@ -390,15 +470,24 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
         *reinterpret_cast<f32x4*>(Es + row * LQ + col) = dz;
       }
     }
+    mark(7);
     lds_barrier();
-    // ---- attention backward: one (session, head) per wave at a time
-    for (int it = wave; it < ns * HEADS; it += NW) {
-      const int s = it / HEADS, h = it - s * HEADS;
+    mark(8);
+    // ---- attention backward: (session, head, pass) work items over the waves
+    for (int it = wave; it < ns * HEADS * 2; it += NW) {
+      const int s = it / (HEADS * 2), hp = it - s * (HEADS * 2), h = hp >> 1;
       const int base = s_start[s], len = s_start[s + 1] - base;
-      if (len > 16) attn_bwd_item<D, DK, 2>(a, Qs, Es, s_stat[wave], base, len, h, r0, lane);
-      else attn_bwd_item<D, DK, 1>(a, Qs, Es, s_stat[wave], base, len, h, r0, lane);
+      if (hp & 1) {
+        if (len > 16) attn_bwd_kv<D, DK, 2>(a, Qs, Es, base, len, h, r0, lane);
+        else attn_bwd_kv<D, DK, 1>(a, Qs, Es, base, len, h, r0, lane);
+      } else {
+        if (len > 16) attn_bwd_q<D, DK, 2>(a, Qs, Es, base, len, h, r0, lane);
+        else attn_bwd_q<D, DK, 1>(a, Qs, Es, base, len, h, r0, lane);
+      }
     }
+    mark(9);
     lds_barrier();        // the next tile's bookkeeping and dZ2 rows go over what the attention reads
+    mark(10);
   }
   // ---- LayerNorm parameter gradients of this workgroup: lanes of one DPP row group share their columns across j; waves through LDS
   __syncthreads();
@@ -448,7 +537,7 @@ struct EncLastBwdCfg {
 template <int D, int DK>
 __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(EncLastBwdArgs a) {
   using C = EncLastBwdCfg<D>;
-  constexpr int LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK, SPW = 16 / C::NW, NW = C::NW;
+  constexpr int LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK, NW = C::NW, SPB = ENC_LAST_SPB, SLOTS = 16 / C::NW;
   static_assert(HEADS == 2 && DK == 64, "one-row attention: lane = (head, key), 32 keys per head");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* zpl = reinterpret_cast<__bf16*>(smem_raw);
@@ -459,16 +548,16 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
   float* red = Ws + 16 * LQ;
   const int tid = threadIdx.x, lane = tid & 63, j = lane >> 4, p = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b0 = blockIdx.x * 16;
+  const int b0 = blockIdx.x * SPB;
   const float scale = 1.0f / sqrtf((float)DK);
   const float inv_n = 1.f / (float)D;
   float pg2[2] = {0.f, 0.f}, pb2[2] = {0.f, 0.f}, pg1[2] = {0.f, 0.f}, pb1[2] = {0.f, 0.f};      // columns lane, 64 + lane
   // ---- LayerNorm2 backward: a wave owns whole sessions, lane = columns lane and 64 + lane
 #pragma unroll 1
-  for (int ss = 0; ss < SPW; ++ss) {
-    const int s = wave * SPW + ss, b = b0 + s;
+  for (int ss = 0; ss < SLOTS; ++ss) {
+    const int s = ss * NW + wave, b = b0 + s;          // tile row s holds session b0 + s when s < SPB
     float z0 = 0.f, z1 = 0.f;
-    if (b < a.B) {
+    if (s < SPB && b < a.B) {
       const float d0 = a.dvec[(size_t)b * a.ldv + lane], d1 = a.dvec[(size_t)b * a.ldv + 64 + lane];
       const float x0 = a.XH2[(size_t)b * D + lane], x1 = a.XH2[(size_t)b * D + 64 + lane];
       const float g0 = d0 * a.g2[lane], g1v = d1 * a.g2[64 + lane];
@@ -490,7 +579,7 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
   }
   lds_barrier();
   const int col = wave * 16 + 4 * j;
-  const bool rowok = b0 + p < a.B;
+  const bool rowok = p < SPB && b0 + p < a.B;
   const size_t growp = (size_t)(rowok ? b0 + p : 0);
   // ---- df1 = (dz2 W2) * [f1 > 0]
   {
@@ -515,10 +604,10 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
   lds_barrier();
   // ---- LayerNorm1 backward, then the one-row attention's backward; a wave owns whole sessions
 #pragma unroll 1
-  for (int ss = 0; ss < SPW; ++ss) {
-    const int s = wave * SPW + ss, b = b0 + s;
+  for (int ss = 0; ss < SLOTS; ++ss) {
+    const int s = ss * NW + wave, b = b0 + s;
     float q0 = 0.f, q1 = 0.f;                      // dq of this session, columns lane and 64 + lane
-    if (b < a.B) {                                 // wave-uniform
+    if (s < SPB && b < a.B) {                      // wave-uniform
       const float c0 = Ws[s * LQ + lane], c1 = Ws[s * LQ + 64 + lane];
       const float x0 = a.XH1[(size_t)b * D + lane], x1 = a.XH1[(size_t)b * D + 64 + lane];
       const float g0 = c0 * a.g1[lane], g1v = c1 * a.g1[64 + lane];
@@ -604,7 +693,7 @@ size_t enc_bwd_slab_floats(int rows, int B, int T, int dm) {
   const int ntiles = cdiv(rows, enc_tile_rows(T));
   int g = num_cus();
   if (g > ntiles) g = ntiles;
-  const int gl = cdiv(B, 16);
+  const int gl = cdiv(B, ENC_LAST_SPB);
   return (size_t)(g > gl ? g : gl) * 4 * dm + 64;
 }
 
@@ -628,8 +717,24 @@ int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
   a.slab = slab;
   allow_lds((enc_block_bwd_kernel<D, 64>), C::SMEM);
   const double M = (double)f.rows;
+  static const int dbg_on = [] { const char* e = getenv("INTEL_ENC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  static unsigned long long* dbg_buf = nullptr;
+  a.dbg = nullptr;
+  if (dbg_on) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_buf, 0, 16 * sizeof(unsigned long long), st);
+    a.dbg = dbg_buf;
+  }
   LAUNCH_S(f.rows, D, 64, 2.0 * M * D * D * 2 + 10.0 * M * f.T * D * 0.5, 4.0 * M * D * 12, (enc_block_bwd_kernel<D, 64>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
   INTEL_CHECK_LAUNCH();
+  if (dbg_on) {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const int iters = (a.ntiles + grid - 1) / grid;
+    fprintf(stderr, "enc_block_bwd grid=%d iters=%d cycles/tile: meta %llu ln2 %llu (+bar %llu) w2 %llu (+bar %llu) w1 %llu (+bar %llu) ln1+stage %llu (+bar %llu) attn %llu (+bar %llu)\n",
+            grid, iters, h[0] / iters, h[1] / iters, h[2] / iters, h[3] / iters, h[4] / iters, h[5] / iters, h[6] / iters, h[7] / iters, h[8] / iters, h[9] / iters, h[10] / iters);
+  }
   float* outs[4] = {f.dg2, f.db2, f.dg1, f.db1};
   const int accs[4] = {f.acc_g2, f.acc_b2, f.acc_g1, f.acc_b1};
   for (int k = 0; k < 4; ++k)
@@ -649,7 +754,7 @@ int launch_enc_last_bwd(const EncLastBwd& f, hipStream_t st, ReduceQueue* q) {
   a.g1 = f.g1; a.g2 = f.g2;
   a.XH2 = f.XH2; a.RSTD2 = f.RSTD2; a.F1 = f.F1; a.XH1 = f.XH1; a.RSTD1 = f.RSTD1; a.PL = f.PL; a.QL = f.QL;
   a.DZ2 = f.DZ2; a.DF1 = f.DF1; a.DQ = f.DQ; a.DXL = f.DXL; a.DKV = f.DKV;
-  const int grid = cdiv(f.B, 16);
+  const int grid = cdiv(f.B, ENC_LAST_SPB);
   float* slab = redq_alloc(q, (size_t)grid * 4 * D);
   INTEL_CHECK_ARG(slab, "enc_last_bwd: reduction arena exhausted");
   a.slab = slab;
