@@ -29,7 +29,11 @@ using namespace planes;
 
 template <int D, int NP>
 struct EncCfg {
-  static constexpr int NW = D / 16;                 // waves
+  // fp32 mode: a wave per 16-column tile of the D-wide products.  bf16 mode: HALF as many waves with two column tiles each -- the
+  // 70 KB tile lets two workgroups share a CU, and with 2 x 4 waves per CU each wave keeps a 256-register budget (8 waves per
+  // workgroup would have to fit 128: the kernel then spills)
+  static constexpr int NW = NP == 1 ? D / 32 : D / 16;
+  static constexpr int CM = (D / 16) / NW;          // column tiles per wave in a D-wide product
   static constexpr int NT = NW * 64;
   static constexpr int KB = D / 32;                 // 32-deep k blocks
   static constexpr int KBT = 4;                     // k blocks per column tile in a weight image (k padded to 128)
@@ -43,7 +47,7 @@ struct EncCfg {
   static constexpr size_t ES_BYTES = (size_t)64 * LQ * 4;
   static_assert(R1_BYTES + ES_BYTES <= R_BYTES, "R1 planes + LayerNorm tile must fit the q/k/v region");
   static constexpr size_t SMEM = P_BYTES + R_BYTES;
-  static constexpr int WPS = NP == 1 ? 4 : 2;       // waves per SIMD the register budget is set for
+  static constexpr int WPS = 2;                     // waves per SIMD the register budget is set for
 };
 
 // acc[c][rt] += A rows (planes at `frag` = planes + p * LDP + 8 * j, RT row tiles of 16) x column tiles ct0 .. ct0 + CT - 1 of a
@@ -118,6 +122,38 @@ __device__ __forceinline__ void gemm_planes_pre(const __bf16* frag, const uint4*
   }
 }
 
+// bf16 mode (one plane): NCT column tiles one after the other, the K / 32 fragments of the NEXT tile requested while this one is
+// multiplied (a tile's whole k extent is 4 x 16 bytes per lane); epi(ct, acc) consumes a finished tile
+template <int D, int NCT, int RT, int ROWS, typename Epi>
+__device__ __forceinline__ void gemm_cols_bf16(const __bf16* frag, const uint4* img, int ct0, Epi epi) {
+  constexpr int KB = D / 32, KBT = 4, LDP = D + 8;
+  uint4 bw[2][KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) bw[0][kb] = img[((size_t)(ct0 * KBT + kb) * 3) * 64];
+  bf16x8 af[RT][KB];               // the activation fragments of the whole tile stay in registers for all column tiles (one LDS pass)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) af[rt][kb] = *reinterpret_cast<const bf16x8*>(frag + rt * 16 * LDP + kb * 32);
+#pragma unroll 2
+  for (int c = 0; c < NCT; ++c) {
+    if (c + 1 < NCT) {
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bw[(c + 1) & 1][kb] = img[((size_t)((ct0 + c + 1) * KBT + kb) * 3) * 64];
+    }
+    f32x4 acc[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bw[c & 1][kb]), af[rt][kb], acc[rt], 0, 0, 0);
+    epi(ct0 + c, acc);
+  }
+  (void)ROWS;
+}
+
 struct EncBlockArgs {
   const float* X;            // [rows, D] packed block input
   int rows, B, T, ntiles;
@@ -163,7 +199,7 @@ __device__ __forceinline__ void attn_ln1_item(const EncBlockArgs& a, const unsig
   }
   // the residual rows of LayerNorm1 (the block input) travel while the attention is computed
   const size_t grow = (size_t)r0 + min(base + q, base + len - 1);       // clamped for the lanes without a query (loads only)
-  constexpr bool HOIST = NP == 3;                  // (the bf16 mode's 128-register budget: loaded where they are used)
+  constexpr bool HOIST = NP == 3 && !TRAIN;        // (training and the bf16 mode: registers -- loaded where they are used)
   f32x4 xres[HOIST ? HEADS : 1][4];
   if constexpr (HOIST) {
 #pragma unroll
@@ -311,8 +347,11 @@ template <int D, int DK, bool TRAIN, int NP>
 __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc_block_fwd_kernel(EncBlockArgs a) {
   using C = EncCfg<D, NP>;
   using PR = EncPar<D>;
-  constexpr int NW = C::NW, NT = C::NT, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ, KBT = C::KBT;
-  constexpr bool PF = NP == 3;          // cross-phase prefetch of weight fragments / residual rows (the bf16 mode's 128-register budget has no room)
+  constexpr int NW = C::NW, NT = C::NT, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ, KBT = C::KBT, CM = C::CM;
+  constexpr bool PF = NP == 3;          // weight fragments of a product's first k block requested across the barrier in front of it (one column tile per wave)
+  constexpr bool PFX = NP == 3;         // the next tile's rows requested a tile ahead (bf16 mode: the CU's second workgroup covers that wait; registers)
+  constexpr bool PFR = true;            // the LayerNorm2 residual rows requested a phase ahead
+  static_assert(!PF || CM == 1, "the cross-phase fragment prefetch assumes one column tile per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int s_start[65];        // first row (inside the tile) of every session of the tile, then the tile's row count
   __shared__ int s_rowlast[64];      // session whose last row this is, or -1
@@ -385,12 +424,12 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
     }
   };
   Tile cur = tile_meta(blockIdx.x);
-  if constexpr (PF) load_tile(cur);
+  if constexpr (PFX) load_tile(cur);
   mark(-1);
   for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
     if (cur.ns <= 0) break;            // only the last window can be without a session start (a window holds 65 - T > T rows)
     const int s_lo = cur.s_lo, ns = cur.ns, r0 = cur.r0, nrows = cur.nrows;
-    if constexpr (!PF) load_tile(cur);
+    if constexpr (!PFX) load_tile(cur);
     // ---- tile bookkeeping (wave 0) + X rows -> planes
     if (wave == 0) {
       s_rowlast[lane] = -1;
@@ -438,14 +477,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         }
       };
       if constexpr (NP == 1) {                                 // register budget of four waves per SIMD: one column tile at a time
-#pragma unroll 1
-        for (int c = 0; c < 3; ++c) {
-          f32x4 acc[1][4];
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          gemm_planes<D, NP, 1, 4, 64>(frag, img, 3 * wave + c, acc);
-          epilogue((3 * wave + c) * 16 + 4 * j, acc[0]);
-        }
+        gemm_cols_bf16<D, 3 * CM, 4, 64>(frag, img, 3 * CM * wave, [&](int ct, const f32x4 (&acc)[4]) { epilogue(ct * 16 + 4 * j, acc); });
       } else {
         f32x4 acc[3][4];
 #pragma unroll
@@ -459,7 +491,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
     }
     // the next tile's bookkeeping and rows travel from here on
     const Tile nxt = tile_meta(t + gridDim.x);
-    if constexpr (PF) { if (nxt.ns > 0) load_tile(nxt); }
+    if constexpr (PFX) { if (nxt.ns > 0) load_tile(nxt); }
     mark(2);
     lds_barrier();
     mark(3);
@@ -482,24 +514,30 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
     // the LayerNorm2 residual rows of this thread come back while the two feed-forward products run
     constexpr int CPL = D / 64;                      // float4 per lane per row (16 lanes per row)
     constexpr int ROUNDS = 64 / (NW * 4);
-    f32x4 cres[PF ? ROUNDS : 1][CPL];
+    f32x4 cres[PFR ? ROUNDS : 1][CPL];
     // ---- R1 = relu(C W1^T + b1) -> planes over the dead q / k / v rows; wave = one column tile
     {
-      f32x4 acc[1][4];
+      auto epi1 = [&](int ct, const f32x4 (&acc)[4]) {
+        const int col = ct * 16 + 4 * j;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B1 + col);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (PF) gemm_planes_pre<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc, bw1);
-      else gemm_planes<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc);
-      const int col = wave * 16 + 4 * j;
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B1 + col);
+        for (int rt = 0; rt < 4; ++rt) {
+          const int row = rt * 16 + p;
+          f32x4 x = acc[rt] + bias;
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int row = rt * 16 + p;
-        f32x4 x = acc[0][rt] + bias;
+          for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+          store4<NP, PLANE>(r1planes + row * LDP + col, x);
+          if (TRAIN && a.F1 && row < nrows) *reinterpret_cast<f32x4*>(a.F1 + ((size_t)r0 + row) * D + col) = x;
+        }
+      };
+      if constexpr (NP == 1) {
+        gemm_cols_bf16<D, CM, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave * CM, epi1);
+      } else {
+        f32x4 acc[1][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
-        store4<NP, PLANE>(r1planes + row * LDP + col, x);
-        if (TRAIN && a.F1 && row < nrows) *reinterpret_cast<f32x4*>(a.F1 + ((size_t)r0 + row) * D + col) = x;
+        for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_planes_pre<D, NP, 1, 4, 64>(planes + p * LDP + 8 * j, launder(a.W1) + lane, wave, acc, bw1);
+        epi1(wave, acc[0]);
       }
     }
     if constexpr (PF) load_w<NP, 1>(bw2[0], launder(a.W2) + lane, wave, 0);
@@ -508,23 +546,30 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
     mark(7);
     // ---- Z = R1 W2^T + b2 -> fp32 tile; the LayerNorm2 residual rows of this thread are requested behind the product's loads
     {
-      f32x4 acc[1][4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       auto res_loads = [&]() {
 #pragma unroll
-        for (int rnd = 0; rnd < (PF ? ROUNDS : 1); ++rnd) {
+        for (int rnd = 0; rnd < (PFR ? ROUNDS : 1); ++rnd) {
           const int row = min((rnd * NW + wave) * 4 + j, nrows - 1);
 #pragma unroll
           for (int cc = 0; cc < CPL; ++cc) cres[rnd][cc] = *reinterpret_cast<const f32x4*>(a.C + ((size_t)r0 + row) * D + (D / 16) * p + 4 * cc);
         }
       };
-      if (PF) gemm_planes_pre<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc, bw2, res_loads);
-      else gemm_planes<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc);
-      const int col = wave * 16 + 4 * j;
-      const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B2 + col);
+      auto epi2 = [&](int ct, const f32x4 (&acc)[4]) {
+        const int col = ct * 16 + 4 * j;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(s_par + PR::B2 + col);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[0][rt] + bias;
+        for (int rt = 0; rt < 4; ++rt) *reinterpret_cast<f32x4*>(Es + (rt * 16 + p) * LQ + col) = acc[rt] + bias;
+      };
+      if constexpr (NP == 1) {
+        gemm_cols_bf16<D, CM, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave * CM, epi2);
+        if constexpr (PFR) res_loads();
+      } else {
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_planes_pre<D, NP, 1, 4, 64>(r1planes + p * LDP + 8 * j, launder(a.W2) + lane, wave, acc, bw2, res_loads);
+        epi2(wave, acc[0]);
+      }
     }
     uint4 bwk[2][PF ? 2 : 1][NP];
     if constexpr (PF) { if (a.Wkv) load_w<NP, 2>(bwk[0], launder(a.Wkv) + lane, 2 * wave, 0); }
@@ -544,7 +589,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
           const int col = (D / 16) * p + 4 * cc;
-          const f32x4 res = PF ? cres[PF ? rnd : 0][cc] : *reinterpret_cast<const f32x4*>(a.C + grow * D + col);
+          const f32x4 res = PFR ? cres[PFR ? rnd : 0][cc] : *reinterpret_cast<const f32x4*>(a.C + grow * D + col);
           v[cc] = *reinterpret_cast<const f32x4*>(Es + row * LQ + col) + res;
           s += (v[cc][0] + v[cc][1]) + (v[cc][2] + v[cc][3]);
         }
@@ -588,14 +633,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         }
       };
       if constexpr (NP == 1) {
-#pragma unroll 1
-        for (int c = 0; c < 2; ++c) {
-          f32x4 acc[1][4];
-#pragma unroll
-          for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          gemm_planes<D, NP, 1, 4, 64>(frag, img, 2 * wave + c, acc);
-          epilogue((2 * wave + c) * 16 + 4 * j, acc[0]);
-        }
+        gemm_cols_bf16<D, 2 * CM, 4, 64>(frag, img, 2 * CM * wave, [&](int ct, const f32x4 (&acc)[4]) { epilogue(ct * 16 + 4 * j, acc); });
       } else {
         f32x4 acc[2][4];
 #pragma unroll
