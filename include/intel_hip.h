@@ -176,6 +176,7 @@ void intel_set_concurrency(IntelCtx* ctx, int on);
 /* stream (may be NULL = off): a stream that intel_backward (the one-call form) makes wait for the completion of
  * grads[INTEL_P_IID_EMB] -- before its tail of shared-weight gradients and deferred reductions.  The caller enqueues the
  * table's optimizer sweep there (HBM-bound, it then runs underneath that tail) and joins the streams before the next forward.
+ * Where the four-branch schedule is not taken (branch concurrency off) the stream is made to wait for the whole backward instead.
  * The two-call form (intel_backward_phase) does not use it: there phase 1 returns at that point. */
 void intel_set_table_stream(IntelCtx* ctx, void* stream);
 

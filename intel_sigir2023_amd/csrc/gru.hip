@@ -1,5 +1,7 @@
-// GRU4Rec encoder on MI355X: the input projection of all B*T rows is one fp32-MFMA GEMM; the
-// recurrence runs T steps of (h W_hh^T GEMM over the batch + fused gate kernel); sessions shorter
+// GRU4Rec encoder on MI355X (models/GeneralSeq.py:58-78): the input projection of all history rows is one GEMM on the bf16 matrix
+// pipe; the RECURRENCE is one kernel per direction (gru_seq_fwd_kernel / gru_seq_bwd_kernel below): a workgroup owns 16 sessions for
+// the whole time loop, W_hh fragments in registers, the state rows in LDS, packed and length-ordered histories.  The per-step form
+// (hidden GEMM + gate kernel per step, INTEL_GRU_SEQ=0) is kept for cross-checking (tests/test_gru_seq_gpu.py).  Sessions shorter
 // than t keep their state (the reference packs sequences by length, GeneralSeq.py:66-71).
 // Gate order r, z, n and the update h' = (1-z) n + z h follow torch.nn.GRU.
 #include "gru.h"

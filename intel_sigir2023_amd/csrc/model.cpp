@@ -123,6 +123,7 @@ struct IntelCtx {
   hipEvent_t ev_fork, ev_join[3];
   hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
   hipStream_t table_stream = nullptr;      // intel_set_table_stream
+  hipEvent_t ev_tab = nullptr;             // ... made to wait on this event where the four-branch schedule is not taken (see backward_entry)
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
   // weight-gradient / LayerNorm partial sums of a backward phase, reduced together when the phase ends
   ReduceQueue* rq;
@@ -1624,7 +1625,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(redq_flush(c->rq, r.st));
     return;
   }
-  static const bool enc0_early = [] { const char* e = getenv("INTEL_ENC0_PHASE"); return !(e && e[0] == '2'); }();
+  constexpr bool enc0_early = true;      // the session-history encoder joins phase 1 on a third stream
   if (phase != 2) {
     // cross-attention backward of both towers first: d(intent) is then complete and the intent path can
     // start while the (heavy) tower layers are still running
@@ -1652,8 +1653,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     // phase 1 branches: item tower layers (main, set 0) || item-history encoder (side 0, set 1): after the
     // join the item-id table gradient is complete
     // Both encoders' backward chains are long runs of small launches (B*H rows): the session-history encoder joins phase 1 on a
-    // third stream (set 2) instead of trailing the score tower in phase 2, where it was the critical path (INTEL_ENC0_PHASE=2
-    // restores that order).
+    // third stream (set 2) instead of trailing the score tower in phase 2, where it was the critical path.
     float *dE1 = nullptr, *dE0 = nullptr;
     fork_streams(r, enc0_early ? 2 : 1);
     {
@@ -1672,7 +1672,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     RUN(redq_flush(r.ctx->rq, r.st));
   }
   if (phase != 1) {
-    // phase 2: score tower layers (main, set 0) [|| session-history encoder (side 0, set 1) with INTEL_ENC0_PHASE=2]
+    // phase 2: score tower layers (main, set 0)
     float* dE0 = nullptr;
     if (!enc0_early) fork_streams(r, 1);
     {
@@ -1760,6 +1760,7 @@ extern "C" void intel_destroy(IntelCtx* ctx) {
     (void)hipEventDestroy(ctx->ev_fork);
     for (int i = 0; i < 4; ++i) (void)hipEventDestroy(ctx->ev_x[i]);
   }
+  if (ctx->ev_tab) (void)hipEventDestroy(ctx->ev_tab);
   redq_destroy(ctx->rq);
   delete ctx;
 }
@@ -1895,6 +1896,22 @@ static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelB
   gemm_set_planes(ctx->d.dtype == INTEL_DTYPE_BF16 ? 1 : 3);
   backward_impl(r, d_weights, d_ens_score, d_intents, phase);
   gemm_set_planes(3);
+  // The caller's table stream (intel_set_table_stream) is promised the finished item-id table gradient.  The four-branch schedule
+  // hands it over as early as possible; every other way through a one-call backward (INTEL_STREAMS=0, INTEL_BWD_WIDE=0) does it
+  // here, after everything: without this wait the caller's optimizer sweep raced the backward (found by the A/B switch tests)
+  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
+  if (r.rc == 0 && phase == 0 && ctx->table_stream && !(wide_on && ctx->streams == 1)) {
+    if (!ctx->ev_tab && hipEventCreateWithFlags(&ctx->ev_tab, hipEventDisableTiming) != hipSuccess) {
+      intel_set_error("intel_backward: event creation failed");
+      return INTEL_E_STATE;
+    }
+    hipError_t e = hipEventRecord(ctx->ev_tab, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->table_stream, ctx->ev_tab, 0);
+    if (e != hipSuccess) {
+      intel_set_error("intel_backward: table stream hand-over failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+  }
   return r.rc;
 }
 

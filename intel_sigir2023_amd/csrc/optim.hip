@@ -155,7 +155,12 @@ __device__ __forceinline__ AdamArgs lazy_consts(const LazyArgs& a) {
 // steps from+1 .. upto with g = 0 (a.zero: a run-time 0 -- the same instruction sequence as a gradient that happens to be 0)
 __device__ __forceinline__ void lazy_replay(f32x4& p, f32x4& m, f32x4& v, int from, int upto, const LazyArgs& a, AdamArgs& c) {
   for (int s = from + 1; s <= upto; ++s) {
-    const float2 sc = reinterpret_cast<const float2*>(a.sched)[s - a.base - 1];
+    // the schedule entries are read with device-scope (cache-bypassing) loads: an entry is written once, by one thread of its step's
+    // kernel, and read from then on by kernels of other streams -- with plain loads single compute units were measured to return the
+    // zero the buffer was created with (a forward pass then gathered rows one step stale: tests/test_fullsize_gpu.py, the stress table)
+    float2 sc;
+    sc.x = __hip_atomic_load(a.sched + 2 * (s - a.base - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sc.y = __hip_atomic_load(a.sched + 2 * (s - a.base - 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     c.step_size = sc.x; c.inv_bc2_sqrt = sc.y;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -663,8 +663,6 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   if (per_cu > 4 * C::WAVES_PER_SIMD / C::NW) per_cu = 4 * C::WAVES_PER_SIMD / C::NW;
   if (per_cu < 1) per_cu = 1;
   int grid = num_cus() * per_cu;
-  static const int grid_cap = [] { const char* e = getenv("INTEL_TOWER_GRID"); return e ? atoi(e) : 0; }();      // experiments: leave CUs to the other branches
-  if (grid_cap > 0 && grid > grid_cap * per_cu) grid = grid_cap * per_cu;
   if (grid > a.B) grid = a.B;
   const double M = (double)a.B * a.L;
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash

@@ -69,11 +69,87 @@ def _on_bf16_pipe(w):
     return _EMU['on'] and w.shape[1] in (64, 128) and w.shape[0] % 4 == 0
 
 
+class _BfLinear(torch.autograd.Function):
+    """y = bf16(x) bf16(w)^T + b with the BACKWARD the HIP build's bf16 mode runs (csrc/gemm.hip, NP = 1): the incoming gradient is
+    rounded to bf16 as an operand of both products -- dx = bf16(dy) bf16(w), dw = bf16(dy)^T bf16(x) --, fp32 accumulation, the bias
+    gradient summed in fp32.  (Plain autograd through the rounded forward would leave dy unrounded.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb, wb = _bf(x), _bf(w)
+        ctx.save_for_backward(xb, wb)
+        ctx.has_b = b is not None
+        return F.linear(xb, wb, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        dyb = _bf(dy)
+        dx = torch.matmul(dyb, wb)
+        dw = torch.matmul(dyb.reshape(-1, dyb.shape[-1]).t(), xb.reshape(-1, xb.shape[-1]))
+        db = dy.reshape(-1, dy.shape[-1]).sum(0) if ctx.has_b else None
+        return dx, dw, db
+
+
+def _bf_linear(x, w, b=None):
+    return _BfLinear.apply(x, w, b)
+
+
+class _BfMatmul(torch.autograd.Function):
+    """bf16(a) @ bf16(b) with bf16-rounded gradient operands (the B-row products of the pooling: csrc/gemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ab, bb = _bf(a), _bf(b)
+        ctx.save_for_backward(ab, bb)
+        return torch.matmul(ab, bb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ab, bb = ctx.saved_tensors
+        dyb = _bf(dy)
+        return torch.matmul(dyb, bb.t()), torch.matmul(ab.t(), dyb)
+
+
+class _BfAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(dk)) v with every matrix-pipe operand rounded to bf16, forward AND backward, as csrc/attn_seq.hip /
+    tower.hip run it in bf16 mode: forward S = bf(q) bf(k)^T, O = bf(e) bf(v) / sum(e) (e = the unnormalised probabilities, row sums
+    fp32); backward P = e / sum(e) in fp32, dP = bf(dO) bf(v)^T, delta = rowsum(P dP) (fp32), dS = P (dP - delta) / sqrt(dk),
+    dV = bf(P)^T bf(dO), dQ = bf(dS) bf(k), dK = bf(dS)^T bf(q)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, scale):
+        qb, kb, vb = _bf(q), _bf(k), _bf(v)
+        s = torch.matmul(qb, kb.transpose(-1, -2)) * scale
+        if key_mask is not None:
+            s = s.masked_fill(~key_mask[:, None, None, :], float('-inf'))
+        m = s.max(dim=-1, keepdim=True)[0]
+        e = torch.exp(s - torch.where(torch.isinf(m), torch.zeros_like(m), m))
+        e = torch.where(torch.isnan(e), torch.zeros_like(e), e)
+        den = e.sum(-1, keepdim=True)
+        den = torch.where(den > 0, den, torch.ones_like(den))
+        ctx.save_for_backward(qb, kb, vb, e / den)
+        ctx.scale = scale
+        return torch.matmul(_bf(e), vb) / den
+
+    @staticmethod
+    def backward(ctx, do):
+        qb, kb, vb, p = ctx.saved_tensors
+        dob = _bf(do)
+        dp = torch.matmul(dob, vb.transpose(-1, -2))
+        delta = (p * dp).sum(-1, keepdim=True)
+        ds = _bf(p * (dp - delta) * ctx.scale)
+        dv = torch.matmul(_bf(p).transpose(-1, -2), dob)
+        dq = torch.matmul(ds, kb)
+        dk = torch.matmul(ds.transpose(-1, -2), qb)
+        return dq, dk, dv, None, None
+
+
 def _lin(x, sd, name, bias=True):
     b = sd.get(name + '.bias') if bias else None
     w = sd[name + '.weight']
     if _on_bf16_pipe(w):
-        x, w = _bf(x), _bf(w)
+        return _bf_linear(x, w, b)
     return F.linear(x, w, b)
 
 
@@ -94,14 +170,7 @@ def mha(x, sd, prefix, heads, key_mask=None, bf16_products=True):
     k = split(_lin(x, sd, prefix + '.k_linear'))
     v = split(_lin(x, sd, prefix + '.v_linear'))
     if _EMU['on'] and bf16_products:
-        s = torch.matmul(_bf(q), _bf(k).transpose(-1, -2)) / dk ** 0.5
-        if key_mask is not None:
-            s = s.masked_fill(~key_mask[:, None, None, :], float('-inf'))
-        m = s.max(dim=-1, keepdim=True)[0]
-        e = torch.exp(s - torch.where(torch.isinf(m), torch.zeros_like(m), m))
-        e = torch.where(torch.isnan(e), torch.zeros_like(e), e)
-        den = e.sum(-1, keepdim=True)
-        o = torch.matmul(_bf(e), _bf(v)) / torch.where(den > 0, den, torch.ones_like(den))
+        o = _BfAttention.apply(q, k, v, key_mask, 1.0 / dk ** 0.5)
         return o.transpose(1, 2).reshape(B, T, D)
     s = torch.matmul(q, k.transpose(-1, -2)) / dk ** 0.5
     if key_mask is not None:
@@ -184,14 +253,14 @@ def single_query_pool(intent, h, valid, sd, prefix, scale):
         # the HIP build's algebra (csrc/session.hip: xatt_pool): att_l = scale * <Wk^T q, h_l>, pooled = Wv (sum_l w_l h_l); the two
         # d x d products run on the bf16 pipe, the scores and the weighted sum in fp32
         wk, wv = sd[prefix + '.key_layer.weight'], sd[prefix + '.value_layer.weight']
-        qk = torch.matmul(_bf(q), _bf(wk)) if _on_bf16_pipe(wk.t()) else torch.matmul(q, wk)                  # [B,d]
+        qk = _BfMatmul.apply(q, wk) if _on_bf16_pipe(wk.t()) else torch.matmul(q, wk)                          # [B,d]
         att = torch.einsum('bd,bld->bl', qk, h) * scale
         att = att - att.max(dim=-1, keepdim=True)[0]
         att = att.masked_fill(~valid, float('-inf'))
         w = torch.softmax(att, dim=-1)
         w = torch.where(torch.isnan(w), torch.zeros_like(w), w)
         xbar = torch.einsum('bl,bld->bd', w, h)
-        pooled = F.linear(_bf(xbar), _bf(wv)) if _on_bf16_pipe(wv) else F.linear(xbar, wv)
+        pooled = _bf_linear(xbar, wv) if _on_bf16_pipe(wv) else F.linear(xbar, wv)
         return pooled[:, None, :] * valid[:, :, None].float()
     k = F.linear(h, sd[prefix + '.key_layer.weight'])                    # [B,L,a]
     v = F.linear(h, sd[prefix + '.value_layer.weight'])                  # [B,L,v]
@@ -271,7 +340,7 @@ def predict_ensemble(sd, data, intent, cfg, dropout_keep=None, taps=None):
         w_all, npad = sd['weight_embeddings.weight'], h_u.shape[-1] + h_int.shape[-1]
         w_pad = w_all[:, w_all.shape[1] - npad:]
         if _on_bf16_pipe(w_pad):
-            pad = F.linear(_bf(torch.cat([h_u, h_int], dim=-1)), _bf(w_pad), sd['weight_embeddings.bias'])
+            pad = _bf_linear(torch.cat([h_u, h_int], dim=-1), w_pad, sd['weight_embeddings.bias'])
             weights = torch.where(valid[:, :, None], weights, pad)
     if getattr(cfg, 'weight_norm', 'none') == 'softmax':      # the build's optional K-way normalisation
         weights = torch.softmax(weights, dim=-1)
@@ -290,7 +359,9 @@ def forward(sd, data, cfg, dropout_keep=None, taps=None):
 
 def forward_bf16(sd, data, cfg):
     """`forward` with the rounding points of the HIP build's `--dtype bf16` mode (see _EMU above): an independent CPU
-    restatement of WHAT that mode computes, for tests/test_bf16_gpu.py.  BERT4Rec encoders, evaluation mode."""
+    restatement of WHAT that mode computes, for tests/test_bf16_gpu.py.  BERT4Rec encoders.  The products are autograd
+    Functions (_BfLinear, _BfMatmul, _BfAttention) whose backward rounds the gradient operands exactly where the HIP backward
+    does, so `loss(forward_bf16(...)).backward()` is the gradient oracle of the mode."""
     _EMU['on'] = True
     try:
         return forward(sd, data, cfg)

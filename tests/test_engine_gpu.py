@@ -89,7 +89,8 @@ def test_engine_two_steps_match_reference_adam(name):
 
 @pytest.mark.parametrize('workload,B', [('tiny', 64), ('tmall', 48), ('tmall', 37), ('lifedata', 16), ('lifedata', 5), ('toyshape', 6)])
 def test_engine_step_matches_oracle_on_synthetic_workloads(workload, B):
-    """Full-size shapes (1M-item table for tmall): loss of one engine step vs the oracle, NDCG@3 on device vs
+    """The benchmark workloads' shapes (lists, histories, widths) on a 20 000-item / 2 000-user table (the full-size tables are
+    covered by tests/test_fullsize_gpu.py): loss of one engine step vs the oracle, NDCG@3 on device vs
     evaluate_method, and a size-independent property: the dense Adam sweep moves EVERY table row (weight decay)
     while only touched rows carry gradient."""
     from intel_sigir2023_amd import synth

@@ -4,6 +4,10 @@ import importlib.util
 import os
 import random
 
+# the GRU recurrence takes its sessions ordered by history length from batches of 1024 sessions on; the sweep's batches are small:
+# order them too, so that the ordered + packed recurrence is compared with the oracle directly (read per prepare_batch call)
+os.environ.setdefault('INTEL_GRU_ORDER_MIN_B', '1')
+
 import pytest
 import torch
 

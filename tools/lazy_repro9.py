@@ -1,0 +1,37 @@
+"""Lazy gathers (replay inside the gather) against the flushed table: model.run_forward before / after eng.flush() (debugging aid)."""
+import os
+import sys
+sys.path.insert(0, '.')
+import torch
+from intel_sigir2023_amd import synth
+from intel_sigir2023_amd.engine import IntELEngine
+from intel_sigir2023_amd.model import IntEL
+
+dev = torch.device('cuda:0')
+wl, items, B = 'stress', 200000, 256
+TRAIN = os.environ.get('TRAINFWD') == '1'
+args = synth.make_args(wl, dev, cal_diversity=1)
+corpus, c = synth.make_corpus(wl, items=items)
+b1 = synth.make_batch(wl, B, dev, seed=40, corpus_over=dict(items=items))
+b2 = synth.make_batch(wl, B, dev, seed=41, corpus_over=dict(items=items))
+for trial in range(5):
+    torch.manual_seed(5)
+    model = IntEL(args, corpus).to(dev)
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4, lazy_table=True)
+    eng.train_step(b1, noise_seed=100)
+    torch.cuda.synchronize()
+    ib, keep = model.prepare_batch(b2)
+    params = [p.detach() for _, _, p in model.slot_items()]
+    outs = []
+    for rep in range(3):
+        w, e, i = model.run_forward(ib, keep, params, train=TRAIN)
+        torch.cuda.synchronize()
+        outs.append((w.clone(), e.clone(), i.clone()))
+    eng.flush()
+    torch.cuda.synchronize()
+    w, e, i = model.run_forward(ib, keep, params, train=TRAIN)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        ses = (outs[rep][1] - e).abs().amax(1)
+        print('trial', trial, 'rep', rep, 'max diffs', float((outs[rep][0] - w).abs().max()), float(ses.max()), float((outs[rep][2] - i).abs().max()), 'sessions off', int((ses > 0).sum()))
+    del eng, model
