@@ -232,12 +232,14 @@ __global__ __launch_bounds__(256) void adam_lazy_ids_kernel(LazyArgs a, const in
     int id = -1;
     if (j < n) id = j < n_a ? ids_a[j] : ids_b[j - n_a];
     const bool valid = id >= 0 && (long long)id < a.rows;
-    // a row that is up to date already (the pad id, popular items: thousands of occurrences) is left alone without an atomic
-    const bool behind = valid && a.last[id] < upto;
+    // a row that is up to date already (the pad id, popular items: thousands of occurrences) is left alone without an atomic.
+    // ONE lane of the group reads last[id] and makes the claim; the group follows its decision (other groups may raise the entry
+    // concurrently: lanes that looked for themselves could disagree and leave a row partially replayed).
+    // Not to be run concurrently with lazy gathers of the same rows: the claim is visible before p / m / v are rewritten.
     int from = upto;
-    if (behind && sub == 0) from = atomicMax(&a.last[id], upto);
+    if (valid && sub == 0 && a.last[id] < upto) from = atomicMax(&a.last[id], upto);
     from = __shfl(from, 0, lpr);
-    if (!behind || from >= upto) continue;
+    if (!valid || from >= upto) continue;
     const long long i = (long long)id * lpr + sub;
     f32x4 p = reinterpret_cast<f32x4*>(a.p)[i];
     f32x4 m = reinterpret_cast<f32x4*>(a.m)[i];

@@ -211,13 +211,17 @@ class ColumnarStore(object):
         return out
 
 
-def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shuffle_lists='device', drop_last=False, rank=0, world=1):
+def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shuffle_lists='device', drop_last=False, rank=0, world=1,
+                  keep_all=False):
     """Batches of one pass over the store: the DataLoader(shuffle=True) + per-access list shuffle of the reference's
     training loop (helpers/BaseRunner.py:275-277, models/BaseModel.py:194-196), assembled on the device.
     Data parallel (world > 1): ``batch_size`` is the GLOBAL batch; rank r assembles sessions [r*B/world, (r+1)*B/world) of
     every global batch, padded to the GLOBAL batch's shape (pad rows are keys) -- the session order, the list
     permutations (keyed by the session's corpus index) and the padding are those of the single-process run.  A global batch
-    must split evenly (each rank's loss is a mean over its shard): a ragged last batch is trimmed to a multiple of world."""
+    must split evenly (each rank's loss is a mean over its shard): a ragged last batch is trimmed to a multiple of world.
+    keep_all (evaluation sets): NO session is dropped -- a global batch that does not split evenly gives the first ranks one
+    session more, and a rank left without a session gets a placeholder (the batch's first session) with weight 0.  Every batch
+    then carries 'eval_weight' ([B] float64: 1 per real session) for the weighted reductions of runner.evaluate."""
     n = store.n_sessions
     order = np.random.RandomState(seed * 1000003 + epoch).permutation(n) if shuffle_sessions else np.arange(n)
     for lo in range(0, n, batch_size):
@@ -225,7 +229,16 @@ def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shu
         if drop_last and len(idx) < batch_size:
             break
         shape = None
-        if world > 1:
+        weight = None
+        if world > 1 and keep_all:
+            shape = store.batch_shape(idx)
+            cuts = [(len(idx) * r) // world for r in range(world + 1)]
+            mine = idx[cuts[rank]:cuts[rank + 1]]
+            weight = np.ones(max(len(mine), 1), dtype=np.float64)
+            if len(mine) == 0:
+                mine, weight[0] = idx[:1], 0.0
+            idx = mine
+        elif world > 1:
             keep = len(idx) - len(idx) % world
             if keep == 0:
                 break
@@ -233,4 +246,9 @@ def epoch_batches(store, batch_size, epoch=0, seed=0, shuffle_sessions=True, shu
             shape = store.batch_shape(idx)
             per = keep // world
             idx = idx[rank * per:(rank + 1) * per]
-        yield store.collate(idx, shuffle=shuffle_lists, seed=(seed << 20) + epoch * 65537 + lo, shape=shape)
+        out = store.collate(idx, shuffle=shuffle_lists, seed=(seed << 20) + epoch * 65537 + lo, shape=shape)
+        if keep_all:
+            import torch
+            w = weight if weight is not None else np.ones(len(idx), dtype=np.float64)
+            out['eval_weight'] = torch.from_numpy(w).to(out['session_len'].device)
+        yield out

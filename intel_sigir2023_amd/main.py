@@ -119,6 +119,11 @@ def main(argv=None):
     model = MODELS[init_args.model_name](args, corpus).to(args.device)
     if world > 1:         # identical replicas: rank 0's initialisation everywhere
         parallel.broadcast_([p.data for p in model.parameters()])
+        model.invalidate_packed()         # raw writes do not move torch's version counters (model._params_key)
+        # every rank's loss is the mean over ITS shard: a training batch must split evenly (a ragged last batch is trimmed to a
+        # multiple of the world size); evaluation sets keep every session (uneven shards, weighted reductions)
+        if args.batch_size % world:
+            raise SystemExit('--batch_size %d is the GLOBAL batch and must be a multiple of the %d ranks' % (args.batch_size, world))
     logging.info('#params: %d' % model.count_variables())
     criterion = LOSSES[init_args.loss_name](args)
     runner = RUNNERS[init_args.runner_name](args, use_engine=bool(args.use_engine))
@@ -128,12 +133,14 @@ def main(argv=None):
         logging.info('columnar corpus in HBM: %s' % ', '.join('%s %d sessions / %.1f MB' % (p, s.n_sessions, s.nbytes() / 1e6)
                                                                for p, s in stores.items()))
         fixed = lambda p: list(feed.epoch_batches(stores[p], args.eval_batch_size, seed=args.random_seed + 1, shuffle_sessions=False,
-                                                  rank=rank, world=world))
+                                                  rank=rank, world=world, keep_all=True))      # evaluation never drops a session
         data = {'train': lambda ep: feed.epoch_batches(stores['train'], args.batch_size, epoch=ep, seed=args.random_seed, rank=rank, world=world),
                 'dev': fixed('dev'), 'test': fixed('test')}
     else:
         # synthetic workloads: every rank generates the same global batch (same seed) and keeps its contiguous shard
         mk = lambda n, seed: parallel.shard_batch(synth.make_batch(args.workload, n, args.device, seed=seed, ragged=True), rank, world)
+        if args.eval_batch_size % world:
+            raise SystemExit('--eval_batch_size %d must be a multiple of the %d ranks for the synthetic workloads' % (args.eval_batch_size, world))
         dev = [mk(args.eval_batch_size, 10_000 + i) for i in range(2)]
         data = {'train': lambda ep: [mk(args.batch_size, ep * 1000 + i) for i in range(args.train_batches)], 'dev': dev, 'test': dev}
     dev_curve = runner.train(model, data, criterion, init_args.loss_name) if args.train > 0 else []

@@ -403,6 +403,12 @@ class IntEL(nn.Module):
             self._generation = getattr(self, '_generation', 0) + 1
         return {'weights': w, 'ens_score': e, 'intents': i}
 
+    def invalidate_packed(self):
+        """Forget the packed weight images of the last evaluation forward.  For writers that change parameters behind torch's
+        version counters (raw ``p.data`` writes: parallel.broadcast_ of the initial replicas, custom loaders)."""
+        self._opt_steps = getattr(self, '_opt_steps', 0) + 1
+        self._packed_key = None
+
     def _params_key(self, param_tensors):
         """Changes whenever a parameter may have changed: torch's version counters (in-place ops, load_state_dict), the
         storage addresses, and the engine's own step counter (its fused optimizer writes through raw pointers)."""

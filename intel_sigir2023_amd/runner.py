@@ -279,33 +279,42 @@ class BaseRunner(object):
     def predict(self, model, batches, criterion):
         model.eval()
         preds, ranks, losses, true_int, pred_int, slens = [], [], [], [], [], []
+        counts = []
         for batch in batches:
             out = model(batch)
             loss, _, _ = criterion(out, batch)
+            # 'eval_weight' (feed.epoch_batches(keep_all=True)): 0 marks a placeholder session of a rank whose shard of a ragged
+            # global batch is empty -- it is evaluated (the kernels need a session) and dropped here
+            w = batch.get('eval_weight')
+            keep = np.ones(int(batch['session_len'].shape[0]), dtype=bool) if w is None else (w.cpu().numpy() > 0)
             losses.append(float(loss))
-            preds.extend(out['ens_score'].cpu().numpy())
-            ranks.extend(batch['ranking'].cpu().numpy())
-            slens.extend(batch['session_len'].cpu().numpy().tolist())
-            true_int.extend(batch['intents'].cpu().numpy())
-            pred_int.extend(out['intents'].cpu().numpy())
+            counts.append(int(keep.sum()))
+            sel = lambda a: [x for x, k in zip(a, keep) if k]
+            preds.extend(sel(out['ens_score'].cpu().numpy()))
+            ranks.extend(sel(batch['ranking'].cpu().numpy()))
+            slens.extend(sel(batch['session_len'].cpu().numpy().tolist()))
+            true_int.extend(sel(batch['intents'].cpu().numpy()))
+            pred_int.extend(sel(out['intents'].cpu().numpy()))
         if parallel.world_size() > 1:
             # data parallel: every rank evaluated its shard of each batch; the metrics are means over ALL sessions, so the
             # per-session records are gathered (rank order = session order) and every rank computes the same numbers
-            parts = parallel.allgather_object((preds, losses, ranks, true_int, pred_int, slens))
+            parts = parallel.allgather_object((preds, losses, ranks, true_int, pred_int, slens, counts))
             preds, ranks, true_int, pred_int, slens = ([x for p in parts for x in p[i]] for i in (0, 2, 3, 4, 5))
-            losses = [float(np.mean([p[1][j] for p in parts])) for j in range(len(losses))]      # equal shards: mean of means
+            # a batch's loss = mean over its sessions: the shard means weighted by the shard sizes (uneven for a ragged batch)
+            losses = [float(sum(p[1][j] * p[6][j] for p in parts) / max(1, sum(p[6][j] for p in parts))) for j in range(len(losses))]
         return preds, float(np.mean(losses)), ranks, true_int, pred_int, slens
 
-    def _eval_set(self, batches):
-        """Per-evaluation-set constants of the device metrics, computed once (dev / test batches are fixed lists): the
-        reference's max_len (the GLOBAL longest list, helpers/BaseRunner.py:66) and every batch's label-sort slots."""
-        key = id(batches)
+    def _eval_set(self, batches, topk):
+        """Per-evaluation-set constants of the device metrics, computed once per (set, largest cutoff) -- dev / test batches are
+        fixed lists: the reference's max_len = max(longest list of the WHOLE set, largest cutoff PASSED, helpers/BaseRunner.py:66)
+        and every batch's label-sort slots at that width."""
+        key = (id(batches), max(topk))
         hit = self._eval_sets.get(key)
         if hit is not None and hit[0] is batches:
             return hit[1], hit[2]
         slens = [b['session_len'].cpu().numpy() for b in batches]
         local_max = max(int(s.max()) for s in slens) if slens else 0
-        width = max(parallel.global_max_([local_max], batches[0]['session_len'].device)[0], max(self.topk))
+        width = max(parallel.global_max_([local_max], batches[0]['session_len'].device)[0], max(topk))
         lps = []
         for b, sl in zip(batches, slens):
             r = b['ranking'].cpu().numpy()
@@ -321,12 +330,12 @@ class BaseRunner(object):
         forward, criterion and every evaluate_method key per batch on the device (intel_eval_metrics); only the column sums
         come back.  Data parallel: sums and counts are all-reduced, so every rank reports the global numbers."""
         model.eval()
-        width, lps = self._eval_set(batches)
+        width, lps = self._eval_set(batches, topk)
         dev = batches[0]['session_len'].device
         nk = len(topk)
         sums = torch.zeros(7 * nk, dtype=torch.float64, device=dev)
         counts = torch.zeros(4, dtype=torch.float64, device=dev)      # valid sessions per behaviour, all sessions
-        losses, true_int, pred_int = [], [], []
+        losses, true_int, pred_int, nsess = [], [], [], []
         for batch, lp in zip(batches, lps):
             out = model(batch)
             loss, _, _ = criterion(out, batch)
@@ -334,18 +343,26 @@ class BaseRunner(object):
             rk = batch['ranking'] if batch['ranking'].dtype == torch.int32 else batch['ranking'].to(torch.int32)
             sl = batch['session_len'] if batch['session_len'].dtype == torch.int32 else batch['session_len'].to(torch.int32)
             vals, valid = self.evaluate_method_device(out['ens_score'], rk, sl, topk, metrics, width=width, label_pos=lp)
-            w = torch.ones_like(vals)
+            ew = batch.get('eval_weight')                 # 0: placeholder session of an empty shard (feed.epoch_batches(keep_all=True))
+            ew = torch.ones(vals.shape[0], dtype=torch.float64, device=dev) if ew is None else ew.to(dev).double()
+            w = ew[:, None].expand_as(vals).clone()
             for t in range(3):
-                w[:, t * nk * 2:(t + 1) * nk * 2] = valid[:, t:t + 1].double()
+                w[:, t * nk * 2:(t + 1) * nk * 2] *= valid[:, t:t + 1].double()
             sums += torch.where(w > 0, vals, torch.zeros_like(vals)).sum(0)
-            counts[:3] += valid.double().sum(0)
-            counts[3] += vals.shape[0]
-            true_int.append(batch['intents'])
-            pred_int.append(out['intents'])
+            counts[:3] += (valid.double() * ew[:, None]).sum(0)
+            counts[3] += ew.sum()
+            nsess.append(ew.sum().reshape(()))
+            keep = ew > 0
+            true_int.append(batch['intents'][keep])
+            pred_int.append(out['intents'][keep])
         lossv = torch.stack(losses)
         if parallel.world_size() > 1:
             parallel.allreduce_sum_([sums, counts])
-            lossv = parallel.allgather(lossv).mean(0)
+            # a batch's loss = mean over its sessions: the shard means weighted by the shard sizes
+            nv = torch.stack(nsess)
+            num, den = lossv * nv, nv.clone()
+            parallel.allreduce_sum_([num, den])
+            lossv = num / den.clamp_min(1.0)
         res = dict()
         if self.test_ensemble:
             res.update(self.reduce_device_metrics(sums.cpu().numpy(), counts.cpu().numpy()[:3], float(counts[3]), topk, metrics))
@@ -359,8 +376,12 @@ class BaseRunner(object):
         return float(lossv.mean().cpu()), res
 
     def evaluate(self, model, batches, topk, metrics, criterion, pos_nums=None, topk_intent=[1, 5, 10, 30]):
-        if self.device_metrics and pos_nums is None and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda \
-                and len(topk) <= 8 and max(b['i_id_s'].shape[1] for b in batches) <= 512:
+        on_device = bool(self.device_metrics and pos_nums is None and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda
+                         and len(topk) <= 8 and max(topk) <= 64 and max(b['i_id_s'].shape[1] for b in batches) <= 512)
+        if parallel.world_size() > 1 and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda:
+            # the two paths use different collectives: every rank must take the same one
+            on_device = parallel.global_max_([0 if on_device else 1], batches[0]['session_len'].device)[0] == 0
+        if on_device:
             return self.evaluate_on_device(model, batches, topk, metrics, criterion, topk_intent)
         preds, loss, ranks, true_int, pred_int, slens = self.predict(model, batches, criterion)
         res = dict()

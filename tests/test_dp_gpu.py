@@ -69,6 +69,64 @@ def _run(rank, world, port, out_dir, exchange='auto', backend='gloo', seeded=Fal
         torch.distributed.destroy_process_group()
 
 
+def _run_tmall(rank, world, port, out_dir, exchange='auto', tag=''):
+    """One rank of a 2-step run at the Tmall SHAPE (BASELINE.json configs[2]: list 50, K = 3, every embedding 64-d, BERT4Rec
+    encoders on packed histories -- the fused encoder kernels, the one-kernel 64-wide tower) on a 20 000-item table: the global
+    batch of 64 synthetic sessions, contiguous shards, BPR tie-breaks drawn in the kernel keyed by the global session index."""
+    os.environ['INTEL_DP_EXCHANGE'] = exchange
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), INTEL_DIST_BACKEND='gloo', INTEL_SINGLE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    from intel_sigir2023_amd import parallel, synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    if world > 1:
+        parallel.init_distributed()
+    dev = torch.device('cuda:0')
+    over = dict(items=20000, users=2000)
+    torch.manual_seed(11)
+    args = synth.make_args('tmall', dev, cal_diversity=1)
+    corpus, _ = synth.make_corpus('tmall', **over)
+    model = IntEL(args, corpus).to(dev)
+    model.train()
+    eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4)
+    parallel.broadcast_(eng.param_buckets())
+    losses = []
+    for step in range(2):
+        batch = synth.make_batch('tmall', 64, dev, seed=300 + step, ragged=True, corpus_over=over)
+        local = parallel.shard_batch(batch, rank, world)
+        if 'history_len' in local:          # host totals of the shard's packed histories (the producer of a shard knows them)
+            local['his_rows'], local['hisitem_rows'] = int(local['history_len'].sum()), int(local['history_item_len'].sum())
+        loss, _, _ = eng.train_step(local, noise_seed=4242 + step)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save({'sd': sd, 'losses': losses}, os.path.join(out_dir, 'tm_w%d_r%d%s.pt' % (world, rank, tag)))
+    if torch.distributed.is_initialized():
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse'), (4, 'dense')])
+def test_n_rank_engine_equals_single_process_at_tmall_shape(world, exchange):
+    """N ranks on the contiguous shards of a 64-session Tmall-shape batch == one process on the whole batch: losses (mean of the
+    shard means), replicas bit-identical, parameters after two Adam steps."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_run_tmall, args=(1, _free_port(), d), nprocs=1, join=True)
+        mp.spawn(_run_tmall, args=(world, _free_port(), d, exchange), nprocs=world, join=True)
+        one = torch.load(os.path.join(d, 'tm_w1_r0.pt'))
+        ranks = [torch.load(os.path.join(d, 'tm_w%d_r%d.pt' % (world, r))) for r in range(world)]
+    for s in range(2):
+        assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
+    for k, v in one['sd'].items():
+        for r in ranks[1:]:
+            assert torch.equal(ranks[0]['sd'][k], r['sd'][k]), 'replicas diverged: ' + k
+        if 'k_linear.bias' in k:
+            continue            # analytically-zero gradient: Adam direction is rounding noise
+        err = float((ranks[0]['sd'][k] - v).abs().max())
+        assert err < 5e-5, (k, err)
+
+
 @pytest.mark.parametrize('world,exchange,schedule', [(2, 'dense', 'wide'), (2, 'sparse', 'wide'), (4, 'sparse', 'wide'),
                                                      (2, 'dense', 'phased'), (2, 'sparse', 'phased')])
 def test_n_rank_engine_equals_single_process(world, exchange, schedule):

@@ -25,15 +25,15 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, root, out_dir, extra):
+def _run(rank, world, port, root, out_dir, extra, batch='16', eval_batch='6'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), INTEL_DIST_BACKEND='gloo', INTEL_SINGLE_DEVICE='1')
     from intel_sigir2023_amd import main as cli
     from intel_sigir2023_amd import parallel
     model_path = os.path.join(out_dir, 'w%d' % world, 'model.pt')
     cli.main(['--model_name', 'IntEL', '--loss_name', 'IntBPRloss', '--workload', 'tiny', '--dataset', 'minidata', '--datapath', root,
-              '--intent_note', '_multi', '--max_session_len', '100', '--model_num', '3', '--epoch', '4', '--batch_size', '16',
-              '--eval_batch_size', '6', '--topk', '3,1,5', '--main_metric', 'NDCG@3', '--lr', '2e-3', '--l2', '1e-5',
+              '--intent_note', '_multi', '--max_session_len', '100', '--model_num', '3', '--epoch', '4', '--batch_size', batch,
+              '--eval_batch_size', eval_batch, '--topk', '3,1,5', '--main_metric', 'NDCG@3', '--lr', '2e-3', '--l2', '1e-5',
               '--model_path', model_path, '--random_seed', '5'] + list(extra))
     run = cli.main.last_run
     sd = torch.load(model_path, map_location='cpu')
@@ -63,3 +63,22 @@ def test_two_rank_cli_training_follows_the_single_process_trajectory(extra):
     for k, v in one['test'].items():
         assert abs(two[0]['test'][k] - v) < 1e-3, k
     assert abs(two[0]['checksum'] - one['checksum']) < 1e-3 * max(1.0, abs(one['checksum']))
+
+
+def test_three_ranks_evaluate_every_session_of_uneven_batches():
+    """Evaluation sets keep EVERY session under data parallelism: evaluation batches of 7 sessions split 2 / 2 / 3 over three ranks
+    (and a ragged last batch with fewer sessions than ranks leaves a rank a zero-weight placeholder), losses and metrics reduced
+    with the shard sizes as weights -- the dev / test numbers equal the single-process run's, which sees the same sessions."""
+    assert torch.cuda.is_available()
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copytree(os.path.join(HERE, 'golden', 'minidata'), os.path.join(d, 'minidata'))
+        root = d + os.sep
+        mp.spawn(_run, args=(1, _free_port(), root, d, (), '18', '7'), nprocs=1, join=True)
+        mp.spawn(_run, args=(3, _free_port(), root, d, (), '18', '7'), nprocs=3, join=True)
+        one = json.load(open(os.path.join(d, 'w1_r0.json')))
+        three = [json.load(open(os.path.join(d, 'w3_r%d.json' % r))) for r in range(3)]
+    assert three[0]['dev'] == three[1]['dev'] == three[2]['dev']
+    for e in range(4):
+        assert abs(three[0]['dev'][e] - one['dev'][e]) < 1e-3, (e, one['dev'], three[0]['dev'])
+    for k, v in one['test'].items():
+        assert abs(three[0]['test'][k] - v) < 1e-3, k
