@@ -143,7 +143,7 @@ class IntELEngine(object):
         import os
         mode = os.environ.get('INTEL_DP_EXCHANGE', 'auto')
         if mode != 'auto':
-            return mode == 'sparse'
+            return mode == 'sparse'           # 'dense' and 'sharded' (see _sharded_table_update) reduce the whole table
         rows = keep['i_id_s'].numel() + keep['his_item_id'].numel()     # same on every rank: _check_global_shape
         d = self.model.iid_embeddings.weight.shape[1]
         return rows * (4 * d + 4) < 2.0 / world * self.gflat['iid'].numel() * 4
@@ -166,6 +166,43 @@ class IntELEngine(object):
         if self._iid_flags is not None:                   # rows of the other ranks (row 0 for the -1 padding: harmless)
             self._iid_flags.index_fill_(0, all_idx.reshape(-1).clamp_min(0).long(), 1)
         self._bufs['xch_keep'] = (all_idx, all_rows)      # alive until the kernels have run
+
+    def _sharded(self):
+        """INTEL_DP_EXCHANGE=sharded and no lazy table: the table's optimizer state is partitioned over the ranks."""
+        import os
+        return os.environ.get('INTEL_DP_EXCHANGE', 'auto') == 'sharded' and self._lazy is None
+
+    def _sharded_table_update(self, stream_ptr):
+        """The item-id table's step with its Adam state SHARDED over the ranks (ZeRO-1 for this one bucket): reduce-scatter of the
+        table gradient -> every rank runs torch.optim.Adam's dense update on ITS 1/world row range only (parameter, both moments,
+        28 B per parameter of HBM traffic instead of world x that) -> all-gather of the updated rows.  Over xGMI the two collectives
+        move what the ring all-reduce of the dense exchange moves ((world-1)/world of the table each way); the sweep's HBM traffic
+        and the moments' memory are divided by world.  Rows are padded to a multiple of world through staging buffers; every
+        replica ends the step with the same table bits (the owner's arithmetic is the dense sweep's, adam_kernel)."""
+        lib = L.lib()
+        w, r = parallel.world_size(), parallel.rank()
+        rows, d = self.model.iid_embeddings.weight.shape
+        per = -(-rows // w)                                   # rows per rank
+        n = per * d
+        g = self.gflat['iid']
+        pad = per * w * d - g.numel()
+        gfull = g if pad == 0 else torch.cat([g, g.new_zeros(pad)])
+        gs = self._buf('shard_g', (n,), torch.float32)
+        parallel.reduce_scatter_sum(gfull, gs)
+        lo = min(r * per, rows) * d
+        hi = min((r + 1) * per, rows) * d
+        if hi > lo:
+            b1, b2 = self.betas
+            L.check(lib.intel_adam_step(L.ptr(self.flat['iid'][lo:hi]), L.ptr(gs), L.ptr(self.m['iid'][lo:hi]), L.ptr(self.v['iid'][lo:hi]), hi - lo,
+                                        self.lr, b1, b2, self.eps, self.l2, self.step_count, 1.0, 0, stream_ptr), 'intel_adam_step')
+        ps = self._buf('shard_p', (n,), torch.float32)
+        ps.zero_()
+        ps[:hi - lo].copy_(self.flat['iid'][lo:hi])
+        allp = parallel.allgather(ps).reshape(-1)
+        self.flat['iid'].copy_(allp[:g.numel()])
+        g.zero_()                                             # the local gradient (every row) and the row marks are consumed
+        if self._iid_flags is not None:
+            self._iid_flags.zero_()
 
     @staticmethod
     def _touched_idx(keep):
@@ -421,11 +458,14 @@ class IntELEngine(object):
                 lib.intel_set_table_stream(model._context(), None)
             with torch.cuda.stream(side):
                 sparse = dp and self._sparse_exchange(keep, world)
-                if sparse:
-                    self._exchange_touched_rows(keep, L.stream_ptr(dev))
-                elif dp:
-                    parallel.allreduce_sum_([self.gflat['iid']])
-                adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=dp and not sparse)
+                if dp and self._sharded():
+                    self._sharded_table_update(L.stream_ptr(dev))
+                else:
+                    if sparse:
+                        self._exchange_touched_rows(keep, L.stream_ptr(dev))
+                    elif dp:
+                        parallel.allreduce_sum_([self.gflat['iid']])
+                    adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=dp and not sparse)
                 loss_total(L.stream_ptr(dev))
             if dp:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
@@ -440,16 +480,20 @@ class IntELEngine(object):
             side = self._table_stream()         # a context stream (idle in phase 2), not a fifth stream of our own
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
             sparse = dp and self._sparse_exchange(keep, world)
-            work = parallel.allreduce_sum_async(self.gflat['iid']) if (dp and not sparse) else None
+            sharded = dp and self._sharded()
+            work = parallel.allreduce_sum_async(self.gflat['iid']) if (dp and not sparse and not sharded) else None
             ev = torch.cuda.Event()
             ev.record(cur)
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 if work is not None:
                     work.wait()
-                if sparse:
-                    self._exchange_touched_rows(keep, L.stream_ptr(dev))
-                adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=work is not None)
+                if sharded:
+                    self._sharded_table_update(L.stream_ptr(dev))
+                else:
+                    if sparse:
+                        self._exchange_touched_rows(keep, L.stream_ptr(dev))
+                    adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=work is not None)
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
             if dp:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
@@ -458,10 +502,14 @@ class IntELEngine(object):
             cur.wait_stream(side)
         else:
             model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+            sharded = dp and self._sharded()
             if dp:
-                parallel.allreduce_sum_([self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']])
+                parallel.allreduce_sum_(([] if sharded else [self.gflat['iid']]) + [self.gflat['decay'], self.gflat['nodecay']])
+            if sharded:
+                self._sharded_table_update(st)
             for gname, wd in (('iid', self.l2), ('decay', self.l2), ('nodecay', 0.0)):
-                adam(gname, wd, st, dense_reduced=dp)
+                if not (sharded and gname == 'iid'):
+                    adam(gname, wd, st, dense_reduced=dp)
         return tot[0], tot[1], tot[2]
 
     # ---- evaluation -----------------------------------------------------------------------------------

@@ -390,6 +390,9 @@ class IntEL(nn.Module):
 
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, data):
+        if os.environ.get('INTEL_MODEL_OP') == '1' and '_intel' not in data:      # the dispatcher-visible whole-model op (ops.py)
+            from . import ops
+            return ops.model_forward(self, data)
         batch, keep = self.prepare_batch(data)
         items = self.slot_items()
         params = [p for _, _, p in items]

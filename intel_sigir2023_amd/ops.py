@@ -75,8 +75,9 @@ def add_layernorm(x, r, gamma, beta, stash=False):
 # torch.library registration: the same entry points as dispatcher-visible custom ops, `torch.ops.intel_mi355x.*`
 # (north_star: "exposed ... as PyTorch-ROCm custom ops").  The C ABI stays the lowest layer; these are
 # thin schemas over it with shape ("fake") functions for tracing and autograd formulas where the reference differentiates
-# through the op.  The whole-model forward / backward keep their struct-based entry points (intel_forward / intel_backward:
-# model.py drives them through one autograd.Function).
+# through the op.  The whole model is registered too: torch.ops.intel_mi355x.intel_forward (+ intel_backward as its autograd
+# formula) over the struct-based C entry points; model.forward takes it with INTEL_MODEL_OP=1 (ops.model_forward), otherwise the
+# equivalent autograd.Function of model.py.
 # ------------------------------------------------------------------------------------------------------------------------
 NAMESPACE = 'intel_mi355x'
 
@@ -171,7 +172,112 @@ def _register():
     def _(ens_score, ranking, session_len, k):
         return ens_score.new_empty(ens_score.shape[0])
 
-    return ['linear', 'linear_dgrad', 'linear_wgrad', 'attention', 'attention_bwd', 'add_layernorm', 'ndcg']
+    # ---- the whole model (models/IntEL/IntEL.py:117-124: IntEL.forward) as ONE dispatcher-visible op + its hand-written backward.
+    # `handle` names the module (model_handle(model)): the op reads the hyper-parameters and the workspace from it; the parameter
+    # tensors travel as a Tensor[] argument in the order of model.slot_items(), so autograd sees them and receives their gradients.
+    from typing import List, Optional
+
+    @custom_op(NAMESPACE + '::intel_forward', mutates_args=(), device_types='cuda')
+    def op_intel_forward(handle: int, train: bool, i_id_s: torch.Tensor, i_class_c: torch.Tensor, scores: torch.Tensor, session_len: torch.Tensor,
+                         u_id_c: torch.Tensor, context_mh: torch.Tensor, his_context_mh: torch.Tensor, his_intents: torch.Tensor,
+                         history_len: torch.Tensor, his_item_id: torch.Tensor, his_item_idx: Optional[torch.Tensor],
+                         his_item_int: Optional[torch.Tensor], history_item_len: torch.Tensor, his_rows: int, hisitem_rows: int,
+                         params: List[torch.Tensor]) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        model = _model_of(handle)
+        data = {'i_id_s': i_id_s, 'i_class_c': i_class_c, 'scores': scores, 'session_len': session_len, 'u_id_c': u_id_c,
+                'context_mh': context_mh, 'his_context_mh': his_context_mh, 'his_intents': his_intents, 'history_len': history_len,
+                'his_item_id': his_item_id, 'history_item_len': history_item_len}
+        if his_item_idx is not None:
+            data['his_item_idx'] = his_item_idx
+        else:
+            data['his_item_int'] = his_item_int
+        if his_rows >= 0 and hisitem_rows >= 0:
+            data['his_rows'], data['hisitem_rows'] = his_rows, hisitem_rows
+        batch, keep = model.prepare_batch(data)
+        out = model.run_forward(batch, keep, [p.detach() for p in params], train=train)
+        model._generation = getattr(model, '_generation', 0) + 1
+        if train:
+            model._op_stash = (model._generation, batch, keep)      # what intel_backward continues from (one forward / backward pair at a time)
+        return out
+
+    @op_intel_forward.register_fake
+    def _(handle, train, i_id_s, i_class_c, scores, session_len, u_id_c, context_mh, his_context_mh, his_intents, history_len, his_item_id,
+          his_item_idx, his_item_int, history_item_len, his_rows, hisitem_rows, params):
+        model = _model_of(handle)
+        B, Lm = i_id_s.shape
+        f = dict(dtype=torch.float32, device=i_id_s.device)
+        return torch.empty(B, Lm, model.model_num, **f), torch.empty(B, Lm, **f), torch.empty(B, model.intent_num, **f)
+
+    @custom_op(NAMESPACE + '::intel_backward', mutates_args=(), device_types='cuda')
+    def op_intel_backward(handle: int, d_weights: torch.Tensor, d_ens_score: torch.Tensor, d_intents: torch.Tensor,
+                          params: List[torch.Tensor]) -> List[torch.Tensor]:
+        model = _model_of(handle)
+        stash = getattr(model, '_op_stash', None)
+        if stash is None or stash[0] != model._generation:
+            raise L.IntelHipError('intel_backward: no matching intel_forward(train=True) (the activation stash was overwritten)')
+        _, batch, keep = stash
+        grads = model.run_backward(batch, keep, [p.detach() for p in params], d_weights.contiguous().float(), d_ens_score.contiguous().float(),
+                                   d_intents.contiguous().float())
+        items = model.slot_items()
+        return [grads[s] if s in grads else torch.zeros_like(p) for (s, _, _), p in zip(items, params)]
+
+    @op_intel_backward.register_fake
+    def _(handle, d_weights, d_ens_score, d_intents, params):
+        return [torch.empty_like(p) for p in params]
+
+    def _model_setup(ctx, inputs, output):
+        ctx.handle = inputs[0]
+        ctx.n_inputs = len(inputs)
+        ctx.save_for_backward(*inputs[-1])
+
+    def _model_backward(ctx, d_weights, d_ens, d_intents):
+        params = list(ctx.saved_tensors)
+        model = _model_of(ctx.handle)
+        B, Lm = model._op_stash[1].B, model._op_stash[1].L
+        dev = params[0].device
+        zw = lambda t, shape: torch.zeros(shape, dtype=torch.float32, device=dev) if t is None else t
+        grads = torch.ops.intel_mi355x.intel_backward(ctx.handle, zw(d_weights, (B, Lm, model.model_num)), zw(d_ens, (B, Lm)),
+                                                      zw(d_intents, (B, model.intent_num)), params)
+        return (None,) * (ctx.n_inputs - 1) + (list(grads),)
+
+    op_intel_forward.register_autograd(_model_backward, setup_context=_model_setup)
+
+    return ['linear', 'linear_dgrad', 'linear_wgrad', 'attention', 'attention_bwd', 'add_layernorm', 'ndcg', 'intel_forward', 'intel_backward']
+
+
+_HANDLES = {}
+
+
+def model_handle(model):
+    """Integer handle of an IntEL module for torch.ops.intel_mi355x.intel_forward / intel_backward (a weak reference is kept)."""
+    import weakref
+    h = id(model)
+    _HANDLES[h] = weakref.ref(model)
+    return h
+
+
+def _model_of(handle):
+    ref = _HANDLES.get(int(handle))
+    model = ref() if ref is not None else None
+    if model is None:
+        raise L.IntelHipError('intel_forward: unknown or dead model handle %r (ops.model_handle(model))' % (handle,))
+    return model
+
+
+def model_forward(model, data):
+    """IntEL.forward(data) through the dispatcher: torch.ops.intel_mi355x.intel_forward over the module's parameters
+    (models/IntEL/IntEL.py:117-124).  Differentiable: the registered autograd formula is intel_backward."""
+    if 'intel_forward' not in REGISTERED_OPS:
+        raise L.IntelHipError('torch.library.custom_op is not available in this torch: %r' % (globals().get('_REGISTER_ERROR'),))
+    params = [p for _, _, p in model.slot_items()]
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    i32 = lambda k: data[k]
+    w, e, i = torch.ops.intel_mi355x.intel_forward(
+        model_handle(model), bool(need_grad), i32('i_id_s'), data.get('i_class_c') if data.get('i_class_c') is not None else torch.zeros_like(data['i_id_s']),
+        data['scores'], i32('session_len'), i32('u_id_c'), i32('context_mh'), i32('his_context_mh'), data['his_intents'], i32('history_len'),
+        i32('his_item_id'), data.get('his_item_idx'), data.get('his_item_int') if 'his_item_idx' not in data else None, i32('history_item_len'),
+        int(data.get('his_rows', -1)), int(data.get('hisitem_rows', -1)), params)
+    return {'weights': w, 'ens_score': e, 'intents': i}
 
 
 try:

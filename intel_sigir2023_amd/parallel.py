@@ -99,6 +99,21 @@ def allreduce_sum_async(t):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
 
 
+def reduce_scatter_sum(full, out):
+    """out <- this rank's chunk of the sum over ranks of ``full`` (world equal chunks of out.numel() elements, rank order).
+    RCCL: one reduce-scatter (the first half of a ring all-reduce).  gloo (tests) has no reduce-scatter: all-reduce + slice."""
+    w, r = world_size(), rank()
+    n = out.numel()
+    assert full.numel() == w * n
+    if not active():
+        out.copy_(full.reshape(-1)[:n])
+    elif dist.get_backend() == 'nccl':
+        dist.reduce_scatter_tensor(out, full)
+    else:
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        out.copy_(full.reshape(-1)[r * n:(r + 1) * n])
+
+
 def allgather(t):
     """[world, *t.shape] tensor holding every rank's ``t`` (same shape on all ranks)."""
     w = world_size()

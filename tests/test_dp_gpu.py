@@ -106,7 +106,7 @@ def _run_tmall(rank, world, port, out_dir, exchange='auto', tag=''):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse'), (4, 'dense')])
+@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse'), (4, 'dense'), (2, 'sharded'), (4, 'sharded')])
 def test_n_rank_engine_equals_single_process_at_tmall_shape(world, exchange):
     """N ranks on the contiguous shards of a 64-session Tmall-shape batch == one process on the whole batch: losses (mean of the
     shard means), replicas bit-identical, parameters after two Adam steps."""
@@ -128,7 +128,8 @@ def test_n_rank_engine_equals_single_process_at_tmall_shape(world, exchange):
 
 
 @pytest.mark.parametrize('world,exchange,schedule', [(2, 'dense', 'wide'), (2, 'sparse', 'wide'), (4, 'sparse', 'wide'),
-                                                     (2, 'dense', 'phased'), (2, 'sparse', 'phased')])
+                                                     (2, 'dense', 'phased'), (2, 'sparse', 'phased'), (2, 'sharded', 'wide'),
+                                                     (4, 'sharded', 'wide'), (2, 'sharded', 'phased')])
 def test_n_rank_engine_equals_single_process(world, exchange, schedule):
     """exchange: dense all-reduce of the item-id table gradient, or the touched-rows all-gather.
     schedule: the one-call backward with the exchange under its tail (default), or the two-call order.
@@ -194,7 +195,8 @@ def test_seeded_bpr_noise_is_keyed_by_global_session():
 
 
 @pytest.mark.parametrize('exchange,overlap,schedule', [('dense', '1', 'wide'), ('sparse', '1', 'wide'), ('dense', '1', 'phased'),
-                                                       ('sparse', '1', 'phased'), ('dense', '0', 'wide')])
+                                                       ('sparse', '1', 'phased'), ('dense', '0', 'wide'), ('sharded', '1', 'wide'),
+                                                       ('sharded', '1', 'phased'), ('sharded', '0', 'wide')])
 def test_rccl_world1_runs_every_collective_branch(exchange, overlap, schedule):
     """RCCL itself: a one-rank `nccl` process group on the test GPU with the engine forced onto its data-parallel branches
     (INTEL_DP_FORCE=1), in both backward schedules -- the (phased: asynchronous) all-reduce on the side stream, the uint8 MAX all-reduce of the row

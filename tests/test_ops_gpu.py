@@ -147,3 +147,47 @@ def test_dispatcher_ops_match_torch_and_differentiate():
         fx = torch.empty(10, 64, device='cuda')
         fy = torch.ops.intel_mi355x.linear(fx, torch.empty(32, 64, device='cuda'), torch.empty(32, device='cuda'), False)
         assert tuple(fy.shape) == (10, 32)
+
+
+def test_whole_model_op_matches_the_reference_fixture():
+    """torch.ops.intel_mi355x.intel_forward: IntEL.forward (models/IntEL/IntEL.py:117-124) as ONE dispatcher-visible custom op over the
+    module's parameters, intel_backward registered as its autograd formula.  Fixture `default`: forward outputs (3e-5), the
+    IntBPRloss value (1e-5) and every parameter gradient of the reference's autograd (2e-4 of the tensor's largest element)."""
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd import ops
+    from tests.helpers import Fixture, build_model
+    assert 'intel_forward' in ops.REGISTERED_OPS and hasattr(torch.ops.intel_mi355x, 'intel_forward')
+    dev = _dev()
+    fx = Fixture('default')
+    model, args = build_model(fx, dev)
+    model.train()
+    batch = fx.batch(dev)
+    out = ops.model_forward(model, batch)
+    ref = fx.group('out')
+    for k in ('weights', 'ens_score', 'intents'):
+        _close(out[k], torch.from_numpy(ref[k]), tol=3e-5, name=k)
+    batch['bpr_noise'] = torch.from_numpy(fx['bpr/noise']).to(dev)
+    args.cal_diversity = 0
+    loss, _, _ = LS.IntBPRloss(args)(out, batch)
+    loss.backward()
+    got = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    # the same through the module's default path (autograd.Function over the same C entry points): identical kernels, so equal
+    model.zero_grad()
+    out2 = model(batch)
+    loss2, _, _ = LS.IntBPRloss(args)(out2, batch)
+    loss2.backward()
+    assert abs(float(loss) - float(loss2)) < 1e-6
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert k in got, k
+        tol = 1e-7 + 2e-6 * float(p.grad.abs().max())
+        assert float((got[k] - p.grad).abs().max()) <= tol, k
+    # opcheck-style: the op is visible to the dispatcher with a fake (shape) function
+    with torch.no_grad():
+        w, e, i = torch.ops.intel_mi355x.intel_forward(ops.model_handle(model), False, batch['i_id_s'], batch['i_class_c'], batch['scores'],
+                                                       batch['session_len'], batch['u_id_c'], batch['context_mh'], batch['his_context_mh'],
+                                                       batch['his_intents'], batch['history_len'], batch['his_item_id'], batch.get('his_item_idx'),
+                                                       batch.get('his_item_int') if 'his_item_idx' not in batch else None, batch['history_item_len'],
+                                                       -1, -1, [p for _, _, p in model.slot_items()])
+    assert w.shape == out['weights'].shape and e.shape == out['ens_score'].shape and i.shape == out['intents'].shape

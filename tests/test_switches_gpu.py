@@ -34,6 +34,7 @@ CASES = [
     ({'INTEL_FUSE_TOWER_D64': '0'}, MODEL),                            # fp32 training keeps the 64-wide tower on the kernel-per-op pipeline
     ({'INTEL_ENC_FUSED_BWD': '0'}, MODEL),                             # kernel-per-op encoder backward on the fused forward's stash
     ({'INTEL_WGRAD_SLABS': '64', 'INTEL_WGRAD_CORESIDENT': '0'}, MODEL),
+    ({'INTEL_MODEL_OP': '1'}, MODEL),                                  # IntEL.forward through torch.ops.intel_mi355x.intel_forward
     ({'INTEL_STREAMS': '0'}, ENGINE),                                  # ... the engine's table sweep still has to wait for the backward
     ({'INTEL_BWD_WIDE': '0'}, ENGINE),
     ({'INTEL_ADAM_ROWS': '0'}, ENGINE),                                # dense Adam kernel over the item-id table
