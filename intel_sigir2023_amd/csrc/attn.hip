@@ -28,20 +28,31 @@ struct AttnSmem {
   static constexpr int LD = DKT * 16 + 4;   // ld % 8 == 4: b128 row reads and b32 column reads conflict-free
 };
 
-// stage rows [r0, r0+64) of one third of qkv (column offset coff) into LDS, zero padded
+// rows [r0, r0 + AT_KB) of one third of qkv (column offset coff), zero padded, on their way to LDS through registers: the loads of the NEXT
+// block are issued before the current block's products and land under them
 template <int DKT>
-__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ base, int ldg, int coff, int dk,
-                                           int r0, int T, int tid) {
-  constexpr int LD = AttnSmem<DKT>::LD;
-  constexpr int C4 = DKT * 4;   // float4 per row
-  for (int i = tid; i < AT_KB * C4; i += 256) {
-    const int r = i / C4, c4 = i - r * C4;
-    const int row = r0 + r, col = c4 * 4;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row < T && col < dk) v = *reinterpret_cast<const f32x4*>(base + (size_t)row * ldg + coff + col);
-    *reinterpret_cast<f32x4*>(dst + r * LD + col) = v;
+struct StageRegs {
+  static constexpr int C4 = DKT * 4;                            // float4 per row
+  static constexpr int NV = (AT_KB * C4 + 255) / 256;           // float4 per thread
+  f32x4 v[NV];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ldg, int coff, int dk, int r0, int T, int tid) {
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + n * 256, r = i / C4, c4 = i - r * C4;
+      const int row = r0 + r, col = c4 * 4;
+      v[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < AT_KB * C4 && row < T && col < dk) v[n] = *reinterpret_cast<const f32x4*>(base + (size_t)row * ldg + coff + col);
+    }
   }
-}
+  __device__ __forceinline__ void store(float* dst, int tid) const {
+    constexpr int LD = AttnSmem<DKT>::LD;
+#pragma unroll
+    for (int n = 0; n < NV; ++n) {
+      const int i = tid + n * 256, r = i / C4, c4 = i - r * C4;
+      if (i < AT_KB * C4) *reinterpret_cast<f32x4*>(dst + r * LD + c4 * 4) = v[n];
+    }
+  }
+};
 
 // fragment of one row (B-operand / "row on the lane" form): element s of group g = x[row][g*16+4*(lane>>4)+s]
 template <int DKT>
@@ -62,11 +73,65 @@ __device__ __forceinline__ float group_sum16(float v) {
   return v + __shfl_xor(v, 32);
 }
 
+// "Head dim on the accumulator rows" products (O^T = V^T P^T, dV^T = dO^T P, dK^T = Q^T dS, dQ^T = K^T dS^T): the A operand is a staged row read
+// ALONG the head dim.  When the head dim is whole 64-column chunks (DKT % 4 == 0: head dims 64 and 128) a lane reads four consecutive dims as ONE
+// b128 and feeds four MFMAs — accumulator 4c+t row i is dim 64c + 4i + t — instead of one b32 read per MFMA (accumulator dt row i = dim 16dt + i).
+#ifndef ATTN_WIDE
+#define ATTN_WIDE 1
+#endif
+template <int DKT>
+__device__ __forceinline__ void dimT_mma(f32x4 (&acc)[DKT], const float* __restrict__ rowp, float bval, int lane) {
+  if constexpr (ATTN_WIDE && DKT % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < DKT / 4; ++c) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(rowp + 64 * c + 4 * (lane & 15));
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[4 * c + t] = mfma16(x[t], bval, acc[4 * c + t]);
+    }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) acc[dt] = mfma16(rowp[dt * 16 + (lane & 15)], bval, acc[dt]);
+  }
+}
+// the lane's share of one output row (16 dims per 64-column chunk / per 16-column tile), scaled
+template <int DKT>
+__device__ __forceinline__ void dimT_store(float* __restrict__ rowp, const f32x4 (&acc)[DKT], int dk, int lane, float mul) {
+  if constexpr (ATTN_WIDE && DKT % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < DKT / 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = 64 * c + 16 * (lane >> 4) + 4 * r;
+        if (col < dk) *reinterpret_cast<f32x4*>(rowp + col) = f32x4{acc[4 * c][r], acc[4 * c + 1][r], acc[4 * c + 2][r], acc[4 * c + 3][r]} * mul;
+      }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const int col = dt * 16 + 4 * (lane >> 4);
+      if (col < dk) *reinterpret_cast<f32x4*>(rowp + col) = acc[dt] * mul;
+    }
+  }
+}
+
+// Workgroup -> ((session, head) pair, 64-row block) for the 1-D grids of the flash-style kernels.  The blocks of one pair re-read the same
+// K / V (forward, dQ) or Q / dO (dK / dV) rows; consecutive workgroup ids land on consecutive XCDs (id % 8), each with its own L2, so the
+// blocks of a pair are given ids 8 apart: same XCD, dispatched together, the second reader is served by that L2.
+struct AttnBlock { int bh, y; };
+__device__ __forceinline__ AttnBlock attn_block(int nbh, int ny) {
+  const int id = blockIdx.x;
+  if ((nbh & 7) == 0) {
+    const int slot = id >> 3, g = slot / ny;
+    return AttnBlock{g * 8 + (id & 7), slot - g * ny};
+  }
+  const int bh = id / ny;
+  return AttnBlock{bh, id - bh * ny};
+}
+
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
 template <int DKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ qkv, int T, int d, int heads,
+__global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_kernel(const float* __restrict__ qkv, int T, int d, int heads,
                                                        const int* __restrict__ key_len, float scale,
                                                        float* __restrict__ out, float* __restrict__ lse) {
   constexpr int LD = AttnSmem<DKT>::LD;
@@ -74,11 +139,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   float* Ks = smem;
   float* Vs = smem + AT_KB * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int ny = (T + AT_QB - 1) / AT_QB;
+  const AttnBlock blk = attn_block((int)gridDim.x / ny, ny);
+  const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
+  const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
   f32x4 qf[DKT];
   load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < T, dk, lane);
   f32x4 oT[DKT];
@@ -86,11 +153,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
+  StageRegs<DKT> kreg, vreg;
+  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
+  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, T, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
-    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
-    stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
+    kreg.store(Ks, tid);
+    vreg.store(Vs, tid);
     __syncthreads();
+    if (kb + AT_KB < nkeys) {
+      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
+      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, T, tid);
+    }
+    if (blk.y * AT_QB + wave * 16 >= T) continue;      // a wave whose 16 queries are all past the list only helps staging
     f32x4 st[AT_KB / 16];
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
@@ -136,21 +211,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
       if (kb + kt * 16 < nkeys) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const float* vrow = Vs + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
-#pragma unroll
-          for (int dt = 0; dt < DKT; ++dt) oT[dt] = mfma16(vrow[dt * 16], st[kt][s], oT[dt]);
+          dimT_mma<DKT>(oT, Vs + (kt * 16 + 4 * (lane >> 4) + s) * LD, st[kt][s], lane);
         }
       }
     }
   }
   if (q < T) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    float* orow = out + ((size_t)b * T + q) * d + h * dk;
-#pragma unroll
-    for (int dt = 0; dt < DKT; ++dt) {
-      const int col = dt * 16 + 4 * (lane >> 4);
-      if (col < dk) *reinterpret_cast<f32x4*>(orow + col) = oT[dt] * inv;
-    }
+    dimT_store<DKT>(out + ((size_t)b * T + q) * d + h * dk, oT, dk, lane, inv);
     if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
   }
 }
@@ -168,11 +236,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   float* Ks = smem;
   float* Vs = smem + AT_KB * LD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int ny = (T + AT_QB - 1) / AT_QB;
+  const AttnBlock blk = attn_block((int)gridDim.x / ny, ny);
+  const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
+  const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
   const bool qok = q < T;
   f32x4 qf[DKT], dof[DKT];
   load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, qok, dk, lane);
@@ -193,11 +263,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  StageRegs<DKT> kreg, vreg;
+  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
+  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, T, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
-    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
-    stage_rows<DKT>(Vs, base, ldg, 2 * d + h * dk, dk, kb, T, tid);
+    kreg.store(Ks, tid);
+    vreg.store(Vs, tid);
     __syncthreads();
+    if (kb + AT_KB < nkeys) {
+      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
+      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, T, tid);
+    }
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
       if (kb + kt * 16 >= nkeys) continue;
@@ -222,19 +299,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float* krow = Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < DKT; ++dt) dqT[dt] = mfma16(krow[dt * 16], dsT[s], dqT[dt]);
+        dimT_mma<DKT>(dqT, Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD, dsT[s], lane);
       }
     }
   }
   if (qok) {
-    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * dk;
-#pragma unroll
-    for (int dt = 0; dt < DKT; ++dt) {
-      const int col = dt * 16 + 4 * (lane >> 4);
-      if (col < dk) *reinterpret_cast<f32x4*>(drow + col) = dqT[dt];
-    }
+    dimT_store<DKT>(dqkv + ((size_t)b * T + q) * ldg + h * dk, dqT, dk, lane, 1.f);
   }
 }
 
@@ -242,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 // backward, dK/dV: wave owns 16 keys, sweeps query blocks (Q and dO staged in LDS).
 // ------------------------------------------------------------------------------------------
 template <int DKT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            int T, int d, int heads, const int* __restrict__ key_len,
                                                            float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS) {
@@ -253,11 +323,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
   float* Ls = smem + 2 * AT_KB * LD;   // [64] lse
   float* Ds = Ls + AT_KB;              // [64] dsum
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int ny = (T + AT_QB - 1) / AT_QB;
+  const AttnBlock blk = attn_block((int)gridDim.x / ny, ny);
+  const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int key = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
+  const int key = blk.y * AT_QB + wave * 16 + (lane & 15);
   const bool kok = key < T;
   f32x4 kf[DKT], vf[DKT];
   load_row_frags<DKT>(kf, base + (size_t)key * ldg + d + h * dk, kok, dk, lane);
@@ -269,16 +341,28 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
     dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const bool key_live = key < nkeys;          // masked keys get exactly zero gradient
-  const bool wave_live = (blockIdx.y * AT_QB + wave * 16) < nkeys;
+  const bool wave_live = (blk.y * AT_QB + wave * 16) < nkeys;
 
+  StageRegs<DKT> qreg, oreg;
+  float lreg = INFINITY, dreg = 0.f;
+  const float* dob = dout + (size_t)b * T * d;
+  // (prefetching the next block's Q / dO rows under the products was measured: no gain — two to four resident workgroups already cover the
+  // staging — and it costs 16-32 registers, i.e. a wave per SIMD at head dim 64)
   for (int qb = 0; qb < T; qb += AT_KB) {
     __syncthreads();
-    stage_rows<DKT>(Qs, base, ldg, h * dk, dk, qb, T, tid);
-    stage_rows<DKT>(Os, dout + (size_t)b * T * d, d, h * dk, dk, qb, T, tid);
-    if (tid < AT_KB) {
+    qreg.load(base, ldg, h * dk, dk, qb, T, tid);
+    oreg.load(dob, d, h * dk, dk, qb, T, tid);
+    {
       const int qq = qb + tid;
-      Ls[tid] = qq < T ? lse[((size_t)b * heads + h) * T + qq] : INFINITY;
-      Ds[tid] = qq < T ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
+      const bool ok = tid < AT_KB && qq < T;
+      lreg = ok ? lse[((size_t)b * heads + h) * T + qq] : INFINITY;
+      dreg = ok ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
+    }
+    qreg.store(Qs, tid);
+    oreg.store(Os, tid);
+    if (tid < AT_KB) {
+      Ls[tid] = lreg;
+      Ds[tid] = dreg;
     }
     __syncthreads();
     if (!wave_live) continue;
@@ -305,29 +389,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const float* __restri
         pr[r] = p;
         ds[r] = p * (dp[r] - Ds[ql]) * scale;
         // the dS tile for the dQ = dS K kernel (row = query, ldS floats per row); keys >= nkeys / queries >= T are never read
-        if (dS && qb + ql < T && kok) dS[((size_t)blockIdx.x * T + qb + ql) * ldS + key] = ds[r];
+        if (dS && qb + ql < T && kok) dS[((size_t)blk.bh * T + qb + ql) * ldS + key] = ds[r];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int roff = (qt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < DKT; ++dt) {
-          dvT[dt] = mfma16(Os[roff + dt * 16], pr[s], dvT[dt]);   // dV^T[dim][key] += dO^T P
-          dkT[dt] = mfma16(Qs[roff + dt * 16], ds[s], dkT[dt]);   // dK^T[dim][key] += Q^T dS
-        }
+        const int roff = (qt * 16 + 4 * (lane >> 4) + s) * LD;
+        dimT_mma<DKT>(dvT, Os + roff, pr[s], lane);   // dV^T[dim][key] += dO^T P
+        dimT_mma<DKT>(dkT, Qs + roff, ds[s], lane);   // dK^T[dim][key] += Q^T dS
       }
     }
   }
   if (kok) {
     float* drow = dqkv + ((size_t)b * T + key) * ldg + h * dk;
-#pragma unroll
-    for (int dt = 0; dt < DKT; ++dt) {
-      const int col = dt * 16 + 4 * (lane >> 4);
-      if (col < dk) {
-        *reinterpret_cast<f32x4*>(drow + d + col) = dkT[dt];
-        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = dvT[dt];
-      }
-    }
+    dimT_store<DKT>(drow + d, dkT, dk, lane, 1.f);
+    dimT_store<DKT>(drow + 2 * d, dvT, dk, lane, 1.f);
   }
 }
 
@@ -362,27 +437,33 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
 }
 
 template <int DKT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_ds_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
                                                              int d, int heads, const int* __restrict__ key_len,
                                                              float* __restrict__ dqkv) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+  const int ny = (T + AT_QB - 1) / AT_QB;
+  const AttnBlock blk = attn_block((int)gridDim.x / ny, ny);
+  const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
   const float* base = qkv + (size_t)b * T * ldg;
-  const int q = blockIdx.y * AT_QB + wave * 16 + (lane & 15);
+  const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
   const bool qok = q < T;
-  const float* dSq = dS + ((size_t)blockIdx.x * T + (qok ? q : 0)) * ldS;
+  const float* dSq = dS + ((size_t)blk.bh * T + (qok ? q : 0)) * ldS;
   f32x4 dqT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  StageRegs<DKT> kreg;
+  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
-    stage_rows<DKT>(Ks, base, ldg, d + h * dk, dk, kb, T, tid);
+    kreg.store(Ks, tid);
     __syncthreads();
+    if (kb + AT_KB < nkeys) kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
+    if (blk.y * AT_QB + wave * 16 >= T) continue;
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
       if (kb + kt * 16 >= nkeys) continue;
@@ -393,19 +474,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_ds_kernel(const float* __rest
       for (int r = 0; r < 4; ++r) dsT[r] = key0 + r < nkeys ? dsT[r] : 0.f;      // masked / padding keys: nothing was stored
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float* krow = Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD + (lane & 15);
-#pragma unroll
-        for (int dt = 0; dt < DKT; ++dt) dqT[dt] = mfma16(krow[dt * 16], dsT[s], dqT[dt]);
+        dimT_mma<DKT>(dqT, Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD, dsT[s], lane);
       }
     }
   }
   if (qok) {
-    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * dk;
-#pragma unroll
-    for (int dt = 0; dt < DKT; ++dt) {
-      const int col = dt * 16 + 4 * (lane >> 4);
-      if (col < dk) *reinterpret_cast<f32x4*>(drow + col) = dqT[dt];
-    }
+    dimT_store<DKT>(dqkv + ((size_t)b * T + q) * ldg + h * dk, dqT, dk, lane, 1.f);
   }
 }
 
@@ -454,7 +528,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   const float scale = 1.0f / sqrtf((float)dk);
   if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
   INTEL_CHECK_ARG(!row_off, "attention: packed rows are supported by the whole-sequence kernels only (T <= 64, head dim 64 / 128)");
-  dim3 grid(B * heads, cdiv(T, AT_QB));
+  dim3 grid(B * heads * cdiv(T, AT_QB));
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_fwd_kernel<DKT>, smem);
@@ -475,7 +549,7 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   if (attn_seq_path(T, dk))
     return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st, row_off, h16);
   INTEL_CHECK_ARG(!row_off && !h16, "attention: packed rows / bf16-stored q,k,v are supported by the whole-sequence kernels only");
-  dim3 grid(B * heads, cdiv(T, AT_QB));
+  dim3 grid(B * heads * cdiv(T, AT_QB));
   if (attn_ds_scheme()) {
     float* dS = scratch + rup_sz((size_t)B * heads * T, 64);
     const int ldS = attn_ds_pitch(T);
