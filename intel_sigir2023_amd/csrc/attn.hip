@@ -133,7 +133,7 @@ __device__ __forceinline__ AttnBlock attn_block(int nbh, int ny) {
 template <int DKT>
 __global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_kernel(const float* __restrict__ qkv, int T, int d, int heads,
                                                        const int* __restrict__ key_len, float scale,
-                                                       float* __restrict__ out, float* __restrict__ lse) {
+                                                       float* __restrict__ out, float* __restrict__ lse, const int* __restrict__ row_off) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -144,28 +144,33 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_kernel(const f
   const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
-  const float* base = qkv + (size_t)b * T * ldg;
+  // packed rows (row_off): the session's nkeys valid rows start at row_off[b] and nothing else of it is in the buffers; the per-(session, head)
+  // statistics (log-sum-exp, dsum, the dS scratch) keep their padded [.., T] index either way
+  const int nrow = row_off ? nkeys : T;
+  const size_t row0 = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (blk.y * AT_QB >= nrow) return;
+  const float* base = qkv + row0 * ldg;
   const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
   f32x4 qf[DKT];
-  load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < T, dk, lane);
+  load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < nrow, dk, lane);
   f32x4 oT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
 
   StageRegs<DKT> kreg, vreg;
-  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
-  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, T, tid);
+  kreg.load(base, ldg, d + h * dk, dk, 0, nrow, tid);
+  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, nrow, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
     kreg.store(Ks, tid);
     vreg.store(Vs, tid);
     __syncthreads();
     if (kb + AT_KB < nkeys) {
-      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
-      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, T, tid);
+      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, nrow, tid);
+      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, nrow, tid);
     }
-    if (blk.y * AT_QB + wave * 16 >= T) continue;      // a wave whose 16 queries are all past the list only helps staging
+    if (blk.y * AT_QB + wave * 16 >= nrow) continue;      // a wave whose 16 queries are all past the list only helps staging
     f32x4 st[AT_KB / 16];
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
@@ -216,9 +221,9 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_kernel(const f
       }
     }
   }
-  if (q < T) {
+  if (q < nrow) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    dimT_store<DKT>(out + ((size_t)b * T + q) * d + h * dk, oT, dk, lane, inv);
+    dimT_store<DKT>(out + (row0 + q) * d + h * dk, oT, dk, lane, inv);
     if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
   }
 }
@@ -230,7 +235,7 @@ template <int DKT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                           const float* __restrict__ dout, const float* __restrict__ lse,
                                                           int T, int d, int heads, const int* __restrict__ key_len,
-                                                          float scale, float* __restrict__ dqkv, float* __restrict__ dsum) {
+                                                          float scale, float* __restrict__ dqkv, float* __restrict__ dsum, const int* __restrict__ row_off) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -241,16 +246,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
-  const float* base = qkv + (size_t)b * T * ldg;
+  // packed rows (row_off): the session's nkeys valid rows start at row_off[b] and nothing else of it is in the buffers; the per-(session, head)
+  // statistics (log-sum-exp, dsum, the dS scratch) keep their padded [.., T] index either way
+  const int nrow = row_off ? nkeys : T;
+  const size_t row0 = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (blk.y * AT_QB >= nrow) return;
+  const float* base = qkv + row0 * ldg;
   const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
-  const bool qok = q < T;
+  const bool qok = q < nrow;
   f32x4 qf[DKT], dof[DKT];
   load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, qok, dk, lane);
-  load_row_frags<DKT>(dof, dout + ((size_t)b * T + q) * d + h * dk, qok, dk, lane);
+  load_row_frags<DKT>(dof, dout + (row0 + q) * d + h * dk, qok, dk, lane);
   float dsm = 0.f;
   {
     f32x4 of[DKT];
-    load_row_frags<DKT>(of, out + ((size_t)b * T + q) * d + h * dk, qok, dk, lane);
+    load_row_frags<DKT>(of, out + (row0 + q) * d + h * dk, qok, dk, lane);
 #pragma unroll
     for (int g = 0; g < DKT; ++g)
 #pragma unroll
@@ -264,16 +274,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
   for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   StageRegs<DKT> kreg, vreg;
-  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
-  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, T, tid);
+  kreg.load(base, ldg, d + h * dk, dk, 0, nrow, tid);
+  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, nrow, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
     kreg.store(Ks, tid);
     vreg.store(Vs, tid);
     __syncthreads();
     if (kb + AT_KB < nkeys) {
-      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
-      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, T, tid);
+      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, nrow, tid);
+      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, nrow, tid);
     }
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
     }
   }
   if (qok) {
-    dimT_store<DKT>(dqkv + ((size_t)b * T + q) * ldg + h * dk, dqT, dk, lane, 1.f);
+    dimT_store<DKT>(dqkv + (row0 + q) * ldg + h * dk, dqT, dk, lane, 1.f);
   }
 }
 
@@ -315,7 +325,7 @@ template <int DKT>
 __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            int T, int d, int heads, const int* __restrict__ key_len,
-                                                           float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS) {
+                                                           float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS, const int* __restrict__ row_off) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;
@@ -328,9 +338,14 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
   const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
-  const float* base = qkv + (size_t)b * T * ldg;
+  // packed rows (row_off): the session's nkeys valid rows start at row_off[b] and nothing else of it is in the buffers; the per-(session, head)
+  // statistics (log-sum-exp, dsum, the dS scratch) keep their padded [.., T] index either way
+  const int nrow = row_off ? nkeys : T;
+  const size_t row0 = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (blk.y * AT_QB >= nrow) return;
+  const float* base = qkv + row0 * ldg;
   const int key = blk.y * AT_QB + wave * 16 + (lane & 15);
-  const bool kok = key < T;
+  const bool kok = key < nrow;
   f32x4 kf[DKT], vf[DKT];
   load_row_frags<DKT>(kf, base + (size_t)key * ldg + d + h * dk, kok, dk, lane);
   load_row_frags<DKT>(vf, base + (size_t)key * ldg + 2 * d + h * dk, kok, dk, lane);
@@ -345,16 +360,16 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
 
   StageRegs<DKT> qreg, oreg;
   float lreg = INFINITY, dreg = 0.f;
-  const float* dob = dout + (size_t)b * T * d;
+  const float* dob = dout + row0 * d;
   // (prefetching the next block's Q / dO rows under the products was measured: no gain — two to four resident workgroups already cover the
   // staging — and it costs 16-32 registers, i.e. a wave per SIMD at head dim 64)
-  for (int qb = 0; qb < T; qb += AT_KB) {
+  for (int qb = 0; qb < nrow; qb += AT_KB) {
     __syncthreads();
-    qreg.load(base, ldg, h * dk, dk, qb, T, tid);
-    oreg.load(dob, d, h * dk, dk, qb, T, tid);
+    qreg.load(base, ldg, h * dk, dk, qb, nrow, tid);
+    oreg.load(dob, d, h * dk, dk, qb, nrow, tid);
     {
       const int qq = qb + tid;
-      const bool ok = tid < AT_KB && qq < T;
+      const bool ok = tid < AT_KB && qq < nrow;
       lreg = ok ? lse[((size_t)b * heads + h) * T + qq] : INFINITY;
       dreg = ok ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
     }
@@ -368,7 +383,7 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
     if (!wave_live) continue;
 #pragma unroll
     for (int qt = 0; qt < AT_KB / 16; ++qt) {
-      if (qb + qt * 16 >= T) continue;
+      if (qb + qt * 16 >= nrow) continue;
       f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < DKT; ++g) {
@@ -389,7 +404,7 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
         pr[r] = p;
         ds[r] = p * (dp[r] - Ds[ql]) * scale;
         // the dS tile for the dQ = dS K kernel (row = query, ldS floats per row); keys >= nkeys / queries >= T are never read
-        if (dS && qb + ql < T && kok) dS[((size_t)blk.bh * T + qb + ql) * ldS + key] = ds[r];
+        if (dS && qb + ql < nrow && kok) dS[((size_t)blk.bh * T + qb + ql) * ldS + key] = ds[r];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
     }
   }
   if (kok) {
-    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * dk;
+    float* drow = dqkv + (row0 + key) * ldg + h * dk;
     dimT_store<DKT>(drow + d, dkT, dk, lane, 1.f);
     dimT_store<DKT>(drow + 2 * d, dvT, dk, lane, 1.f);
   }
@@ -412,14 +427,22 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
 // scratch costs 8 T^2 bytes of traffic per (session, head)).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict__ out, const float* __restrict__ dout, int T, int d,
-                                                        int heads, long long rows, float* __restrict__ dsum) {
-  // 16 lanes per (row, head), four of them per wave, 16-byte loads
+                                                        int heads, long long rows, float* __restrict__ dsum,
+                                                        const int* __restrict__ key_len, const int* __restrict__ row_off) {
+  // 16 lanes per (row, head), four of them per wave, 16-byte loads.  rows = B * T positions; packed rows: position (b, t) is data row
+  // row_off[b] + t when t < key_len[b] and absent otherwise
   const int lane = threadIdx.x & 63, sub = lane & 15;
   const long long i = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);      // (b*T + t, h) flattened
-  const bool ok = i < rows * heads;
+  bool ok = i < rows * heads;
   const long long ic = ok ? i : 0;
-  const long long row = ic / heads;
-  const int h = (int)(ic - row * heads), dk = d / heads;
+  const long long pos = ic / heads;
+  const int h = (int)(ic - pos * heads), dk = d / heads;
+  const long long b = pos / T, t = pos - b * T;
+  long long row = pos;
+  if (row_off) {
+    ok = ok && t < min(key_len[b], T);
+    row = ok ? (long long)row_off[b] + t : 0;
+  }
   float s = 0.f;
   for (int c = sub * 4; c < dk; c += 64) {
     const f32x4 o = *reinterpret_cast<const f32x4*>(out + row * d + h * dk + c);
@@ -430,16 +453,13 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
   s += __shfl_xor(s, 2);
   s += __shfl_xor(s, 4);
   s += __shfl_xor(s, 8);
-  if (ok && sub == 0) {
-    const long long b = row / T, t = row - b * T;
-    dsum[(b * heads + h) * T + t] = s;
-  }
+  if (ok && sub == 0) dsum[(b * heads + h) * T + t] = s;
 }
 
 template <int DKT>
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
                                                              int d, int heads, const int* __restrict__ key_len,
-                                                             float* __restrict__ dqkv) {
+                                                             float* __restrict__ dqkv, const int* __restrict__ row_off) {
   constexpr int LD = AttnSmem<DKT>::LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;
@@ -449,21 +469,26 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __r
   const int b = blk.bh / heads, h = blk.bh - b * heads;
   const int dk = d / heads, ldg = 3 * d;
   const int nkeys = key_len ? min(key_len[b], T) : T;
-  const float* base = qkv + (size_t)b * T * ldg;
+  // packed rows (row_off): the session's nkeys valid rows start at row_off[b] and nothing else of it is in the buffers; the per-(session, head)
+  // statistics (log-sum-exp, dsum, the dS scratch) keep their padded [.., T] index either way
+  const int nrow = row_off ? nkeys : T;
+  const size_t row0 = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (blk.y * AT_QB >= nrow) return;
+  const float* base = qkv + row0 * ldg;
   const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
-  const bool qok = q < T;
+  const bool qok = q < nrow;
   const float* dSq = dS + ((size_t)blk.bh * T + (qok ? q : 0)) * ldS;
   f32x4 dqT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   StageRegs<DKT> kreg;
-  kreg.load(base, ldg, d + h * dk, dk, 0, T, tid);
+  kreg.load(base, ldg, d + h * dk, dk, 0, nrow, tid);
   for (int kb = 0; kb < nkeys; kb += AT_KB) {
     __syncthreads();
     kreg.store(Ks, tid);
     __syncthreads();
-    if (kb + AT_KB < nkeys) kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, T, tid);
-    if (blk.y * AT_QB + wave * 16 >= T) continue;
+    if (kb + AT_KB < nkeys) kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, nrow, tid);
+    if (blk.y * AT_QB + wave * 16 >= nrow) continue;
 #pragma unroll
     for (int kt = 0; kt < AT_KB / 16; ++kt) {
       if (kb + kt * 16 >= nkeys) continue;
@@ -479,7 +504,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __r
     }
   }
   if (qok) {
-    dimT_store<DKT>(dqkv + ((size_t)b * T + q) * ldg + h * dk, dqT, dk, lane, 1.f);
+    dimT_store<DKT>(dqkv + (row0 + q) * ldg + h * dk, dqT, dk, lane, 1.f);
   }
 }
 
@@ -490,6 +515,7 @@ static inline bool attn_ds_scheme() {
 }
 
 static inline bool attn_seq_path(int T, int dk) { return attn_seq_supported(T, dk); }
+bool attn_packed_supported(int T, int dk) { return attn_seq_path(T, dk) ? attn_seq_packed_supported(T, dk) : true; }
 
 size_t attn_bwd_scratch_floats(int B, int T, int d, int heads) {
   size_t f = rup_sz((size_t)B * heads * T, 64);
@@ -527,12 +553,12 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   const int dk = d / heads, dkt = cdiv(dk, 16);
   const float scale = 1.0f / sqrtf((float)dk);
   if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
-  INTEL_CHECK_ARG(!row_off, "attention: packed rows are supported by the whole-sequence kernels only (T <= 64, head dim 64 / 128)");
+  INTEL_CHECK_ARG(!row_off || key_len, "attention: packed rows need the session lengths");
   dim3 grid(B * heads * cdiv(T, AT_QB));
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_fwd_kernel<DKT>, smem);
-    LAUNCH_S(B * heads, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, attn_fwd_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse);
+    LAUNCH_S(B * heads, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, attn_fwd_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse, row_off);
   });
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -548,25 +574,26 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   float* dsum = scratch;
   if (attn_seq_path(T, dk))
     return launch_attn_seq_bwd(qkv, out, dout, lse, B, T, d, heads, key_len, dqkv, scratch + rup_sz((size_t)B * heads * T, 64), st, row_off, h16);
-  INTEL_CHECK_ARG(!row_off && !h16, "attention: packed rows / bf16-stored q,k,v are supported by the whole-sequence kernels only");
+  INTEL_CHECK_ARG(!h16, "attention: bf16-stored q,k,v are supported by the whole-sequence kernels only");
+  INTEL_CHECK_ARG(!row_off || key_len, "attention: packed rows need the session lengths");
   dim3 grid(B * heads * cdiv(T, AT_QB));
   if (attn_ds_scheme()) {
     float* dS = scratch + rup_sz((size_t)B * heads * T, 64);
     const int ldS = attn_ds_pitch(T);
     const long long rows = (long long)B * T;
-    LAUNCH_W(0.0, 8.0 * (double)rows * d, attn_dsum_kernel, dim3((unsigned)((rows * heads + 15) / 16)), dim3(256), 0, st, out, dout, T, d, heads, rows, dsum);
+    LAUNCH_W(0.0, 8.0 * (double)rows * d, attn_dsum_kernel, dim3((unsigned)((rows * heads + 15) / 16)), dim3(256), 0, st, out, dout, T, d, heads, rows, dsum, key_len, row_off);
     INTEL_CHECK_LAUNCH();
     ATTN_DISPATCH(dkt, {
       size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
       allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
       LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
-                         scale, dqkv, dS, ldS);
+                         scale, dqkv, dS, ldS, row_off);
     });
     INTEL_CHECK_LAUNCH();
     ATTN_DISPATCH(dkt, {
       size_t smem = (size_t)AT_KB * AttnSmem<DKT>::LD * sizeof(float);
       allow_lds(attn_bwd_dq_ds_kernel<DKT>, smem);
-      LAUNCH_S(B * heads, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d + 4.0 * B * heads * (double)T * T, attn_bwd_dq_ds_kernel<DKT>, grid, dim3(256), smem, st, qkv, dS, ldS, T, d, heads, key_len, dqkv);
+      LAUNCH_S(B * heads, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d + 4.0 * B * heads * (double)T * T, attn_bwd_dq_ds_kernel<DKT>, grid, dim3(256), smem, st, qkv, dS, ldS, T, d, heads, key_len, dqkv, row_off);
     });
     INTEL_CHECK_LAUNCH();
     return 0;
@@ -575,14 +602,14 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_bwd_dq_kernel<DKT>, smem);
     LAUNCH_S(B * heads, T, dk, 6.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dq_kernel<DKT>, grid, dim3(256), smem, st, qkv, out, dout, lse, T, d, heads, key_len,
-                       scale, dqkv, dsum);
+                       scale, dqkv, dsum, row_off);
   });
   INTEL_CHECK_LAUNCH();
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
     allow_lds(attn_bwd_dkv_kernel<DKT>, smem);
     LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
-                       scale, dqkv, nullptr, 0);
+                       scale, dqkv, nullptr, 0, row_off);
   });
   INTEL_CHECK_LAUNCH();
   return 0;

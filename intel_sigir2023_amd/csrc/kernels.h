@@ -98,8 +98,10 @@ int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int 
 // ---- attention (attn.hip) -------------------------------------------------------------------
 // qkv: [B*T, 3*d] rows = [q | k | v]; out [B*T, d]; lse [B*heads*T]; key_len optional [B].
 // row_off (optional, [B]): PACKED rows -- session b owns rows row_off[b] .. row_off[b] + key_len[b] - 1 of qkv / out / dout /
-// dqkv instead of rows b*T .. b*T + T - 1 (no padding rows in memory); whole-sequence kernels only
+// dqkv instead of rows b*T .. b*T + T - 1 (no padding rows in memory); needs key_len
 bool attn_seq_packed_supported(int T, int dk);
+// packed rows (row_off) through launch_attn_fwd / launch_attn_bwd: the general kernels take them at any length, the whole-sequence ones in their fused form
+bool attn_packed_supported(int T, int dk);
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                     hipStream_t st, const int* row_off = nullptr);
 // whole-sequence kernels (attn_seq.hip): T <= 64, head dim 64 / 128

@@ -1854,7 +1854,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
       const int* off = e == 0 ? batch->his_off : batch->hisitem_off;
       const int nrows = e == 0 ? batch->n_his_rows : batch->n_hisitem_rows;
       const bool pk = pack_on && off && nrows > 0 && nrows <= batch->B * T &&
-                      ((D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 1 && attn_seq_packed_supported(T, dm / D.enc_heads)) ||
+                      ((D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 1 && attn_packed_supported(T, dm / D.enc_heads)) ||
                        (D.encoder == INTEL_ENC_GRU4REC && gru_packed_supported(D.gru_hidden)));
       ctx->enc_packed[e] = pk;
       ctx->enc_rows[e] = pk ? nrows : batch->B * T;

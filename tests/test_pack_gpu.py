@@ -18,7 +18,7 @@ def _dev():
     return torch.device('cuda:0')
 
 
-@pytest.mark.parametrize('name', ['default', 'tmall64', 'noxatt'])
+@pytest.mark.parametrize('name', ['default', 'tmall64', 'noxatt', 'stress'])      # stress: histories of 200 -> the general attention kernels on packed rows
 def test_packed_histories_equal_padded_histories(name):
     from intel_sigir2023_amd import loss as LS
     fx = Fixture(name)
