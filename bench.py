@@ -372,7 +372,8 @@ def main():
     if prof_shapes is not None:
         pmc, pmc_eval, src = None, None, None
         try:        # HBM traffic per launch from the committed rocprofv3 PMC passes (tools/pmc_summary.py)
-            src = 'profiles/r02_pmc_traffic_bf16.json' if a.dtype == 'bf16' else 'profiles/r02_pmc_traffic.json'
+            import glob         # the latest round's summary
+            src = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic%s.json' % ('_bf16' if a.dtype == 'bf16' else ''))))[-1]
             j = json.load(open(os.path.join(ROOT, src)))
             pmc, pmc_eval = j.get('kernels'), j.get('kernels_eval', j.get('kernels'))
             src += ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950), bytes per launch'

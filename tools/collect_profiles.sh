@@ -3,7 +3,7 @@
 # branches), the PMC passes (each counter in its own run, kernel-trace only; training steps and evaluation steps
 # separately) and the other workloads.  Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py and a copy into
 # profiles/ follow in the build container.
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -45,6 +45,9 @@ INTEL_GRU_SEQ=0 timeout 600 python bench.py --workload tmall_pub --no_cpu_baseli
 timeout 600 python bench.py --zipf 1 --no_cpu_baseline > $out/bench_zipf.json 2>/dev/null < /dev/null
 INTEL_FUSE_TOWER=0 timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_unfused.json 2>/dev/null < /dev/null
 INTEL_BWD_SCHEDULE=phased timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_phased.json 2>/dev/null < /dev/null
+INTEL_ENC_FUSED=0 timeout 600 python bench.py --no_cpu_baseline > $out/bench_enc_unfused.json 2>/dev/null < /dev/null
+INTEL_ENC_FUSED_BWD=0 timeout 600 python bench.py --no_cpu_baseline --no_bf16_line > $out/bench_enc_unfused_bwd.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload lifedata --batch 4096 --no_cpu_baseline > $out/bench_lifedata_b4096.json 2>/dev/null < /dev/null
 for b in 8192 16384 32768; do timeout 600 python bench.py --batch $b --steps 10 --no_cpu_baseline --no_roofline --no_feed --nbatches 4 > $out/bench_b$b.json 2>/dev/null < /dev/null; done
 fi
 # keep the merge small: only the summaries travel back

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the summaries `tools/collect_profiles.sh <tag>` left under gpurun_out/<tag>/ into profiles/ under their round names
 (bench lines pretty-printed, kernel-stats CSVs, PMC traffic summaries, event timelines, the batch sweep as one array).
-usage: python tools/publish_profiles.py <tag> [round=r02]"""
+usage: python tools/publish_profiles.py <tag> [round=r03]"""
 import glob
 import json
 import os
@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r02'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
 src = os.path.join('gpurun_out', tag)
 dst = 'profiles'
 
@@ -28,7 +28,8 @@ def bench(name, out):
 names = {'bench.json': 'bench_tmall', 'bench_bf16.json': 'bench_tmall_bf16', 'bench_lifedata.json': 'bench_lifedata', 'bench_stress.json': 'bench_stress',
          'bench_stress_b1024.json': 'bench_stress_b1024', 'bench_pl_div.json': 'bench_pl_div', 'bench_gru4rec.json': 'bench_gru4rec',
          'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_gru4rec_steps.json': 'bench_gru4rec_per_step', 'bench_tmall_pub_steps.json': 'bench_tmall_pub_per_step', 'bench_stress_dense.json': 'bench_stress_dense_adam', 'bench_stress_b1024_dense.json': 'bench_stress_b1024_dense_adam',
-         'bench_tmall_b1024_dense.json': 'bench_tmall_b1024_dense_adam', 'bench_tmall_b1024.json': 'bench_tmall_b1024', 'bench_tmall_lazy.json': 'bench_tmall_lazy_adam', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased'}
+         'bench_tmall_b1024_dense.json': 'bench_tmall_b1024_dense_adam', 'bench_tmall_b1024.json': 'bench_tmall_b1024', 'bench_tmall_lazy.json': 'bench_tmall_lazy_adam', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased',
+         'bench_enc_unfused.json': 'bench_enc_unfused', 'bench_enc_unfused_bwd.json': 'bench_enc_unfused_bwd', 'bench_lifedata_b4096.json': 'bench_lifedata_b4096'}
 for k, v in names.items():
     bench(k, '%s_%s.json' % (rnd, v))
 sweep = []
