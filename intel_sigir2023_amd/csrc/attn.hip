@@ -17,6 +17,7 @@
 //   log-sum-exp): attn_bwd_dq (wave owns 16 queries, sweeps keys) and attn_bwd_dkv (wave owns 16
 //   keys, sweeps queries); neither needs a cross-wave reduction or atomics.
 #include "kernels.h"
+#include "planes.h"
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -111,6 +112,46 @@ __device__ __forceinline__ void dimT_store(float* __restrict__ rowp, const f32x4
       if (col < dk) *reinterpret_cast<f32x4*>(rowp + col) = acc[dt] * mul;
     }
   }
+}
+
+// bf16 mode (gemm_planes() == 1, lists longer than 64, head dims 64 / 128): the same products as ONE v_mfma_f32_16x16x16_bf16 per four fp32 steps, both
+// operands rounded to bf16 as they leave LDS / the accumulators (lane (i, j) supplies k = 4j..4j+3: the element order of the four fp32 steps, so the
+// accumulator-as-operand layouts carry over).  tile = the 16 staged rows the k index runs over; b = their four probabilities / dS values of this lane.
+template <int DKT>
+__device__ __forceinline__ void dimT_mma_bf(f32x4 (&acc)[DKT], const float* __restrict__ tile, int LD, s16x4 b, int lane) {
+  const float* r0 = tile + 4 * (lane >> 4) * LD;
+  if constexpr (DKT % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < DKT / 4; ++c) {
+      f32x4 x[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) x[s] = *reinterpret_cast<const f32x4*>(r0 + s * LD + 64 * c + 4 * (lane & 15));
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[4 * c + t] = planes::mma4_bf16(planes::to_bf16x4(f32x4{x[0][t], x[1][t], x[2][t], x[3][t]}), b, acc[4 * c + t]);
+    }
+  } else {
+#pragma unroll
+    for (int dt = 0; dt < DKT; ++dt) {
+      const float* cp = r0 + dt * 16 + (lane & 15);
+      acc[dt] = planes::mma4_bf16(planes::to_bf16x4(f32x4{cp[0], cp[LD], cp[2 * LD], cp[3 * LD]}), b, acc[dt]);
+    }
+  }
+}
+// S-type tile product: 16 staged rows (A operand, read along the head dim) against the lane's own row fragments
+template <int DKT, bool BF>
+__device__ __forceinline__ f32x4 rowT_mma(const float* __restrict__ tile, int LD, const f32x4 (&bf32)[DKT], const s16x4 (&bbf)[DKT], f32x4 acc, int lane) {
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(tile + (lane & 15) * LD + g * 16 + 4 * (lane >> 4));
+    if constexpr (BF) {
+      acc = planes::mma4_bf16(planes::to_bf16x4(a), bbf[g], acc);
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = mfma16(a[s], bf32[g][s], acc);
+    }
+  }
+  return acc;
 }
 
 // Workgroup -> ((session, head) pair, 64-row block) for the 1-D grids of the flash-style kernels.  The blocks of one pair re-read the same
@@ -228,6 +269,93 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_kernel(const f
   }
 }
 
+// bf16 mode forward.  The mode's arithmetic is O = bf(e) bf(V) / sum(e) with e = exp(s - rowmax) (the tests' emulation restates it): the
+// rounding of e depends on the row's FINAL maximum, which an online softmax does not know when it rounds.  Hence two sweeps over the keys: the first
+// computes S = bf(Q) bf(K)^T alone for the row maximum (a sixteenth of the fp32 MFMA cycles), the second e, its fp32 row sum and the O product.
+template <int DKT>
+__global__ __launch_bounds__(256, DKT >= 6 ? 3 : 4) void attn_fwd_bf_kernel(const float* __restrict__ qkv, int T, int d, int heads,
+                                                       const int* __restrict__ key_len, float scale,
+                                                       float* __restrict__ out, float* __restrict__ lse, const int* __restrict__ row_off) {
+  constexpr int LD = AttnSmem<DKT>::LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ks = smem;
+  float* Vs = smem + AT_KB * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ny = (T + AT_QB - 1) / AT_QB;
+  const AttnBlock blk = attn_block((int)gridDim.x / ny, ny);
+  const int b = blk.bh / heads, h = blk.bh - b * heads;
+  const int dk = d / heads, ldg = 3 * d;
+  const int nkeys = key_len ? min(key_len[b], T) : T;
+  const int nrow = row_off ? nkeys : T;
+  const size_t row0 = row_off ? (size_t)row_off[b] : (size_t)b * T;
+  if (blk.y * AT_QB >= nrow) return;
+  const float* base = qkv + row0 * ldg;
+  const int q = blk.y * AT_QB + wave * 16 + (lane & 15);
+  const bool wave_live = blk.y * AT_QB + wave * 16 < nrow;
+  f32x4 qf[DKT];
+  s16x4 qb[DKT];
+  load_row_frags<DKT>(qf, base + (size_t)q * ldg + h * dk, q < nrow, dk, lane);
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) qb[g] = planes::to_bf16x4(qf[g]);
+  StageRegs<DKT> kreg, vreg;
+  // sweep 1: row maximum
+  float mx = -INFINITY;
+  kreg.load(base, ldg, d + h * dk, dk, 0, nrow, tid);
+  for (int kb = 0; kb < nkeys; kb += AT_KB) {
+    __syncthreads();
+    kreg.store(Ks, tid);
+    __syncthreads();
+    if (kb + AT_KB < nkeys) kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, nrow, tid);
+    if (!wave_live) continue;
+#pragma unroll
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
+      if (kb + kt * 16 >= nkeys) continue;
+      const f32x4 st = rowT_mma<DKT, true>(Ks + kt * 16 * LD, LD, qf, qb, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (kb + kt * 16 + 4 * (lane >> 4) + r < nkeys) mx = fmaxf(mx, st[r] * scale);
+    }
+  }
+  const float m = group_max16(mx);
+  const float m_use = (m == -INFINITY) ? 0.f : m;
+  // sweep 2: e, its row sum, O
+  f32x4 oT[DKT];
+#pragma unroll
+  for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float ps = 0.f;
+  kreg.load(base, ldg, d + h * dk, dk, 0, nrow, tid);
+  vreg.load(base, ldg, 2 * d + h * dk, dk, 0, nrow, tid);
+  for (int kb = 0; kb < nkeys; kb += AT_KB) {
+    __syncthreads();
+    kreg.store(Ks, tid);
+    vreg.store(Vs, tid);
+    __syncthreads();
+    if (kb + AT_KB < nkeys) {
+      kreg.load(base, ldg, d + h * dk, dk, kb + AT_KB, nrow, tid);
+      vreg.load(base, ldg, 2 * d + h * dk, dk, kb + AT_KB, nrow, tid);
+    }
+    if (!wave_live) continue;
+#pragma unroll
+    for (int kt = 0; kt < AT_KB / 16; ++kt) {
+      if (kb + kt * 16 >= nkeys) continue;
+      f32x4 st = rowT_mma<DKT, true>(Ks + kt * 16 * LD, LD, qf, qb, f32x4{0.f, 0.f, 0.f, 0.f}, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = (kb + kt * 16 + 4 * (lane >> 4) + r < nkeys) ? expf(st[r] * scale - m_use) : 0.f;
+        st[r] = e;
+        ps += e;
+      }
+      dimT_mma_bf<DKT>(oT, Vs + kt * 16 * LD, LD, planes::to_bf16x4(st), lane);
+    }
+  }
+  const float l = group_sum16(ps);
+  if (q < nrow) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    dimT_store<DKT>(out + (row0 + q) * d + h * dk, oT, dk, lane, inv);
+    if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l > 0.f ? m_use + logf(l) : INFINITY;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // backward, dQ: wave owns 16 queries, sweeps key blocks.  Also writes dsum[q] = sum_d dO*O.
 // ------------------------------------------------------------------------------------------
@@ -321,8 +449,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const float* __restric
 // ------------------------------------------------------------------------------------------
 // backward, dK/dV: wave owns 16 keys, sweeps query blocks (Q and dO staged in LDS).
 // ------------------------------------------------------------------------------------------
-template <int DKT>
-__global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+template <int DKT, bool BF>
+__device__ __forceinline__ void attn_bwd_dkv_body(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ dsum,
                                                            int T, int d, int heads, const int* __restrict__ key_len,
                                                            float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS, const int* __restrict__ row_off) {
@@ -349,6 +477,12 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
   f32x4 kf[DKT], vf[DKT];
   load_row_frags<DKT>(kf, base + (size_t)key * ldg + d + h * dk, kok, dk, lane);
   load_row_frags<DKT>(vf, base + (size_t)key * ldg + 2 * d + h * dk, kok, dk, lane);
+  s16x4 kb16[DKT], vb16[DKT];      // bf16 mode: the wave's K / V rows rounded once
+#pragma unroll
+  for (int g = 0; g < DKT; ++g) {
+    kb16[g] = planes::to_bf16x4(kf[g]);
+    vb16[g] = planes::to_bf16x4(vf[g]);
+  }
   f32x4 dkT[DKT], dvT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) {
@@ -384,18 +518,8 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
 #pragma unroll
     for (int qt = 0; qt < AT_KB / 16; ++qt) {
       if (qb + qt * 16 >= nrow) continue;
-      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < DKT; ++g) {
-        const int off = (qt * 16 + (lane & 15)) * LD + g * 16 + 4 * (lane >> 4);
-        const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + off);
-        const f32x4 of = *reinterpret_cast<const f32x4*>(Os + off);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sa = mfma16(qf[s], kf[g][s], sa);     // S[query][key]
-          dp = mfma16(of[s], vf[g][s], dp);     // dP[query][key]
-        }
-      }
+      const f32x4 sa = rowT_mma<DKT, BF>(Qs + qt * 16 * LD, LD, kf, kb16, f32x4{0.f, 0.f, 0.f, 0.f}, lane);     // S[query][key]
+      const f32x4 dp = rowT_mma<DKT, BF>(Os + qt * 16 * LD, LD, vf, vb16, f32x4{0.f, 0.f, 0.f, 0.f}, lane);     // dP[query][key]
       f32x4 pr, ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -406,11 +530,16 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
         // the dS tile for the dQ = dS K kernel (row = query, ldS floats per row); keys >= nkeys / queries >= T are never read
         if (dS && qb + ql < nrow && kok) dS[((size_t)blk.bh * T + qb + ql) * ldS + key] = ds[r];
       }
+      if constexpr (BF) {
+        dimT_mma_bf<DKT>(dvT, Os + qt * 16 * LD, LD, planes::to_bf16x4(pr), lane);
+        dimT_mma_bf<DKT>(dkT, Qs + qt * 16 * LD, LD, planes::to_bf16x4(ds), lane);
+      } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int roff = (qt * 16 + 4 * (lane >> 4) + s) * LD;
-        dimT_mma<DKT>(dvT, Os + roff, pr[s], lane);   // dV^T[dim][key] += dO^T P
-        dimT_mma<DKT>(dkT, Qs + roff, ds[s], lane);   // dK^T[dim][key] += Q^T dS
+        for (int s = 0; s < 4; ++s) {
+          const int roff = (qt * 16 + 4 * (lane >> 4) + s) * LD;
+          dimT_mma<DKT>(dvT, Os + roff, pr[s], lane);   // dV^T[dim][key] += dO^T P
+          dimT_mma<DKT>(dkT, Qs + roff, ds[s], lane);   // dK^T[dim][key] += Q^T dS
+        }
       }
     }
   }
@@ -420,6 +549,14 @@ __global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_b
     dimT_store<DKT>(drow + 2 * d, dvT, dk, lane, 1.f);
   }
 }
+
+#define DKV_PARAMS const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ dsum, int T, int d, \
+                   int heads, const int* __restrict__ key_len, float scale, float* __restrict__ dqkv, float* __restrict__ dS, int ldS, const int* __restrict__ row_off
+#define DKV_ARGS qkv, dout, lse, dsum, T, d, heads, key_len, scale, dqkv, dS, ldS, row_off
+template <int DKT>
+__global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_bwd_dkv_kernel(DKV_PARAMS) { attn_bwd_dkv_body<DKT, false>(DKV_ARGS); }
+template <int DKT>
+__global__ __launch_bounds__(256, DKT >= 6 ? 2 : (DKT >= 3 ? 3 : 4)) void attn_bwd_dkv_bf_kernel(DKV_PARAMS) { attn_bwd_dkv_body<DKT, true>(DKV_ARGS); }
 
 // ------------------------------------------------------------------------------------------
 // backward without recomputation in the dQ pass: dsum = rowsum(dO * O) first (one wave per row), the dK/dV kernel above
@@ -456,8 +593,8 @@ __global__ __launch_bounds__(256) void attn_dsum_kernel(const float* __restrict_
   if (ok && sub == 0) dsum[(b * heads + h) * T + t] = s;
 }
 
-template <int DKT>
-__global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
+template <int DKT, bool BF>
+__device__ __forceinline__ void attn_bwd_dq_ds_body(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T,
                                                              int d, int heads, const int* __restrict__ key_len,
                                                              float* __restrict__ dqkv, const int* __restrict__ row_off) {
   constexpr int LD = AttnSmem<DKT>::LD;
@@ -497,9 +634,11 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __r
       if (qok && key0 < ldS) dsT = *reinterpret_cast<const f32x4*>(dSq + key0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsT[r] = key0 + r < nkeys ? dsT[r] : 0.f;      // masked / padding keys: nothing was stored
+      if constexpr (BF) {
+        dimT_mma_bf<DKT>(dqT, Ks + kt * 16 * LD, LD, planes::to_bf16x4(dsT), lane);
+      } else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        dimT_mma<DKT>(dqT, Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD, dsT[s], lane);
+        for (int s = 0; s < 4; ++s) dimT_mma<DKT>(dqT, Ks + (kt * 16 + 4 * (lane >> 4) + s) * LD, dsT[s], lane);
       }
     }
   }
@@ -507,6 +646,13 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(const float* __r
     dimT_store<DKT>(dqkv + (row0 + q) * ldg + h * dk, dqT, dk, lane, 1.f);
   }
 }
+
+#define DQDS_PARAMS const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T, int d, int heads, const int* __restrict__ key_len, \
+                    float* __restrict__ dqkv, const int* __restrict__ row_off
+template <int DKT>
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_kernel(DQDS_PARAMS) { attn_bwd_dq_ds_body<DKT, false>(qkv, dS, ldS, T, d, heads, key_len, dqkv, row_off); }
+template <int DKT>
+__global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_bf_kernel(DQDS_PARAMS) { attn_bwd_dq_ds_body<DKT, true>(qkv, dS, ldS, T, d, heads, key_len, dqkv, row_off); }
 
 static inline int attn_ds_pitch(int T) { return (T + 3) & ~3; }
 static inline bool attn_ds_scheme() {
@@ -535,6 +681,12 @@ static int check_attn_shape(int T, int d, int heads) {
   return 0;
 }
 
+// bf16 mode on the general path: lists / histories longer than 64 (the shorter ones are the whole-sequence and one-kernel paths' business and have
+// their own rules), head dims 64 and 128, the dS scheme.  The tests' bf16 emulation restates exactly this condition.
+static inline bool attn_bf16_products(int T, int dk) { return gemm_planes() == 1 && T > 64 && (dk == 64 || dk == 128) && attn_ds_scheme(); }
+#define ATTN_DISPATCH_BF(DKT_RT, CALL)            \
+  if ((DKT_RT) == 4) { constexpr int DKT = 4; CALL; } else { constexpr int DKT = 8; CALL; }
+
 #define ATTN_DISPATCH(DKT_RT, CALL)               \
   switch (DKT_RT) {                               \
     case 1: { constexpr int DKT = 1; CALL; } break; \
@@ -555,6 +707,15 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
   INTEL_CHECK_ARG(!row_off || key_len, "attention: packed rows need the session lengths");
   dim3 grid(B * heads * cdiv(T, AT_QB));
+  if (attn_bf16_products(T, dk)) {
+    ATTN_DISPATCH_BF(dkt, {
+      size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
+      allow_lds(attn_fwd_bf_kernel<DKT>, smem);
+      LAUNCH_S(B * heads, T, dk, 4.0 * B * T * (double)T * d, 16.0 * B * T * (double)d, attn_fwd_bf_kernel<DKT>, grid, dim3(256), smem, st, qkv, T, d, heads, key_len, scale, out, lse, row_off);
+    });
+    INTEL_CHECK_LAUNCH();
+    return 0;
+  }
   ATTN_DISPATCH(dkt, {
     size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
     allow_lds(attn_fwd_kernel<DKT>, smem);
@@ -583,6 +744,22 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
     const long long rows = (long long)B * T;
     LAUNCH_W(0.0, 8.0 * (double)rows * d, attn_dsum_kernel, dim3((unsigned)((rows * heads + 15) / 16)), dim3(256), 0, st, out, dout, T, d, heads, rows, dsum, key_len, row_off);
     INTEL_CHECK_LAUNCH();
+    if (attn_bf16_products(T, dk)) {
+      ATTN_DISPATCH_BF(dkt, {
+        size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
+        allow_lds(attn_bwd_dkv_bf_kernel<DKT>, smem);
+        LAUNCH_S(B * heads, T, dk, 8.0 * B * T * (double)T * d, 24.0 * B * T * (double)d, attn_bwd_dkv_bf_kernel<DKT>, grid, dim3(256), smem, st, qkv, dout, lse, dsum, T, d, heads, key_len,
+                           scale, dqkv, dS, ldS, row_off);
+      });
+      INTEL_CHECK_LAUNCH();
+      ATTN_DISPATCH_BF(dkt, {
+        size_t smem = (size_t)AT_KB * AttnSmem<DKT>::LD * sizeof(float);
+        allow_lds(attn_bwd_dq_ds_bf_kernel<DKT>, smem);
+        LAUNCH_S(B * heads, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d + 4.0 * B * heads * (double)T * T, attn_bwd_dq_ds_bf_kernel<DKT>, grid, dim3(256), smem, st, qkv, dS, ldS, T, d, heads, key_len, dqkv, row_off);
+      });
+      INTEL_CHECK_LAUNCH();
+      return 0;
+    }
     ATTN_DISPATCH(dkt, {
       size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);
       allow_lds(attn_bwd_dkv_kernel<DKT>, smem);

@@ -115,10 +115,12 @@ class _BfAttention(torch.autograd.Function):
     """softmax(q k^T / sqrt(dk)) v with every matrix-pipe operand rounded to bf16, forward AND backward, as csrc/attn_seq.hip /
     tower.hip run it in bf16 mode: forward S = bf(q) bf(k)^T, O = bf(e) bf(v) / sum(e) (e = the unnormalised probabilities, row sums
     fp32); backward P = e / sum(e) in fp32, dP = bf(dO) bf(v)^T, delta = rowsum(P dP) (fp32), dS = P (dP - delta) / sqrt(dk),
-    dV = bf(P)^T bf(dO), dQ = bf(dS) bf(k), dK = bf(dS)^T bf(q)."""
+    dV = bf(P)^T bf(dO), dQ = bf(dS) bf(k), dK = bf(dS)^T bf(q).
+    delta_from_output: the flash-style general kernels (csrc/attn.hip: lists / histories longer than 64) take delta = rowsum(dO * O) from the
+    stored fp32 output instead (their key-stationary dK/dV sweep cannot sum over all keys); everything else is the same."""
 
     @staticmethod
-    def forward(ctx, q, k, v, key_mask, scale):
+    def forward(ctx, q, k, v, key_mask, scale, delta_from_output=False):
         qb, kb, vb = _bf(q), _bf(k), _bf(v)
         s = torch.matmul(qb, kb.transpose(-1, -2)) * scale
         if key_mask is not None:
@@ -128,21 +130,23 @@ class _BfAttention(torch.autograd.Function):
         e = torch.where(torch.isnan(e), torch.zeros_like(e), e)
         den = e.sum(-1, keepdim=True)
         den = torch.where(den > 0, den, torch.ones_like(den))
-        ctx.save_for_backward(qb, kb, vb, e / den)
+        o = torch.matmul(_bf(e), vb) / den
+        ctx.save_for_backward(qb, kb, vb, e / den, o)
         ctx.scale = scale
-        return torch.matmul(_bf(e), vb) / den
+        ctx.delta_from_output = delta_from_output
+        return o
 
     @staticmethod
     def backward(ctx, do):
-        qb, kb, vb, p = ctx.saved_tensors
+        qb, kb, vb, p, o = ctx.saved_tensors
         dob = _bf(do)
         dp = torch.matmul(dob, vb.transpose(-1, -2))
-        delta = (p * dp).sum(-1, keepdim=True)
+        delta = (do * o).sum(-1, keepdim=True) if ctx.delta_from_output else (p * dp).sum(-1, keepdim=True)
         ds = _bf(p * (dp - delta) * ctx.scale)
         dv = torch.matmul(_bf(p).transpose(-1, -2), dob)
         dq = torch.matmul(ds, kb)
         dk = torch.matmul(ds.transpose(-1, -2), qb)
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 def _lin(x, sd, name, bias=True):
@@ -170,7 +174,7 @@ def mha(x, sd, prefix, heads, key_mask=None, bf16_products=True):
     k = split(_lin(x, sd, prefix + '.k_linear'))
     v = split(_lin(x, sd, prefix + '.v_linear'))
     if _EMU['on'] and bf16_products:
-        o = _BfAttention.apply(q, k, v, key_mask, 1.0 / dk ** 0.5)
+        o = _BfAttention.apply(q, k, v, key_mask, 1.0 / dk ** 0.5, T > 64)
         return o.transpose(1, 2).reshape(B, T, D)
     s = torch.matmul(q, k.transpose(-1, -2)) / dk ** 0.5
     if key_mask is not None:
@@ -190,7 +194,8 @@ def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0, taps=No
         res = h
         # (bf16 emulation, evaluation: the one-kernel tower layer takes lists of up to 64 rows, widths 64 / 128, head dims 32 / 64 / 128)
         D_, dk_ = h.shape[-1], h.shape[-1] // heads
-        h = mha(h, sd, attn, heads, bf16_products=h.shape[1] <= 64 and D_ in (64, 128) and dk_ in (32, 64, 128))
+        # ... and the general attention kernels run longer lists on the bf16 pipe at head dims 64 / 128 (csrc/attn.hip: attn_bf16_products)
+        h = mha(h, sd, attn, heads, bf16_products=(h.shape[1] <= 64 and D_ in (64, 128) and dk_ in (32, 64, 128)) or (h.shape[1] > 64 and dk_ in (64, 128)))
         h = _lin(h, sd, w1)
         if taps is not None:
             taps.setdefault(w1, []).append(h.detach())
@@ -212,7 +217,7 @@ def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2, taps=None):
         p = '%s.transformer_block.%d' % (prefix, l)
         # (bf16 emulation: the LAST block is run pruned by the HIP build -- one query row per session in an fp32 kernel)
         # and the whole-sequence attention kernels take histories of up to 64 rows with head dims 64 / 128)
-        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid, bf16_products=l + 1 < layers and T <= 64 and D // heads in (64, 128))
+        ctx = mha(x, sd, p + '.masked_attn_head', heads, key_mask=valid, bf16_products=l + 1 < layers and D // heads in (64, 128))      # any length: whole-sequence kernels up to 64 rows, the general ones beyond
         ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
         pre = _lin(ctx, sd, p + '.linear1')
         if taps is not None:

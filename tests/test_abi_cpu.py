@@ -87,7 +87,7 @@ def test_product_never_imports_the_oracle():
 def test_dispatcher_ops_are_registered():
     """`torch.ops.intel_mi355x.*` exist with schemas after importing the package's ops module (no GPU needed to register)."""
     from intel_sigir2023_amd import ops
-    assert ops.REGISTERED_OPS == ['linear', 'linear_dgrad', 'linear_wgrad', 'attention', 'attention_bwd', 'add_layernorm', 'ndcg'], \
+    assert ops.REGISTERED_OPS == ['linear', 'linear_dgrad', 'linear_wgrad', 'attention', 'attention_bwd', 'add_layernorm', 'ndcg', 'intel_forward', 'intel_backward'], \
         getattr(ops, '_REGISTER_ERROR', None)
     for name in ops.REGISTERED_OPS:
         assert getattr(torch.ops.intel_mi355x, name).default._schema.name == 'intel_mi355x::' + name
