@@ -792,12 +792,13 @@ __global__ __launch_bounds__(256) void pos_grad_kernel(const float* __restrict__
 #define PGP_SESS 8            // sessions whose rows are in flight together
 __global__ __launch_bounds__(256) void pos_grad_packed_kernel(const float* __restrict__ dE, int dm, const int* __restrict__ off,
                                                               const int* __restrict__ len, int B, int T, float* __restrict__ slabs) {
-  const int c = threadIdx.x % dm, tsub = threadIdx.x / dm, tpp = 256 / dm;
+  // a thread keeps FOUR columns (16-byte loads): dm / 4 lanes per position, 1024 / dm positions in flight per workgroup
+  const int dm4 = dm >> 2, c = (threadIdx.x % dm4) * 4, tsub = threadIdx.x / dm4, tpp = 256 / dm4;
   const int per = (B + gridDim.x - 1) / gridDim.x;
   const int b_begin = blockIdx.x * per, b_end = min(B, b_begin + per);
   float* slab = slabs + (size_t)blockIdx.x * T * dm;
   for (int t = tsub; t < T; t += tpp) {
-    float acc = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int b0 = b_begin; b0 < b_end; b0 += PGP_SESS) {
       int o[PGP_SESS], l[PGP_SESS];
 #pragma unroll
@@ -806,13 +807,14 @@ __global__ __launch_bounds__(256) void pos_grad_packed_kernel(const float* __res
         o[u] = off[b];
         l[u] = (b0 + u < b_end) ? min(len[b], T) : 0;
       }
-      float v[PGP_SESS];
+      f32x4 v[PGP_SESS];
 #pragma unroll
-      for (int u = 0; u < PGP_SESS; ++u) v[u] = (t < l[u]) ? dE[(size_t)(o[u] + t) * dm + c] : 0.f;
+      for (int u = 0; u < PGP_SESS; ++u)
+        v[u] = (t < l[u]) ? *reinterpret_cast<const f32x4*>(dE + (size_t)(o[u] + t) * dm + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < PGP_SESS; ++u) acc += v[u];
     }
-    slab[(size_t)t * dm + c] = acc;
+    *reinterpret_cast<f32x4*>(slab + (size_t)t * dm + c) = acc;
   }
 }
 
@@ -826,8 +828,9 @@ int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, i
                     ReduceQueue* q, const int* off, int B) {
   if (rows <= 0) return 0;
   static const bool packed_on = [] { const char* e = getenv("INTEL_POS_GRAD_PACKED"); return !(e && e[0] == '0'); }();
-  if (packed_on && off && row_t && B > 0 && dm <= 256 && 256 % dm == 0 && q) {
-    const int S = (B + 7) / 8 < 1 ? 1 : ((B + 7) / 8 > 512 ? 512 : (B + 7) / 8);
+  if (packed_on && off && row_t && B > 0 && dm >= 4 && dm <= 1024 && 1024 % dm == 0 && q) {
+    // four sessions per workgroup up to 512 workgroups (long histories at small batches: the loop over positions is the kernel's latency)
+    const int S = (B + 3) / 4 < 1 ? 1 : ((B + 3) / 4 > 512 ? 512 : (B + 3) / 4);
     float* slabs = redq_alloc(q, (size_t)S * T * dm);
     if (!slabs) {
       intel_set_error("pos_grad: reduction arena exhausted");
@@ -995,10 +998,18 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const float* __rest
     P[(size_t)bh * T + j] = w;
   }
   __builtin_amdgcn_wave_barrier();
-  for (int c = lane; c < dk; c += 64) {
-    float acc = 0.f;
-    for (int j = 0; j < n; ++j) acc += att[j] * vb[(size_t)j * 2 * dm + c];
-    out[(size_t)b * dm + h * dk + c] = acc;
+  // out = sum_j w_j V_j: four rows per step (one per 16-lane group, 16-byte loads), the four partial sums joined at the end -- a lane per
+  // column walking all rows one by one is a chain of n dependent loads (130 us per launch at histories of 200)
+  for (int c = sub * 4; c < dk; c += 64) {
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = grp; j < n; j += 4) acc += att[j] * *reinterpret_cast<const f32x4*>(vb + (size_t)j * 2 * dm + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k] += __shfl_xor(acc[k], 16);
+      acc[k] += __shfl_xor(acc[k], 32);
+    }
+    if (grp == 0) *reinterpret_cast<f32x4*>(out + (size_t)b * dm + h * dk + c) = acc;
   }
 }
 int launch_attn_lastq_fwd(const float* kv, const float* q, const int* len, int B, int T, int dm, int heads, float* out,
@@ -1058,17 +1069,24 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const float* __rest
   for (int j = lane; j < T; j += 64) ds[j] = j < n ? p[j] * (ds[j] - dsum) * scale : 0.f;
   __builtin_amdgcn_wave_barrier();
   float* dkb = dkv + rbase * 2 * dm + h * dk;
-  for (int c = lane; c < dk; c += 64) {
-    const float qc = qh[c], gc = doh[c];
-    float acc = 0.f;
-    for (int j = 0; j < twr; ++j) {
+  // dK_j = dS_j q, dV_j = p_j dO, dq = sum_j dS_j K_j: four rows per step (one per 16-lane group), 16-byte accesses (see the forward)
+  for (int c = sub * 4; c < dk; c += 64) {
+    const f32x4 qc = *reinterpret_cast<const f32x4*>(qh + c), gc = *reinterpret_cast<const f32x4*>(doh + c);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int j = grp; j < twr; j += 4) {
       const float dsj = ds[j];
       const float pj = j < n ? p[j] : 0.f;
-      if (j < n) acc += dsj * kb[(size_t)j * 2 * dm + c];
-      dkb[(size_t)j * 2 * dm + c] = dsj * qc;
-      dkb[(size_t)j * 2 * dm + dm + c] = pj * gc;
+      if (j < n) acc += dsj * *reinterpret_cast<const f32x4*>(kb + (size_t)j * 2 * dm + c);
+      *reinterpret_cast<f32x4*>(dkb + (size_t)j * 2 * dm + c) = dsj * qc;
+      *reinterpret_cast<f32x4*>(dkb + (size_t)j * 2 * dm + dm + c) = pj * gc;
     }
-    dq[(size_t)b * dm + h * dk + c] = acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      acc[k] += __shfl_xor(acc[k], 16);
+      acc[k] += __shfl_xor(acc[k], 32);
+    }
+    if (grp == 0) *reinterpret_cast<f32x4*>(dq + (size_t)b * dm + h * dk + c) = acc;
   }
 }
 int launch_attn_lastq_bwd(const float* kv, const float* q, const float* P, const float* d_out, const int* len, int B, int T,
