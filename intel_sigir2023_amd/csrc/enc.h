@@ -44,7 +44,7 @@ struct EncLastFwd {
 };
 int launch_enc_last_fwd(const EncLastFwd& f, hipStream_t st);
 
-// ---- backward (enc_bwd.hip; fp32 mode) -------------------------------------------------------------------------------------
+// ---- backward (enc_bwd.hip; the arithmetic mode follows gemm_planes() like the forward) ----------------------------------------
 // the pruned last block: d(output vector) -> B-row gradients for the weight-gradient products, d(x_last), d[K' | V']
 struct EncLastBwd {
   const float* dvec = nullptr; int ldv = 0;      // [B, ldv]

@@ -12,7 +12,8 @@
 //                          transposed: 7 tile products).  Leaves dZ2, dF1, dZ1 and dQKV = [dQ | dK | dV] for the weight-gradient
 //                          products and the final dX = dQKV Wqkv + dZ1.
 // LayerNorm parameter gradients: per-workgroup partial sums -> slabs -> the batched slab reduction (ReduceQueue).
-// fp32 (three-plane) mode only: the bf16 mode's backward keeps the kernel-per-op path.
+// Template parameter NP = 3: fp32 accuracy (six plane products, exact fp32 attention); NP = 1: the bf16 mode (hi planes, single bf16 MFMAs in the
+// attention backward, rounding points as the kernel-per-op path of that mode).
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -28,35 +29,45 @@ using namespace planes;
 // `tail_loads` runs right behind the product's last fragment loads (vmcnt retires in order: global loads for a LATER phase issued
 // there delay nothing of this product)
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int D, int CT, int RT, int ROWS, typename Hook = NoHook>
+// NP = 3: six plane products (fp32 accuracy); NP = 1 (bf16 mode): the hi planes alone -- the images keep their three-plane layout
+template <int D, int CT, int RT, int ROWS, int NP, typename Hook = NoHook>
 __device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img, int ct0, f32x4 (&acc)[CT][RT], Hook tail_loads = Hook()) {
   constexpr int KB = D / 32, KBT = 4, LDP = D + 8, PLANE = ROWS * LDP;
-  uint4 bw[2][CT][3];
+  uint4 bw[2][CT][NP];
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bw[0][c][pl] = img[((size_t)((ct0 + c) * KBT) * 3 + pl) * 64];
+    for (int pl = 0; pl < NP; ++pl) bw[0][c][pl] = img[((size_t)((ct0 + c) * KBT) * 3 + pl) * 64];
 #pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + 1 < KB) {
 #pragma unroll
       for (int c = 0; c < CT; ++c)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) bw[(kb + 1) & 1][c][pl] = img[((size_t)((ct0 + c) * KBT + kb + 1) * 3 + pl) * 64];
+        for (int pl = 0; pl < NP; ++pl) bw[(kb + 1) & 1][c][pl] = img[((size_t)((ct0 + c) * KBT + kb + 1) * 3 + pl) * 64];
     }
     if (kb == (KB >= 2 ? KB - 2 : 0)) tail_loads();
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
-      const bf16x8 am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
-      const bf16x8 al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+      bf16x8 am = ah, al = ah;
+      if constexpr (NP == 3) {
+        am = *reinterpret_cast<const bf16x8*>(fp + PLANE);
+        al = *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE);
+      }
 #pragma unroll
       for (int c = 0; c < CT; ++c)
-        acc[c][rt] = mma<3>(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][1]),
-                            __builtin_bit_cast(bf16x8, bw[kb & 1][c][2]), ah, am, al, acc[c][rt]);
+        acc[c][rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw[kb & 1][c][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][c][NP == 3 ? 1 : 0]),
+                             __builtin_bit_cast(bf16x8, bw[kb & 1][c][NP == 3 ? 2 : 0]), ah, am, al, acc[c][rt]);
     }
   }
+}
+// the attention backward's tile products: exact fp32 MFMAs, or (bf16 mode) one bf16 MFMA on the rounded operands
+template <bool BF>
+__device__ __forceinline__ f32x4 amma(const f32x4& x, const f32x4& y, f32x4 c) {
+  if constexpr (BF) return mma4_bf16(to_bf16x4(x), to_bf16x4(y), c);
+  else return mma4(x, y, c);
 }
 
 // ======================================================================================================================
@@ -105,7 +116,7 @@ __device__ __forceinline__ float row16_max(float v) {
   return v;
 }
 
-template <int D, int DK, int KT>
+template <int D, int DK, int KT, bool BF>
 __device__ __forceinline__ void attn_bwd_q(const EncBlockBwdArgs& a, const float* Qs, const float* Es, int base, int len, int h, int r0, int lane) {
   constexpr int LQ = D + 4;
   static_assert(DK == 64, "head dim 64");
@@ -134,8 +145,8 @@ __device__ __forceinline__ void attn_bwd_q(const EncBlockBwdArgs& a, const float
         const int krow = rowp(kb);
         const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow * LQ + hc + 4 * j + 16 * g);
         const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + krow * LQ + hc + 4 * j + 16 * g);
-        st[kb] = mma4(kf, qf, st[kb]);
-        dpt[kb] = mma4(vf, of, dpt[kb]);
+        st[kb] = amma<BF>(kf, qf, st[kb]);
+        dpt[kb] = amma<BF>(vf, of, dpt[kb]);
       }
       if (KT > 1) __builtin_amdgcn_sched_barrier(0);      // keep the fragment loads of the later k groups behind these products (registers)
     }
@@ -185,7 +196,7 @@ __device__ __forceinline__ void attn_bwd_q(const EncBlockBwdArgs& a, const float
 #pragma unroll
       for (int s = 0; s < 4; ++s) kv[s] = *reinterpret_cast<const f32x4*>(Ks + row4(kb, s) * LQ + hc + 4 * p);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dq[t] = mma4(st[kb], f32x4{kv[0][t], kv[1][t], kv[2][t], kv[3][t]}, dq[t]);
+      for (int t = 0; t < 4; ++t) dq[t] = amma<BF>(st[kb], f32x4{kv[0][t], kv[1][t], kv[2][t], kv[3][t]}, dq[t]);
     }
     // register r of product t at lane (p, j) = query 16 qa + 4j + r, dim 4p + t
 #pragma unroll
@@ -196,7 +207,7 @@ __device__ __forceinline__ void attn_bwd_q(const EncBlockBwdArgs& a, const float
   }
 }
 
-template <int D, int DK, int KT>
+template <int D, int DK, int KT, bool BF>
 __device__ __forceinline__ void attn_bwd_kv(const EncBlockBwdArgs& a, const float* Qs, const float* Es, int base, int len, int h, int r0, int lane) {
   constexpr int LQ = D + 4;
   const int j = lane >> 4, p = lane & 15;
@@ -228,8 +239,8 @@ __device__ __forceinline__ void attn_bwd_kv(const EncBlockBwdArgs& a, const floa
         const int krow = rowp(kb);
         const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + krow * LQ + hc + 4 * j + 16 * g);
         const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + krow * LQ + hc + 4 * j + 16 * g);
-        s2[kb] = mma4(qf, kf, s2[kb]);
-        dp2[kb] = mma4(of, vf, dp2[kb]);
+        s2[kb] = amma<BF>(qf, kf, s2[kb]);
+        dp2[kb] = amma<BF>(of, vf, dp2[kb]);
       }
       if (KT > 1) __builtin_amdgcn_sched_barrier(0);
     }
@@ -275,8 +286,8 @@ __device__ __forceinline__ void attn_bwd_kv(const EncBlockBwdArgs& a, const floa
     for (int kb = 0; kb < KT; ++kb)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        dk[kb][t] = mma4(dp2[kb], f32x4{qv[0][t], qv[1][t], qv[2][t], qv[3][t]}, dk[kb][t]);
-        dv[kb][t] = mma4(s2[kb], f32x4{ov[0][t], ov[1][t], ov[2][t], ov[3][t]}, dv[kb][t]);
+        dk[kb][t] = amma<BF>(dp2[kb], f32x4{qv[0][t], qv[1][t], qv[2][t], qv[3][t]}, dk[kb][t]);
+        dv[kb][t] = amma<BF>(s2[kb], f32x4{ov[0][t], ov[1][t], ov[2][t], ov[3][t]}, dv[kb][t]);
       }
   }
 #pragma unroll
@@ -292,7 +303,7 @@ __device__ __forceinline__ void attn_bwd_kv(const EncBlockBwdArgs& a, const floa
     }
 }
 
-template <int D, int DK>
+template <int D, int DK, int NP>
 __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(EncBlockBwdArgs a) {
   using C = EncBwdCfg<D>;
   constexpr int NW = C::NW, NT = C::NT, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK;
@@ -372,7 +383,7 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
           *reinterpret_cast<f32x4*>(a.DZ2 + grow * D + col) = dz;
         }
         *reinterpret_cast<f32x4*>(Es + row * LQ + col) = dz;
-        store4<3, PLANE>(zplanes + row * LDP + col, dz);
+        store4<NP, PLANE>(zplanes + row * LDP + col, dz);
       }
     }
     mark(1);
@@ -399,14 +410,14 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
           warm[u] = *src;
         }
       };
-      gemm_planes<D, 1, 4, 64>(zplanes + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc, touch);
+      gemm_planes<D, 1, 4, 64, NP>(zplanes + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc, touch);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const int row = rt * 16 + p;
         f32x4 x = acc[0][rt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = mk[rt][r] > 0.f ? x[r] : 0.f;
-        store4<3, PLANE>(fplanes + row * LDP + col, x);
+        store4<NP, PLANE>(fplanes + row * LDP + col, x);
         if (row < nrows) *reinterpret_cast<f32x4*>(a.DF1 + ((size_t)r0 + row) * D + col) = x;
       }
     }
@@ -418,7 +429,7 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
       f32x4 acc[1][4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[0][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gemm_planes<D, 1, 4, 64>(fplanes + p * LDP + 8 * j, launder(a.W1T) + lane, wave, acc);
+      gemm_planes<D, 1, 4, 64, NP>(fplanes + p * LDP + 8 * j, launder(a.W1T) + lane, wave, acc);
       const int col = wave * 16 + 4 * j;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
@@ -478,11 +489,11 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
       const int s = it / (HEADS * 2), hp = it - s * (HEADS * 2), h = hp >> 1;
       const int base = s_start[s], len = s_start[s + 1] - base;
       if (hp & 1) {
-        if (len > 16) attn_bwd_kv<D, DK, 2>(a, Qs, Es, base, len, h, r0, lane);
-        else attn_bwd_kv<D, DK, 1>(a, Qs, Es, base, len, h, r0, lane);
+        if (len > 16) attn_bwd_kv<D, DK, 2, NP == 1>(a, Qs, Es, base, len, h, r0, lane);
+        else attn_bwd_kv<D, DK, 1, NP == 1>(a, Qs, Es, base, len, h, r0, lane);
       } else {
-        if (len > 16) attn_bwd_q<D, DK, 2>(a, Qs, Es, base, len, h, r0, lane);
-        else attn_bwd_q<D, DK, 1>(a, Qs, Es, base, len, h, r0, lane);
+        if (len > 16) attn_bwd_q<D, DK, 2, NP == 1>(a, Qs, Es, base, len, h, r0, lane);
+        else attn_bwd_q<D, DK, 1, NP == 1>(a, Qs, Es, base, len, h, r0, lane);
       }
     }
     mark(9);
@@ -534,7 +545,7 @@ struct EncLastBwdCfg {
   static constexpr size_t SMEM = 3 * PL_BYTES + 2 * T_BYTES + RED_BYTES;      // dz2 / df1 / dq planes; dz2 rows, working rows; reduction
 };
 
-template <int D, int DK>
+template <int D, int DK, int NP>
 __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(EncLastBwdArgs a) {
   using C = EncLastBwdCfg<D>;
   constexpr int LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, HEADS = D / DK, NW = C::NW, SPB = ENC_LAST_SPB, SLOTS = 16 / C::NW;
@@ -586,11 +597,11 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
     f32x4 acc[1][1];
     acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 mk = *reinterpret_cast<const f32x4*>(a.F1 + growp * D + col);
-    gemm_planes<D, 1, 1, 16>(zpl + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc);
+    gemm_planes<D, 1, 1, 16, NP>(zpl + p * LDP + 8 * j, launder(a.W2T) + lane, wave, acc);
     f32x4 x = acc[0][0];
 #pragma unroll
     for (int r = 0; r < 4; ++r) x[r] = (rowok && mk[r] > 0.f) ? x[r] : 0.f;
-    store4<3, PLANE>(fpl + p * LDP + col, x);
+    store4<NP, PLANE>(fpl + p * LDP + col, x);
     if (rowok) *reinterpret_cast<f32x4*>(a.DF1 + growp * D + col) = x;
   }
   lds_barrier();
@@ -598,7 +609,7 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
   {
     f32x4 acc[1][1];
     acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_planes<D, 1, 1, 16>(fpl + p * LDP + 8 * j, launder(a.W1T) + lane, wave, acc);
+    gemm_planes<D, 1, 1, 16, NP>(fpl + p * LDP + 8 * j, launder(a.W1T) + lane, wave, acc);
     *reinterpret_cast<f32x4*>(Ws + p * LQ + col) = acc[0][0] + *reinterpret_cast<const f32x4*>(DZs + p * LQ + col);
   }
   lds_barrier();
@@ -670,7 +681,7 @@ __global__ __launch_bounds__((EncLastBwdCfg<D>::NT)) void enc_last_bwd_kernel(En
   {
     f32x4 acc[1][1];
     acc[0][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_planes<D, 1, 1, 16>(qpl + p * LDP + 8 * j, launder(a.WqT) + lane, wave, acc);
+    gemm_planes<D, 1, 1, 16, NP>(qpl + p * LDP + 8 * j, launder(a.WqT) + lane, wave, acc);
     if (rowok) *reinterpret_cast<f32x4*>(a.DXL + growp * D + col) = acc[0][0] + *reinterpret_cast<const f32x4*>(Ws + p * LQ + col);
   }
   // ---- LayerNorm parameter gradients of this workgroup
@@ -699,7 +710,7 @@ size_t enc_bwd_slab_floats(int rows, int B, int T, int dm) {
 
 int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
   if (f.B <= 0 || f.rows <= 0) return 0;
-  INTEL_CHECK_ARG(enc_fused_supported(f.T, f.dm, f.heads) && gemm_planes() == 3, "enc_block_bwd: unsupported shape T=%d dm=%d heads=%d planes=%d", f.T, f.dm, f.heads, gemm_planes());
+  INTEL_CHECK_ARG(enc_fused_supported(f.T, f.dm, f.heads), "enc_block_bwd: unsupported shape T=%d dm=%d heads=%d", f.T, f.dm, f.heads);
   INTEL_CHECK_ARG(q, "enc_block_bwd: needs the reduce queue");
   constexpr int D = 128;
   using C = EncBwdCfg<D>;
@@ -715,7 +726,9 @@ int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
   float* slab = redq_alloc(q, (size_t)grid * 4 * D);
   INTEL_CHECK_ARG(slab, "enc_block_bwd: reduction arena exhausted");
   a.slab = slab;
-  allow_lds((enc_block_bwd_kernel<D, 64>), C::SMEM);
+  const bool bf = gemm_planes() == 1;
+  if (bf) allow_lds((enc_block_bwd_kernel<D, 64, 1>), C::SMEM);
+  else allow_lds((enc_block_bwd_kernel<D, 64, 3>), C::SMEM);
   const double M = (double)f.rows;
   static const int dbg_on = [] { const char* e = getenv("INTEL_ENC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
   static unsigned long long* dbg_buf = nullptr;
@@ -725,7 +738,8 @@ int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
     (void)hipMemsetAsync(dbg_buf, 0, 16 * sizeof(unsigned long long), st);
     a.dbg = dbg_buf;
   }
-  LAUNCH_S(f.rows, D, 64, 2.0 * M * D * D * 2 + 10.0 * M * f.T * D * 0.5, 4.0 * M * D * 12, (enc_block_bwd_kernel<D, 64>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  if (bf) LAUNCH_S(f.rows, D, 64, 2.0 * M * D * D * 2 + 10.0 * M * f.T * D * 0.5, 4.0 * M * D * 12, (enc_block_bwd_kernel<D, 64, 1>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  else LAUNCH_S(f.rows, D, 64, 2.0 * M * D * D * 2 + 10.0 * M * f.T * D * 0.5, 4.0 * M * D * 12, (enc_block_bwd_kernel<D, 64, 3>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
   INTEL_CHECK_LAUNCH();
   if (dbg_on) {
     unsigned long long h[16];
@@ -744,7 +758,7 @@ int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
 
 int launch_enc_last_bwd(const EncLastBwd& f, hipStream_t st, ReduceQueue* q) {
   if (f.B <= 0) return 0;
-  INTEL_CHECK_ARG(enc_fused_supported(f.T, f.dm, f.heads) && gemm_planes() == 3, "enc_last_bwd: unsupported shape T=%d dm=%d heads=%d planes=%d", f.T, f.dm, f.heads, gemm_planes());
+  INTEL_CHECK_ARG(enc_fused_supported(f.T, f.dm, f.heads), "enc_last_bwd: unsupported shape T=%d dm=%d heads=%d", f.T, f.dm, f.heads);
   INTEL_CHECK_ARG(q, "enc_last_bwd: needs the reduce queue");
   constexpr int D = 128;
   using C = EncLastBwdCfg<D>;
@@ -758,8 +772,13 @@ int launch_enc_last_bwd(const EncLastBwd& f, hipStream_t st, ReduceQueue* q) {
   float* slab = redq_alloc(q, (size_t)grid * 4 * D);
   INTEL_CHECK_ARG(slab, "enc_last_bwd: reduction arena exhausted");
   a.slab = slab;
-  allow_lds((enc_last_bwd_kernel<D, 64>), C::SMEM);
-  LAUNCH_S(f.B, D, 64, 2.0 * f.B * (double)D * D * 3, 4.0 * f.B * (double)D * (8.0 + 2.0 * f.T), (enc_last_bwd_kernel<D, 64>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  if (gemm_planes() == 1) {
+    allow_lds((enc_last_bwd_kernel<D, 64, 1>), C::SMEM);
+    LAUNCH_S(f.B, D, 64, 2.0 * f.B * (double)D * D * 3, 4.0 * f.B * (double)D * (8.0 + 2.0 * f.T), (enc_last_bwd_kernel<D, 64, 1>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  } else {
+    allow_lds((enc_last_bwd_kernel<D, 64, 3>), C::SMEM);
+    LAUNCH_S(f.B, D, 64, 2.0 * f.B * (double)D * D * 3, 4.0 * f.B * (double)D * (8.0 + 2.0 * f.T), (enc_last_bwd_kernel<D, 64, 3>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  }
   INTEL_CHECK_LAUNCH();
   float* outs[4] = {f.dg2, f.db2, f.dg1, f.db1};
   const int accs[4] = {f.acc_g2, f.acc_b2, f.acc_g1, f.acc_b1};

@@ -937,7 +937,7 @@ float* bert_bwd(Run& r, int e) {
   const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
   float *dX = r.T->dXa, *dXalt = r.T->dXb;
   static const bool fused_bwd_on = [] { const char* e = getenv("INTEL_ENC_FUSED_BWD"); return !(e && e[0] == '0'); }();      // 0: kernel-per-op backward on the fused forward's stash
-  const bool fused_bwd = fused_bwd_on && r.ctx->enc_fused[e] && gemm_planes() == 3;
+  const bool fused_bwd = fused_bwd_on && r.ctx->enc_fused[e];
   if (fused_bwd) {
     // the data-gradient chain of every block as one kernel (enc_bwd.hip); the weight gradients (reductions over all rows) and
     // the two K > 128 data-gradient products stay on the GEMM kernels

@@ -20,7 +20,7 @@ def _dev():
     return torch.device('cuda:0')
 
 
-def _case(history_max, B, seed, train):
+def _case(history_max, B, seed, train, dtype='f32'):
     from intel_sigir2023_amd import loss as LS
     from intel_sigir2023_amd import synth
     from intel_sigir2023_amd.model import IntEL
@@ -33,7 +33,9 @@ def _case(history_max, B, seed, train):
     w['batch'] = dict(L=12, H=history_max)
     synth.WORKLOADS[name] = w
     torch.manual_seed(seed)
-    args = synth.make_args(name, dev, cal_diversity=0)
+    args = synth.make_args(name, dev, cal_diversity=0, dtype=dtype)
+    bf = dtype == 'bf16'
+    oracle_forward = O.forward_bf16 if bf else O.forward      # bf16 mode: the emulating oracle, forward and autograd (tests/test_bf16_gpu.py)
     corpus, c = synth.make_corpus(name)
     model = IntEL(args, corpus).to(dev)
     sd = {k: v.detach().cpu().clone().requires_grad_(train) for k, v in model.state_dict().items()}
@@ -55,7 +57,7 @@ def _case(history_max, B, seed, train):
     batch['his_item_idx'] = torch.where(hiv, torch.randint(0, 30, (B, H), generator=g, device=dev), torch.full((B, H), -1, device=dev)).int()
     batch['his_rows'], batch['hisitem_rows'] = int(batch['history_len'].sum()), int(batch['history_item_len'].sum())
     ref_batch = synth.to_reference_layout(batch, c['I'])
-    cfg = O.Config(**{k: v for k, v in vars(args).items() if k != 'device'})
+    cfg = O.Config(**{k: v for k, v in vars(args).items() if k not in ('device', 'dtype')})
     L = batch['i_id_s'].shape[1]
     noise = torch.rand(B, L, L, device=dev)
     batch['bpr_noise'] = noise
@@ -65,18 +67,25 @@ def _case(history_max, B, seed, train):
         assert 'his_off' in model.prepare_batch(batch)[1]          # the encoders do run packed
         loss, _, _ = LS.IntBPRloss(args)(out, batch)
         loss.backward()
-        ref = O.forward(sd, ref_batch, cfg)
+        ref = oracle_forward(sd, ref_batch, cfg)
         rl = O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
         rl[0].backward()
-        assert abs(float(loss) - float(rl[0])) < 1e-5
+        assert abs(float(loss) - float(rl[0])) < (2e-5 if bf else 1e-5)
     else:
         model.eval()
         with torch.no_grad():
             out = model(batch)
-            ref = O.forward(sd, ref_batch, cfg)
+            ref = oracle_forward(sd, ref_batch, cfg)
     for k in ('weights', 'ens_score', 'intents'):
-        err = float((out[k].detach().cpu() - ref[k].detach()).abs().max())
-        assert err <= 3e-5 * max(1.0, float(ref[k].abs().max())), (k, err)
+        e = (out[k].detach().cpu() - ref[k].detach()).abs().flatten().float()
+        scale = max(1.0, float(ref[k].abs().max()))
+        if bf:
+            # bf16 mode against its emulation: equal to summation order (<= 3e-5 like fp32) EXCEPT where a pre-rounding value sits on a bf16
+            # boundary and the two summation orders round it to different neighbours -- one such flip moves that session's outputs by
+            # ~2^-9 of an activation; with hundreds of sessions a few flips occur (the 2-4-session fixtures of tests/test_bf16_gpu.py see none)
+            assert float(torch.quantile(e, 0.95)) <= 3e-5 * scale and float(e.max()) <= 2e-3 * scale, (k, float(torch.quantile(e, 0.95)), float(e.max()))
+        else:
+            assert float(e.max()) <= 3e-5 * scale, (k, float(e.max()))
     if train:
         worst = 0.0
         for k, p in model.named_parameters():
@@ -84,9 +93,9 @@ def _case(history_max, B, seed, train):
             if gr is None:
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
                 continue
-            tol = 2e-4 * max(float(gr.abs().max()), 1e-6) + 1e-7
+            tol = (5e-3 if bf else 2e-4) * max(float(gr.abs().max()), 1e-6) + 1e-7      # bf16 mode: the bar of test_bf16_gradients_match_the_emulating_oracle
             err = float((p.grad.detach().cpu() - gr).abs().max())
-            if any(k.endswith(s) for s in ('linear1.weight', 'linear1.bias', '_W1.weight', '_W1.bias')):
+            if not bf and any(k.endswith(s) for s in ('linear1.weight', 'linear1.bias', '_W1.weight', '_W1.bias')):
                 tol *= 50                                            # one flipped relu moves one row (tools/fuzz_parity.py)
             worst = max(worst, err / tol)
             assert err <= tol, (k, err, tol)
@@ -102,6 +111,13 @@ def test_fused_encoder_inference_matches_oracle(history_max, B, seed):
 @pytest.mark.parametrize('history_max,B,seed', [(20, 257, 10), (32, 130, 11), (7, 200, 12), (20, 5, 13)])
 def test_fused_encoder_training_step_matches_oracle_autograd(history_max, B, seed):
     _case(history_max, B, seed, train=True)
+
+
+@pytest.mark.parametrize('history_max,B,seed,train', [(20, 130, 20, True), (32, 70, 21, True), (20, 257, 22, False)])
+def test_fused_encoder_bf16_mode_matches_the_emulating_oracle(history_max, B, seed, train):
+    """--dtype bf16: the NP = 1 variants of the forward AND backward kernels (hi planes only, single bf16 MFMAs in the attention) against
+    oracle.forward_bf16 and its autograd, which restate the mode's rounding points."""
+    _case(history_max, B, seed, train=train, dtype='bf16')
 
 
 def test_kernel_per_op_encoder_when_forced_off():
