@@ -2238,6 +2238,150 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// wgrad_tr_kernel: the bf16 mode's slab product for 128 x 128 output blocks.  With ONE bf16 plane the kernel above is bound by its
+// transposed staging (4 x 4 register transposes, 8-byte LDS stores), not by HBM.  gfx950 can transpose on the way OUT of LDS instead:
+// the 32-row tile is staged row-major as bf16 (one 16-byte store per 8 elements, chunks XOR-swizzled) and every lane gets its
+// k-contiguous operand -- 8 consecutive rows of one column -- from two ds_read_b64_tr_b16 (per 16-lane group a 4-row x 16-column block,
+// delivered column-major).  Two LDS buffers of 16 KB (one barrier per tile, three workgroups per CU by registers), the next tile
+// prefetched into registers as 8 packed dwords per thread.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wtr_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }      // byte offset of 16-byte chunk ch of row `row`
+typedef short wtr_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 wtr_frag(const unsigned char* img, int off_lo, int off_hi) {
+  const wtr_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wtr_s16x4*)(img + off_lo));
+  const wtr_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wtr_s16x4*)(img + off_hi));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  return __builtin_bit_cast(bf16x8, s16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+template <bool TAIL, bool Y16, bool X16>
+__global__ __launch_bounds__(256, 3) void wgrad_tr_kernel(WgradArgs a) {
+  constexpr int NB = 128, KB = 128, IMG = 32 * 256;               // bytes of one operand's image
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned char* lds = reinterpret_cast<unsigned char*>(smem);   // [2][dY image | X image]
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
+  const int ntiles = (a.M + WG_RT - 1) / WG_RT, S = gridDim.x;
+  // staging: thread = chunk (tid & 15) of rows (tid >> 4) and (tid >> 4) + 16, of both operands
+  const int ch = tid & 15, rowa = tid >> 4;
+  uint4 ry[2], rx[2];
+  float dbacc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) dbacc[e] = 0.f;
+  auto pack8 = [](const f32x4& lo, const f32x4& hi) -> uint4 {
+    typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(uint4, b8{(__bf16)lo[0], (__bf16)lo[1], (__bf16)lo[2], (__bf16)lo[3], (__bf16)hi[0], (__bf16)hi[1], (__bf16)hi[2], (__bf16)hi[3]});
+  };
+  auto load_tile = [&](int tt) {
+    const size_t m0 = (size_t)tt * WG_RT;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const size_t row = m0 + rowa + 16 * u;
+      const bool ok = !TAIL || row < (size_t)a.M;
+      const size_t rr = ok ? row : 0;
+      if (Y16) {
+        uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.dY) + rr * a.lddy + n0 + 8 * ch);
+        if (TAIL && !ok) v = uint4{0u, 0u, 0u, 0u};
+        ry[u] = v;
+        if (a.want_db) {
+          typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+          const b8 h = __builtin_bit_cast(b8, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dbacc[e] += (float)h[e];
+        }
+      } else {
+        f32x4 lo = *reinterpret_cast<const f32x4*>(a.dY + rr * a.lddy + n0 + 8 * ch);
+        f32x4 hi = *reinterpret_cast<const f32x4*>(a.dY + rr * a.lddy + n0 + 8 * ch + 4);
+        if (TAIL && !ok) lo = hi = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dbacc[e] += lo[e];
+          dbacc[4 + e] += hi[e];
+        }
+        ry[u] = pack8(lo, hi);
+      }
+      if (X16) {
+        uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.X) + rr * a.ldx + k0 + 8 * ch);
+        if (TAIL && !ok) v = uint4{0u, 0u, 0u, 0u};
+        rx[u] = v;
+      } else {
+        f32x4 lo = *reinterpret_cast<const f32x4*>(a.X + rr * a.ldx + k0 + 8 * ch);
+        f32x4 hi = *reinterpret_cast<const f32x4*>(a.X + rr * a.ldx + k0 + 8 * ch + 4);
+        if (TAIL && !ok) lo = hi = f32x4{0.f, 0.f, 0.f, 0.f};
+        rx[u] = pack8(lo, hi);
+      }
+    }
+  };
+  const int so0 = wtr_off(rowa, ch), so1 = wtr_off(rowa + 16, ch);
+  auto store_tile = [&](int buf) {
+    unsigned char* b = lds + buf * 2 * IMG;
+    *reinterpret_cast<uint4*>(b + so0) = ry[0];
+    *reinterpret_cast<uint4*>(b + so1) = ry[1];
+    *reinterpret_cast<uint4*>(b + IMG + so0) = rx[0];
+    *reinterpret_cast<uint4*>(b + IMG + so1) = rx[1];
+  };
+  // transposed-read addresses: lane 4q + pp of a 16-lane group names row q, columns 4pp .. 4pp+3 of the group's 4 x 16 block;
+  // group g takes rows 8g .. 8g+3 (lo) and 8g+4 .. 8g+7 (hi) of the 16 columns of tile `tl` (chunks 2 tl, 2 tl + 1)
+  const int q = p >> 2, pp = p & 3;
+  auto fo = [&](int tl, int half) { return wtr_off(8 * g + 4 * half + q, 2 * tl + (pp >> 1)) + 8 * (pp & 1); };
+  int ylo[4], yhi[4], xlo[4], xhi[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ylo[i] = fo(wn * 4 + i, 0); yhi[i] = fo(wn * 4 + i, 1);
+    xlo[i] = IMG + fo(wk * 4 + i, 0); xhi[i] = IMG + fo(wk * 4 + i, 1);
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int t = blockIdx.x, buf = 0;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += S) {
+    store_tile(buf);
+    __syncthreads();
+    if (t + S < ntiles) load_tile(t + S);
+    const unsigned char* b = lds + buf * 2 * IMG;
+    bf16x8 xf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xf[j] = wtr_frag(b, xlo[j], xhi[j]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bf16x8 yf = wtr_frag(b, ylo[i], yhi[i]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf[j], acc[i][j], 0, 0, 0);
+    }
+    buf ^= 1;
+  }
+  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + p;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * g + r;
+        slab[(size_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
+  if (a.want_db && blockIdx.z == 0) {
+    __syncthreads();
+    float* red = smem;                          // [16][NB]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rowa * NB + 8 * ch + e] = dbacc[e];
+    __syncthreads();
+    if (tid < NB) {
+      float sdb = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < 16; ++rb) sdb += red[rb * NB + tid];
+      slab[(size_t)a.N * a.K + n0 + tid] = sdb;
+    }
+  }
+}
+
 // out[i] (+)= sum_s slabs[s][i]; i < n.  16 slab lanes x 16 output groups per workgroup; each lane
 // sums its strided slabs with 4 independent accumulators, then a fixed-order LDS tree: reproducible.
 template <int VEC>
@@ -2613,6 +2757,31 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
     else if (a.dy_bf16) { if (tail) WB_LAUNCH16(A_, B_, true, true, false); else WB_LAUNCH16(A_, B_, false, true, false); }             \
     else { if (tail) WB_LAUNCH16(A_, B_, true, false, true); else WB_LAUNCH16(A_, B_, false, false, true); }                            \
   }
+      static const int use_tr = [] { const char* e = getenv("INTEL_WGRAD_TR"); return (e && e[0] == '0') ? 0 : 1; }();
+      if (use_tr && g_planes == 1 && ntw == 4 && ktw == 4) {      // bf16 mode, 128 x 128 blocks: row-major staging + transposing LDS reads
+        const size_t smem_tr = (size_t)2 * 2 * 32 * 256;
+#define WTR_LAUNCH(T_, Y_, X_)                                                                                        \
+  do {                                                                                                                \
+    allow_lds((wgrad_tr_kernel<T_, Y_, X_>), smem_tr);                                                                \
+    LAUNCH_S(M, N, K, 2.0 * M * N * K, (X_ ? 2.0 : 4.0) * (double)M * K + (Y_ ? 2.0 : 4.0) * (double)M * N + 4.0 * (double)K * N, \
+             (wgrad_tr_kernel<T_, Y_, X_>), grid, dim3(256), smem_tr, st, a);                                         \
+  } while (0)
+        const bool tail = M % WG_RT != 0;
+        const int sel = (tail ? 4 : 0) | (a.dy_bf16 ? 2 : 0) | (a.x_bf16 ? 1 : 0);
+        switch (sel) {
+          case 0: WTR_LAUNCH(false, false, false); break;
+          case 1: WTR_LAUNCH(false, false, true); break;
+          case 2: WTR_LAUNCH(false, true, false); break;
+          case 3: WTR_LAUNCH(false, true, true); break;
+          case 4: WTR_LAUNCH(true, false, false); break;
+          case 5: WTR_LAUNCH(true, false, true); break;
+          case 6: WTR_LAUNCH(true, true, false); break;
+          default: WTR_LAUNCH(true, true, true); break;
+        }
+#undef WTR_LAUNCH
+        INTEL_CHECK_LAUNCH();
+        goto reduce;
+      }
       if (a.dy_bf16 || a.x_bf16) {          // bf16-stored operands: the square tower shapes only (d = 128, d = 64; N = d or 3d)
         bool done16 = false;
         WB_CASE16(4, 4) WB_CASE16(2, 2)

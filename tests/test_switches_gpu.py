@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 MODEL = ['tests/test_model_gpu.py', '-k', 'forward or grads']
 ENGINE = ['tests/test_engine_gpu.py', '-k', 'synthetic_workloads or adam']
+BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode's forward / gradient parity against its emulating oracle
 
 CASES = [
     ({'INTEL_GEMM_B3': '0'}, MODEL),                                   # fp32-MFMA row GEMMs (LDS-DMA form)
@@ -42,6 +43,7 @@ CASES = [
     ({'INTEL_BWD_SCHEDULE': 'phased'}, ENGINE),                        # two-call backward
     ({'INTEL_SCATTER_SORTED': '1'}, ENGINE),                           # always the sorted embedding scatter
     ({'INTEL_BPR_NOISE': 'tensor'}, ENGINE),                           # BPR tie-breaking noise as a torch.rand tensor
+    ({'INTEL_WGRAD_TR': '0'}, BF16),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
 
 
