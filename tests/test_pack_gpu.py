@@ -94,3 +94,59 @@ def test_packed_engine_step_matches_oracle_with_short_histories():
     loss, _, _ = eng.train_step(batch, noise=noise)
     ref_loss, _, _ = O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
     assert abs(float(loss) - float(ref_loss)) < 1e-5
+
+
+def test_packed_long_histories_with_empty_and_boundary_lengths():
+    """Histories of up to 200 events (the general attention kernels on packed rows) with the lengths that matter pinned: empty histories
+    (no rows at all for the session), one event, exactly 64 / 65 events (one / two 64-row blocks) and the full 200: the packed run equals the
+    padded run bit for bit, and everything is finite."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    torch.manual_seed(0)
+    over = dict(items=50000)
+    args = synth.make_args('stress', dev, cal_diversity=0)
+    corpus, c = synth.make_corpus('stress', **over)
+    model = IntEL(args, corpus).to(dev).eval()
+    b = synth.make_batch('stress', 24, dev, seed=3, ragged=True, corpus_over=over)
+    H = b['his_context_mh'].shape[1]
+    for key in ('history_len', 'history_item_len'):
+        for i, v in ((1, 0), (5, 0), (7, 1), (9, H), (11, 65), (12, 64), (23, 0)):
+            b[key][i] = v
+    hv = torch.arange(H, device=dev)[None, :] < b['history_len'][:, None]
+    hiv = torch.arange(H, device=dev)[None, :] < b['history_item_len'][:, None]
+    b['his_intents'] = b['his_intents'] * hv[:, :, None]
+    b['his_context_mh'] = b['his_context_mh'] * hv
+    b['his_item_id'] = b['his_item_id'] * hiv
+    b['his_item_idx'] = torch.where(hiv, b['his_item_idx'].clamp_min(0), torch.full_like(b['his_item_idx'], -1))
+    outs = {}
+    for packed in (False, True):
+        bb = {k: v for k, v in b.items() if k not in ('his_rows', 'hisitem_rows')}
+        if packed:
+            bb['his_rows'], bb['hisitem_rows'] = int(b['history_len'].sum()), int(b['history_item_len'].sum())
+        with torch.no_grad():
+            o = model(bb)
+        assert packed == ('his_off' in model.prepare_batch(bb)[1])
+        outs[packed] = {k: v.clone() for k, v in o.items()}
+    for k in ('weights', 'ens_score', 'intents'):
+        assert bool(torch.isfinite(outs[True][k]).all()), k
+        assert torch.equal(outs[True][k], outs[False][k]), (k, float((outs[True][k] - outs[False][k]).abs().max()))
+    # ... and through the backward: every parameter gradient, up to the summation order of the weight gradients (their row tiles differ)
+    from intel_sigir2023_amd import loss as LS
+    L = b['i_id_s'].shape[1]
+    noise = torch.rand(24, L, L, device=dev)
+    grads = {}
+    model.train()
+    for packed in (False, True):
+        bb = {k: v for k, v in b.items() if k not in ('his_rows', 'hisitem_rows')}
+        if packed:
+            bb['his_rows'], bb['hisitem_rows'] = int(b['history_len'].sum()), int(b['history_item_len'].sum())
+        bb['bpr_noise'] = noise
+        model.zero_grad()
+        loss, _, _ = LS.IntBPRloss(args)(model(bb), bb)
+        loss.backward()
+        grads[packed] = (float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert grads[True][0] == grads[False][0]
+    for k, g in grads[False][1].items():
+        assert bool(torch.isfinite(grads[True][1][k]).all()), k
+        assert float((grads[True][1][k] - g).abs().max()) <= 1e-7 + 2e-6 * float(g.abs().max()), k
