@@ -2041,7 +2041,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
 // TAIL: M is not a multiple of 32 (zero-padded last tile); Y16 / X16 (bf16 mode, NP = 1): dY / X is stored as a bf16 array
 // (compile-time: a run-time choice in the tile loader costs this kernel 80 % of its speed)
 template <int NTW, int KTW, int NP = 3, bool TAIL = false, bool Y16 = false, bool X16 = false>
-__global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
+__device__ __forceinline__ void wgrad_b3_body(const WgradArgs& a, const int bx, const int by, const int bz, const int S) {
   constexpr int NB = 32 * NTW, KB = 32 * KTW;
   constexpr int YBL = 8 * (NB / 4), XBL = 8 * (KB / 4);          // 4x4 blocks per tile of each operand
   constexpr int YPT = (YBL + 255) / 256, XPT = (XBL + 255) / 256;  // blocks per thread (1 at 128 columns)
@@ -2051,8 +2051,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
-  const int ntiles = (a.M + WG_RT - 1) / WG_RT, S = gridDim.x;      // a ragged last tile is padded with zero rows
+  const int n0 = by * NB, k0 = bz * KB;
+  const int ntiles = (a.M + WG_RT - 1) / WG_RT;      // a ragged last tile is padded with zero rows
   // staging blocks of this thread: block b -> rows 4*(b % 8) .., columns 4*(b / 8) ..  (row block fastest: the stores of
   // eight adjacent lanes fill one column's 64 bytes)
   f32x4 py[YPT][4], px[XPT][4];
@@ -2159,7 +2159,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
     for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int t = blockIdx.x;
+  int t = bx;
   if (t < ntiles) load_tile(t);
   // fragment addresses: column (wn*16*NTW + i*16 + p) of dY, (NB + wk*16*KTW + j*16 + p) of X, rows 8g .. 8g+7
   const __bf16* fy = planes + (wn * 16 * NTW + p) * WB_LDT + 8 * g;
@@ -2204,7 +2204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
     }
     __syncthreads();
   }
-  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
+  float* slab = a.slabs + (size_t)bx * ((size_t)a.N * a.K + a.N);
 #pragma unroll
   for (int i = 0; i < NTW; ++i)
 #pragma unroll
@@ -2216,7 +2216,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
         slab[(size_t)n * a.K + k] = acc[i][j][r];
       }
     }
-  if (a.want_db && blockIdx.z == 0) {
+  if (a.want_db && bz == 0) {
     // column sums: the 8 row-blocks of a column block live in threads cb, cb + NB/4, ... ; reduce through LDS
     float* red = smem;                          // [8][NB] after the last barrier of the loop
 #pragma unroll
@@ -2236,6 +2236,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
       slab[(size_t)a.N * a.K + n0 + tid] = sdb;
     }
   }
+}
+
+template <int NTW, int KTW, int NP = 3, bool TAIL = false, bool Y16 = false, bool X16 = false>
+__global__ __launch_bounds__(256, 2) void wgrad_b3_kernel(WgradArgs a) {
+  wgrad_b3_body<NTW, KTW, NP, TAIL, Y16, X16>(a, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+// Several SMALL weight-gradient products in one launch (rows <= 32 768: a launch of its own costs such a product more than its work; the
+// published hyper-parameters' 32-wide tower layers issue five per layer on their critical chain).  Job table in the kernel arguments; a
+// workgroup finds its job and its (slab, column block, k block) in it.  launch_wgrad records, wgrad_batch_flush launches.
+#define WGRAD_BATCH_MAX 8
+struct WgradBatch { int n; int blk0[WGRAD_BATCH_MAX + 1]; WgradArgs j[WGRAD_BATCH_MAX]; };
+template <int NTW, int KTW, int NP, bool TAIL>
+__global__ __launch_bounds__(256, 2) void wgrad_b3_batch_kernel(WgradBatch jb) {
+  int ji = 0;
+  while (ji + 1 < jb.n && (int)blockIdx.x >= jb.blk0[ji + 1]) ++ji;
+  const WgradArgs a = jb.j[ji];
+  const int ny = a.N / (32 * NTW);
+  const int local = blockIdx.x - jb.blk0[ji];
+  const int bx = local % a.S, rest = local / a.S;
+  wgrad_b3_body<NTW, KTW, NP, TAIL, false, false>(a, bx, rest % ny, rest / ny, a.S);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2705,6 +2725,55 @@ static int redq_flush_impl(ReduceQueue* q, int tag, hipStream_t st) {
 int redq_flush(ReduceQueue* q, hipStream_t st) { return redq_flush_impl(q, -1, st); }
 int redq_flush_tag(ReduceQueue* q, int tag, hipStream_t st) { return redq_flush_impl(q, tag, st); }
 
+struct WgradPending { int planes, tail; WgradArgs a; };
+static thread_local std::vector<WgradPending> g_wq;
+static thread_local bool g_wq_on = false;
+void wgrad_batch_begin() {
+  g_wq.clear();        // (anything a failed earlier call left recorded is dropped)
+  g_wq_on = true;
+}
+int wgrad_batch_flush(hipStream_t st) {
+  g_wq_on = false;
+  for (int planes = 1; planes <= 3; planes += 2)
+    for (int tail = 0; tail < 2; ++tail) {
+      WgradBatch jb;
+      jb.n = 0;
+      int blocks = 0;
+      double flops = 0.0, bytes = 0.0;
+      auto fire = [&]() -> int {
+        if (jb.n == 0) return 0;
+        jb.blk0[jb.n] = blocks;
+        const size_t smem = (size_t)3 * 32 * 2 * WB_LDT * sizeof(__bf16);
+#define WBB_LAUNCH(P_, T_)                                                                                        \
+  do {                                                                                                            \
+    allow_lds((wgrad_b3_batch_kernel<1, 1, P_, T_>), smem);                                                       \
+    LAUNCH_W(flops, bytes, (wgrad_b3_batch_kernel<1, 1, P_, T_>), dim3(blocks), dim3(256), smem, st, jb);       \
+  } while (0)
+        if (planes == 3 && !tail) WBB_LAUNCH(3, false);
+        else if (planes == 3) WBB_LAUNCH(3, true);
+        else if (!tail) WBB_LAUNCH(1, false);
+        else WBB_LAUNCH(1, true);
+#undef WBB_LAUNCH
+        INTEL_CHECK_LAUNCH();
+        jb.n = 0; blocks = 0; flops = bytes = 0.0;
+        return 0;
+      };
+      for (const WgradPending& w : g_wq) {
+        if (w.planes != planes || w.tail != tail) continue;
+        if (jb.n == WGRAD_BATCH_MAX) { int rc = fire(); if (rc) { g_wq.clear(); return rc; } }
+        jb.blk0[jb.n] = blocks;
+        jb.j[jb.n++] = w.a;
+        blocks += w.a.S * (w.a.N / 32) * (w.a.K / 32);
+        flops += 2.0 * w.a.M * w.a.N * w.a.K;
+        bytes += 4.0 * ((double)w.a.M * w.a.K + (double)w.a.M * w.a.N + (double)w.a.K * w.a.N);
+      }
+      int rc = fire();
+      if (rc) { g_wq.clear(); return rc; }
+    }
+  g_wq.clear();
+  return 0;
+}
+
 int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw,
                  float* db, int accumulate, float* slabs, hipStream_t st, ReduceQueue* q, const WgradSplit* split, int io16) {
   if (N <= 0 || K <= 0) return 0;
@@ -2787,6 +2856,12 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
         WB_CASE16(4, 4) WB_CASE16(2, 2)
         INTEL_CHECK_ARG(done16, "wgrad: bf16-stored operands are supported for 64- and 128-wide products only");
         INTEL_CHECK_LAUNCH();
+        goto reduce;
+      }
+      if (g_wq_on && ntw == 1 && ktw == 1 && M <= 32768) {          // small product inside a batch scope: recorded, launched by wgrad_batch_flush
+        WgradPending w;
+        w.planes = g_planes; w.tail = (M % WG_RT != 0) ? 1 : 0; w.a = a;
+        g_wq.push_back(w);
         goto reduce;
       }
 #define WB_CASE(A_, B_)                                                                                             \

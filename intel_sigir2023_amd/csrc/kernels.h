@@ -92,6 +92,10 @@ bool smallk_supported(int N, int K);
 int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, const float* bias, int N, float* Y, int ldy,
                          int relu, hipStream_t st, const float* pos = nullptr, const int* row_t = nullptr);      // pos: Y[m, n] += pos[row_t[m] * ldy + n]
 int smallk_wgrad_slabs(int M);
+// batch scope for SMALL weight-gradient products (rows <= 32 768, 32-wide blocks): between begin and flush launch_wgrad records them, flush issues one
+// launch per arithmetic mode.  The operands must stay untouched until the flush; the reduce-queue jobs are pushed at record time as usual.
+void wgrad_batch_begin();
+int wgrad_batch_flush(hipStream_t st);
 int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,
                         int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
 

@@ -749,6 +749,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
   for (int l = D.layers - 1; l >= 0; --l) {
     TowerLayerBufs& b = w.layer[l];
     const float* Xin = l == 0 ? w.X0 : w.layer[l - 1].Xout;
+    wgrad_batch_begin();                   // the layer's small weight-gradient products (32-wide towers) leave as one launch at its end
     const float* dZ = r.T->dZ;             // gradient behind this layer's LayerNorm
     if (l == D.layers - 1 && last_ln_done) {
       dZ = dX;                              // the pooling backward already applied it (fused tail)
@@ -789,6 +790,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     er.a_bf16 = h16;
     lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
+    if (!r.ok(wgrad_batch_flush(r.st))) return nullptr;      // (dZ, dF1, dQKV and the stashes are still this layer's)
     float* t = dX; dX = dXalt; dXalt = t;
   }
   return dX;

@@ -6,13 +6,15 @@ from intel_sigir2023_amd import synth
 from intel_sigir2023_amd.engine import IntELEngine
 from intel_sigir2023_amd.model import IntEL
 dev = torch.device('cuda:0')
-args = synth.make_args('tmall', dev)
-corpus, _ = synth.make_corpus('tmall', items=20000, users=2000)
-for B in (16, 256, 1024):
+wl = sys.argv[1] if len(sys.argv) > 1 else 'tmall'              # usage: host_cost_probe.py [workload] [batch ...]
+batches = [int(x) for x in sys.argv[2:]] or [16, 256, 1024]
+args = synth.make_args(wl, dev)
+corpus, _ = synth.make_corpus(wl, items=20000, users=2000)
+for B in batches:
     torch.manual_seed(0)
     m = IntEL(args, corpus).to(dev)
     e = IntELEngine(m, 'IntBPRloss', args)
-    b = synth.make_batch('tmall', B, dev, seed=1, corpus_over=dict(items=20000, users=2000))
+    b = synth.make_batch(wl, B, dev, seed=1, corpus_over=dict(items=20000, users=2000))
     for _ in range(5):
         e.train_step(b)
     torch.cuda.synchronize()
@@ -24,6 +26,8 @@ for B in (16, 256, 1024):
     torch.cuda.synchronize()
     t2 = time.time()
     print('B=%d: enqueue %.3f ms/step, incl. drain %.3f ms/step' % (B, (t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+if len(sys.argv) > 1:
+    sys.exit(0)
 import cProfile, pstats
 pr = cProfile.Profile()
 pr.enable()
