@@ -738,7 +738,10 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
   INTEL_CHECK_ARG(!h16, "attention: bf16-stored q,k,v are supported by the whole-sequence kernels only");
   INTEL_CHECK_ARG(!row_off || key_len, "attention: packed rows need the session lengths");
   dim3 grid(B * heads * cdiv(T, AT_QB));
-  if (attn_ds_scheme()) {
+  // small problems (short lists, few rows: the 32-wide towers of the published hyper-parameters) are bound by the number of dependent launches, not by
+  // their products: there the recompute form's two kernels beat the three of the dS scheme
+  const bool small = T <= 64 && (long long)B * T <= 32768;
+  if (attn_ds_scheme() && !small) {
     float* dS = scratch + rup_sz((size_t)B * heads * T, 64);
     const int ldS = attn_ds_pitch(T);
     const long long rows = (long long)B * T;
