@@ -749,7 +749,9 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
   for (int l = D.layers - 1; l >= 0; --l) {
     TowerLayerBufs& b = w.layer[l];
     const float* Xin = l == 0 ? w.X0 : w.layer[l - 1].Xout;
-    wgrad_batch_begin();                   // the layer's small weight-gradient products (32-wide towers) leave as one launch at its end
+    // the layer's small weight-gradient products (32-wide towers) leave as one launch at its end.  With dropout the first one's dY (dZ * mask) sits
+    // in the dA buffer, which the layer rewrites below: that product is launched at once, the scope opens behind it
+    if (!r.ctx->fwd_dropout) wgrad_batch_begin();
     const float* dZ = r.T->dZ;             // gradient behind this layer's LayerNorm
     if (l == D.layers - 1 && last_ln_done) {
       dZ = dX;                              // the pooling backward already applied it (fused tail)
@@ -769,6 +771,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     // matrix products (dF1, dA, dQKV) are bf16 arrays; dZ stays fp32 (it is also the residual gradient)
     const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
     wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2, h16 ? 2 : 0);
+    if (r.ctx->fwd_dropout) wgrad_batch_begin();
     GemmEpilogue em;
     em.mask = b.R1; em.ldmask = d;
     em.mask_bf16 = h16; em.c_bf16 = h16;
