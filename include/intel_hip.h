@@ -126,7 +126,7 @@ typedef struct IntelBatch {
                                    NULL when his_item_int is given                       */
   const float* his_item_int;    /* [B,Hi,I] dense form (reference layout) or NULL        */
   const int* history_item_len;  /* [B]              */
-  /* ---- ABI version 2: optional packing of the two histories (BERT4Rec encoders, history_max <= 64).  The padded positions
+  /* ---- ABI version 2: optional packing of the two histories (BERT4Rec encoders at any history length, GRU4Rec encoders).  The padded positions
    * t >= history_len[b] of a history never reach a valid row (their keys are masked, GeneralSeq.py:100; the block is row-wise
    * otherwise; the output is multiplied by `valid` and only row len-1 is used, :103-105), so the encoder may run on the valid
    * rows alone.  his_off / hisitem_off = exclusive prefix sums of history_len / history_item_len ([B] ints, device);
