@@ -24,7 +24,7 @@ def one_case(rng, idx, dev):
     e = lambda: rng.choice([16, 32, 64])
     flags = dict(model_num=rng.choice([2, 3, 5]), context_emb_size=e(), i_emb_size=e(), u_emb_size=e(), s_emb_size=rng.choice([32, 64, 128]),
                  im_emb_size=e(), intent_emb_size=e(), cross_attn_qsize=rng.choice([16, 64]), num_heads=rng.choice([1, 2]),
-                 num_layers=rng.choice([1, 1, 2]), encoder=rng.choice(['BERT4Rec', 'BERT4Rec', 'GRU4Rec']), history_max=rng.choice([5, 20]))
+                 num_layers=rng.choice([1, 1, 2]), encoder=rng.choice(['BERT4Rec', 'BERT4Rec', 'GRU4Rec']), history_max=rng.choice([5, 20, 20, 70]))      # 70: packed histories through the general attention kernels
     if rng.random() < 0.5:      # the benchmarked widths (fused tower tails, register-resident pooling)
         flags.update(i_emb_size=64, im_emb_size=64, s_emb_size=64)
     L = rng.choice([2, 7, 20, 33, 50, 52, 53, 64, 65, 100])
