@@ -130,7 +130,13 @@ typedef struct IntelBatch {
    * t >= history_len[b] of a history never reach a valid row (their keys are masked, GeneralSeq.py:100; the block is row-wise
    * otherwise; the output is multiplied by `valid` and only row len-1 is used, :103-105), so the encoder may run on the valid
    * rows alone.  his_off / hisitem_off = exclusive prefix sums of history_len / history_item_len ([B] ints, device);
-   * n_his_rows / n_hisitem_rows = their totals (HOST ints: they size the launches).  NULL / 0 = run the padded [B,H] rows. */
+   * n_his_rows / n_hisitem_rows = their totals (HOST ints: they size the launches).  NULL / 0 = run the padded [B,H] rows.
+   * PRECONDITION for packed rows: history_len[b] >= 1 and history_item_len[b] >= 1, as the reference's Dataset guarantees (a
+   * session without history carries ONE all-zero event, GeneralSeq.py:48-52, IntEL.py:234-237; torch's pack_padded_sequence
+   * rejects a zero length).  An isolated empty history is tolerated (its encoder output is the pruned block applied to a zero
+   * row, no out-of-bounds access), but the fused BERT4Rec kernels take at most 64 session starts per 33..64-row tile window,
+   * which only histories of >= 1 row guarantee: a batch that may hold empty histories should leave his_off NULL.  The Python
+   * producers (data.collate_batch, feed, synth) omit the totals -- and with them the packing -- when a length is 0. */
   const int* his_off;
   const int* hisitem_off;
   int n_his_rows, n_hisitem_rows;

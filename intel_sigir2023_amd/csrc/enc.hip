@@ -438,7 +438,7 @@ __global__ __launch_bounds__((EncCfg<D, NP>::NT), (EncCfg<D, NP>::WPS)) void enc
         const int start = w_st - r0;
         ln = w_en - w_st;
         s_start[lane] = start;
-        s_rowlast[start + ln - 1] = s_lo + lane;
+        if (ln > 0) s_rowlast[start + ln - 1] = s_lo + lane;      // an empty history has no last row (x_last stays unwritten: enc_last reads 0)
         s_items[lane] = lane;
       }
       if (lane == 0) s_start[ns] = nrows;
@@ -698,7 +698,7 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
   for (int i = tid; i < 16 * (D / 4); i += C::NT) {
     const int row = i / (D / 4), col = (i - row * (D / 4)) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row < SPB && b0 + row < a.B) v = *reinterpret_cast<const f32x4*>(a.xlast + (size_t)(b0 + row) * D + col);
+    if (row < SPB && b0 + row < a.B && a.len[b0 + row] > 0) v = *reinterpret_cast<const f32x4*>(a.xlast + (size_t)(b0 + row) * D + col);      // the block kernel writes x_last of non-empty histories only
     store4<NP, PLANE>(xpl + row * LDP + col, v);
   }
   lds_barrier();
@@ -753,7 +753,7 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
     float sum = e;
 #pragma unroll
     for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o);
-    const float pw = e / sum;                         // n >= 1
+    const float pw = n > 0 ? e / sum : 0.f;           // an empty history attends to nothing (the kernel-per-op path's NaN -> 0)
     if (TRAIN && a.PL && t < a.T) a.PL[((size_t)b * HEADS + h) * a.T + t] = pw;
     float o0 = 0.f, o1 = 0.f;                         // columns lane (head 0) and 64 + lane (head 1)
     const float* vr = a.KV + rb * (2 * D) + D;
@@ -762,7 +762,7 @@ __global__ __launch_bounds__((EncLastCfg<D, NP>::NT)) void enc_last_fwd_kernel(E
       o0 = __builtin_fmaf(p0, vr[(size_t)tt * (2 * D) + lane], o0);
       o1 = __builtin_fmaf(p1, vr[(size_t)tt * (2 * D) + 64 + lane], o1);
     }
-    float z0 = o0 + a.xlast[(size_t)b * D + lane], z1 = o1 + a.xlast[(size_t)b * D + 64 + lane];
+    float z0 = o0 + (n > 0 ? a.xlast[(size_t)b * D + lane] : 0.f), z1 = o1 + (n > 0 ? a.xlast[(size_t)b * D + 64 + lane] : 0.f);      // n == 0: x_last = 0 (select_last_kernel)
     const float mean = wave_sum(z0 + z1) * (1.f / (float)D);
     z0 -= mean; z1 -= mean;
     const float rs = 1.f / sqrtf(wave_sum(z0 * z0 + z1 * z1) * (1.f / (float)D) + 1e-5f);
@@ -832,7 +832,11 @@ __global__ void enc_tiles_kernel(const int* __restrict__ off, int B, int R, int 
   if (b > B) return;
   const int hi = b < B ? off[b] / R : ntiles;                  // b == B: the sentinel and the empty windows behind the last session
   const int lo = b == 0 ? -1 : off[b - 1] / R;
-  for (int t = lo + 1; t <= hi && t <= ntiles; ++t) tile_s[t] = b;
+  // (trailing EMPTY histories have off[b] == rows: when rows % R == 0 that is window `ntiles`, which belongs to the sentinel b == B alone --
+  // sessions are cut at ntiles - 1, the sentinel always writes tile_s[ntiles])
+  const int cap = b < B ? ntiles - 1 : ntiles;
+  for (int t = lo + 1; t <= hi && t <= cap; ++t) tile_s[t] = b;
+  if (b == B && lo + 1 > ntiles) tile_s[ntiles] = B;
 }
 
 template <int D, int DK, bool TRAIN, int NP>

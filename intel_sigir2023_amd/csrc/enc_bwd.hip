@@ -344,7 +344,7 @@ __global__ __launch_bounds__((EncBwdCfg<D>::NT), 2) void enc_block_bwd_kernel(En
         const int start = a.off[s_lo + lane] - r0;
         const int en = (s_lo + lane + 1 < a.B ? a.off[s_lo + lane + 1] : a.rows) - r0;
         s_start[lane] = start;
-        s_rowlast[en - 1] = s_lo + lane;
+        if (en > start) s_rowlast[en - 1] = s_lo + lane;       // an empty history has no last row
       }
       if (lane == 0) s_start[ns] = nrows;
     }

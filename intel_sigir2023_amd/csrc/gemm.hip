@@ -2728,6 +2728,10 @@ int redq_flush_tag(ReduceQueue* q, int tag, hipStream_t st) { return redq_flush_
 struct WgradPending { int planes, tail; WgradArgs a; };
 static thread_local std::vector<WgradPending> g_wq;
 static thread_local bool g_wq_on = false;
+void wgrad_batch_reset() {      // an error exit between begin and flush must not leave the scope open for the next backward
+  g_wq.clear();
+  g_wq_on = false;
+}
 void wgrad_batch_begin() {
   g_wq.clear();        // (anything a failed earlier call left recorded is dropped)
   g_wq_on = true;
@@ -2858,7 +2862,7 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
         INTEL_CHECK_LAUNCH();
         goto reduce;
       }
-      if (g_wq_on && ntw == 1 && ktw == 1 && M <= 32768) {          // small product inside a batch scope: recorded, launched by wgrad_batch_flush
+      if (g_wq_on && q && ntw == 1 && ktw == 1 && M <= 32768) {          // small product inside a batch scope: recorded, launched by wgrad_batch_flush
         WgradPending w;
         w.planes = g_planes; w.tail = (M % WG_RT != 0) ? 1 : 0; w.a = a;
         g_wq.push_back(w);

@@ -96,6 +96,7 @@ int smallk_wgrad_slabs(int M);
 // launch per arithmetic mode.  The operands must stay untouched until the flush; the reduce-queue jobs are pushed at record time as usual.
 void wgrad_batch_begin();
 int wgrad_batch_flush(hipStream_t st);
+void wgrad_batch_reset();      // close the scope and drop what it recorded (entry of every backward: an earlier error exit may have left it open)
 int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,
                         int accumulate, float* slabs, hipStream_t st, ReduceQueue* q = nullptr);
 

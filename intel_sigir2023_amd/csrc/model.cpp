@@ -1899,7 +1899,9 @@ static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelB
   INTEL_CHECK_ARG(d_weights || d_ens_score || d_intents, "intel_backward: all output gradients are null");
   Run r{ctx, ctx->d, ctx->lay, params, grads, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], 1};
   gemm_set_planes(ctx->d.dtype == INTEL_DTYPE_BF16 ? 1 : 3);
+  wgrad_batch_reset();
   backward_impl(r, d_weights, d_ens_score, d_intents, phase);
+  wgrad_batch_reset();
   gemm_set_planes(3);
   // The caller's table stream (intel_set_table_stream) is promised the finished item-id table gradient.  The four-branch schedule
   // hands it over as early as possible; every other way through a one-call backward (INTEL_STREAMS=0, INTEL_BWD_WIDE=0) does it

@@ -264,7 +264,7 @@ class Dataset(torch.utils.data.Dataset):
         out['phase'] = self.phase
         # host-side totals of the valid history rows (not in the reference's dict): model.prepare_batch runs the BERT4Rec
         # encoders on those rows only when they are present
-        if 'history_len' in out and 'history_item_len' in out:
+        if 'history_len' in out and 'history_item_len' in out and int(out['history_len'].min()) >= 1 and int(out['history_item_len'].min()) >= 1:
             out['his_rows'] = int(out['history_len'].sum())
             out['hisitem_rows'] = int(out['history_item_len'].sum())
         return out

@@ -206,7 +206,8 @@ class ColumnarStore(object):
         out['phase'] = self.phase
         if idx_host is not None:          # host-known totals of the valid history rows (model.prepare_batch: packed encoders)
             hl, hil = self.history_lens(idx_host)
-            out['his_rows'], out['hisitem_rows'] = int(hl.sum()), int(hil.sum())
+            if int(hl.min()) >= 1 and int(hil.min()) >= 1:      # packed rows need histories of >= 1 event (include/intel_hip.h); the reference's Dataset guarantees it
+                out['his_rows'], out['hisitem_rows'] = int(hl.sum()), int(hil.sum())
         out['_keep'] = (idx_dev, perm_dev)          # inputs of the asynchronous launch
         return out
 

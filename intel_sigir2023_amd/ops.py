@@ -175,6 +175,10 @@ def _register():
     # ---- the whole model (models/IntEL/IntEL.py:117-124: IntEL.forward) as ONE dispatcher-visible op + its hand-written backward.
     # `handle` names the module (model_handle(model)): the op reads the hyper-parameters and the workspace from it; the parameter
     # tensors travel as a Tensor[] argument in the order of model.slot_items(), so autograd sees them and receives their gradients.
+    # EAGER-ONLY: the op keeps hidden per-module state that its schema does not declare (the workspace with the activation stash, the
+    # one-slot _op_stash that intel_backward continues from, _generation) -- exactly the state the reference's autograd graph would hold.
+    # A tracing compiler (torch.compile / functionalization) may reorder, deduplicate or re-run a "pure" op and would corrupt that
+    # stash: do not trace it.  One training forward per backward, as in the reference's loop (BaseRunner.py:283-289).
     from typing import List, Optional
 
     @custom_op(NAMESPACE + '::intel_forward', mutates_args=(), device_types='cuda')

@@ -110,8 +110,9 @@ def reduce_scatter_sum(full, out):
     elif dist.get_backend() == 'nccl':
         dist.reduce_scatter_tensor(out, full)
     else:
-        dist.all_reduce(full, op=dist.ReduceOp.SUM)
-        out.copy_(full.reshape(-1)[r * n:(r + 1) * n])
+        tmp = full.clone()          # the fallback must not clobber the caller's buffer (the RCCL branch does not either)
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+        out.copy_(tmp.reshape(-1)[r * n:(r + 1) * n])
 
 
 def allgather(t):

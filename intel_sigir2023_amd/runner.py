@@ -378,9 +378,14 @@ class BaseRunner(object):
     def evaluate(self, model, batches, topk, metrics, criterion, pos_nums=None, topk_intent=[1, 5, 10, 30]):
         on_device = bool(self.device_metrics and pos_nums is None and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda
                          and len(topk) <= 8 and max(topk) <= 64 and max(b['i_id_s'].shape[1] for b in batches) <= 512)
-        if parallel.world_size() > 1 and isinstance(batches, list) and len(batches) and batches[0]['session_len'].is_cuda:
-            # the two paths use different collectives: every rank must take the same one
-            on_device = parallel.global_max_([0 if on_device else 1], batches[0]['session_len'].device)[0] == 0
+        if parallel.world_size() > 1:
+            # the two paths use different collectives: every rank must take the same one.  EVERY rank enters this vote -- whatever its own
+            # batches look like (a generator, an empty list, host batches: all of that is folded into its `on_device`) -- on a device that
+            # does not depend on the batches
+            dev = getattr(model, 'device', None)
+            if dev is None or torch.device(dev).type != 'cuda':
+                dev = torch.device('cuda', torch.cuda.current_device()) if (torch.cuda.is_available() and torch.distributed.get_backend() == 'nccl') else torch.device('cpu')
+            on_device = parallel.global_max_([0 if on_device else 1], dev)[0] == 0
         if on_device:
             return self.evaluate_on_device(model, batches, topk, metrics, criterion, topk_intent)
         preds, loss, ranks, true_int, pred_int, slens = self.predict(model, batches, criterion)

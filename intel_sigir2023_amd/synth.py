@@ -129,9 +129,10 @@ def make_batch(workload, B, device, seed=0, zipf=False, ragged=False, corpus_ove
         'his_item_id': (randint(1, c['items'], (B, H)) * hiv).int(),
         'his_item_idx': torch.where(hiv, randint(0, I, (B, H)), torch.full((B, H), -1, device=device)).int(),
         'batch_size': B, 'phase': 'train',
-        # totals of the valid history rows, known to the producer on the host (model.prepare_batch: packed encoders)
-        'his_rows': int(hl.sum()), 'hisitem_rows': int(hil.sum()),
     }
+    if int(hl.min()) >= 1 and int(hil.min()) >= 1:
+        # totals of the valid history rows, known to the producer on the host (model.prepare_batch: packed encoders; histories of >= 1 event)
+        batch['his_rows'], batch['hisitem_rows'] = int(hl.sum()), int(hil.sum())
     return batch
 
 

@@ -65,3 +65,35 @@ def build_model(fx, device):
     missing = model.load_state_dict(fx.state_dict(), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return model.to(device), args
+
+
+# parameters whose gradient a single flipped relu can move by one whole row: the first linear (weight and bias) of a
+# feed-forward block -- tower W1 (IntEL.py:61,69) and the BERT4Rec blocks' linear1 (layers.py:74)
+RELU_FLIP_PARAMS = ('_W1.weight', '_W1.bias', 'linear1.weight', 'linear1.bias')
+
+
+def relu_flip_forgiven_error(name, got, ref, tol, taps, max_units=1):
+    """max |got - ref| of one parameter gradient, with the ONE exemption the parity sets allow (tools/fuzz_parity.py, tests/test_enc_gpu.py):
+    a hidden unit of a feed-forward block whose pre-activation rounds to the other side of 0 in the two implementations moves exactly one
+    row of that block's first-linear gradient.  Rows (hidden units) above `tol` are dropped from the maximum ONLY for RELU_FLIP_PARAMS,
+    only for at most `max_units` rows, only up to 50x the tolerance, and only when the ORACLE's own pre-activation of that unit is within
+    1e-6 * max|x| of zero somewhere (taps: oracle.forward(taps=...)); everything else must meet the plain tolerance."""
+    diff = (got - ref).abs()
+    err = float(diff.max()) if diff.numel() else 0.0
+    if err <= tol or not name.endswith(RELU_FLIP_PARAMS) or diff.dim() < 1 or diff.shape[0] <= 4:
+        return err
+    pre = taps.get(name.rsplit('.', 1)[0]) if taps else None
+    if pre is None:
+        return err
+    rows = diff.reshape(diff.shape[0], -1).max(dim=1)[0]
+    over = [int(u) for u in torch.nonzero(rows > tol).flatten()]
+    if len(over) > max_units:
+        return err
+    pa = torch.cat([t.reshape(-1, t.shape[-1]) for t in pre]).abs()
+    lim = 1e-6 * max(1.0, float(pa.max()))
+    for u in over:
+        if not (float(pa[:, u].min()) < lim and float(rows[u]) <= 50 * tol):
+            return err
+    keep = torch.ones_like(rows, dtype=torch.bool)
+    keep[over] = False
+    return float(rows[keep].max()) if bool(keep.any()) else 0.0

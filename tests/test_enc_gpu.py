@@ -10,7 +10,7 @@ import sys
 import pytest
 import torch
 
-from tests.helpers import ROOT
+from tests.helpers import ROOT, relu_flip_forgiven_error
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +67,8 @@ def _case(history_max, B, seed, train, dtype='f32'):
         assert 'his_off' in model.prepare_batch(batch)[1]          # the encoders do run packed
         loss, _, _ = LS.IntBPRloss(args)(out, batch)
         loss.backward()
-        ref = oracle_forward(sd, ref_batch, cfg)
+        taps = {}
+        ref = oracle_forward(sd, ref_batch, cfg) if bf else O.forward(sd, ref_batch, cfg, taps=taps)
         rl = O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
         rl[0].backward()
         assert abs(float(loss) - float(rl[0])) < (2e-5 if bf else 1e-5)
@@ -76,16 +77,28 @@ def _case(history_max, B, seed, train, dtype='f32'):
         with torch.no_grad():
             out = model(batch)
             ref = oracle_forward(sd, ref_batch, cfg)
+    flipped = torch.zeros(B, dtype=torch.bool)
     for k in ('weights', 'ens_score', 'intents'):
-        e = (out[k].detach().cpu() - ref[k].detach()).abs().flatten().float()
+        e = (out[k].detach().cpu() - ref[k].detach()).abs().float().reshape(B, -1).max(dim=1)[0]      # per session
         scale = max(1.0, float(ref[k].abs().max()))
         if bf:
-            # bf16 mode against its emulation: equal to summation order (<= 3e-5 like fp32) EXCEPT where a pre-rounding value sits on a bf16
-            # boundary and the two summation orders round it to different neighbours -- one such flip moves that session's outputs by
-            # ~2^-9 of an activation; with hundreds of sessions a few flips occur (the 2-4-session fixtures of tests/test_bf16_gpu.py see none)
-            assert float(torch.quantile(e, 0.95)) <= 3e-5 * scale and float(e.max()) <= 2e-3 * scale, (k, float(torch.quantile(e, 0.95)), float(e.max()))
+            # bf16 mode against its emulation: equal to summation order (<= 3e-5 like fp32) EXCEPT in a session where a pre-rounding value sits
+            # on a bf16 boundary and the two summation orders round it to different neighbours: one such flip moves that SESSION's outputs
+            # by up to ~2^-9 of an activation (sessions are independent: nothing else moves).  Counted below per session, not per element.
+            assert float(e.max()) <= 2e-3 * scale, (k, float(e.max()))
+            flipped |= e > 3e-5 * scale
         else:
             assert float(e.max()) <= 3e-5 * scale, (k, float(e.max()))
+    if bf:
+        # how many sessions may carry a visible flip.  A session rounds R ~ 2.5e4 activations to bf16 (two encoders x ~10 packed rows x 128
+        # columns x 6 rounded tensors + the towers' 12 x 192 x 5); two fp32 summation orders of a 128-term product differ by ~2^-22 of the
+        # value against the bf16 half-spacing 2^-9: p ~ 2^-13 per element, i.e. ~3 boundary flips per session -- but a flipped element is
+        # one of 128 terms of the next product (2^-9 / 128 of its output, far below 3e-5); only a flip in the last few values of a session's
+        # chain (the 2 x 128 encoder outputs and the pooled / fused vectors, ~5e2 values) is visible: 5e2 x 2^-13 ~ 0.06 per session.  The
+        # bound is twice that expectation plus two sessions; measured on the GPU box: MEASURE_ME.
+        n_flip = int(flipped.sum())
+        print('bf16 fused-encoder case H=%d B=%d: %d sessions with a visible rounding flip' % (history_max, B, n_flip))
+        assert n_flip <= 2 + int(0.12 * B), (n_flip, B)
     if train:
         worst = 0.0
         for k, p in model.named_parameters():
@@ -95,8 +108,10 @@ def _case(history_max, B, seed, train, dtype='f32'):
                 continue
             tol = (5e-3 if bf else 2e-4) * max(float(gr.abs().max()), 1e-6) + 1e-7      # bf16 mode: the bar of test_bf16_gradients_match_the_emulating_oracle
             err = float((p.grad.detach().cpu() - gr).abs().max())
-            if not bf and any(k.endswith(s) for s in ('linear1.weight', 'linear1.bias', '_W1.weight', '_W1.bias')):
-                tol *= 50                                            # one flipped relu moves one row (tools/fuzz_parity.py)
+            if not bf and err > tol:
+                # one flipped relu moves one row of a first-linear gradient: forgiven only where the ORACLE's pre-activation of that hidden
+                # unit touches zero, at most two units (these batches hold up to 257 sessions), each within 50x (tests/helpers.py)
+                err = relu_flip_forgiven_error(k, p.grad.detach().cpu(), gr, tol, taps, max_units=2)
             worst = max(worst, err / tol)
             assert err <= tol, (k, err, tol)
         return worst

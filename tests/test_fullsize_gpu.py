@@ -30,7 +30,11 @@ def _take(b, idx, B):
     return out
 
 
-@pytest.mark.parametrize('workload,dtype,B,sub', [('tmall', 'bf16', 4096, [0, 1, 2, 777, 2048, 4095]), ('lifedata', 'f32', 2048, [0, 1, 1000, 2047])])
+@pytest.mark.parametrize('workload,dtype,B,sub', [('tmall', 'bf16', 4096, [0, 1, 2, 777, 2048, 4095]), ('lifedata', 'f32', 2048, [0, 1, 1000, 2047]),
+                                                  # the reference's PUBLISHED hyper-parameters (script/IntEL.sh:15: 16/16/32/32-wide, GRU4Rec, 2 heads x 2 tied
+                                                  # layers) at its batch of 512 and at 1024: 25 600 / 51 200 candidate rows = both sides of the 32 768-row
+                                                  # thresholds of the short-list attention backward (csrc/attn.hip) and the batched small weight gradients (csrc/gemm.hip)
+                                                  ('tmall_pub', 'f32', 512, [0, 1, 2, 255, 256, 511]), ('tmall_pub', 'f32', 1024, [0, 1, 2, 511, 512, 1023])])
 def test_full_size_properties(workload, dtype, B, sub):
     from intel_sigir2023_amd import loss as LS
     from intel_sigir2023_amd import synth
@@ -56,8 +60,13 @@ def test_full_size_properties(workload, dtype, B, sub):
     noise = torch.rand(B, L, L, device=dev)
     named = dict(model.named_parameters())
     check = ['i_W1.weight', 'i_attn_head.q_linear.weight', 's_W2.bias', 'weight_embeddings.weight', 'pred_layer.weight',
-             'encoder.transformer_block.0.linear1.weight', 'item_encoder.transformer_block.1.masked_attn_head.v_linear.weight',
-             'item_encoder.transformer_block.0.layer_norm1.weight', 'intent_embeddings.weight', 'context_embeddings.weight']
+             'intent_embeddings.weight', 'context_embeddings.weight', 'i_layer_norm.weight', 's_attn_head.v_linear.weight', 'score_embeddings.weight',
+             'intent_item_attention.key_layer.weight', 'item_embeddings.weight']
+    if args.encoder == 'GRU4Rec':
+        check += ['encoder.rnn.weight_ih_l0', 'item_encoder.rnn.weight_hh_l0', 'item_encoder.out.weight', 'encoder.rnn.bias_hh_l0']
+    else:
+        check += ['encoder.transformer_block.0.linear1.weight', 'item_encoder.transformer_block.1.masked_attn_head.v_linear.weight',
+                  'item_encoder.transformer_block.0.layer_norm1.weight']
 
     def run(idx):
         sb = _take(batch, idx, B)
@@ -101,9 +110,10 @@ def test_full_size_properties(workload, dtype, B, sub):
     assert bool(((nd >= 0) & (nd <= 1 + 1e-6)).all())
 
 
-def test_stress_table_lazy_adam_equals_the_dense_sweep_at_full_size():
+@pytest.mark.parametrize('B', [256, 1024])      # 1024 = the per-GPU batch SURVEY 8-d gives configs[4]
+def test_stress_table_lazy_adam_equals_the_dense_sweep_at_full_size(B):
     """configs[4] on one GPU: the 10 M-item table (2.56 GB; parameter + gradient + two moments = 10 GB per engine), lists and
-    histories of 200, K = 8, 256 sessions per step.  Three fused training steps with the lazy form of the table's Adam (rows without
+    histories of 200, K = 8, 256 / 1024 sessions per step.  Three fused training steps with the lazy form of the table's Adam (rows without
     a gradient replayed when they are next read) against three with the dense sweep, same initialisation, batches and BPR
     tie-breaks: equal losses, and after the flush the table and both moments bit for bit in the 97 % of the rows no batch touched
     (the touched rows to the order of the scatter's float atomics).  The first step's loss is checked
@@ -112,7 +122,6 @@ def test_stress_table_lazy_adam_equals_the_dense_sweep_at_full_size():
     from intel_sigir2023_amd.engine import IntELEngine
     from intel_sigir2023_amd.model import IntEL
     dev = _dev()
-    B = 256
     args = synth.make_args('stress', dev, cal_diversity=1)
     corpus, c = synth.make_corpus('stress')
     assert c['items'] == 10000000
@@ -157,7 +166,7 @@ def test_stress_table_lazy_adam_equals_the_dense_sweep_at_full_size():
     for bt in batches:
         touched[bt['i_id_s'].reshape(-1).long()] = True
         touched[bt['his_item_id'].reshape(-1).long()] = True
-    assert 0.005 < float(touched.float().mean()) < 0.2
+    assert 0.005 < float(touched.float().mean()) < 0.25
     quiet = ~touched
     assert torch.equal(wl[quiet], wd[quiet]) and float((wl[quiet] - el._w0[quiet]).abs().max()) > 0      # moved (weight decay), identically
     assert torch.equal(el.m['iid'].view_as(wl)[quiet], ed.m['iid'].view_as(wl)[quiet])

@@ -26,3 +26,12 @@ def test_random_configs_match_oracle_autograd(seed):
     for i in range(6):
         worst, bad, desc = fuzz.one_case(rng, 1000 * seed + i, dev)
         assert worst <= 1.0, (worst, bad, desc)
+
+
+@pytest.mark.parametrize('seed', [7, 8])
+def test_reference_widths_beyond_the_row_count_thresholds(seed):
+    """32-wide towers (the reference's default and published widths) with B * L > 32 768 candidate rows: the other side of the size
+    thresholds in csrc/attn.hip (short-list attention backward) and csrc/gemm.hip (batched small weight gradients)."""
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    worst, bad, desc = fuzz.one_case(random.Random(seed), 5000 + seed, torch.device('cuda:0'), big=True)
+    assert worst <= 1.0, (worst, bad, desc)

@@ -15,12 +15,13 @@ from intel_sigir2023_amd.model import IntEL
 from oracle import intel_oracle as O
 
 
-# parameters whose gradient a single flipped relu can move by one whole row: the first linear (weight and bias) of a
-# feed-forward block -- tower W1 (IntEL.py:61,69) and the BERT4Rec blocks' linear1 (layers.py:74)
-RELU_FLIP_PARAMS = ('_W1.weight', '_W1.bias', 'linear1.weight', 'linear1.bias')
+from tests.helpers import relu_flip_forgiven_error
 
 
-def one_case(rng, idx, dev):
+def one_case(rng, idx, dev, big=None):
+    """big: None = decided per case (about one case in 25), True / False = forced.  A 'big' case is the reference's own tower widths
+    (16/16/32/32, script/IntEL.sh:15,21) at lists of 50 / 90 with more than 32 768 candidate rows per batch: the far side of the
+    row-count thresholds of the short-list attention backward and the batched small weight gradients."""
     e = lambda: rng.choice([16, 32, 64])
     flags = dict(model_num=rng.choice([2, 3, 5]), context_emb_size=e(), i_emb_size=e(), u_emb_size=e(), s_emb_size=rng.choice([32, 64, 128]),
                  im_emb_size=e(), intent_emb_size=e(), cross_attn_qsize=rng.choice([16, 64]), num_heads=rng.choice([1, 2]),
@@ -30,6 +31,12 @@ def one_case(rng, idx, dev):
     L = rng.choice([2, 7, 20, 33, 50, 52, 53, 64, 65, 100])
     B = rng.choice([2, 3, 5, 17])
     I = rng.choice([4, 10, 30])
+    if big is None:
+        big = random.Random(7919 * idx + 13).random() < 0.04      # its own generator: the other cases keep their draws
+    if big:
+        flags.update(i_emb_size=16, im_emb_size=16, s_emb_size=32, history_max=min(flags['history_max'], 20))
+        L = rng.choice([50, 90])
+        B = 32768 // L + rng.choice([1, 40, 300])
     H = flags['history_max']
     name = 'fuzz%d' % idx
     synth.WORKLOADS[name] = dict(flags=flags, corpus=dict(items=3000, users=300, classes=40, ctx=50, I=I), batch=dict(L=L, H=H))
@@ -72,24 +79,9 @@ def one_case(rng, idx, dev):
         g = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
         r = sd[k].grad if sd[k].grad is not None else torch.zeros(p.shape)
         tol = 1e-6 + 2e-4 * float(r.abs().max())            # the fixture tests' tolerance
-        diff = (g - r).abs()
-        err = float(diff.max())
-        if err > tol and k.endswith(RELU_FLIP_PARAMS) and diff.shape[0] > 4:
-            # relu-flip: ONE hidden unit of one row rounds to the other side of 0 in the two implementations (the three-plane
-            # bf16 products round differently from the oracle's fmaf chain) and moves exactly one row of that block's first
-            # linear's gradient.  Forgiven ONLY for those parameters, only for a single row (hidden unit), only up to 50x the
-            # tolerance, and only when the oracle's own pre-activation of that unit really touches zero somewhere
-            # (|x| < 1e-6 * max|x|): everything else -- and every other parameter -- must meet the plain tolerance.
-            rows = diff.reshape(diff.shape[0], -1).max(dim=1)[0]
-            unit = int(rows.argmax())
-            rest = torch.cat([rows[:unit], rows[unit + 1:]])
-            pre = taps.get(k.rsplit('.', 1)[0])
-            touches_zero = False
-            if pre is not None:
-                pa = torch.cat([t.reshape(-1, t.shape[-1]) for t in pre]).abs()
-                touches_zero = float(pa[:, unit].min()) < 1e-6 * max(1.0, float(pa.max()))
-            if touches_zero and float(rest.max()) <= tol and err <= 50 * tol:
-                err = float(rest.max())
+        err = float((g - r).abs().max())
+        if err > tol:      # the relu-flip exemption (tests/helpers.py: one row of a first-linear gradient, only when the oracle's pre-activation touches zero)
+            err = relu_flip_forgiven_error(k, g, r, tol, taps)
         if err / tol > worst:
             worst, bad = err / tol, k
     return worst, bad, desc
