@@ -134,6 +134,18 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
                            float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16 = 0);
 
+// ---- the whole tied tower at the reference's own 32-wide shapes, one kernel per direction (tower32.hip) ---------------------------
+// d = 32, 1-2 heads, L <= 128, any number of tied layers; raw (unpacked) reference weights W [32, 32], vectors [32].  No activation stash:
+// the backward recomputes the forward from the tower input.  INTEL_TOWER32=0 turns the path off.
+bool tower32_supported(int L, int d, int heads, int layers, int train);
+size_t tower32_slab_floats(int B);      // arena floats one launch_tower32_bwd takes from the reduce queue
+int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv, const float* W1,
+                       const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* out, hipStream_t st);
+// grads / accumulate: dWq, dWk, dWv, dW1, db1, dW2, db2, dgamma, dbeta (NULL = not wanted); valid after the queue's flush
+int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv,
+                       const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
+                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st);
+
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu
 int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,

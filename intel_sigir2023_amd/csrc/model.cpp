@@ -142,6 +142,7 @@ struct IntelCtx {
   bool params_unchanged = false, pack_ok = false, pack_train = false;
   const void* pack_ws = nullptr;
   int pack_shape[5] = {0, 0, 0, 0, 0};      // B, L, H, Hi, dropout layout
+  bool tw32[2] = {false, false};       // this forward ran tower t as the one-kernel 32-wide tower (tower32.hip): no stash, the backward recomputes
   bool tw_qkv16[2] = {false, false};   // this forward stored tower t's q/k/v stash as bf16 (bf16 mode; the backward reads it and writes dQKV the same way)
   int enc_rows[2];             // rows of encoder e: B * T, or the packed total
 };
@@ -395,6 +396,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += Wf((size_t)B * H, D.d_int, I) + Wf((size_t)B * Hi, D.d_int, I);  // shared intent embedding from the histories
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
+    a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
     a += 2 * (Wf(B, mx, qs) + Wf(B, qs, mx));                             // gate MLPs (cross_attention = 0)
     y.arena_floats = a + 4096;
     y.ARENA = ar.f(y.arena_floats);
@@ -683,6 +685,15 @@ void tower_fwd(Run& r, TowerBufs& w) {
   const IntelDesc& D = r.D;
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
   const float* X = w.X0;
+  const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
+  // the reference's own widths (32-wide towers): ALL tied layers in one kernel, nothing stashed (tower32.hip)
+  r.ctx->tw32[tw_i] = D.layers > 0 && tower32_supported(L, d, D.heads, D.layers, r.train) && !(r.train && r.ctx->drop_p > 0.f);
+  if (r.ctx->tw32[tw_i]) {
+    r.ctx->tw_qkv16[tw_i] = false;
+    RUN(launch_tower32_fwd(X, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1), r.P(pb + T_W2),
+                           r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), w.layer[D.layers - 1].Xout, r.st));
+    return;
+  }
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
   // bf16-mode training: the one-kernel layer leaves its stashes as bf16 arrays, which needs the whole-sequence attention backward
   const bool h16_ok = attn_seq_h16_supported(L, d / D.heads) && (d == 64 || d == 128);
@@ -690,7 +701,6 @@ void tower_fwd(Run& r, TowerBufs& w) {
                      !(r.train && gemm_planes() == 1 && !h16_ok);
   // bf16 mode: q/k/v (and, in the backward, their gradients) live in HBM as bf16 arrays -- every consumer rounds them to bf16
   // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)
-  const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
   r.ctx->tw_qkv16[tw_i] = fused && r.train && gemm_planes() == 1;
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
@@ -746,6 +756,19 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const int M = y.M, d = w.d, B = y.B, L = y.L, pb = w.pbase;
+  if (r.ctx->tw32[&w == &r.y.tw[0] ? 0 : 1]) {      // every tied layer, data and parameter gradients, in one kernel (tower32.hip)
+    static const int slots[9] = {T_WQ, T_WK, T_WV, T_W1, T_B1, T_W2, T_B2, T_LNG, T_LNB};
+    float* g[9];
+    int acc[9];
+    for (int p = 0; p < 9; ++p) {
+      g[p] = r.G(pb + slots[p]);
+      acc[p] = r.acc(pb + slots[p]);
+    }
+    if (!r.ok(launch_tower32_bwd(w.X0, dX, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1),
+                                 r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st)))
+      return nullptr;
+    return dXalt;
+  }
   for (int l = D.layers - 1; l >= 0; --l) {
     TowerLayerBufs& b = w.layer[l];
     const float* Xin = l == 0 ? w.X0 : w.layer[l - 1].Xout;

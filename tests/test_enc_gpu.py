@@ -95,10 +95,10 @@ def _case(history_max, B, seed, train, dtype='f32'):
         # value against the bf16 half-spacing 2^-9: p ~ 2^-13 per element, i.e. ~3 boundary flips per session -- but a flipped element is
         # one of 128 terms of the next product (2^-9 / 128 of its output, far below 3e-5); only a flip in the last few values of a session's
         # chain (the 2 x 128 encoder outputs and the pooled / fused vectors, ~5e2 values) is visible: 5e2 x 2^-13 ~ 0.06 per session.  The
-        # bound is twice that expectation plus two sessions; measured on the GPU box: MEASURE_ME.
+        # bound is that expectation plus two sessions; measured on the GPU box (round 4): 1 of 130, 2 of 70, 5 of 257 sessions.
         n_flip = int(flipped.sum())
         print('bf16 fused-encoder case H=%d B=%d: %d sessions with a visible rounding flip' % (history_max, B, n_flip))
-        assert n_flip <= 2 + int(0.12 * B), (n_flip, B)
+        assert n_flip <= 2 + int(0.06 * B), (n_flip, B)
     if train:
         worst = 0.0
         for k, p in model.named_parameters():
