@@ -2533,11 +2533,12 @@ __global__ __launch_bounds__(256) void slab_reduce_wb_kernel(const float* __rest
 }
 
 // ---- deferred reductions: job queue + one batched kernel per dependency round ----------------
-#define RED_MAX_JOBS 64
+#define RED_MAX_JOBS 56
 struct RedJob {
   const float* slabs; float* out; unsigned long long stride;
   int S, n, cols, ldo;
   int accumulate, mode, blk0, round;
+  int next, pad_;      // next: the job (index in this launch's table, -1 = none) that adds ITS slabs into the same destination right after this one
 };
 struct RedJobs { int n; int pad; RedJob j[RED_MAX_JOBS]; };      // 3.6 KB of kernel arguments
 
@@ -2546,12 +2547,16 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(RedJobs jobs) {
   __shared__ float red[16 * 65];
   int ji = 0;
   while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].blk0) ++ji;
+  const int blk = blockIdx.x - jobs.j[ji].blk0;
+  // a destination shared by several producers (tied layers, the shared intent embedding): their jobs have the same shape and are chained --
+  // the same thread adds them one after the other, in push order, instead of one launch per producer
+  for (int first = 1; ji >= 0; ji = jobs.j[ji].next, first = 0) {
+  if (!first) __syncthreads();                    // `red` is reused
   const float* __restrict__ slabs = jobs.j[ji].slabs;
   float* __restrict__ out = jobs.j[ji].out;
   const size_t stride = jobs.j[ji].stride;
   const int S = jobs.j[ji].S, n = jobs.j[ji].n, cols = jobs.j[ji].cols, ldo = jobs.j[ji].ldo;
-  const int accumulate = jobs.j[ji].accumulate, mode = jobs.j[ji].mode;
-  const int blk = blockIdx.x - jobs.j[ji].blk0;
+  const int accumulate = first ? jobs.j[ji].accumulate : 1, mode = jobs.j[ji].mode;
   if (mode == 0) {
     const int o = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int i0 = (blk * 16 + o) * 4;
@@ -2630,6 +2635,7 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(RedJobs jobs) {
       *dst = accumulate ? (*dst + acc) : acc;
     }
   }
+  }
 }
 
 struct ReduceQueue {
@@ -2681,33 +2687,91 @@ void redq_push(ReduceQueue* q, const float* slabs, size_t stride, int S, int row
 // tag < 0: every job, then the arena is free again; tag >= 0: the jobs pushed under that tag only (a branch reduces its own weight
 // gradients on its own stream as soon as it has produced them; destinations shared between branches must stay untagged)
 static int redq_flush_impl(ReduceQueue* q, int tag, hipStream_t st) {
-  for (int rnd = 0; rnd <= q->max_round; ++rnd) {
-    RedJobs jb;
-    jb.n = 0; jb.pad = 0;
-    int blocks = 0;
-    double bytes = 0.0;
-    auto fire = [&]() -> int {
-      if (jb.n == 0) return 0;
+  // the jobs of this flush in push order; their rounds are recomputed among themselves (a destination that overlaps an earlier job
+  // is reduced after it) -- except that jobs of IDENTICAL shape on the same destination are chained behind the first one: one
+  // launch, the same thread adds them in push order
+  std::vector<int> sel;
+  for (size_t ji = 0; ji < q->jobs.size(); ++ji)
+    if (tag < 0 || q->tags[ji] == tag) sel.push_back((int)ji);
+  const int ns = (int)sel.size();
+  std::vector<int> eff(ns, 0), head(ns, -1), nxt(ns, -1);
+  int max_eff = -1;
+  auto span_hi = [](const RedJob& e) { return e.out + (size_t)(e.n / e.cols - 1) * e.ldo + e.cols; };
+  for (int a = 0; a < ns; ++a) {
+    const RedJob& f = q->jobs[sel[a]];
+    bool all_same = true;
+    int first = -1, rmax = -1;
+    for (int b = 0; b < a; ++b) {
+      const RedJob& e = q->jobs[sel[b]];
+      if (!(f.out < span_hi(e) && e.out < span_hi(f))) continue;
+      if (!(e.out == f.out && e.n == f.n && e.cols == f.cols && e.ldo == f.ldo)) all_same = false;
+      if (first < 0) first = b;
+      if (eff[b] > rmax) rmax = eff[b];
+    }
+    if (first >= 0 && all_same) {
+      const int h = head[first] >= 0 ? head[first] : first;
+      head[a] = h;
+      eff[a] = eff[h];
+      int t = h;
+      while (nxt[t] >= 0) t = nxt[t];
+      nxt[t] = a;
+    } else {
+      eff[a] = rmax + 1;
+    }
+    if (eff[a] > max_eff) max_eff = eff[a];
+  }
+  for (int rnd = 0; rnd <= max_eff; ++rnd) {
+    // chains are kept whole within one launch: heads first (they own the blocks), chained jobs behind them in the table
+    std::vector<int> heads;
+    for (int a = 0; a < ns; ++a)
+      if (eff[a] == rnd && head[a] < 0) heads.push_back(a);
+    size_t hi = 0;
+    while (hi < heads.size()) {
+      RedJobs jb;
+      jb.n = 0; jb.pad = 0;
+      int blocks = 0;
+      double bytes = 0.0;
+      std::vector<int> members;      // sel indices in table order
+      size_t h2 = hi;
+      int used = 0;
+      for (; h2 < heads.size(); ++h2) {
+        int len = 0;
+        for (int t = heads[h2]; t >= 0; t = nxt[t]) ++len;
+        if (used + len > RED_MAX_JOBS) break;
+        used += len;
+      }
+      if (h2 == hi) { intel_set_error("slab reduction: a chain of more than %d jobs on one destination", RED_MAX_JOBS); return -1; }
+      const int nh = (int)(h2 - hi);
+      // table: [heads ... | chained jobs ...]
+      std::vector<int> pos(ns, -1);
+      int at = 0;
+      for (size_t k = hi; k < h2; ++k) pos[heads[k]] = at++;
+      for (size_t k = hi; k < h2; ++k)
+        for (int t = nxt[heads[k]]; t >= 0; t = nxt[t]) pos[t] = at++;
+      for (size_t k = hi; k < h2; ++k) {
+        for (int t = heads[k]; t >= 0; t = nxt[t]) {
+          RedJob j = q->jobs[sel[t]];
+          // the members of a chain must map threads to outputs identically: where their strategies differ, all take the scalar one
+          for (int u = heads[k]; u >= 0; u = nxt[u])
+            if (q->jobs[sel[u]].mode != q->jobs[sel[heads[k]]].mode) j.mode = 1;
+          j.next = nxt[t] >= 0 ? pos[nxt[t]] : -1;
+          j.pad_ = 0;
+          if (t == heads[k]) {
+            j.blk0 = blocks;
+            blocks += cdiv(j.n, j.mode == 0 ? 64 : (j.mode == 1 ? 16 : 4));
+          } else {
+            j.blk0 = 0x7fffffff;
+          }
+          bytes += 4.0 * (double)j.S * j.n;
+          jb.j[pos[t]] = j;
+        }
+      }
+      jb.n = nh;      // the kernel searches the heads only; chained entries are reached through `next`
+      (void)used;
       LAUNCH_W(0.0, bytes, slab_reduce_batch_kernel, dim3(blocks), dim3(256), 0, st, jb);
       INTEL_CHECK_LAUNCH();
-      jb.n = 0; blocks = 0; bytes = 0.0;
-      return 0;
-    };
-    for (size_t ji = 0; ji < q->jobs.size(); ++ji) {
-      const RedJob& e = q->jobs[ji];
-      if (e.round != rnd || (tag >= 0 && q->tags[ji] != tag)) continue;
-      if (jb.n == RED_MAX_JOBS) {
-        int rc = fire();
-        if (rc) return rc;
-      }
-      RedJob j = e;
-      j.blk0 = blocks;
-      blocks += cdiv(j.n, j.mode == 0 ? 64 : (j.mode == 1 ? 16 : 4));
-      bytes += 4.0 * (double)j.S * j.n;
-      jb.j[jb.n++] = j;
+      hi = h2;
     }
-    int rc = fire();
-    if (rc) return rc;
   }
   if (tag < 0) {
     q->jobs.clear();

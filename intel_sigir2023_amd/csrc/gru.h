@@ -10,7 +10,11 @@ struct GruBufs {
   float *GI, *HP, *GATES, *GHN, *GH, *HCUR;
   // backward
   float *dGI, *dGH, *dHa, *dHb, *dVEC;
+  // the bias-free output projection vec = h_last Wout^T (GeneralSeq.py:76) is done by the caller (model.cpp: the session-head chains read
+  // HCUR [B, H] and write dHa [B, H]): gru_fwd stops at HCUR, gru_bwd starts from dHa and leaves dWout alone
+  bool ext_proj = false;
 };
+bool gru_ext_proj_supported(int dm, int Hd);
 struct GruGrads { float *dWih, *dWhh, *dbih, *dbhh, *dWout; };
 
 void gru_layout_packed(GruBufs& g, int dm, int Hd, char* base, size_t& off);

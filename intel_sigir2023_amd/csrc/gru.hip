@@ -294,6 +294,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
         }
       }
       if (STASH && b < B && t + 1 < (off ? lr[r] : T)) HP[(row + 1) * GS_H + unit] = h[r];      // packed: row t+1 exists only below len
+      if (STASH && t == 0 && b < B && (off ? lr[r] > 0 : true)) HP[row * GS_H + unit] = 0.f;      // h_0 = 0: the first row of every session (no separate fill launch)
     }
     gs_lds_barrier();                     // every wave has read h_{t-1}
 #pragma unroll
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
       // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
       // (padded rows only: packed histories have no rows past len)
       for (int t = max(tmax, 0); t + 1 < T && !off && STASH; ++t) HP[((size_t)b * T + t + 1) * GS_H + unit] = h[r];
+      if (STASH && !off && tmax <= 0) HP[(size_t)b * T * GS_H + unit] = 0.f;      // (the time loop, which writes h_0 = 0, did not run at all)
     }
   }
 }
@@ -482,6 +484,7 @@ static bool gru_seq_on(int Hd, const float* Whh) {
 }
 
 bool gru_packed_supported(int Hd) { return gru_seq_mode() != 0 && Hd == GS_H; }
+bool gru_ext_proj_supported(int dm, int Hd) { return gru_seq_mode() != 0 && Hd == GS_H && dm % 16 == 0; }
 
 int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int* len, const float* bih, const float* bhh,
             float* out, int ldo, int col0, hipStream_t st, const float* Whh, const int* off, int rows, const int* order, bool stash) {
@@ -492,7 +495,6 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     GemmEpilogue ei;
     ei.bias = bih;
     if ((rc = launch_gemm_rows(E0, dm, rows, dm, g.pWih, 3 * Hd, g.GI, 3 * Hd, ei, st))) return rc;
-    if (stash && (rc = launch_fill(g.HP, (long long)rows * Hd, 0.f, st))) return rc;       // h_0 = 0 (the first row of every session)
     if (gru_seq_mode() == 1)
       LAUNCH(gru_seq_fwd_kernel<false>, dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     else if (stash)
@@ -500,6 +502,7 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     else
       LAUNCH((gru_seq_fwd_kernel<true, false>), dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     INTEL_CHECK_LAUNCH();
+    if (g.ext_proj) return 0;
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);
   }
@@ -536,10 +539,10 @@ int gru_bwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
   INTEL_CHECK_ARG(!off || gru_seq_on(Hd, Whh), "gru: packed history rows need the one-kernel recurrence (hidden size 128, aligned W_hh)");
   int rc;
   // vec = HCUR Wout^T
-  if (gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st, q))) return rc;
+  if (!g.ext_proj && gg.dWout && (rc = launch_wgrad(dout + col0, ldo, g.HCUR, Hd, B, dm, Hd, gg.dWout, Hd, nullptr, 0, slabs, st, q))) return rc;
   GemmEpilogue e0;
   float *dH = g.dHa, *dHn = g.dHb;
-  if ((rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
+  if (!g.ext_proj && (rc = launch_gemm_rows(dout + col0, ldo, B, dm, g.pWoutT, Hd, dH, Hd, e0, st))) return rc;
   const bool seq = gru_seq_on(Hd, Whh);
   if (seq) {
     if (gru_seq_mode() == 1)

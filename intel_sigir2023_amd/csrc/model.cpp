@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <functional>
 #include <new>
 #include <vector>
@@ -18,6 +19,7 @@
 #include "session.h"
 #include "gru.h"
 #include "enc.h"
+#include "chain.h"
 
 #define MAX_TOWER_LAYERS 8
 
@@ -397,6 +399,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
+    a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
+                                rup_sz((size_t)d_i * d_i + (size_t)d_s * d_s + (size_t)(d_i + d_s) * I + (size_t)I * y.Pin + I, 64) + 64 +
+                                rup_sz((size_t)(dm0 + dm1) * (size_t)gh, 64));      // session-head chains (chain.hip)
     a += 2 * (Wf(B, mx, qs) + Wf(B, qs, mx));                             // gate MLPs (cross_attention = 0)
     y.arena_floats = a + 4096;
     y.ARENA = ar.f(y.arena_floats);
@@ -588,7 +593,8 @@ void pack_all(Run& r) {
   // bf16 three-plane images of the K > 128 weights (data gradients through the fused q/k/v weights)
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
-    RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
+    if (!(D.layers > 0 && tower32_supported(y.L, w.d, D.heads, D.layers, r.train) && !(r.train && r.ctx->drop_p > 0.f)))      // (tower32.hip reads the raw weights)
+      RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
     if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train, w.d)) {
       RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
       RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
@@ -1144,6 +1150,287 @@ float* bert_bwd(Run& r, int e) {
   return dX;
 }
 
+
+// ---- the session head as B-row chains (chain.hip) -------------------------------------------------------------------------------
+// IntEL.py:147-153 (intent prediction) and :201-215 (pooling queries, fusion weights, score aggregation) are ~13 dependent small
+// launches forward and ~20 backward on one row per session.  With per-session fusion weights (the reference's default:
+// --cross_attention 1, no weight normalisation) they run as two chain launches per direction around the pooling kernels; every
+// buffer a later launch reads (the stash, the operands of the deferred weight-gradient products) is written as before.
+// INTEL_HEAD_FUSED=0 keeps the kernel-per-op head.
+static bool head_fused_ok(const IntelDesc& D, const Layout& y) {
+  static const int on = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
+  if (!on || !D.cross_attention || D.pool_mean || D.weight_norm != 0 || D.model_num > 16) return false;
+  if (D.dtype != INTEL_DTYPE_F32) return false;      // bf16 mode rounds the operands of the 64 / 128-deep B-row products (oracle.forward_bf16): kernel-per-op head
+  if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
+  // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
+  const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
+  size_t w = Pp + 2 * Ip + D.d_u + D.d_int + 8 + 2 * dd;                                   // forward a
+  w = std::max(w, 2 * 20 + 2 * Fp + 2 * ((size_t)D.d_int + 4) + 2 * Ip + 2 * dd);          // backward a
+  w = std::max(w, 5 * Ip + 2 * Pp + 3 * dd);                                                // backward b
+  return 16 * w * sizeof(float) < 150 * 1024;
+}
+
+static void chain_run(Run& r, ChainPlan& p) {
+  if (!p.ok) {
+    intel_set_error("session-head chain: op table / tile layout overflow");
+    r.ok(INTEL_E_ARG);
+    return;
+  }
+  p.a.B = r.y.B;
+  std::stable_sort(p.a.ops, p.a.ops + p.a.nops, [](const ChainOp& x, const ChainOp& z) { return x.level < z.level; });      // the kernel walks level by level
+  r.ok(launch_chain(p.a, (size_t)p.lds, r.st));
+}
+
+// forward a: [ctx | user | encoder outputs] -> intent logits -> softmax -> relu(h_intent), relu(h_u), pooling queries QV, QK of both towers
+static void head_fwd_a(Run& r, const IntelOut* out) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const IntelBatch& bt = *r.bt;
+  const int I = D.intent_num, Pin = y.Pin, F = y.F;
+  TowerBufs &ti = y.tw[0], &ts = y.tw[1];
+  const int off_u = ti.d + ts.d, off_int = off_u + D.d_u, enc0 = D.d_c + D.d_u;
+  ChainPlan p;
+  ChainTile PRED = p.tile(Pin), LOG = p.tile(I), INT = p.tile(I), HU = p.tile(D.d_u), HI = p.tile(D.d_int);
+  ChainTile QV[2] = {p.tile(ti.d), p.tile(ts.d)}, QK[2] = {p.tile(ti.d), p.tile(ts.d)};
+  p.load(0, r.P(INTEL_P_CTX_EMB), D.d_c, 0, D.d_c, PRED, 0, 0, bt.context_mh, false, y.PREDIN, Pin, 0);
+  p.load(0, r.P(INTEL_P_UID_EMB), D.d_u, 0, D.d_u, PRED, D.d_c, 0, bt.u_id_c, false, y.PREDIN, Pin, D.d_c);
+  int lv = 1;
+  if (D.encoder == INTEL_ENC_GRU4REC && y.enc[0].gru.ext_proj && y.enc[1].gru.ext_proj) {
+    // GRU4Rec: the encoders stop at their last hidden state; vec = h_last Wout^T (GeneralSeq.py:76) is the chain's first link
+    if (Pin > enc0 + y.enc[0].dm + y.enc[1].dm || PRED.width > Pin) p.load(0, y.PREDIN, Pin, Pin, 0, PRED, Pin, PRED.width - Pin);      // (zero padding)
+    for (int e = 0; e < 2; ++e) {
+      EncBufs& n = y.enc[e];
+      ChainTile HC = p.tile(D.gru_hidden);
+      p.load(0, n.gru.HCUR, D.gru_hidden, 0, D.gru_hidden, HC, 0);
+      p.lin(1, HC, 0, D.gru_hidden, n.gru.pWout, n.dm, nullptr, PRED, n.predin_off, 0, y.PREDIN, Pin, n.predin_off);
+    }
+    lv = 2;
+  } else {
+    p.load(0, y.PREDIN, Pin, enc0, Pin - enc0, PRED, enc0, PRED.width - enc0);
+  }
+  p.load(0, r.P(INTEL_P_UID_EMB), D.d_u, 0, D.d_u, HU, 0, 0, bt.u_id_c, true, y.FEAT, F, off_u);      // relu(h_u), IntEL.py:178
+  p.lin(lv, PRED, 0, Pin, y.pPred, I, r.P(INTEL_P_PRED_B), LOG, 0);
+  {
+    ChainOp& o = p.add(CH_SOFTMAX, lv + 1);
+    o.in_off = LOG.off; o.in_ld = LOG.ld; o.out_off = INT.off; o.out_ld = INT.ld; o.N = I; o.NP = INT.width;
+    o.gout = y.INTENTS; o.gld = I; o.gcol = 0; o.gout2 = out->intents;
+  }
+  p.lin(lv + 2, INT, 0, I, y.pInt, D.d_int, r.P(INTEL_P_INTENT_B), HI, 0, CH_RELU, y.FEAT, F, off_int);     // relu(h_intent), IntEL.py:212
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    p.lin(lv + 2, INT, 0, I, w.pXq, w.d, nullptr, QV[t], 0, 0, w.QV, w.d, 0);
+    p.lin(lv + 3, QV[t], 0, w.d, w.pXkT, w.d, nullptr, QK[t], 0, 0, w.QK, w.d, 0);
+  }
+  chain_run(r, p);
+}
+
+// forward b: pooled value projections -> fusion feature -> weight_embeddings (valid rows / pad rows) -> weights, ens_score
+static void head_fwd_b(Run& r, const IntelOut* out) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const IntelBatch& bt = *r.bt;
+  const int K = D.model_num, F = y.F;
+  TowerBufs &ti = y.tw[0], &ts = y.tw[1];
+  const int off_u = ti.d + ts.d, npad = D.d_u + D.d_int;
+  ChainPlan p;
+  ChainTile XB[2] = {p.tile(ti.d), p.tile(ts.d)}, FEAT = p.tile(F), WV = p.tile(16), WP = p.tile(16);
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    p.load(0, w.XBAR, w.d, 0, w.d, XB[t], 0);
+    p.lin(1, XB[t], 0, w.d, w.pXv, w.d, nullptr, FEAT, w.feat_off, 0, y.FEAT, F, w.feat_off);
+  }
+  p.load(0, y.FEAT, F, off_u, npad, FEAT, off_u, FEAT.width - off_u);
+  p.lin(2, FEAT, 0, F, y.pWe, K, r.P(INTEL_P_WE_B), WV, 0, 0, y.WV, K, 0);
+  p.lin(2, FEAT, off_u, npad, y.pWePad, K, r.P(INTEL_P_WE_B), WP, 0, 0, y.WPAD, K, 0);
+  {
+    ChainOp& o = p.add(CH_ENS_FWD, 3);
+    o.in_off = WV.off; o.in_ld = WV.ld; o.aux_off = WP.off; o.aux_ld = WP.ld;
+    p.a.ens.scores = bt.scores; p.a.ens.slen = bt.session_len; p.a.ens.L = y.L; p.a.ens.K = K;
+    p.a.ens.weights = out->weights; p.a.ens.ens = out->ens_score;
+  }
+  chain_run(r, p);
+}
+
+// backward a: d(weights), d(ens_score) -> d(fusion weights) -> dFEAT -> d(h_intent) -> first share of d(intent); d(pooled) -> dxbar of both towers
+static void head_bwd_a(Run& r, const float* d_weights, const float* d_ens) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const IntelBatch& bt = *r.bt;
+  const int I = D.intent_num, K = D.model_num, F = y.F;
+  TowerBufs &ti = y.tw[0], &ts = y.tw[1];
+  const int off_u = ti.d + ts.d, off_int = off_u + D.d_u, npad = D.d_u + D.d_int;
+  ChainPlan p;
+  ChainTile DWV = p.tile(16), DWP = p.tile(16), DF = p.tile(F), MASK = p.tile(D.d_int), DH = p.tile(D.d_int), DI = p.tile(I);
+  ChainTile G1[2] = {p.tile(ti.d), p.tile(ts.d)};
+  {
+    ChainOp& o = p.add(CH_ENS_BWD, 0);
+    o.out_off = DWV.off; o.out_ld = DWV.ld; o.aux_off = DWP.off; o.aux_ld = DWP.ld;
+    p.a.ens.scores = bt.scores; p.a.ens.slen = bt.session_len; p.a.ens.L = y.L; p.a.ens.K = K;
+    p.a.ens.d_weights = d_weights; p.a.ens.d_ens = d_ens; p.a.ens.dwv = y.dWV; p.a.ens.dwpad = y.dWPAD;
+  }
+  p.load(0, y.FEAT, F, off_int, D.d_int, MASK, 0);
+  p.lin(1, DWV, 0, K, y.pWeT, F, nullptr, DF, 0, 0, y.dFEAT, F, 0);
+  p.lin(2, DWP, 0, K, y.pWePadT, npad, nullptr, DF, off_u, CH_ACCUM, y.dFEAT, F, off_u);      // padded rows only see [h_u | h_intent]
+  {
+    ChainOp& o = p.add(CH_MASKCOPY, 3);
+    o.in_off = DF.off + off_int; o.in_ld = DF.ld; o.aux_off = MASK.off; o.aux_ld = MASK.ld; o.out_off = DH.off; o.out_ld = DH.ld;
+    o.N = D.d_int; o.NP = DH.width; o.gout = y.dHINT; o.gld = D.d_int; o.gcol = 0;
+  }
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    p.lin(3, DF, w.feat_off, w.d, w.pXvT, w.d, nullptr, G1[t], 0, 0, y.dHB[t][0], w.d, 0);      // dxbar
+  }
+  p.lin(4, DH, 0, D.d_int, y.pIntT, I, nullptr, DI, 0, 0, y.dINTENT, I, 0);
+  chain_run(r, p);
+}
+
+// the weight gradients of head_bwd_a's links -- weight_embeddings (valid + pad rows), intent_embeddings (h_intent's share), the two
+// value projections of the pooling -- as their own chain launch: LEAVES of the backward (nothing reads them before the optimizer),
+// issued on a side stream so that they do not lengthen the critical chain.  One partial per workgroup -> the reduce queue (final flush).
+static void head_bwd_a_leaves(Run& r) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const int I = D.intent_num, K = D.model_num, F = y.F;
+  TowerBufs &ti = y.tw[0], &ts = y.tw[1];
+  const int off_u = ti.d + ts.d, npad = D.d_u + D.d_int;
+  ChainPlan p;
+  const int S = cdiv(y.B, 16);
+  const int o_we = 0, o_be = o_we + K * F, o_wi = o_be + K, o_bi = o_wi + D.d_int * I, o_v0 = o_bi + D.d_int, o_v1 = o_v0 + ti.d * ti.d,
+            stride = (int)rup_sz((size_t)o_v1 + ts.d * ts.d, 64);
+  float* slab = redq_alloc(r.ctx->rq, (size_t)S * stride);
+  if (!slab) { intel_set_error("head_bwd_a: reduction arena exhausted"); r.ok(INTEL_E_WORKSPACE); return; }
+  const bool g_we = r.G(INTEL_P_WE_W) != nullptr, g_wi = r.G(INTEL_P_INTENT_W) != nullptr;
+  if (g_we) {
+    ChainTile FE = p.tile(F), DWV = p.tile(16), DWP = p.tile(16);
+    p.load(0, y.FEAT, F, 0, F, FE, 0, FE.width);
+    p.load(0, y.dWV, K, 0, K, DWV, 0, DWV.width);
+    p.load(0, y.dWPAD, K, 0, K, DWP, 0, DWP.width);
+    p.wgrad(1, DWV, 0, K, FE, 0, F, slab + o_we, F, 0, stride, slab + o_be);
+    p.wgrad(2, DWP, 0, K, FE, off_u, npad, slab + o_we, F, off_u, stride, slab + o_be, true);      // padded rows only see [h_u | h_intent]
+    const int a = r.acc(INTEL_P_WE_W), ab = r.acc(INTEL_P_WE_B);
+    redq_push(r.ctx->rq, slab + o_we, stride, S, K, F, r.G(INTEL_P_WE_W), F, a);
+    redq_push(r.ctx->rq, slab + o_be, stride, S, 1, K, r.G(INTEL_P_WE_B), K, ab);
+  }
+  if (g_wi) {
+    ChainTile IN = p.tile(I), DH = p.tile(D.d_int);
+    p.load(0, y.INTENTS, I, 0, I, IN, 0, IN.width);
+    p.load(0, y.dHINT, D.d_int, 0, D.d_int, DH, 0, DH.width);
+    p.wgrad(1, DH, 0, D.d_int, IN, 0, I, slab + o_wi, I, 0, stride, slab + o_bi);
+    const int a = r.acc(INTEL_P_INTENT_W), ab = r.acc(INTEL_P_INTENT_B);
+    redq_push(r.ctx->rq, slab + o_wi, stride, S, D.d_int, I, r.G(INTEL_P_INTENT_W), I, a);
+    redq_push(r.ctx->rq, slab + o_bi, stride, S, 1, D.d_int, r.G(INTEL_P_INTENT_B), D.d_int, ab);
+  }
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    if (!r.G(w.xbase + 2)) continue;
+    ChainTile XB = p.tile(w.d), DFt = p.tile(w.d);
+    p.load(0, w.XBAR, w.d, 0, w.d, XB, 0);
+    p.load(0, y.dFEAT, F, w.feat_off, w.d, DFt, 0);
+    p.wgrad(1, DFt, 0, w.d, XB, 0, w.d, slab + (t == 0 ? o_v0 : o_v1), w.d, 0, stride);      // pooled = xbar Wv^T
+    redq_push(r.ctx->rq, slab + (t == 0 ? o_v0 : o_v1), stride, S, w.d, w.d, r.G(w.xbase + 2), w.d, r.acc(w.xbase + 2));
+  }
+  if (p.a.nops) chain_run(r, p);
+}
+
+// backward b: dQK of both towers -> dQV -> their shares of d(intent); + the intent loss's own gradient; softmax backward; d(pred_layer input)
+static void head_bwd_b(Run& r, const float* d_intents) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const int I = D.intent_num, Pin = y.Pin;
+  ChainPlan p;
+  ChainTile DA = p.tile(I), DB = p.tile(I), DC = p.tile(I), Y = p.tile(I), DL = p.tile(I), DP = p.tile(Pin);
+  ChainTile G2[2] = {p.tile(y.tw[0].d), p.tile(y.tw[1].d)}, G3[2] = {p.tile(y.tw[0].d), p.tile(y.tw[1].d)};
+  p.load(0, y.dINTENT, I, 0, I, DA, 0, DA.width);
+  p.load(0, y.INTENTS, I, 0, I, Y, 0, Y.width);
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    p.load(0, y.dHB[t][1], w.d, 0, w.d, G2[t], 0);
+    p.lin(1, G2[t], 0, w.d, w.pXk, w.d, nullptr, G3[t], 0, 0, y.dHB[t][2], w.d, 0);            // dQV
+    p.lin(2, G3[t], 0, w.d, w.pXqT, I, nullptr, t == 0 ? DB : DC, 0);
+  }
+  {
+    ChainOp& o = p.add(CH_SOFTMAX_BWD, 3);
+    o.in_off = DA.off; o.in_ld = DA.ld; o.in2_off = DB.off; o.in3_off = DC.off; o.aux_off = Y.off; o.aux_ld = Y.ld;
+    o.out_off = DL.off; o.out_ld = DL.ld; o.N = I; o.NP = DL.width; o.gadd = d_intents;
+    o.gout = y.dLOGITS; o.gld = I; o.gcol = 0;
+  }
+  p.lin(4, DL, 0, I, y.pPredT, Pin, nullptr, DP, 0, 0, y.dPREDIN, Pin, 0);
+  const bool gru_ext = D.encoder == INTEL_ENC_GRU4REC && y.enc[0].gru.ext_proj && y.enc[1].gru.ext_proj;
+  if (gru_ext) {
+    // GRU4Rec: d(h_last) = d(vec) Wout, d(vec) = the encoder's columns of d(pred_layer input)
+    for (int e = 0; e < 2; ++e) {
+      EncBufs& n = y.enc[e];
+      ChainTile DH = p.tile(D.gru_hidden);
+      p.lin(5, DP, n.predin_off, n.dm, n.gru.pWoutT, D.gru_hidden, nullptr, DH, 0, 0, n.gru.dHa, D.gru_hidden, 0);
+    }
+  }
+  chain_run(r, p);
+}
+
+// the weight gradients of head_bwd_b's links (key / query projections of both poolings, pred_layer, the GRU output projections) as a
+// leaf chain launch (see head_bwd_a_leaves)
+static void head_bwd_b_leaves(Run& r) {
+  const IntelDesc& D = r.D;
+  Layout& y = r.y;
+  const int I = D.intent_num, Pin = y.Pin;
+  ChainPlan p;
+  const int S = cdiv(y.B, 16);
+  int off = 0;
+  int o_k[2], o_q[2];
+  for (int t = 0; t < 2; ++t) { o_k[t] = off; off += y.tw[t].d * y.tw[t].d; o_q[t] = off; off += y.tw[t].d * I; }
+  const int o_wp = off, o_bp = o_wp + I * Pin;
+  const bool gru_ext = D.encoder == INTEL_ENC_GRU4REC && y.enc[0].gru.ext_proj && y.enc[1].gru.ext_proj;
+  int o_go[2] = {0, 0};
+  o_go[0] = (int)rup_sz((size_t)o_bp + I, 64);
+  o_go[1] = o_go[0] + (gru_ext ? y.enc[0].dm * D.gru_hidden : 0);
+  const int stride = o_go[1] + (gru_ext ? (int)rup_sz((size_t)y.enc[1].dm * D.gru_hidden, 64) : 0);
+  float* slab = redq_alloc(r.ctx->rq, (size_t)S * stride);
+  if (!slab) { intel_set_error("head_bwd_b: reduction arena exhausted"); r.ok(INTEL_E_WORKSPACE); return; }
+  ChainTile Y{0, 0, 0};
+  bool haveY = false;
+  for (int t = 0; t < 2; ++t) {
+    TowerBufs& w = y.tw[t];
+    if (r.G(w.xbase + 1)) {          // QK = QV Wk: dWk[i][j] = sum_b QV[b][i] dQK[b][j]
+      ChainTile QVt = p.tile(w.d), G2 = p.tile(w.d);
+      p.load(0, w.QV, w.d, 0, w.d, QVt, 0);
+      p.load(0, y.dHB[t][1], w.d, 0, w.d, G2, 0);
+      p.wgrad(1, QVt, 0, w.d, G2, 0, w.d, slab + o_k[t], w.d, 0, stride);
+      redq_push(r.ctx->rq, slab + o_k[t], stride, S, w.d, w.d, r.G(w.xbase + 1), w.d, r.acc(w.xbase + 1));
+    }
+    if (r.G(w.xbase + 0)) {          // QV = intent Wq^T
+      if (!haveY) { Y = p.tile(I); p.load(0, y.INTENTS, I, 0, I, Y, 0, Y.width); haveY = true; }
+      ChainTile G3 = p.tile(w.d);
+      p.load(0, y.dHB[t][2], w.d, 0, w.d, G3, 0);
+      p.wgrad(1, G3, 0, w.d, Y, 0, I, slab + o_q[t], I, 0, stride);
+      redq_push(r.ctx->rq, slab + o_q[t], stride, S, w.d, I, r.G(w.xbase + 0), I, r.acc(w.xbase + 0));
+    }
+  }
+  ChainTile DPt{0, 0, 0};
+  if (r.G(INTEL_P_PRED_W)) {
+    ChainTile PR = p.tile(Pin), DL = p.tile(I);
+    p.load(0, y.PREDIN, Pin, 0, Pin, PR, 0, PR.width);
+    p.load(0, y.dLOGITS, I, 0, I, DL, 0, DL.width);
+    p.wgrad(1, DL, 0, I, PR, 0, Pin, slab + o_wp, Pin, 0, stride, slab + o_bp);
+    const int a = r.acc(INTEL_P_PRED_W), ab = r.acc(INTEL_P_PRED_B);
+    redq_push(r.ctx->rq, slab + o_wp, stride, S, I, Pin, r.G(INTEL_P_PRED_W), Pin, a);
+    redq_push(r.ctx->rq, slab + o_bp, stride, S, 1, I, r.G(INTEL_P_PRED_B), I, ab);
+  }
+  if (gru_ext) {      // dWout = d(vec)^T h_last
+    for (int e = 0; e < 2; ++e) {
+      EncBufs& n = y.enc[e];
+      const int Hd = D.gru_hidden, ws = enc_slot(e, INTEL_ENC_GRU_OUT);
+      if (!r.G(ws)) continue;
+      ChainTile HC = p.tile(Hd), DV = p.tile(n.dm);
+      p.load(0, n.gru.HCUR, Hd, 0, Hd, HC, 0);
+      p.load(0, y.dPREDIN, Pin, n.predin_off, n.dm, DV, 0, DV.width);
+      p.wgrad(1, DV, 0, n.dm, HC, 0, Hd, slab + o_go[e], Hd, 0, stride);
+      redq_push(r.ctx->rq, slab + o_go[e], stride, S, n.dm, Hd, r.G(ws), Hd, r.acc(ws));
+    }
+  }
+  (void)DPt;
+  if (p.a.nops) chain_run(r, p);
+}
+
 // ---- forward ------------------------------------------------------------------------------------
 void forward_impl(Run& r, const IntelOut* out) {
   const IntelDesc& D = r.D;
@@ -1152,6 +1439,8 @@ void forward_impl(Run& r, const IntelOut* out) {
   const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
   // the side branches start with work that needs no packed weights (history packing, embedding gathers): they fork BEFORE the
   // packing launches of the main stream and wait for them (ev_pack) in front of their first matrix product
+  for (int e = 0; e < 2; ++e)      // GRU4Rec with the fused session head: the output projections are links of the head's chains
+    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
   fork_streams(r, 3);
   hipEvent_t ev_pack = r.ctx->ev_x[0];
   {
@@ -1252,6 +1541,32 @@ void forward_impl(Run& r, const IntelOut* out) {
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
   if (r.rc) return;
+  if (head_fused_ok(D, y)) {
+    // the session head as two chain launches around the two pooling kernels (chain.hip)
+    const float scale = 1.0f / sqrtf((float)D.q_size);
+    head_fwd_a(r, out);
+    if (r.rc) return;
+    fork_streams(r, 1);
+    {
+      Run b1 = branch(r, 0, 1);
+      for (int t = 1; t >= 0; --t) {
+        Run& q = t == 1 ? b1 : r;
+        TowerBufs& w = y.tw[t];
+        wait_side(q, 1 + t, q.st);                 // tower t ran on side stream 1 + t
+        if (tail_fusable(r.ctx, D, L, w.d, r.train)) {
+          q.ok(launch_xatt_pool_fwd(w.layer[D.layers - 1].XH, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, q.st,
+                                    r.P(w.pbase + T_LNG), r.P(w.pbase + T_LNB)));
+        } else {
+          q.ok(launch_xatt_pool_fwd(D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0, B, L, w.d, w.QK, bt.session_len, scale, w.XBAR, w.ATTW, q.st));
+        }
+      }
+      r.ok(b1.rc);
+    }
+    join_streams(r, 1);
+    if (r.rc) return;
+    head_fwd_b(r, out);
+    return;
+  }
   RUN(launch_gather_rows(r.P(INTEL_P_CTX_EMB), D.d_c, bt.context_mh, B, y.PREDIN, y.Pin, 0, 0, r.st));
   RUN(launch_gather_rows(r.P(INTEL_P_UID_EMB), D.d_u, bt.u_id_c, B, y.PREDIN, y.Pin, D.d_c, 0, r.st));
   {
@@ -1389,6 +1704,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     redq_set_tag(r.ctx->rq, tag);
     v.clear();
   };
+  // the session head's data-gradient chain as two chain launches around the pooling backward (chain.hip): one-call schedule only
+  const bool hfused = wide && head_fused_ok(D, y);
+  if (!hfused)      // (the forward may have left the GRU output projections to its chains: this backward does them in gru_bwd)
+    for (int e = 0; e < 2; ++e) y.enc[e].gru.ext_proj = false;
   if (phase != 2) {
     memset(r.ctx->touched, 0, sizeof(r.ctx->touched));
     // embedding tables accumulate with atomics into caller-zeroed buffers
@@ -1396,7 +1715,12 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ctx->touched[INTEL_P_UID_EMB] = r.ctx->touched[INTEL_P_CTX_EMB] = 1;
 
     // ===== fusion weights + aggregation (IntEL.py:212-215)
-    if (per_session_weights(D)) {
+    if (hfused) {
+      // dWV, dWPAD, dFEAT, dHINT, first share of d(intent), dxbar of both towers + the weight gradients of weight_embeddings,
+      // intent_embeddings (h_intent's share) and the pooling value projections
+      head_bwd_a(r, d_weights, d_ens);
+      if (r.rc) return;
+    } else if (per_session_weights(D)) {
       RUN(launch_ens_bwd(d_weights, d_ens, bt.scores, bt.session_len, B, L, K, 0, y.dWV, y.dWPAD, nullptr, r.st));
       if (D.pool_mean) RUN(launch_add2(y.dWV, y.dWPAD, (long long)B * K, y.dWV, r.st));      // pad rows carry the same vector
       for (int s = D.weight_norm - 1; s >= 0; --s) {                                           // softmax stages, last first
@@ -1429,9 +1753,9 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         RUN(launch_scatter_add_rows(y.dFEAT, y.F, off_u, r.D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), y.FEAT, y.F, off_u, r.st));
       });
     // h_intent = relu(intent_embeddings(intent)): dpre -> dHINT [B, d_int]
-    RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dHINT, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
-    leaf(r, [=, &y](Run& r) { wgrad(r, y.dHINT, r.D.d_int, y.INTENTS, I, B, r.D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B); }, true);
-    lin(r, y.dHINT, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
+    if (!hfused) RUN(launch_copy_cols(y.dFEAT, y.F, off_int, D.d_int, B, y.dHINT, D.d_int, 0, y.FEAT, y.F, off_int, 0, r.st));
+    if (!hfused) leaf(r, [=, &y](Run& r) { wgrad(r, y.dHINT, r.D.d_int, y.INTENTS, I, B, r.D.d_int, I, INTEL_P_INTENT_W, INTEL_P_INTENT_B); }, true);
+    if (!hfused) lin(r, y.dHINT, D.d_int, B, D.d_int, y.pIntT, I, y.dINTENT, I, e0);      // first contribution to d(intent)
     if (r.rc) return;
   }
 
@@ -1476,6 +1800,23 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       lin(r, g1, d, B, d, w.pM2T, D.q_size, g2, D.q_size, em);            // d(pre-relu hidden)
       leaf(r, [=, &y](Run& r) { wgrad(r, g2, qs, y.INTENTS, I, B, qs, I, mb + 0, mb + 1); });
       lin(r, g2, D.q_size, B, D.q_size, w.pM0T, I, dint, I, e0);
+    }
+  };
+  // the same with the chain launches around it (hfused): only the pooling kernel; dxbar (g1) comes from head_bwd_a, dQV (g3), the
+  // share of d(intent) and the three projections' weight gradients from the chains
+  auto pool_bwd_fused = [&](Run& r, int t, float* dXout) {
+    TowerBufs& w = y.tw[t];
+    const int d = w.d;
+    float *g1 = y.dHB[t][0], *g2 = y.dHB[t][1];
+    if (r.ctx->fused_tail[t]) {       // dXout receives dZ: the gradient BEHIND the last layer's LayerNorm
+      const int pb = w.pbase;
+      TowerLayerBufs& lb = w.layer[D.layers - 1];
+      const int a = r.acc(pb + T_LNG);
+      r.acc(pb + T_LNB);
+      RUN(launch_xatt_pool_ln_bwd(lb.XH, lb.RSTD, r.P(pb + T_LNG), r.P(pb + T_LNB), B, L, d, w.QK, w.ATTW, g1, d, scale, dXout,
+                                  g2, r.G(pb + T_LNG), r.G(pb + T_LNB), a, r.st, r.ctx->rq));
+    } else {
+      RUN(launch_xatt_pool_bwd(D.layers > 0 ? w.layer[D.layers - 1].Xout : w.X0, B, L, d, w.QK, w.ATTW, g1, d, scale, dXout, g2, r.st));
     }
   };
   // ===== tied self-attention layers of the item tower + its embedding-table gradients
@@ -1559,6 +1900,92 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   //   side 0:  wait c -> session-history encoder (set 2)
   //   main:    join; [iid] (the caller's table stream waits for it: intel_set_table_stream); shared intent-embedding gradients, reductions
   // The two-call form (phases 1 and 2) keeps its order: there the caller overlaps the table's all-reduce with phase 2.
+  if (wide && hfused) {
+    // The same four branches with the session head as chain launches.  The d(intent) chain (head_bwd_b) is the critical link -- both
+    // encoders wait for it -- and it is a SMALL launch (B / 16 workgroups) that must not queue behind the towers' kernels for LDS:
+    //   main:    [head_bwd_a above] -> pooling backward of the item tower -> [x0] -> wait x1 -> head_bwd_b -> [c] -> item-history encoder
+    //   side 2:  pooling backward of the score tower -> [x1] -> wait c -> score tower (set 3) -> the head's table scatters
+    //   side 1:  wait x0, c -> item tower + item-id / class table gradients (set 0)
+    //   side 0:  wait c -> session-history encoder (set 2)
+    IntelCtx* c = r.ctx;
+    r.T = &y.tmp[0];
+    Run m = r;
+    Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2);
+    // every branch reduces its own weight-gradient slabs on its own stream (large batches: 0.5 GB off the tail); at small batches the
+    // towers' reductions (a few MB) are one more launch on a branch, and the final flush takes them in one
+    const bool branch_flush = (size_t)M >= 65536;
+    defer = &lv_main;
+    r.ok((int)hipEventRecord(c->ev_fork, r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
+    redq_set_tag(c->rq, 1);
+    pool_bwd_fused(s2, 1, y.dXS);                      // (its LayerNorm partials, when the tail is fused, belong to the score tower's tag)
+    r.ok((int)hipEventRecord(c->ev_x[1], s2.st));
+    redq_set_tag(c->rq, 2);
+    pool_bwd_fused(m, 0, y.tmp[0].dXa);
+    r.ok(m.rc); r.ok(s2.rc);
+    if (r.rc) return;
+    r.ok((int)hipEventRecord(c->ev_x[0], r.st));
+    redq_set_tag(c->rq, 0);
+    r.ok((int)hipStreamWaitEvent(r.st, c->ev_x[1], 0));
+    head_bwd_b(r, d_intents);                          // dQV of both towers, d(intent), softmax backward, d(pred_layer input) + their weight gradients
+    if (r.rc) return;
+    r.ok((int)hipEventRecord(c->ev_x[2], r.st));
+    r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
+    r.ok((int)hipStreamWaitEvent(c->side[1], c->ev_x[0], 0));
+    {   // score tower: it needs its pooling backward only (the tower kernels leave room for the chain launches: tower32.hip)
+      redq_set_tag(c->rq, 1);
+      Run t3 = s2;
+      t3.T = &y.tmp[3];
+      t3.rc = 0;
+      TowerBufs& w = y.tw[1];
+      float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
+      if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
+      if (!t3.rc && branch_flush) t3.ok(redq_flush_tag(c->rq, 1, t3.st));
+      // the head's leaves (nothing in this backward reads them): table scatters and the weight gradients of head_bwd_b's links
+      defer = nullptr;
+      redq_set_tag(c->rq, 0);
+      t3.ok((int)hipStreamWaitEvent(t3.st, c->ev_x[2], 0));
+      if (!t3.rc) run_leaves(t3, lv_main, 0);
+      if (!t3.rc && r.G(INTEL_P_CTX_EMB))
+        t3.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, t3.st));
+      if (!t3.rc && r.G(INTEL_P_UID_EMB))
+        t3.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, t3.st));
+      r.ok(t3.rc);
+    }
+    redq_set_tag(c->rq, 2);
+    item_tower_bwd(s1, y.tmp[0].dXa);
+    if (!s1.rc && branch_flush) s1.ok(redq_flush_tag(c->rq, 2, s1.st));
+    redq_set_tag(c->rq, 0);
+    // ... and the weight gradients of the head's links behind the item tower (two chain launches off the critical chain)
+    if (!s1.rc) head_bwd_a_leaves(s1);
+    s1.ok((int)hipStreamWaitEvent(s1.st, c->ev_x[2], 0));
+    if (!s1.rc) head_bwd_b_leaves(s1);
+    r.ok(s1.rc);
+    if (r.rc) return;
+    redq_set_tag(c->rq, 3);
+    float* dE0 = encoder_branch(s0, 0);
+    if (!s0.rc) s0.ok(redq_flush_tag(c->rq, 3, s0.st));      // (the encoders' slabs are large whatever the batch: always branch-local)
+    redq_set_tag(c->rq, 0);
+    if (!s0.rc && dE0) intent_wgrad(s0, 0, dE0);
+    Run e1 = r;
+    e1.T = &y.tmp[1];
+    e1.rc = 0;
+    redq_set_tag(c->rq, 4);
+    float* dE1 = encoder_branch(e1, 1);
+    if (!e1.rc) e1.ok(redq_flush_tag(c->rq, 4, e1.st));
+    redq_set_tag(c->rq, 0);
+    if (!e1.rc && dE1) intent_wgrad(e1, 1, dE1);
+    r.ok(e1.rc); r.ok(s0.rc);
+    if (c->table_stream) {
+      r.ok((int)hipEventRecord(c->ev_x[3], r.st));
+      r.ok((int)hipStreamWaitEvent(c->table_stream, c->ev_x[3], 0));
+      if (c->table_stream != c->side[1]) wait_side(r, 1, c->table_stream);
+    }
+    join_streams(r, 3);
+    if (r.rc || !dE1 || !dE0) return;
+    RUN(redq_flush(c->rq, r.st));
+    return;
+  }
   if (wide) {
     IntelCtx* c = r.ctx;
     r.T = &y.tmp[0];
@@ -1569,9 +1996,10 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     // score tower (side 2): cross-attention backward, then its layers with set 3, then the pooling's weight gradients
     // (every branch reduces the slabs of ITS weights on its own stream when it is done -- tags 1..4 -- instead of leaving
     // 0.5 GB of reduction to the tail; the shared intent-embedding slot and the session head stay in the final flush)
-    defer = &lv_score;
+    defer = hfused ? &lv_main : &lv_score;      // (hfused: dQV is produced later, by head_bwd_b on the main stream -- every leaf goes behind it)
     redq_set_tag(c->rq, 1);
-    xatt_bwd(s2, 1, y.dXS, y.tmp[1].dINT);
+    if (hfused) pool_bwd_fused(s2, 1, y.dXS);
+    else xatt_bwd(s2, 1, y.dXS, y.tmp[1].dINT);
     defer = &lv_main;
     r.ok((int)hipEventRecord(c->ev_x[1], s2.st));
     {
@@ -1587,7 +2015,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     redq_set_tag(c->rq, 2);
     r.ok(s2.rc);
     // item tower: cross-attention backward on the main stream, layers on side 1
-    xatt_bwd(m, 0, y.tmp[0].dXa, y.tmp[0].dINT);
+    if (hfused) pool_bwd_fused(m, 0, y.tmp[0].dXa);
+    else xatt_bwd(m, 0, y.tmp[0].dXa, y.tmp[0].dINT);
     r.ok(m.rc);
     if (r.rc) return;
     r.ok((int)hipEventRecord(c->ev_x[0], r.st));
@@ -1598,11 +2027,15 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     redq_set_tag(c->rq, 0);
     // d(intent) chain (needs both cross-attention backwards)
     r.ok((int)hipStreamWaitEvent(r.st, c->ev_x[1], 0));
-    RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
-    RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
-    if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
-    RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
-    lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+    if (hfused) {
+      head_bwd_b(r, d_intents);      // dQV of both towers, d(intent) summed, softmax backward, d(pred_layer input)
+    } else {
+      RUN(launch_add2(y.dINTENT, y.tmp[0].dINT, (long long)B * I, y.dINTENT, r.st));
+      RUN(launch_add2(y.dINTENT, y.tmp[1].dINT, (long long)B * I, y.dINTENT, r.st));
+      if (d_intents) RUN(launch_add2(y.dINTENT, d_intents, (long long)B * I, y.dINTENT, r.st));
+      RUN(launch_softmax_rows_bwd(y.INTENTS, y.dINTENT, B, I, y.dLOGITS, r.st));
+      lin(r, y.dLOGITS, I, B, I, y.pPredT, y.Pin, y.dPREDIN, y.Pin, e0);
+    }
     if (r.rc) return;
     // the two encoders need the chain's d(pred_layer input): session history on side 0 (set 2), item history on the main
     // stream (set 1).  The leaves of the session head go to side 2 behind the score tower (the shortest branch): off the
@@ -1617,7 +2050,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       // the leaves' own slots (fusion weights, pooling projections, pred_layer) are reduced right here (tag 5); the
       // intent-embedding slot, shared with the encoders, stays untagged for the final flush
       run_leaves(lf, lv_main, 5);
-      wgrad(lf, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
+      if (!hfused) wgrad(lf, y.dLOGITS, I, y.PREDIN, y.Pin, B, I, y.Pin, INTEL_P_PRED_W, INTEL_P_PRED_B);
       if (!lf.rc) lf.ok(redq_flush_tag(c->rq, 5, lf.st));
       redq_set_tag(c->rq, 0);
       if (!lf.rc && r.G(INTEL_P_CTX_EMB))

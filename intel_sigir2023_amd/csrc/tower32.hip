@@ -584,7 +584,13 @@ bool tower32_supported(int L, int d, int heads, int layers, int train) {
   return true;
 }
 
-int tower32_grid(int B) { return B < 1024 ? B : 1024; }
+// small batches: one workgroup per CU (launch_tower32_bwd) on 3/8 of the CUs -- the two towers' backward kernels run side by side and must
+// leave whole CUs to the sequence encoders' kernels of the step's critical chain (the GRU recurrence needs a CU's entire register file)
+int tower32_grid(int B) {
+  if (B > 4 * num_cus()) return 1024;
+  const int g = num_cus() * 3 / 8;
+  return B < g ? B : g;
+}
 size_t tower32_slab_floats(int B) { return (size_t)tower32_grid(B) * TW32_SLAB; }
 
 #define TW32_DISPATCH(KERNEL, ...)                                   \
@@ -641,7 +647,12 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
   a.X = X; a.dout = dout; a.dX = dX; a.slabs = slabs; a.B = B; a.L = L; a.layers = layers;
   a.p = Tw32Params{Wq, Wk, Wv, W1, b1, W2, b2, gamma, beta};
   const int nt = tiles_for(L);
-  const size_t smem = bwd_smem(nt, heads, layers);
+  size_t smem = bwd_smem(nt, heads, layers);
+  // Small batches (the reference trains at 512 sessions): the step is a chain of small dependent launches on other streams (sequence
+  // encoders, session head) and this kernel is OFF that chain -- but two of its workgroups per CU take all of a CU's LDS for the whole
+  // kernel, and a 8-workgroup GEMM of the critical chain then waits for one of them to finish (measured: the GRU branch 90 us later).
+  // Asking for more than half of the LDS keeps it to one workgroup per CU; the rest of the CU stays available.
+  if (B <= 4 * num_cus() && smem < 82 * 1024) smem = 82 * 1024;
   const double rows = (double)B * L;
   const double flops = layers * 3.5 * (rows * 2.0 * D * D * 5 + 4.0 * rows * L * D);
   const double bytes = rows * D * 4 * 3;
