@@ -321,6 +321,20 @@ def main():
         ndcg3 = float(nd.float().nan_to_num(0).mean())
     model.train()
 
+    # ---- data-parallel exchange timing (N > 1, or a forced one-rank group): a few extra steps with HIP events around every collective
+    exchange = None
+    if parallel.active() and eng.overlap_table_update and eng.wide_backward:
+        eng.time_exchange = True
+        for i in range(5):
+            one_step(i)
+            eng.exchange_collect()
+        eng.time_exchange = False
+        exchange = eng.exchange_report()
+        if exchange is not None:      # the slowest rank's view
+            for k in ('table_exchange_ms', 'table_branch_ms', 'dense_buckets_allreduce_ms', 'exposed_ms'):
+                exchange[k] = round(parallel.allreduce_max_float(exchange[k], dev), 4)
+            exchange['ms_per_step'] = round(el / max(a.steps, 1) * 1e3, 4)
+
     # ---- per-kernel profile: EVERY rank runs the same extra steps (they contain the gradient all-reduce)
     prof_shapes, prof_eval, psteps = None, None, 3
     if not a.no_roofline:
@@ -364,6 +378,8 @@ def main():
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
     }
+    if exchange is not None:      # data parallel: what the gradient exchange cost and how much of it was NOT hidden (slowest rank, 5 extra steps)
+        res['exchange'] = exchange
     if rank == 0 and not a.no_feed:
         res['feed'] = feed_throughput(w, cinfo, B, dev)
     bytes_train = algorithmic_bytes_per_session(w['flags'], cinfo, w['batch'], True)

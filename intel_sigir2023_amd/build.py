@@ -15,6 +15,8 @@ LIB = os.path.join(HERE, 'libintel_hip.so')
 OBJ = os.path.join(HERE, 'build')
 ARCH = 'gfx950'
 FLAGS = ['-O3', '-std=c++17', '-fPIC', '--offload-arch=' + ARCH, '-Wall', '-Wno-unused-function']
+if os.environ.get('INTEL_DEBUG_BUILD') == '1':      # probe / ablation hooks (csrc/common.h: INTEL_DEBUG_ENV); never set for the product library
+    FLAGS.append('-DINTEL_DEBUG')
 
 
 def _hipcc():

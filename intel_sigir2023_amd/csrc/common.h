@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "prof.h"
 
@@ -59,6 +60,15 @@ static inline int num_cus() {
   }();
   return n;
 }
+
+// Probe / ablation hooks (per-phase shader clocks of the fused kernels, the GEMM ablation bits, the small-M threshold) exist only in
+// builds with -DINTEL_DEBUG (`INTEL_DEBUG_BUILD=1 python -m intel_sigir2023_amd.build`; tools/tower_probe.py, enc_probe.py,
+// gemm_ablate.py): the product library reads none of these variables.
+#ifdef INTEL_DEBUG
+#define INTEL_DEBUG_ENV(name, dflt) ([] { const char* e__ = getenv(name); return e__ ? atoi(e__) : (dflt); }())
+#else
+#define INTEL_DEBUG_ENV(name, dflt) (dflt)
+#endif
 
 // ---- error reporting (host) ----------------------------------------------------------------
 void intel_set_error(const char* fmt, ...);

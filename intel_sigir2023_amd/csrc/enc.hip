@@ -853,7 +853,7 @@ int launch_block(const EncBlockArgs& a, hipStream_t st) {
   const double flops = 2.0 * M * D * D * (5 + (a.Wkv ? 2 : 0)) + 4.0 * M * a.T * D * 0.5;
   double bytes = 4.0 * M * D * (2.0 + (a.out ? 1.0 : 0.0) + (a.KV ? 2.0 : 0.0));
   if (TRAIN) bytes += 4.0 * M * D * ((a.QKV ? 3.0 : 0.0) + (a.XH1 ? 1.0 : 0.0) + (a.F1 ? 1.0 : 0.0) + (a.XH2 ? 1.0 : 0.0));
-  static const int dbg_on = [] { const char* e = getenv("INTEL_ENC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  static const int dbg_on = INTEL_DEBUG_ENV("INTEL_ENC_DBG", 0);      // phase clocks: debug builds only (common.h)
   EncBlockArgs aa = a;
   static unsigned long long* dbg_buf = nullptr;
   if (dbg_on) {

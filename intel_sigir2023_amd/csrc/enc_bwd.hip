@@ -730,7 +730,7 @@ int launch_enc_block_bwd(const EncBlockBwd& f, hipStream_t st, ReduceQueue* q) {
   if (bf) allow_lds((enc_block_bwd_kernel<D, 64, 1>), C::SMEM);
   else allow_lds((enc_block_bwd_kernel<D, 64, 3>), C::SMEM);
   const double M = (double)f.rows;
-  static const int dbg_on = [] { const char* e = getenv("INTEL_ENC_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  static const int dbg_on = INTEL_DEBUG_ENV("INTEL_ENC_DBG", 0);      // phase clocks: debug builds only (common.h)
   static unsigned long long* dbg_buf = nullptr;
   a.dbg = nullptr;
   if (dbg_on) {

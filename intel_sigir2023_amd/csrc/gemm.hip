@@ -1641,8 +1641,7 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   INTEL_CHECK_ARG(K > 0, "gemm_rows: K must be positive");
   INTEL_CHECK_ARG(!(ep.gamma && N > 128), "gemm_rows: fused LayerNorm needs N <= 128 (got %d)", N);
   GemmRowsArgs a;
-  static int dbg = -1;
-  if (dbg < 0) { const char* e = getenv("INTEL_DEBUG_GEMM"); dbg = e ? atoi(e) : 0; }
+  static const int dbg = INTEL_DEBUG_ENV("INTEL_DEBUG_GEMM", 0);      // ablation bits: debug builds only (common.h)
   a.dbg = dbg;
   {
     uintptr_t bits = reinterpret_cast<uintptr_t>(C) | (uintptr_t)(ldc & 3) << 60;
@@ -1669,7 +1668,7 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
       }
       // few row tiles (the B-row products of the pooling / fusion chains): 32-column workgroups, one tile pair per wave --
       // four times the workgroups and a quarter of the MFMA chain per wave (the A tile is re-read from L2 by the column chunks)
-      static const int small_m = [] { const char* e = getenv("INTEL_GEMM_SMALLM"); return e ? atoi(e) : 8192; }();
+      static const int small_m = INTEL_DEBUG_ENV("INTEL_GEMM_SMALLM", 8192);
       if (M <= small_m && N > 32) return launch_b3<1, false>(a, st);
       if (N > 64) return launch_b3<4, false>(a, st);
       if (N > 32) return launch_b3<2, false>(a, st);

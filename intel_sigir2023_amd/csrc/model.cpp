@@ -1157,10 +1157,16 @@ float* bert_bwd(Run& r, int e) {
 // --cross_attention 1, no weight normalisation) they run as two chain launches per direction around the pooling kernels; every
 // buffer a later launch reads (the stash, the operands of the deferred weight-gradient products) is written as before.
 // INTEL_HEAD_FUSED=0 keeps the kernel-per-op head.
-static bool head_fused_ok(const IntelDesc& D, const Layout& y) {
+static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   static const int on = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!on || !D.cross_attention || D.pool_mean || D.weight_norm != 0 || D.model_num > 16) return false;
   if (D.dtype != INTEL_DTYPE_F32) return false;      // bf16 mode rounds the operands of the 64 / 128-deep B-row products (oracle.forward_bf16): kernel-per-op head
+  // Training: the chains pay where the step is launch-bound (the reference's hyper-parameters at its batch of 512: +8.5 % sessions/s
+  // same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers' kernels while a chain launch holds
+  // whole CUs (measured same-box, round 4: Tmall shape 1024 / 2048 / 4096 sessions -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress
+  // 1024 +-0) -- there only inference takes the chains (+2 ... +7 % evaluation sessions/s).  INTEL_HEAD_FUSED=2 forces them on.
+  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
+  if (train && y.B > 768 && !force) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
   const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
@@ -1440,7 +1446,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // the side branches start with work that needs no packed weights (history packing, embedding gathers): they fork BEFORE the
   // packing launches of the main stream and wait for them (ev_pack) in front of their first matrix product
   for (int e = 0; e < 2; ++e)      // GRU4Rec with the fused session head: the output projections are links of the head's chains
-    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
+    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
   fork_streams(r, 3);
   hipEvent_t ev_pack = r.ctx->ev_x[0];
   {
@@ -1541,7 +1547,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
   if (r.rc) return;
-  if (head_fused_ok(D, y)) {
+  if (head_fused_ok(D, y, r.train)) {
     // the session head as two chain launches around the two pooling kernels (chain.hip)
     const float scale = 1.0f / sqrtf((float)D.q_size);
     head_fwd_a(r, out);
@@ -1705,7 +1711,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     v.clear();
   };
   // the session head's data-gradient chain as two chain launches around the pooling backward (chain.hip): one-call schedule only
-  const bool hfused = wide && head_fused_ok(D, y);
+  const bool hfused = wide && head_fused_ok(D, y, 1);
   if (!hfused)      // (the forward may have left the GRU output projections to its chains: this backward does them in gru_bwd)
     for (int e = 0; e < 2; ++e) y.enc[e].gru.ext_proj = false;
   if (phase != 2) {

@@ -669,7 +669,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
   if (TRAIN) bytes += 4.0 * M * D * (((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0)) * (a.qkv16 ? 0.5 : 1.0) + (a.XH ? 1.0 : 0.0));
-  static const int dbg_on = [] { const char* e = getenv("INTEL_TOWER_DBG"); return (e && e[0] == '1') ? 1 : 0; }();
+  static const int dbg_on = INTEL_DEBUG_ENV("INTEL_TOWER_DBG", 0);      // phase clocks: debug builds only (common.h)
   TowerFwdArgs aa = a;
   static unsigned long long* dbg_buf = nullptr;
   if (dbg_on) {

@@ -456,22 +456,43 @@ class IntELEngine(object):
                 model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
             finally:
                 lib.intel_set_table_stream(model._context(), None)
+            # exchange observability (bench.py --gpus N: `exchange` object): HIP events around the table exchange (+ its Adam sweep) on the
+            # side stream and around the dense buckets' all-reduce on the main stream, and at the point where the main stream has nothing
+            # left but to wait for the side stream -- exposed = how long the table branch outlasts everything else of the step
+            tx = self._exchange_events if (dp and getattr(self, 'time_exchange', False)) else None
             with torch.cuda.stream(side):
                 sparse = dp and self._sparse_exchange(keep, world)
+                if tx is not None:
+                    tx['form'] = 'sharded' if self._sharded() else ('touched_rows' if sparse else 'dense')
+                    tx['t0'].record(side)
                 if dp and self._sharded():
                     self._sharded_table_update(L.stream_ptr(dev))
+                    if tx is not None:
+                        tx['t1'].record(side)
                 else:
                     if sparse:
                         self._exchange_touched_rows(keep, L.stream_ptr(dev))
                     elif dp:
                         parallel.allreduce_sum_([self.gflat['iid']])
+                    if tx is not None:
+                        tx['t1'].record(side)
                     adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=dp and not sparse)
                 loss_total(L.stream_ptr(dev))
+                if tx is not None:
+                    tx['t2'].record(side)
+            if tx is not None:
+                tx['b0'].record(cur)
             if dp:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
+            if tx is not None:
+                tx['b1'].record(cur)
             adam('decay', self.l2, st)
             adam('nodecay', 0.0, st)
+            if tx is not None:
+                tx['m'].record(cur)
             cur.wait_stream(side)
+            if tx is not None:
+                self._exchange_pending = True
         elif self.overlap_table_update:
             # phase 1 completes the item-id table gradient (the 256 MB bucket).  Its all-reduce (data parallel) and its
             # dense Adam sweep -- HBM-bound, 28 B per parameter -- then run on a side stream underneath phase 2 (score-tower
@@ -511,6 +532,39 @@ class IntELEngine(object):
                 if not (sharded and gname == 'iid'):
                     adam(gname, wd, st, dense_reduced=dp)
         return tot[0], tot[1], tot[2]
+
+    # ---- data-parallel exchange timing (observability only) ---------------------------------------------
+    @property
+    def _exchange_events(self):
+        ev = getattr(self, '_tx_events', None)
+        if ev is None:
+            ev = {k: torch.cuda.Event(enable_timing=True) for k in ('t0', 't1', 't2', 'b0', 'b1', 'm')}
+            ev['form'] = None
+            self._tx_events = ev
+            self._tx_acc = {'steps': 0, 'table_exchange_ms': 0.0, 'table_branch_ms': 0.0, 'buckets_ms': 0.0, 'exposed_ms': 0.0}
+        return ev
+
+    def exchange_collect(self):
+        """After a step run with ``time_exchange = True`` (synchronises): add its timings to the running totals."""
+        if not getattr(self, '_exchange_pending', False):
+            return
+        torch.cuda.synchronize(self.device)
+        ev, acc = self._tx_events, self._tx_acc
+        acc['steps'] += 1
+        acc['table_exchange_ms'] += ev['t0'].elapsed_time(ev['t1'])       # the collective(s) of the item-id table gradient (sharded: + Adam on the slice + all-gather)
+        acc['table_branch_ms'] += ev['t0'].elapsed_time(ev['t2'])         # ... + the table's Adam sweep
+        acc['buckets_ms'] += ev['b0'].elapsed_time(ev['b1'])              # all-reduce of the two dense buckets on the main stream
+        acc['exposed_ms'] += max(0.0, ev['m'].elapsed_time(ev['t2']))     # the side stream still busy when the main stream has finished its own work
+        self._exchange_pending = False
+
+    def exchange_report(self):
+        acc = getattr(self, '_tx_acc', None)
+        if not acc or not acc['steps']:
+            return None
+        n = acc['steps']
+        return {'form': self._tx_events['form'], 'steps': n, 'table_exchange_ms': round(acc['table_exchange_ms'] / n, 4),
+                'table_branch_ms': round(acc['table_branch_ms'] / n, 4), 'dense_buckets_allreduce_ms': round(acc['buckets_ms'] / n, 4),
+                'exposed_ms': round(acc['exposed_ms'] / n, 4), 'schedule': 'one-call backward, table exchange + sweep on a side stream'}
 
     # ---- evaluation -----------------------------------------------------------------------------------
     @torch.no_grad()

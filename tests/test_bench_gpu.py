@@ -44,3 +44,8 @@ def test_two_rank_launch_line_runs_end_to_end():
     j = _line(r.stdout)
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['config']['global_batch'] == 2 * j['config']['per_gpu_batch'] and j['config']['parallelism'] == 'dp2'
     assert j['value'] > 0 and abs(j['value'] - j['config']['global_batch'] / (j['ms_per_step'] * 1e-3)) <= 1e-3 * j['value']
+    # data parallel: the line says which exchange form ran and what it cost / how much of it stayed exposed (HIP events around every collective)
+    ex = j['exchange']
+    assert ex['form'] in ('dense', 'touched_rows', 'sharded') and ex['steps'] == 5
+    assert ex['table_exchange_ms'] > 0 and ex['table_branch_ms'] >= ex['table_exchange_ms'] and ex['dense_buckets_allreduce_ms'] > 0
+    assert 0 <= ex['exposed_ms'] <= 10 * j['ms_per_step']

@@ -43,6 +43,9 @@ CASES = [
     ({'INTEL_BWD_SCHEDULE': 'phased'}, ENGINE),                        # two-call backward
     ({'INTEL_SCATTER_SORTED': '1'}, ENGINE),                           # always the sorted embedding scatter
     ({'INTEL_BPR_NOISE': 'tensor'}, ENGINE),                           # BPR tie-breaking noise as a torch.rand tensor
+    ({'INTEL_TOWER32': '0'}, MODEL),                                   # 32-wide towers on the kernel-per-op pipeline instead of the one-kernel tower (tower32.hip)
+    ({'INTEL_HEAD_FUSED': '0'}, MODEL),                                # session head as one launch per link instead of the chain launches (chain.hip)
+    ({'INTEL_HEAD_FUSED': '0'}, ENGINE),
     ({'INTEL_WGRAD_TR': '0'}, BF16),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
 
