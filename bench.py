@@ -24,7 +24,7 @@ B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel')
 FUSED_KERNELS = ('tower_fwd_fused_kernel',)
 MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
                 'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_kv_kernel',
-                'attn_seq_bwd_q_kernel')
+                'attn_seq_bwd_q_kernel', 'attn_seq_bwd_fused_kernel', 'attn_bwd_dq_ds_kernel', 'tw32_fwd_kernel', 'tw32_bwd_kernel')      # exact fp32 MFMAs (v_mfma_f32_16x16x4_f32)
 
 
 def feed_throughput(w, cinfo, B, dev, reps=20):

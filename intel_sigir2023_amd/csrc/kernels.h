@@ -139,12 +139,16 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
 // the backward recomputes the forward from the tower input.  INTEL_TOWER32=0 turns the path off.
 bool tower32_supported(int L, int d, int heads, int layers, int train);
 size_t tower32_slab_floats(int B);      // arena floats one launch_tower32_bwd takes from the reduce queue
+// training-mode nn.Dropout of the tower layers (IntEL.py:187,196): the draw of launch_dropout_mask (same seed, stream id stream0 + layer) or
+// external keep flags [layers, B*L, 32]
+struct Tower32Dropout { float p; unsigned long long seed; unsigned stream0; const float* ext; };
 int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv, const float* W1,
-                       const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* out, hipStream_t st);
+                       const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* out, hipStream_t st,
+                       const Tower32Dropout* drop = nullptr);
 // grads / accumulate: dWq, dWk, dWv, dW1, db1, dW2, db2, dgamma, dbeta (NULL = not wanted); valid after the queue's flush
 int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
-                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st);
+                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop = nullptr);
 
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu

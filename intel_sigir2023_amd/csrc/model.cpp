@@ -593,7 +593,7 @@ void pack_all(Run& r) {
   // bf16 three-plane images of the K > 128 weights (data gradients through the fused q/k/v weights)
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
-    if (!(D.layers > 0 && tower32_supported(y.L, w.d, D.heads, D.layers, r.train) && !(r.train && r.ctx->drop_p > 0.f)))      // (tower32.hip reads the raw weights)
+    if (!(D.layers > 0 && tower32_supported(y.L, w.d, D.heads, D.layers, r.train)))      // (tower32.hip reads the raw weights)
       RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
     if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train, w.d)) {
       RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
@@ -687,17 +687,31 @@ static bool tail_fusable(const IntelCtx* ctx, const IntelDesc& D, int L, int d, 
   return on && train && D.cross_attention && D.layers > 0 && !(ctx->drop_p > 0.f) && d <= 128 && xatt_ln_fused_supported(L, d);
 }
 
+// the training-mode dropout of tower t for the one-kernel 32-wide tower: the same draw as launch_dropout_mask below (stream id = tower *
+// MAX_TOWER_LAYERS + layer; external keep flags laid out item-tower layers first, then score-tower layers)
+static Tower32Dropout tower32_dropout(const Run& r, int tower) {
+  Tower32Dropout d{0.f, 0ull, 0u, nullptr};
+  const bool on = r.train ? r.ctx->drop_p > 0.f : false;
+  if (!on) return d;
+  d.p = r.ctx->drop_p;
+  d.seed = r.ctx->drop_seed;
+  d.stream0 = (unsigned)(tower * MAX_TOWER_LAYERS);
+  if (r.ctx->drop_ext) d.ext = r.ctx->drop_ext + (tower == 0 ? 0 : (size_t)r.D.layers * r.y.M * r.y.tw[0].d);
+  return d;
+}
+
 void tower_fwd(Run& r, TowerBufs& w) {
   const IntelDesc& D = r.D;
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
   const float* X = w.X0;
   const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
   // the reference's own widths (32-wide towers): ALL tied layers in one kernel, nothing stashed (tower32.hip)
-  r.ctx->tw32[tw_i] = D.layers > 0 && tower32_supported(L, d, D.heads, D.layers, r.train) && !(r.train && r.ctx->drop_p > 0.f);
+  r.ctx->tw32[tw_i] = D.layers > 0 && tower32_supported(L, d, D.heads, D.layers, r.train);
   if (r.ctx->tw32[tw_i]) {
     r.ctx->tw_qkv16[tw_i] = false;
+    Tower32Dropout dr = tower32_dropout(r, tw_i);
     RUN(launch_tower32_fwd(X, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1), r.P(pb + T_W2),
-                           r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), w.layer[D.layers - 1].Xout, r.st));
+                           r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), w.layer[D.layers - 1].Xout, r.st, &dr));
     return;
   }
   // one kernel per layer (tower.hip): the session's tile stays on chip from the q/k/v projection to the LayerNorm
@@ -770,8 +784,10 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
       g[p] = r.G(pb + slots[p]);
       acc[p] = r.acc(pb + slots[p]);
     }
+    Tower32Dropout dr = tower32_dropout(r, &w == &r.y.tw[0] ? 0 : 1);
+    if (!r.ctx->fwd_dropout) dr.p = 0.f;
     if (!r.ok(launch_tower32_bwd(w.X0, dX, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1),
-                                 r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st)))
+                                 r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st, &dr)))
       return nullptr;
     return dXalt;
   }

@@ -1,6 +1,6 @@
 // The WHOLE tied tower of IntEL.predict_ensemble (models/IntEL/IntEL.py:182-188 / 191-197) at the reference's OWN widths -- 32-wide
 // towers (its defaults IntEL.py:20-26 and its published runs script/IntEL.sh:15,21: --i_emb_size 16 --im_emb_size 16 --s_emb_size 32),
-// 1-2 heads, any number of tied layers, lists of up to 128 candidates -- as ONE kernel per direction:
+// 1-2 heads, any number of tied layers, lists of up to 128 candidates (training: up to 96) -- as ONE kernel per direction:
 //
 //     repeat n times with the same weights:  res = h;  h = MHA(h, h, h)  (no mask, no output projection: modules/layers.py:31-60)
 //                                             h = W1 h + b1;  h = W2 relu(h) + b2;  h = LayerNorm(h + res)
@@ -34,7 +34,39 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 struct Tw32Params {
   const float *Wq, *Wk, *Wv, *W1, *b1, *W2, *b2, *gamma, *beta;      // raw reference layouts: W [out, in], vectors [32]
+  // nn.Dropout in front of the residual add (IntEL.py:187,196), training only: keep / (1 - p) per element of the layer's [B*L, 32] output,
+  // keep from `drop_ext` (0/1 floats, layer-major: parity tests pin the reference's draw) or from the counter-based generator of
+  // rowops.hip's dropout_mask_kernel keyed by (seed, stream0 + layer, element) -- the same draw as the kernel-per-op path
+  float drop_p;
+  unsigned long long drop_seed;
+  unsigned drop_stream0;
+  const float* drop_ext;
+  long long drop_layer_stride;      // elements between two layers' keep flags in drop_ext (= B * L * 32)
 };
+
+template <bool DROP>
+__device__ __forceinline__ f32x4 drop_mask4(const Tw32Params& p, int layer, long long elem) {
+  f32x4 m = {1.f, 1.f, 1.f, 1.f};
+  if (DROP) {
+    const float scale = 1.f / (1.f - p.drop_p);
+    if (p.drop_ext) {
+      const f32x4 k = *reinterpret_cast<const f32x4*>(p.drop_ext + (long long)layer * p.drop_layer_stride + elem);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) m[r] = k[r] * scale;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        unsigned long long z = p.drop_seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)(p.drop_stream0 + layer) * 0x100000000ull + (unsigned long long)(elem + r) + 1ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+        m[r] = u >= p.drop_p ? scale : 0.f;
+      }
+    }
+  }
+  return m;
+}
 
 struct Tw32FwdArgs {
   const float* X;      // [B*L, 32] tower input rows
@@ -164,8 +196,8 @@ __device__ __forceinline__ f32x4 cvec(const float* Ws, int off, int g, int j) { 
 
 // One layer forward on the wave's row tile.  x -> x (in place).  Two workgroup barriers (K / V rows of all waves).
 // KEEP: leave what the backward needs in the out-parameters (q / k / v / attention output / relu output / x-hat / rstd / lse2).
-template <int HEADS, int NT, bool KEEP>
-__device__ __forceinline__ void layer32_fwd(const float* Ws, float* Ks, float* Vs, float* Qs, int L, int row, int i, int j,
+template <int HEADS, int NT, bool KEEP, bool DROP>
+__device__ __forceinline__ void layer32_fwd(const Tw32Params& prm, int layer, long long erow, const float* Ws, float* Ks, float* Vs, float* Qs, int L, int row, int i, int j,
                                             f32x4 (&x)[2], f32x4 (&q)[2], f32x4 (&k)[2], f32x4 (&v)[2], f32x4 (&a)[2], f32x4 (&r1)[2],
                                             f32x4 (&xh)[2], float& rstd, float (&lse2)[HEADS]) {
   lin32(Ws + 0 * WMAT, i, j, x, q);
@@ -195,9 +227,10 @@ __device__ __forceinline__ void layer32_fwd(const float* Ws, float* Ks, float* V
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
     const f32x4 b2 = cvec(Ws, C_B2, g, j);
+    const f32x4 dm = drop_mask4<DROP>(prm, layer, erow + 16 * g + 4 * j);      // erow: element index of this row's column 0 in a layer's [B*L, 32] tensor
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      z[g][r] += b2[r] + x[g][r];
+      z[g][r] = (z[g][r] + b2[r]) * dm[r] + x[g][r];
       s += z[g][r];
     }
   }
@@ -222,7 +255,7 @@ __device__ __forceinline__ void layer32_fwd(const float* Ws, float* Ks, float* V
   }
 }
 
-template <int HEADS, int NT>
+template <int HEADS, int NT, bool DROP>
 __global__ __launch_bounds__(64 * NT) void tw32_fwd_kernel(Tw32FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;
@@ -241,7 +274,7 @@ __global__ __launch_bounds__(64 * NT) void tw32_fwd_kernel(Tw32FwdArgs a) {
     for (int l = 0; l < a.layers; ++l) {
       f32x4 q[2], k[2], v[2], at[2], r1[2], xh[2];
       float rstd, lse2[HEADS];
-      layer32_fwd<HEADS, NT, false>(Ws, Ks, Vs, nullptr, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
+      layer32_fwd<HEADS, NT, false, DROP>(a.p, l, (long long)(rok ? base : 0), Ws, Ks, Vs, nullptr, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
     }
     if (rok) {
 #pragma unroll
@@ -299,7 +332,7 @@ __device__ __forceinline__ void colsum32(float* T, int i, int j, const f32x4 (&y
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int HEADS, int NT>
+template <int HEADS, int NT, bool DROP>
 __global__ __launch_bounds__(64 * NT) void tw32_bwd_kernel(Tw32BwdArgs a) {
   constexpr int CG = 2 / HEADS, ROWS = NT * 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(64 * NT) void tw32_bwd_kernel(Tw32BwdArgs a) {
 #pragma unroll
       for (int g = 0; g < 2; ++g) x[g] = rok ? *reinterpret_cast<const f32x4*>(a.X + base + 16 * g + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
       for (int l = 0; l + 1 < a.layers; ++l) {
-        layer32_fwd<HEADS, NT, false>(Ws, Ks, Vs, nullptr, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
+        layer32_fwd<HEADS, NT, false, DROP>(a.p, l, (long long)(rok ? base : 0), Ws, Ks, Vs, nullptr, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
 #pragma unroll
         for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(Xl + ((size_t)l * ROWS + row) * D + 16 * g + 4 * j) = x[g];
       }
@@ -357,7 +390,7 @@ __global__ __launch_bounds__(64 * NT) void tw32_bwd_kernel(Tw32BwdArgs a) {
         float rstd;
 #pragma unroll
         for (int g = 0; g < 2; ++g) x[g] = (l > 0 || rok) ? *reinterpret_cast<const f32x4*>(xrow + 16 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        layer32_fwd<HEADS, NT, true>(Ws, Ks, Vs, Qs, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
+        layer32_fwd<HEADS, NT, true, DROP>(a.p, l, (long long)(rok ? base : 0), Ws, Ks, Vs, Qs, a.L, row, i, j, x, q, k, v, at, r1, xh, rstd, lse2);
         // ---- LayerNorm backward (rows of width 32 over the lanes (i, 0..3))
         float m1 = 0.f, m2 = 0.f;
         f32x4 t[2];
@@ -381,10 +414,19 @@ __global__ __launch_bounds__(64 * NT) void tw32_bwd_kernel(Tw32BwdArgs a) {
         for (int g = 0; g < 2; ++g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dz[g][r] = (dz[g][r] - m1 - xh[g][r] * m2) * rstd;
-        // ---- feed-forward backward
-        wgrad32<true>(T, i, j, dz, r1, gW[4], gb2);
+        // ---- feed-forward backward (the dropout sits between W2 and the residual add: the W2 path sees dz * mask, the residual dz)
+        f32x4 dzd[2] = {dz[0], dz[1]};
+        if (DROP) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            const f32x4 dm = drop_mask4<DROP>(a.p, l, (long long)(rok ? base : 0) + 16 * g + 4 * j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dzd[g][r] *= dm[r];
+          }
+        }
+        wgrad32<true>(T, i, j, dzd, r1, gW[4], gb2);
         f32x4 df[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        linT32(Ws + 4 * WMAT, i, j, dz, df);
+        linT32(Ws + 4 * WMAT, i, j, dzd, df);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -581,6 +623,7 @@ bool tower32_supported(int L, int d, int heads, int layers, int train) {
   if (!on_switch() || d != 32 || (heads != 1 && heads != 2) || L < 1 || L > 128 || layers < 1) return false;
   const int nt = tiles_for(L);
   if (train && bwd_smem(nt, heads, layers) > 160 * 1024 - 512) return false;
+  if (train && nt == 8) return false;      // lists of 97 .. 128: the backward kernel's eight-wave form spills ~100 registers; kernel-per-op pipeline
   return true;
 }
 
@@ -593,40 +636,48 @@ int tower32_grid(int B) {
 }
 size_t tower32_slab_floats(int B) { return (size_t)tower32_grid(B) * TW32_SLAB; }
 
-#define TW32_DISPATCH(KERNEL, ...)                                   \
+#define TW32_DISPATCH_D(KERNEL, DROP_)                                \
   do {                                                               \
     if (heads == 1) {                                                \
-      if (nt == 2) KERNEL(1, 2, __VA_ARGS__);                        \
-      else if (nt == 4) KERNEL(1, 4, __VA_ARGS__);                   \
-      else if (nt == 6) KERNEL(1, 6, __VA_ARGS__);                   \
-      else KERNEL(1, 8, __VA_ARGS__);                                \
+      if (nt == 2) KERNEL(1, 2, DROP_);                              \
+      else if (nt == 4) KERNEL(1, 4, DROP_);                         \
+      else if (nt == 6) KERNEL(1, 6, DROP_);                         \
+      else KERNEL(1, 8, DROP_);                                      \
     } else {                                                         \
-      if (nt == 2) KERNEL(2, 2, __VA_ARGS__);                        \
-      else if (nt == 4) KERNEL(2, 4, __VA_ARGS__);                   \
-      else if (nt == 6) KERNEL(2, 6, __VA_ARGS__);                   \
-      else KERNEL(2, 8, __VA_ARGS__);                                \
+      if (nt == 2) KERNEL(2, 2, DROP_);                              \
+      else if (nt == 4) KERNEL(2, 4, DROP_);                         \
+      else if (nt == 6) KERNEL(2, 6, DROP_);                         \
+      else KERNEL(2, 8, DROP_);                                      \
     }                                                                \
+  } while (0)
+#define TW32_DISPATCH(KERNEL, drop)                                  \
+  do {                                                               \
+    if (drop) TW32_DISPATCH_D(KERNEL, true);                         \
+    else TW32_DISPATCH_D(KERNEL, false);                             \
   } while (0)
 
 int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv, const float* W1,
-                       const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* out, hipStream_t st) {
+                       const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* out, hipStream_t st,
+                       const Tower32Dropout* drop) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower32_supported(L, 32, heads, layers, 0), "tower32_fwd: unsupported shape L=%d heads=%d layers=%d", L, heads, layers);
   Tw32FwdArgs a;
   a.X = X; a.out = out; a.B = B; a.L = L; a.layers = layers;
-  a.p = Tw32Params{Wq, Wk, Wv, W1, b1, W2, b2, gamma, beta};
+  const bool dropping = drop && drop->p > 0.f;
+  a.p = Tw32Params{Wq, Wk, Wv, W1, b1, W2, b2, gamma, beta, dropping ? drop->p : 0.f, dropping ? drop->seed : 0ull, dropping ? drop->stream0 : 0u,
+                   dropping ? drop->ext : nullptr, (long long)B * L * D};
   const int nt = tiles_for(L);
   const size_t smem = fwd_smem(nt);
   const int grid = B < 2048 ? B : 2048;
   const double rows = (double)B * L;
   const double flops = layers * (rows * 2.0 * D * D * 5 + 4.0 * rows * L * D);
   const double bytes = rows * D * 4 * 2;
-#define FWD_K(H_, NT_, ...)                                                                                       \
-  do {                                                                                                            \
-    allow_lds((tw32_fwd_kernel<H_, NT_>), smem);                                                                  \
-    LAUNCH_S(B * L, D, layers, flops, bytes, (tw32_fwd_kernel<H_, NT_>), dim3(grid), dim3(64 * NT_), smem, st, a); \
+#define FWD_K(H_, NT_, DR_)                                                                                            \
+  do {                                                                                                                 \
+    allow_lds((tw32_fwd_kernel<H_, NT_, DR_>), smem);                                                                  \
+    LAUNCH_S(B * L, D, layers, flops, bytes, (tw32_fwd_kernel<H_, NT_, DR_>), dim3(grid), dim3(64 * NT_), smem, st, a); \
   } while (0)
-  TW32_DISPATCH(FWD_K, 0);
+  TW32_DISPATCH(FWD_K, dropping);
 #undef FWD_K
   INTEL_CHECK_LAUNCH();
   return 0;
@@ -636,7 +687,7 @@ int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, cons
 // The partial sums go to `q`'s arena and are valid after its flush (redq_flush / redq_flush_tag).
 int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
-                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st) {
+                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower32_supported(L, 32, heads, layers, 1), "tower32_bwd: unsupported shape L=%d heads=%d layers=%d", L, heads, layers);
   INTEL_CHECK_ARG(q, "tower32_bwd: needs the reduce queue");
@@ -645,7 +696,9 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
   INTEL_CHECK_ARG(slabs, "tower32_bwd: reduction arena exhausted");
   Tw32BwdArgs a;
   a.X = X; a.dout = dout; a.dX = dX; a.slabs = slabs; a.B = B; a.L = L; a.layers = layers;
-  a.p = Tw32Params{Wq, Wk, Wv, W1, b1, W2, b2, gamma, beta};
+  const bool dropping = drop && drop->p > 0.f;
+  a.p = Tw32Params{Wq, Wk, Wv, W1, b1, W2, b2, gamma, beta, dropping ? drop->p : 0.f, dropping ? drop->seed : 0ull, dropping ? drop->stream0 : 0u,
+                   dropping ? drop->ext : nullptr, (long long)B * L * D};
   const int nt = tiles_for(L);
   size_t smem = bwd_smem(nt, heads, layers);
   // Small batches (the reference trains at 512 sessions): the step is a chain of small dependent launches on other streams (sequence
@@ -654,14 +707,14 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
   // Asking for more than half of the LDS keeps it to one workgroup per CU; the rest of the CU stays available.
   if (B <= 4 * num_cus() && smem < 82 * 1024) smem = 82 * 1024;
   const double rows = (double)B * L;
-  const double flops = layers * 3.5 * (rows * 2.0 * D * D * 5 + 4.0 * rows * L * D);
+  const double flops = layers * 2.0 * (rows * 2.0 * D * D * 5 + 4.0 * rows * L * D);      // algorithmic: data + weight gradients (the forward recompute is overhead, not work)
   const double bytes = rows * D * 4 * 3;
-#define BWD_K(H_, NT_, ...)                                                                                       \
-  do {                                                                                                            \
-    allow_lds((tw32_bwd_kernel<H_, NT_>), smem);                                                                  \
-    LAUNCH_S(B * L, D, layers, flops, bytes, (tw32_bwd_kernel<H_, NT_>), dim3(grid), dim3(64 * NT_), smem, st, a); \
+#define BWD_K(H_, NT_, DR_)                                                                                            \
+  do {                                                                                                                 \
+    allow_lds((tw32_bwd_kernel<H_, NT_, DR_>), smem);                                                                  \
+    LAUNCH_S(B * L, D, layers, flops, bytes, (tw32_bwd_kernel<H_, NT_, DR_>), dim3(grid), dim3(64 * NT_), smem, st, a); \
   } while (0)
-  TW32_DISPATCH(BWD_K, 0);
+  TW32_DISPATCH(BWD_K, dropping);
 #undef BWD_K
   INTEL_CHECK_LAUNCH();
   // slab -> destination jobs: dWq dWk dWv dW1 db1 dW2 db2 dgamma dbeta
