@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define INTEL_ABI_VERSION 3
+#define INTEL_ABI_VERSION 4
 
 enum {
   INTEL_OK = 0,
@@ -284,6 +284,14 @@ int intel_loss_total(const float* ensemble_loss, const double* intent_out3, doub
  * (g += wd*p), bias-corrected moments, dense over all n elements.  zero_grad != 0 also clears g. */
 int intel_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, int zero_grad, void* stream);
+
+/* ABI version 4: the same update for TWO parameter groups in one launch (BaseModel.customize_parameters makes exactly two: names
+ * without 'bias' -> weight_decay = --l2, names with 'bias' -> 0; models/BaseModel.py:53-62).  p / g / m / v / n / weight_decay are
+ * HOST arrays of two entries (device pointers, element counts, decays); a group with n <= 0 is skipped.  Bit-identical to two
+ * intel_adam_step calls. */
+int intel_adam_step_pair(float* const* p, float* const* g, float* const* m, float* const* v, const long long* n,
+                         const float* weight_decay, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                         int zero_grad, void* stream);
 
 /* The same update over a [rows, d] embedding table whose gradient g is zero outside the rows flagged in row_flags
  * (one byte per row; see intel_set_iid_grad_row_flags): g is read, cleared and the flag reset only in flagged rows, every

@@ -37,7 +37,7 @@ def lib():
         except OSError as e:
             raise IntelHipError('cannot load %s: %s' % (LIB_PATH, e))
         _declare(_lib)
-        if _lib.intel_abi_version() != 3:
+        if _lib.intel_abi_version() != 4:
             raise IntelHipError('ABI version mismatch')
         sizes = (C.c_int * 4)()
         _lib.intel_abi_sizes(sizes)
@@ -131,7 +131,7 @@ P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 EXPORTS = [
     'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_params_unchanged', 'intel_set_table_stream', 'intel_side_stream', 'intel_set_dropout', 'intel_set_iid_grad_row_flags', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_bpr_loss_seeded', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
-    'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
+    'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_pair', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
     'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_prof_timeline', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add',
     'intel_lazy_table_sizeof', 'intel_adam_lazy_step', 'intel_adam_lazy_catchup', 'intel_adam_lazy_flush', 'intel_set_lazy_table',
@@ -170,6 +170,7 @@ def _declare(l):
     sig('intel_loss_total', i, [vp, vp, d, d, vp, vp])
     sig('intel_adam_step', i, [vp, vp, vp, vp, ll, f, f, f, f, f, i, f, i, vp])
     sig('intel_adam_step_rows', i, [vp, vp, vp, vp, ll, i, vp, f, f, f, f, f, i, f, vp])
+    sig('intel_adam_step_pair', i, [vp, vp, vp, vp, vp, vp, f, f, f, f, i, f, i, vp])
     sig('intel_lazy_table_sizeof', i, [])
     sig('intel_adam_lazy_step', i, [C.POINTER(IntelLazyTable), vp, vp, f, i, vp])
     sig('intel_adam_lazy_catchup', i, [C.POINTER(IntelLazyTable), vp, ll, vp, ll, i, vp])

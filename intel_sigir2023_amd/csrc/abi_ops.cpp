@@ -154,6 +154,13 @@ extern "C" int intel_adam_step(float* p, float* g, float* m, float* v, long long
   return launch_adam(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, zero_grad, (hipStream_t)stream);
 }
 
+extern "C" int intel_adam_step_pair(float* const* p, float* const* g, float* const* m, float* const* v, const long long* n, const float* weight_decay,
+                                    float lr, float beta1, float beta2, float eps, int step, float grad_scale, int zero_grad, void* stream) {
+  INTEL_CHECK_ARG(p && g && m && v && n && weight_decay, "adam_pair: null argument");
+  for (int k = 0; k < 2; ++k) INTEL_CHECK_ARG(n[k] <= 0 || (p[k] && g[k] && m[k] && v[k]), "adam_pair: null tensor in group %d", k);
+  return launch_adam_pair(p, g, m, v, n, weight_decay, lr, beta1, beta2, eps, step, grad_scale, zero_grad, (hipStream_t)stream);
+}
+
 extern "C" int intel_lazy_table_sizeof(void) { return (int)sizeof(IntelLazyTable); }
 
 extern "C" int intel_adam_lazy_step(const IntelLazyTable* t, float* g, unsigned char* row_flags, float lr, int step, void* stream) {

@@ -2752,7 +2752,7 @@ static int redq_flush_impl(ReduceQueue* q, int tag, hipStream_t st) {
           RedJob j = q->jobs[sel[t]];
           // the members of a chain must map threads to outputs identically: where their strategies differ, all take the scalar one
           for (int u = heads[k]; u >= 0; u = nxt[u])
-            if (q->jobs[sel[u]].mode != q->jobs[sel[heads[k]]].mode) j.mode = 1;
+            if (q->jobs[sel[u]].mode != q->jobs[sel[heads[k]]].mode) j.mode = j.n < 1024 ? 2 : 1;      // (2: 64 slab lanes per output -- the members with hundreds of slabs set the pace)
           j.next = nxt[t] >= 0 ? pos[nxt[t]] : -1;
           j.pad_ = 0;
           if (t == heads[k]) {

@@ -186,3 +186,5 @@ int launch_softmax_rows_bwd(const float* y, const float* dy, int M, int N, float
 // generic elementwise: y = a (+ b)
 int launch_add2(const float* a, const float* b, long long n, float* y, hipStream_t st);
 int launch_fill(float* p, long long n, float v, hipStream_t st);
+int launch_adam_pair(float* const* p, float* const* g, float* const* m, float* const* v, const long long* n, const float* wd, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_scale, int zero_grad, hipStream_t st);

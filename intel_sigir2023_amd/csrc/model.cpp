@@ -1309,7 +1309,7 @@ static void head_bwd_a(Run& r, const float* d_weights, const float* d_ens) {
 // the weight gradients of head_bwd_a's links -- weight_embeddings (valid + pad rows), intent_embeddings (h_intent's share), the two
 // value projections of the pooling -- as their own chain launch: LEAVES of the backward (nothing reads them before the optimizer),
 // issued on a side stream so that they do not lengthen the critical chain.  One partial per workgroup -> the reduce queue (final flush).
-static void head_bwd_a_leaves(Run& r) {
+static void head_bwd_a_leaves(Run& r, int leaf_tag) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   const int I = D.intent_num, K = D.model_num, F = y.F;
@@ -1339,8 +1339,10 @@ static void head_bwd_a_leaves(Run& r) {
     p.load(0, y.dHINT, D.d_int, 0, D.d_int, DH, 0, DH.width);
     p.wgrad(1, DH, 0, D.d_int, IN, 0, I, slab + o_wi, I, 0, stride, slab + o_bi);
     const int a = r.acc(INTEL_P_INTENT_W), ab = r.acc(INTEL_P_INTENT_B);
+    redq_set_tag(r.ctx->rq, 0);            // the intent-embedding slot is shared with the encoders' branches: final flush
     redq_push(r.ctx->rq, slab + o_wi, stride, S, D.d_int, I, r.G(INTEL_P_INTENT_W), I, a);
     redq_push(r.ctx->rq, slab + o_bi, stride, S, 1, D.d_int, r.G(INTEL_P_INTENT_B), D.d_int, ab);
+    redq_set_tag(r.ctx->rq, leaf_tag);
   }
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
@@ -1933,9 +1935,8 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.T = &y.tmp[0];
     Run m = r;
     Run s2 = branch(r, 2, 1), s1 = branch(r, 1, 0), s0 = branch(r, 0, 2);
-    // every branch reduces its own weight-gradient slabs on its own stream (large batches: 0.5 GB off the tail); at small batches the
-    // towers' reductions (a few MB) are one more launch on a branch, and the final flush takes them in one
-    const bool branch_flush = (size_t)M >= 65536;
+    // every branch reduces its own weight-gradient slabs on its own stream: the final flush (on the critical tail, in front of the dense
+    // groups' Adam) is left with the shared intent-embedding slot
     defer = &lv_main;
     r.ok((int)hipEventRecord(c->ev_fork, r.st));
     r.ok((int)hipStreamWaitEvent(c->side[2], c->ev_fork, 0));
@@ -1962,7 +1963,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
       TowerBufs& w = y.tw[1];
       float* dX0 = tower_bwd(t3, w, y.dXS, y.tmp[3].dXb, c->fused_tail[1]);
       if (!t3.rc && dX0) wgrad(t3, dX0, w.d, bt.scores, K, M, w.d, K, INTEL_P_SCORE_W, INTEL_P_SCORE_B);
-      if (!t3.rc && branch_flush) t3.ok(redq_flush_tag(c->rq, 1, t3.st));
+      if (!t3.rc) t3.ok(redq_flush_tag(c->rq, 1, t3.st));
       // the head's leaves (nothing in this backward reads them): table scatters and the weight gradients of head_bwd_b's links
       defer = nullptr;
       redq_set_tag(c->rq, 0);
@@ -1976,12 +1977,16 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     }
     redq_set_tag(c->rq, 2);
     item_tower_bwd(s1, y.tmp[0].dXa);
-    if (!s1.rc && branch_flush) s1.ok(redq_flush_tag(c->rq, 2, s1.st));
+    if (!s1.rc) s1.ok(redq_flush_tag(c->rq, 2, s1.st));
     redq_set_tag(c->rq, 0);
-    // ... and the weight gradients of the head's links behind the item tower (two chain launches off the critical chain)
-    if (!s1.rc) head_bwd_a_leaves(s1);
+    // ... and the weight gradients of the head's links behind the item tower (two chain launches off the critical chain), reduced right
+    // there (tag 5; the shared intent-embedding slot stays for the final flush)
+    redq_set_tag(c->rq, 5);
+    if (!s1.rc) head_bwd_a_leaves(s1, 5);
     s1.ok((int)hipStreamWaitEvent(s1.st, c->ev_x[2], 0));
     if (!s1.rc) head_bwd_b_leaves(s1);
+    if (!s1.rc) s1.ok(redq_flush_tag(c->rq, 5, s1.st));
+    redq_set_tag(c->rq, 0);
     r.ok(s1.rc);
     if (r.rc) return;
     redq_set_tag(c->rq, 3);

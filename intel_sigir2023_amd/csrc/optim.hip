@@ -110,6 +110,66 @@ int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int
   return 0;
 }
 
+// two parameter groups (torch's "decay" / "no decay" groups differ in the weight decay only) in ONE launch: the update of a group is a
+// pure function of its own elements, so the grid is simply cut in two
+__global__ __launch_bounds__(256) void adam_pair_kernel(AdamArgs a, AdamArgs b, int blocks_a) {
+  const bool first = (int)blockIdx.x < blocks_a;
+  const AdamArgs& c = first ? a : b;
+  const long long blk = first ? blockIdx.x : blockIdx.x - blocks_a;
+  const long long nblk = first ? blocks_a : (long long)gridDim.x - blocks_a;
+  const long long stride = nblk * blockDim.x;
+  const long long n4 = c.n >> 2;
+  for (long long i = blk * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 p = reinterpret_cast<f32x4*>(c.p)[i];
+    f32x4 g = reinterpret_cast<f32x4*>(c.g)[i];
+    f32x4 m = reinterpret_cast<f32x4*>(c.m)[i];
+    f32x4 v = reinterpret_cast<f32x4*>(c.v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = p[k], mk = m[k], vk = v[k];
+      adam_one(pk, g[k], mk, vk, c);
+      p[k] = pk; m[k] = mk; v[k] = vk;
+    }
+    reinterpret_cast<f32x4*>(c.p)[i] = p;
+    reinterpret_cast<f32x4*>(c.m)[i] = m;
+    reinterpret_cast<f32x4*>(c.v)[i] = v;
+    if (c.zero_grad) reinterpret_cast<f32x4*>(c.g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (long long i = (n4 << 2) + blk * blockDim.x + threadIdx.x; i < c.n; i += stride) {
+    float p = c.p[i], m = c.m[i], v = c.v[i];
+    adam_one(p, c.g[i], m, v, c);
+    c.p[i] = p; c.m[i] = m; c.v[i] = v;
+    if (c.zero_grad) c.g[i] = 0.f;
+  }
+}
+
+static void adam_fill(AdamArgs& a, float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float wd,
+                      int step, float grad_scale, int zero_grad) {
+  a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.step_size = (float)((double)lr / bc1);
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+}
+
+int launch_adam_pair(float* const* p, float* const* g, float* const* m, float* const* v, const long long* n, const float* wd, float lr, float beta1,
+                     float beta2, float eps, int step, float grad_scale, int zero_grad, hipStream_t st) {
+  INTEL_CHECK_ARG(step >= 1, "adam: step must be >= 1");
+  if (n[0] <= 0 && n[1] <= 0) return 0;
+  for (int k = 0; k < 2; ++k)
+    INTEL_CHECK_ARG(n[k] <= 0 || ((reinterpret_cast<uintptr_t>(p[k]) | reinterpret_cast<uintptr_t>(g[k]) | reinterpret_cast<uintptr_t>(m[k]) |
+                                   reinterpret_cast<uintptr_t>(v[k])) & 15) == 0, "adam: tensors must be 16-byte aligned");
+  AdamArgs a, b;
+  adam_fill(a, p[0], g[0], m[0], v[0], n[0] > 0 ? n[0] : 0, lr, beta1, beta2, eps, wd[0], step, grad_scale, zero_grad);
+  adam_fill(b, p[1], g[1], m[1], v[1], n[1] > 0 ? n[1] : 0, lr, beta1, beta2, eps, wd[1], step, grad_scale, zero_grad);
+  auto blocks_for = [](long long nn) { long long bl = ((nn >> 2) + 255) / 256; return (int)(bl < 1 ? 1 : (bl > 2048 ? 2048 : bl)); };
+  const int ba = blocks_for(a.n), bb = blocks_for(b.n);
+  LAUNCH_W(0.0, (zero_grad ? 32.0 : 28.0) * (double)(a.n + b.n), adam_pair_kernel, dim3((unsigned)(ba + bb)), dim3(256), 0, st, a, b, ba);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
                 float wd, int step, float grad_scale, int zero_grad, hipStream_t st) {
   if (n <= 0) return 0;

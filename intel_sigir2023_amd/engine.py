@@ -486,8 +486,7 @@ class IntELEngine(object):
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
             if tx is not None:
                 tx['b1'].record(cur)
-            adam('decay', self.l2, st)
-            adam('nodecay', 0.0, st)
+            self._adam_dense_groups(st)
             if tx is not None:
                 tx['m'].record(cur)
             cur.wait_stream(side)
@@ -532,6 +531,16 @@ class IntELEngine(object):
                 if not (sharded and gname == 'iid'):
                     adam(gname, wd, st, dense_reduced=dp)
         return tot[0], tot[1], tot[2]
+
+    def _adam_dense_groups(self, stream_ptr):
+        """torch's two dense parameter groups ('decay': weight_decay = l2, 'nodecay': biases, 0) in ONE launch (intel_adam_step_pair)."""
+        names = ('decay', 'nodecay')
+        arr = lambda d: (C.c_void_p * 2)(*[d[n].data_ptr() if d[n].numel() else None for n in names])
+        pa = (arr(self.flat), arr(self.gflat), arr(self.m), arr(self.v), (C.c_longlong * 2)(*[self.flat[n].numel() for n in names]))
+        b1, b2 = self.betas
+        wd = (C.c_float * 2)(self.l2, 0.0)
+        L.check(L.lib().intel_adam_step_pair(pa[0], pa[1], pa[2], pa[3], pa[4], wd, self.lr, b1, b2, self.eps, self.step_count, 1.0, 1, stream_ptr),
+                'intel_adam_step_pair')
 
     # ---- data-parallel exchange timing (observability only) ---------------------------------------------
     @property
