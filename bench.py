@@ -228,7 +228,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', type=str, default='tmall', help='tmall | tmall_pub | lifedata | stress | tiny')
+    ap.add_argument('--workload', type=str, default='tmall', help='tmall | tmall_pub | tmall_pub_mse | lifedata | stress | tiny')
     ap.add_argument('--batch', type=int, default=0, help='sessions per GPU per step (weak scaling); 0: 4096, or 512 for tmall_pub')
     ap.add_argument('--loss', type=str, default='IntBPRloss')
     ap.add_argument('--cal_diversity', type=int, default=-1, help='-1: the workload default')

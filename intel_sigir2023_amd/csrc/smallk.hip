@@ -153,7 +153,9 @@ int launch_linear_smallk(const float* X, int ldx, int M, int K, const float* W, 
   return 0;
 }
 
-int smallk_wgrad_slabs(int M) { return min(cdiv(M, 4), 2 * num_cus()); }
+// one slab per workgroup; a workgroup takes at least 64 rows (16 per wave): with cdiv(M, 4) workgroups a 5 000-row product left 512 slabs
+// of a 960-element gradient -- 2 MB of partials whose reduction (one uncoalesced 4-byte read per slab and output) took longer than the product
+int smallk_wgrad_slabs(int M) { return max(1, min(cdiv(M, 64), 2 * num_cus())); }
 
 // dW[N,K] (+)= dY^T X, db[N] (+)= colsum(dY) through the reduce queue (or immediately when q == nullptr, using `slabs`)
 int launch_wgrad_smallk(const float* dY, int lddy, const float* X, int ldx, int M, int N, int K, float* dW, int lddw, float* db,

@@ -26,6 +26,13 @@ WORKLOADS = {
                                  cal_diversity=1, diversity_alpha=1e-5, intent_weight=0.01),
                       corpus=dict(items=1000000, users=100000, classes=357, ctx=931, I=30),
                       batch=dict(L=50, H=20), bench_batch=512, optim=(1e-4, 1e-4)),
+    # ... and the PUBLISHED IntEL-MSE hyper-parameters (script/IntEL.sh:9, the paper's best Tmall model): the model's default widths
+    # (16/16/32/32, context 16, intent 16, 1 head x 1 layer, BERT4Rec encoders), dropout 0.5, cal_diversity 1 (alpha 1e-5), batch 512, lr 1e-3, l2 1e-6
+    'tmall_pub_mse': dict(flags=dict(model_num=3, context_emb_size=16, i_emb_size=16, u_emb_size=32, s_emb_size=32, im_emb_size=16,
+                                     intent_emb_size=16, cross_attn_qsize=32, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=20,
+                                     cal_diversity=1, diversity_alpha=1e-5, intent_weight=0.003, dropout=0.5),
+                          corpus=dict(items=1000000, users=100000, classes=357, ctx=931, I=30),
+                          batch=dict(L=50, H=20), bench_batch=512, optim=(1e-3, 1e-6)),
     # configs[3]: LifeData-shape (K=5, 10 intents, list=100)
     'lifedata': dict(flags=dict(model_num=5, context_emb_size=64, i_emb_size=64, u_emb_size=64, s_emb_size=64,
                                 im_emb_size=64, intent_emb_size=64, cross_attn_qsize=64, num_heads=1, num_layers=1,

@@ -3,7 +3,7 @@
 # branches), the PMC passes (each counter in its own run, kernel-trace only; training steps and evaluation steps
 # separately) and the other workloads.  Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py and a copy into
 # profiles/ follow in the build container.
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -28,7 +28,18 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ou
 timeout 300 python tools/step_timeline.py f32 train full > $out/timeline_f32_train.txt 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py bf16 train full > $out/timeline_bf16_train.txt 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py f32 eval full > $out/timeline_f32_eval.txt 2>&1 < /dev/null
+# round 4: the reference's published hyper-parameters (tmall_pub, batch 512) -- kernel stats, the step as it overlaps, the GPU-bound step time
+# with every launch queued ahead, and the same-box A/B lines of the two kernel families that replaced the kernel-per-op pipeline there
+INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_pub -- python3 bench.py --workload tmall_pub --steps 20 --warmup 5 --eval_steps 0 $PMCARGS > $out/stats1s_pub.log 2>&1 < /dev/null
+timeout 300 python tools/step_timeline.py f32 train full tmall_pub 512 > $out/timeline_pub_f32_train.txt 2>&1 < /dev/null
+timeout 300 python tools/step_timeline.py f32 eval full tmall_pub 512 > $out/timeline_pub_f32_eval.txt 2>&1 < /dev/null
+timeout 300 python tools/gpu_bound_probe.py tmall_pub 512 30 > $out/gpu_bound_pub.txt 2>&1 < /dev/null
+timeout 300 python tools/gpu_bound_probe.py tmall 4096 20 > $out/gpu_bound_tmall.txt 2>&1 < /dev/null
+timeout 900 python tools/ab_bench.py "--workload tmall_pub --steps 300 --warmup 30" INTEL_TOWER32=1,0 INTEL_HEAD_FUSED=1,0 > $out/ab_pub.txt 2>&1 < /dev/null
 if [ "$2" != "quick" ]; then
+timeout 600 python bench.py --workload tmall_pub --steps 300 --warmup 30 --no_cpu_baseline > $out/bench_tmall_pub_long.json 2>/dev/null < /dev/null
+timeout 600 python bench.py --workload tmall_pub_mse --loss IntMSEloss --steps 300 --warmup 30 --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_pub_mse.json 2>/dev/null < /dev/null
+INTEL_TOWER32=0 INTEL_HEAD_FUSED=0 timeout 600 python bench.py --workload tmall_pub_mse --loss IntMSEloss --steps 300 --warmup 30 --no_cpu_baseline --no_bf16_line --no_feed --no_roofline > $out/bench_tmall_pub_mse_kernel_per_op.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload lifedata --batch 2048 --no_cpu_baseline > $out/bench_lifedata.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 256 --steps 20 --warmup 3 --no_cpu_baseline > $out/bench_stress.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload stress --batch 1024 --steps 20 --warmup 3 --no_cpu_baseline > $out/bench_stress_b1024.json 2>/dev/null < /dev/null

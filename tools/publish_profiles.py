@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r03'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
 src = os.path.join('gpurun_out', tag)
 dst = 'profiles'
 
@@ -29,7 +29,8 @@ names = {'bench.json': 'bench_tmall', 'bench_bf16.json': 'bench_tmall_bf16', 'be
          'bench_stress_b1024.json': 'bench_stress_b1024', 'bench_pl_div.json': 'bench_pl_div', 'bench_gru4rec.json': 'bench_gru4rec',
          'bench_tmall_pub.json': 'bench_tmall_pub', 'bench_gru4rec_steps.json': 'bench_gru4rec_per_step', 'bench_tmall_pub_steps.json': 'bench_tmall_pub_per_step', 'bench_stress_dense.json': 'bench_stress_dense_adam', 'bench_stress_b1024_dense.json': 'bench_stress_b1024_dense_adam',
          'bench_tmall_b1024_dense.json': 'bench_tmall_b1024_dense_adam', 'bench_tmall_b1024.json': 'bench_tmall_b1024', 'bench_tmall_lazy.json': 'bench_tmall_lazy_adam', 'bench_zipf.json': 'bench_zipf', 'bench_unfused.json': 'bench_unfused', 'bench_phased.json': 'bench_phased',
-         'bench_enc_unfused.json': 'bench_enc_unfused', 'bench_enc_unfused_bwd.json': 'bench_enc_unfused_bwd', 'bench_lifedata_b4096.json': 'bench_lifedata_b4096'}
+         'bench_enc_unfused.json': 'bench_enc_unfused', 'bench_enc_unfused_bwd.json': 'bench_enc_unfused_bwd', 'bench_lifedata_b4096.json': 'bench_lifedata_b4096',
+         'bench_tmall_pub_long.json': 'bench_tmall_pub_300steps', 'bench_tmall_pub_mse.json': 'bench_tmall_pub_mse', 'bench_tmall_pub_mse_kernel_per_op.json': 'bench_tmall_pub_mse_kernel_per_op'}
 for k, v in names.items():
     bench(k, '%s_%s.json' % (rnd, v))
 sweep = []
@@ -46,7 +47,7 @@ def one(pattern):
     return fs[0] if fs else None
 
 
-for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'),
+for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'), ('stats1s_pub', 'bench_tmall_pub_kernel_stats.csv'),
                  ('stats_eval', 'bench_tmall_eval_kernel_stats.csv'), ('stats1s_bf16', 'bench_tmall_bf16_kernel_stats.csv')):
     f = one('%s/**/*kernel_stats.csv' % sub)
     if f:
@@ -65,7 +66,11 @@ if fb and wb:
 fl, wl = one('fetch_lazy/**/*counter_collection.csv'), one('write_lazy/**/*counter_collection.csv')
 if fl and wl:
     subprocess.run([sys.executable, 'tools/pmc_summary.py', fl, wl, '4', os.path.join(dst, '%s_pmc_traffic_lazy_adam.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
-for t in ('f32_train', 'bf16_train', 'f32_eval'):
+for name in ('gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt'):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, name)))
+for t in ('f32_train', 'bf16_train', 'f32_eval', 'pub_f32_train', 'pub_f32_eval'):
     f = os.path.join(src, 'timeline_%s.txt' % t)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_timeline_%s.txt' % (rnd, t)))
