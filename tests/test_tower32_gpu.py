@@ -1,0 +1,42 @@
+"""The one-kernel 32-wide tower (csrc/tower32.hip: models/IntEL/IntEL.py:182-197 at the reference's default / published widths) and the
+session-head chain launches (csrc/chain.hip: IntEL.py:147-153, 201-215) through the model (C ABI) against the oracle's autograd:
+outputs, the Int* loss and EVERY parameter gradient, at the shapes that matter for these kernels -- lists of 2 / 16 / 17 / 33 / 50 /
+64 / 65 / 90 / 96 candidates (1 .. 6 row tiles, tile boundaries), 1 and 2 heads, 1 .. 3 tied layers, both encoders, batches that are
+not a multiple of the chains' 16 sessions per workgroup; inference also at 128 candidates (training: kernel-per-op pipeline there)."""
+import importlib.util
+import os
+import random
+
+os.environ.setdefault('INTEL_GRU_ORDER_MIN_B', '1')
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_parity.py'))
+fuzz = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fuzz)
+
+W32 = dict(i_emb_size=16, im_emb_size=16, s_emb_size=32, u_emb_size=32, intent_emb_size=32, context_emb_size=64, cross_attn_qsize=32)
+
+
+@pytest.mark.parametrize('L,heads,layers,B,encoder,loss', [
+    (2, 1, 1, 3, 'BERT4Rec', 'IntBPRloss'), (16, 2, 2, 5, 'GRU4Rec', 'IntBPRloss'), (17, 1, 2, 17, 'GRU4Rec', 'IntListloss'),
+    (33, 2, 1, 16, 'BERT4Rec', 'IntMSEloss'), (50, 2, 2, 33, 'GRU4Rec', 'IntBPRloss'), (64, 1, 3, 4, 'BERT4Rec', 'IntListloss'),
+    (65, 2, 2, 7, 'GRU4Rec', 'IntBPRloss'), (90, 1, 1, 6, 'BERT4Rec', 'IntBPRloss'), (96, 2, 1, 3, 'GRU4Rec', 'IntMSEloss'),
+    (128, 2, 2, 3, 'GRU4Rec', 'IntBPRloss')])
+def test_reference_widths_match_oracle_autograd(L, heads, layers, B, encoder, loss):
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    force = dict(W32, L=L, B=B, I=30, num_heads=heads, num_layers=layers, encoder=encoder, history_max=20, model_num=3, loss=loss,
+                 cross_attention=1, cal_diversity=1)
+    worst, bad, desc = fuzz.one_case(random.Random(L * 100 + heads * 10 + layers), 7000 + L, torch.device('cuda:0'), big=False, force=force)
+    assert worst <= 1.0, (worst, bad, desc)
+
+
+def test_gate_variant_keeps_the_one_kernel_towers():
+    """--cross_attention 0 (IntEL.py:206-209): the chains do not apply, the 32-wide towers still do."""
+    force = dict(W32, L=50, B=9, I=30, num_heads=2, num_layers=2, encoder='GRU4Rec', history_max=20, model_num=3, loss='IntBPRloss',
+                 cross_attention=0, cal_diversity=0)
+    worst, bad, desc = fuzz.one_case(random.Random(5), 7999, torch.device('cuda:0'), big=False, force=force)
+    assert worst <= 1.0, (worst, bad, desc)

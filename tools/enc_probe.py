@@ -1,5 +1,5 @@
 """Per-phase shader-clock breakdown of the fused encoder block kernel (INTEL_ENC_DBG=1; synchronises every launch).
-usage (GPU box): INTEL_ENC_DBG=1 python tools/enc_probe.py [bf16]"""
+usage (GPU box; library built with INTEL_DEBUG_BUILD=1 python -m intel_sigir2023_amd.build): INTEL_ENC_DBG=1 python tools/enc_probe.py [bf16]"""
 import sys
 
 sys.path.insert(0, '.')

@@ -18,7 +18,7 @@ from oracle import intel_oracle as O
 from tests.helpers import relu_flip_forgiven_error
 
 
-def one_case(rng, idx, dev, big=None):
+def one_case(rng, idx, dev, big=None, force=None):
     """big: None = decided per case (about one case in 25), True / False = forced.  A 'big' case is the reference's own tower widths
     (16/16/32/32, script/IntEL.sh:15,21) at lists of 50 / 90 with more than 32 768 candidate rows per batch: the far side of the
     row-count thresholds of the short-list attention backward and the batched small weight gradients."""
@@ -37,11 +37,19 @@ def one_case(rng, idx, dev, big=None):
         flags.update(i_emb_size=16, im_emb_size=16, s_emb_size=32, history_max=min(flags['history_max'], 20))
         L = rng.choice([50, 90])
         B = 32768 // L + rng.choice([1, 40, 300])
+    if force:      # tests pin shapes: keys of `flags` plus 'L', 'B', 'I', 'loss', 'cross_attention', 'cal_diversity'
+        for k, v in force.items():
+            if k in flags:
+                flags[k] = v
+        L, B, I = force.get('L', L), force.get('B', B), force.get('I', I)
     H = flags['history_max']
     name = 'fuzz%d' % idx
     synth.WORKLOADS[name] = dict(flags=flags, corpus=dict(items=3000, users=300, classes=40, ctx=50, I=I), batch=dict(L=L, H=H))
     over = dict(cross_attention=rng.choice([1, 1, 0]), cal_diversity=rng.choice([0, 1]))
     loss_name = rng.choice(['IntBPRloss', 'IntListloss', 'IntMSEloss'])
+    if force:
+        over.update({k: force[k] for k in ('cross_attention', 'cal_diversity') if k in force})
+        loss_name = force.get('loss', loss_name)
     torch.manual_seed(100 + idx)
     args = synth.make_args(name, dev, **over)
     corpus, c = synth.make_corpus(name)

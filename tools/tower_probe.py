@@ -1,5 +1,5 @@
 """Per-phase shader-clock breakdown of the one-kernel tower layer (csrc/tower.hip) at the headline shape.
-usage (GPU box): INTEL_TOWER_DBG=1 INTEL_FUSE_TOWER=1 python tools/tower_probe.py [workload] [batch] [f32|bf16]"""
+usage (GPU box; library built with INTEL_DEBUG_BUILD=1 python -m intel_sigir2023_amd.build): INTEL_TOWER_DBG=1 INTEL_FUSE_TOWER=1 python tools/tower_probe.py [workload] [batch] [f32|bf16]"""
 import sys
 import time
 
