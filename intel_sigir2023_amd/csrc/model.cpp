@@ -1181,8 +1181,11 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   // same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers' kernels while a chain launch holds
   // whole CUs (measured same-box, round 4: Tmall shape 1024 / 2048 / 4096 sessions -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress
   // 1024 +-0) -- there only inference takes the chains (+2 ... +7 % evaluation sessions/s).  INTEL_HEAD_FUSED=2 forces them on.
-  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
-  if (train && y.B > 768 && !force) return false;
+  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : ((e && e[0] == '3') ? 2 : 0); }();
+  // train: 0 = inference forward, 1 = training BACKWARD, 2 = training FORWARD (the forward chains write the kernel-per-op path's stash,
+  // so the two directions decide independently; INTEL_HEAD_FUSED=3: training forward at any batch size, backward by the policy)
+  if (train == 2 && force == 2) return true;
+  if (train && y.B > 768 && force != 1) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
   const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
@@ -1464,7 +1467,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // the side branches start with work that needs no packed weights (history packing, embedding gathers): they fork BEFORE the
   // packing launches of the main stream and wait for them (ev_pack) in front of their first matrix product
   for (int e = 0; e < 2; ++e)      // GRU4Rec with the fused session head: the output projections are links of the head's chains
-    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
+    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train ? 2 : 0) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
   fork_streams(r, 3);
   hipEvent_t ev_pack = r.ctx->ev_x[0];
   {
@@ -1565,7 +1568,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
   if (r.rc) return;
-  if (head_fused_ok(D, y, r.train)) {
+  if (head_fused_ok(D, y, r.train ? 2 : 0)) {
     // the session head as two chain launches around the two pooling kernels (chain.hip)
     const float scale = 1.0f / sqrtf((float)D.q_size);
     head_fwd_a(r, out);
