@@ -1747,9 +1747,12 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
 #define WG_MAXS 512       // max slabs: 2 resident workgroups per CU (72 KB LDS each)
 
 static inline int wgrad_num_slabs(int M, int N = 128, int K = 128) {
-  static const int maxs = [] { const char* e = getenv("INTEL_WGRAD_SLABS"); int v = e ? atoi(e) : 256; return v < 1 ? 1 : (v > WG_MAXS ? WG_MAXS : v); }();
-  // default 256 = one workgroup per CU: with the products on the bf16 pipe the kernel is HBM-bound and the slab traffic
-  // (write here, read by the batched reduction) matters more than a second resident workgroup (measured: -1.5 % step time).
+  static const int maxs = [] { const char* e = getenv("INTEL_WGRAD_SLABS"); int v = e ? atoi(e) : 128; return v < 1 ? 1 : (v > WG_MAXS ? WG_MAXS : v); }();
+  // default 128 = one workgroup on every second CU: with the products on the bf16 pipe the STEP is HBM-bound, and the slab traffic (written
+  // here, read by the batched reduction: 0.6 GB of 12.7 GB per headline step at 256 slabs) matters more than this kernel's own time --
+  // measured same-box at the headline (round 4, 100 steps, twice): 64 / 96 / 128 / 160 / 192 / 256 slabs = 1.166 / 1.191 / 1.204 / 1.198 /
+  // 1.175 / 1.170 M sessions/s although the kernel itself takes 0.90 instead of 0.67 ms per step at 128; bf16 mode +1 %, published
+  // hyper-parameters +1.5 %, LifeData / stress unchanged.
   // Narrow products (N + K <= 128: 30 KB of LDS, 16 KB slabs) are latency-bound instead: two workgroups per CU.
   int cap = (N + K <= 128 && N % 32 == 0 && K % 32 == 0) ? 2 * maxs : maxs;
   if (cap > WG_MAXS) cap = WG_MAXS;

@@ -1177,15 +1177,14 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   static const int on = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
   if (!on || !D.cross_attention || D.pool_mean || D.weight_norm != 0 || D.model_num > 16) return false;
   if (D.dtype != INTEL_DTYPE_F32) return false;      // bf16 mode rounds the operands of the 64 / 128-deep B-row products (oracle.forward_bf16): kernel-per-op head
-  // Training: the chains pay where the step is launch-bound (the reference's hyper-parameters at its batch of 512: +8.5 % sessions/s
-  // same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers' kernels while a chain launch holds
-  // whole CUs (measured same-box, round 4: Tmall shape 1024 / 2048 / 4096 sessions -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress
-  // 1024 +-0) -- there only inference takes the chains (+2 ... +7 % evaluation sessions/s).  INTEL_HEAD_FUSED=2 forces them on.
-  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : ((e && e[0] == '3') ? 2 : 0); }();
-  // train: 0 = inference forward, 1 = training BACKWARD, 2 = training FORWARD (the forward chains write the kernel-per-op path's stash,
-  // so the two directions decide independently; INTEL_HEAD_FUSED=3: training forward at any batch size, backward by the policy)
-  if (train == 2 && force == 2) return true;
-  if (train && y.B > 768 && force != 1) return false;
+  // train: 0 = inference forward, 1 = training BACKWARD, 2 = training FORWARD -- the forward chains write the kernel-per-op path's stash, so
+  // the two directions decide independently.  The BACKWARD chains pay where the step is launch-bound (the reference's hyper-parameters at
+  // its batch of 512: +8.5 % sessions/s same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers'
+  // kernels while a chain launch holds whole CUs (measured same-box, round 4, both directions on: Tmall shape 1024 / 2048 / 4096 sessions
+  // -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress 1024 +-0): they stop at 768 sessions per step.  The FORWARD chains run at any batch
+  // size (evaluation +2 ... +7 %, the training forward at the headline +0.5 %).  INTEL_HEAD_FUSED=2 forces the backward chains on too.
+  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
+  if (train == 1 && y.B > 768 && !force) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
   const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
