@@ -150,6 +150,18 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
                        float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop = nullptr);
 
+// BERT4Rec at the reference's default widths (dm = 32, <= 2 blocks, 1-2 heads, histories of <= 32 events): the whole encoder of a session
+// history as one kernel per direction (tower32.hip: enc32_*).  X: [rows, 32] input rows incl. the position embedding, packed (off) or
+// padded [B, T]; out[b * ldo + c]: row len-1 of the last block.  INTEL_ENC32=0 turns the path off.
+struct Enc32Block { const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *g1, *be1, *W1, *b1, *W2, *b2, *g2, *be2; };
+bool enc32_supported(int T, int dm, int heads, int layers, int train);
+bool enc32_batch_ok(int B, int train);      // training: one slab per session and block, batches of <= 2048 sessions
+size_t enc32_slab_floats(int B, int layers);
+int launch_enc32_fwd(const float* X, const int* off, const int* len, int B, int T, int heads, int layers, const Enc32Block* blk, float* out, int ldo,
+                     hipStream_t st);
+int launch_enc32_bwd(const float* X, const int* off, const int* len, int B, int T, int heads, int layers, const Enc32Block* blk, const float* dout,
+                     int ldd, float* dX, float* const (*grads)[14], const int (*accumulate)[14], ReduceQueue* q, hipStream_t st);
+
 // ---- row / session kernels (rowops.hip) -----------------------------------------------------
 // dst[m, col0:col0+d] = table[idx[m], :]  (idx<0 -> zeros); optional relu
 int launch_gather_rows(const float* table, int d, const int* idx, int M, float* dst, int ldd, int col0, int relu,

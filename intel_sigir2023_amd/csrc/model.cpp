@@ -144,6 +144,7 @@ struct IntelCtx {
   bool params_unchanged = false, pack_ok = false, pack_train = false;
   const void* pack_ws = nullptr;
   int pack_shape[5] = {0, 0, 0, 0, 0};      // B, L, H, Hi, dropout layout
+  bool enc32[2] = {false, false};      // this forward ran encoder e as the one-kernel 32-wide BERT4Rec encoder (tower32.hip: enc32_*): no stash
   bool tw32[2] = {false, false};       // this forward ran tower t as the one-kernel 32-wide tower (tower32.hip): no stash, the backward recomputes
   bool tw_qkv16[2] = {false, false};   // this forward stored tower t's q/k/v stash as bf16 (bf16 mode; the backward reads it and writes dQKV the same way)
   int enc_rows[2];             // rows of encoder e: B * T, or the packed total
@@ -399,6 +400,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
+    if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
                                 rup_sz((size_t)d_i * d_i + (size_t)d_s * d_s + (size_t)(d_i + d_s) * I + (size_t)I * y.Pin + I, 64) + 64 +
                                 rup_sz((size_t)(dm0 + dm1) * (size_t)gh, 64));      // session-head chains (chain.hip)
@@ -845,6 +847,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
 }
 
 // ---- BERT4Rec encoder (GeneralSeq.py:89-106) -----------------------------------------------------
+static void enc32_blocks(const Run& r, int e, Enc32Block* blk);
 void bert_fwd(Run& r, int e) {
   const IntelDesc& D = r.D;
   EncBufs& n = r.y.enc[e];
@@ -858,6 +861,12 @@ void bert_fwd(Run& r, int e) {
   else
     RUN(launch_add_pos(n.E0, dm, r.P(enc_slot(e, INTEL_ENC_POS)), len, B, T, r.st));
   const float* X = n.E0;
+  if (r.ctx->enc32[e]) {      // the reference's default widths: the whole encoder in one kernel, nothing stashed (tower32.hip)
+    Enc32Block blk[INTEL_ENC_MAX_BLOCKS];
+    enc32_blocks(r, e, blk);
+    RUN(launch_enc32_fwd(X, off, len, B, T, D.enc_heads, D.enc_layers, blk, r.y.PREDIN + n.predin_off, r.y.Pin, r.st));
+    return;
+  }
   if (r.ctx->enc_fused[e]) {
     // two kernels for the whole encoder (enc.hip): every full block as one kernel over tiles of whole sessions -- the last full
     // block also projects the pruned last block's keys / values --, then the pruned last block, 16 sessions per workgroup
@@ -978,7 +987,17 @@ void bert_fwd(Run& r, int e) {
 }
 
 // returns dE0 (gradient w.r.t. the encoder input rows, pos-emb already handled)
-float* bert_bwd(Run& r, int e) {
+// the parameters of encoder e's blocks in the order of Enc32Block (raw reference tensors)
+static void enc32_blocks(const Run& r, int e, Enc32Block* blk) {
+  for (int l = 0; l < r.D.enc_layers; ++l) {
+    auto P = [&](int o) { return r.P(enc_blk_slot(e, l, o)); };
+    blk[l] = Enc32Block{P(INTEL_ENC_WQ), P(INTEL_ENC_BQ), P(INTEL_ENC_WK), P(INTEL_ENC_BK), P(INTEL_ENC_WV), P(INTEL_ENC_BV), P(INTEL_ENC_LN1G), P(INTEL_ENC_LN1B),
+                        P(INTEL_ENC_W1), P(INTEL_ENC_B1), P(INTEL_ENC_W2), P(INTEL_ENC_B2), P(INTEL_ENC_LN2G), P(INTEL_ENC_LN2B)};
+  }
+}
+
+// the blocks' backward: returns the gradient of the encoder's input rows (position-embedding gradient: bert_bwd below)
+float* bert_bwd_blocks(Run& r, int e) {
   const IntelDesc& D = r.D;
   Layout& y = r.y;
   EncBufs& n = y.enc[e];
@@ -986,6 +1005,19 @@ float* bert_bwd(Run& r, int e) {
   const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
   const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
   float *dX = r.T->dXa, *dXalt = r.T->dXb;
+  if (r.ctx->enc32[e]) {      // every block, data and parameter gradients, in one kernel (tower32.hip: enc32_bwd_kernel)
+    Enc32Block blk[INTEL_ENC_MAX_BLOCKS];
+    enc32_blocks(r, e, blk);
+    float* g[INTEL_ENC_MAX_BLOCKS][14];
+    int acc[INTEL_ENC_MAX_BLOCKS][14];
+    for (int l = 0; l < D.enc_layers; ++l)
+      for (int o = 0; o < 14; ++o) {
+        g[l][o] = r.G(enc_blk_slot(e, l, o));
+        acc[l][o] = r.acc(enc_blk_slot(e, l, o));
+      }
+    if (!r.ok(launch_enc32_bwd(n.E0, off, len, B, T, D.enc_heads, D.enc_layers, blk, y.dPREDIN + n.predin_off, y.Pin, dX, g, acc, r.ctx->rq, r.st))) return nullptr;
+    return dX;
+  }
   static const bool fused_bwd_on = [] { const char* e = getenv("INTEL_ENC_FUSED_BWD"); return !(e && e[0] == '0'); }();      // 0: kernel-per-op backward on the fused forward's stash
   const bool fused_bwd = fused_bwd_on && r.ctx->enc_fused[e];
   if (fused_bwd) {
@@ -1150,6 +1182,18 @@ float* bert_bwd(Run& r, int e) {
     if (r.rc) return nullptr;
     float* t = dX; dX = dXalt; dXalt = t;
   }
+  return dX;
+}
+
+// returns dE0 (gradient w.r.t. the encoder input rows, pos-emb already handled)
+float* bert_bwd(Run& r, int e) {
+  const IntelDesc& D = r.D;
+  EncBufs& n = r.y.enc[e];
+  const int T = n.T, dm = n.dm, rows = r.ctx->enc_rows[e];
+  const int* len = e == 0 ? r.bt->history_len : r.bt->history_item_len;
+  const int* off = r.ctx->enc_packed[e] ? (e == 0 ? r.bt->his_off : r.bt->hisitem_off) : nullptr;     // packed rows
+  float* dX = bert_bwd_blocks(r, e);
+  if (!dX || r.rc) return nullptr;
   // position embedding gradient: dpos[p,:] = sum of dE over the rows at position p (per-workgroup LDS tables + one atomic per entry)
   if (r.G(enc_slot(e, INTEL_ENC_POS)) && pos_grad_supported(T, dm)) {
     const int ps = enc_slot(e, INTEL_ENC_POS);
@@ -2349,6 +2393,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
       ctx->enc_packed[e] = pk;
       ctx->enc_rows[e] = pk ? nrows : batch->B * T;
       ctx->enc_fused[e] = pk && D.encoder == INTEL_ENC_BERT4REC && D.enc_layers >= 2 && enc_fused_supported(T, dm, D.enc_heads);
+      ctx->enc32[e] = D.encoder == INTEL_ENC_BERT4REC && enc32_supported(T, dm, D.enc_heads, D.enc_layers, train) && enc32_batch_ok(batch->B, train);
     }
   }
   ctx->fused_tail[0] = tail_fusable(ctx, ctx->d, batch->L, ctx->lay.tw[0].d, train != 0);

@@ -604,6 +604,440 @@ __global__ __launch_bounds__(64 * NT) void tw32_bwd_kernel(Tw32BwdArgs a) {
   for (int e = tid * 4; e < TW32_SLAB; e += 64 * NT * 4) *reinterpret_cast<f32x4*>(slab + e) = *reinterpret_cast<const f32x4*>(R + e);
 }
 
+// =================================================================================================================================
+// BERT4Rec at the reference's DEFAULT widths (models/GeneralSeq.py:80-106 with modules/layers.py:63-88 blocks; dm = context_emb_size +
+// intent_emb_size = i_emb_size + intent_emb_size = 32 with the defaults of IntEL.py:20-26 / GeneralSeq.py, 2 blocks x 2 heads hard-coded
+// at IntEL.py:108-109): the whole encoder of one session history (<= 32 events) as one kernel per direction, with the machinery of the
+// tower kernels above.  Differences from a tower layer: q / k / v have biases, keys are masked at the history length (GeneralSeq.py:100),
+// a LayerNorm follows the attention (x = LN1(attention + x)), the blocks have their own weights (nothing tied), and the encoder's output
+// is row len-1 of the last block (GeneralSeq.py:103-105) -- so the backward starts from ONE non-zero row.
+// Per-block weight image in LDS: Wq | Wk | Wv | W1 | W2 (pitch LDW) | bq | bk | bv | b1 | b2 | g1 | be1 | g2 | be2.
+constexpr int EB = 5 * WMAT + 9 * 32;
+enum { EV_BQ = 5 * WMAT, EV_BK = EV_BQ + 32, EV_BV = EV_BK + 32, EV_B1 = EV_BV + 32, EV_B2 = EV_B1 + 32, EV_G1 = EV_B2 + 32, EV_BE1 = EV_G1 + 32,
+       EV_G2 = EV_BE1 + 32, EV_BE2 = EV_G2 + 32 };
+constexpr int ENC32_MAXL = 2;
+constexpr int ENC32_SLAB = 5 * 1024 + 9 * 32;      // per block: dWq dWk dWv dW1 dW2 | dbq dbk dbv db1 db2 dg1 dbe1 dg2 dbe2
+
+struct Enc32Args {
+  const float* X;            // [rows, 32] input rows (position embedding already added); packed (off) or padded [B, T]
+  const int* off;            // packed: first row of session b, else null
+  const int* len;            // [B]
+  int B, T, layers;
+  const float* W[ENC32_MAXL][5];      // Wq Wk Wv W1 W2, raw [32, 32]
+  const float* V[ENC32_MAXL][9];      // bq bk bv b1 b2 g1 be1 g2 be2
+  float* out; int ldo;       // forward: out[b * ldo + c] = encoder output (row len-1)
+  const float* dout; int ldd;// backward: gradient of that vector
+  float* dX;                 // backward: [rows, 32] gradient of the input rows
+  float* slabs;              // backward: [grid, layers * ENC32_SLAB]
+};
+
+__device__ __forceinline__ void enc32_stage(const Enc32Args& a, float* Ws, int tid, int nthreads) {
+  for (int l = 0; l < a.layers; ++l) {
+    for (int e = tid; e < 5 * 32 * 8; e += nthreads) {
+      const int m = e / 256, rem = e - m * 256, row = rem >> 3, c4 = (rem & 7) * 4;
+      *reinterpret_cast<f32x4*>(Ws + l * EB + m * WMAT + row * LDW + c4) = *reinterpret_cast<const f32x4*>(a.W[l][m] + row * 32 + c4);
+    }
+    for (int e = tid; e < 9 * 32; e += nthreads) Ws[l * EB + 5 * WMAT + e] = a.V[l][e >> 5][e & 31];
+  }
+}
+
+// rows of width 32 over the lanes (i, 0..3): y = LayerNorm(z) (in place), x-hat and 1/std out
+__device__ __forceinline__ void ln32(f32x4 (&z)[2], const float* Wb, int og, int ob, int j, f32x4 (&xh)[2], float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s += z[g][r];
+  const float mean = row_sum(s) * (1.0f / D);
+  float s2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      z[g][r] -= mean;
+      s2 += z[g][r] * z[g][r];
+    }
+  rstd = 1.0f / sqrtf(row_sum(s2) * (1.0f / D) + 1e-5f);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f32x4 ga = cvec(Wb, og, g, j), be = cvec(Wb, ob, g, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      xh[g][r] = z[g][r] * rstd;
+      z[g][r] = xh[g][r] * ga[r] + be[r];
+    }
+  }
+}
+// dz = LayerNorm backward of dy (in place): dz = (dy*g - mean(dy*g) - xhat * mean(dy*g*xhat)) * rstd
+__device__ __forceinline__ void ln32_bwd(f32x4 (&dy)[2], const float* Wb, int og, int j, const f32x4 (&xh)[2], float rstd) {
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f32x4 ga = cvec(Wb, og, g, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dy[g][r] *= ga[r];
+      m1 += dy[g][r];
+      m2 += dy[g][r] * xh[g][r];
+    }
+  }
+  m1 = row_sum(m1) * (1.0f / D);
+  m2 = row_sum(m2) * (1.0f / D);
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dy[g][r] = (dy[g][r] - m1 - xh[g][r] * m2) * rstd;
+}
+
+// one block forward on the wave's row tile: x -> x.  n = history length (keys >= n are masked).  Two workgroup barriers.
+template <int HEADS, int NT, bool KEEP>
+__device__ __forceinline__ void enc32_block_fwd(const float* Wb, float* Ks, float* Vs, float* Qs, int n, int row, int i, int j, f32x4 (&x)[2],
+                                                f32x4 (&q)[2], f32x4 (&at)[2], f32x4 (&c)[2], f32x4 (&xh1)[2], float& rstd1, f32x4 (&f)[2],
+                                                f32x4 (&xh2)[2], float& rstd2, float (&lse2)[HEADS]) {
+  f32x4 k[2], v[2];
+  lin32(Wb + 0 * WMAT, i, j, x, q);
+  lin32(Wb + 1 * WMAT, i, j, x, k);
+  lin32(Wb + 2 * WMAT, i, j, x, v);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    q[g] += cvec(Wb, EV_BQ, g, j);
+    k[g] += cvec(Wb, EV_BK, g, j);
+    v[g] += cvec(Wb, EV_BV, g, j);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    *reinterpret_cast<f32x4*>(Ks + row * LDR + 16 * g + 4 * j) = k[g];
+    *reinterpret_cast<f32x4*>(Vs + row * LDR + 16 * g + 4 * j) = v[g];
+    if (KEEP) *reinterpret_cast<f32x4*>(Qs + row * LDR + 16 * g + 4 * j) = q[g];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < HEADS; ++h) attn32_fwd<HEADS, NT>(Ks, Vs, n, i, j, h, q, at, lse2[h]);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) c[g] = at[g] + x[g];
+  ln32(c, Wb, EV_G1, EV_BE1, j, xh1, rstd1);
+  f32x4 t[2];
+  lin32(Wb + 3 * WMAT, i, j, c, t);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const f32x4 b1 = cvec(Wb, EV_B1, g, j);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f[g][r] = fmaxf(t[g][r] + b1[r], 0.f);
+  }
+  lin32(Wb + 4 * WMAT, i, j, f, x);
+#pragma unroll
+  for (int g = 0; g < 2; ++g) x[g] += cvec(Wb, EV_B2, g, j) + c[g];
+  ln32(x, Wb, EV_G2, EV_BE2, j, xh2, rstd2);
+}
+
+template <int HEADS, int NT>
+__global__ __launch_bounds__(64 * NT) void enc32_fwd_kernel(Enc32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;
+  float* Ks = Ws + a.layers * EB;
+  float* Vs = Ks + NT * 16 * LDR;
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, j = lane >> 4;
+  const int wave = tid >> 6, row = 16 * wave + i;
+  enc32_stage(a, Ws, tid, 64 * NT);
+  __syncthreads();
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const int n = min(a.len[b], a.T);
+    float* orow = a.out + (size_t)b * a.ldo;
+    if (n <= 0) {                                   // (outside the reference's domain: GeneralSeq.py:48-52 gives every session one event)
+      if (tid < 8) *reinterpret_cast<f32x4*>(orow + 4 * tid) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    const size_t base = ((a.off ? (size_t)a.off[b] : (size_t)b * a.T) + row) * D;
+    const bool rok = row < n;
+    f32x4 x[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) x[g] = rok ? *reinterpret_cast<const f32x4*>(a.X + base + 16 * g + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < a.layers; ++l) {
+      f32x4 q[2], at[2], c[2], xh1[2], f[2], xh2[2];
+      float rstd1, rstd2, lse2[HEADS];
+      enc32_block_fwd<HEADS, NT, false>(Ws + l * EB, Ks, Vs, nullptr, n, row, i, j, x, q, at, c, xh1, rstd1, f, xh2, rstd2, lse2);
+    }
+    if (row == n - 1) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(orow + 16 * g + 4 * j) = x[g];
+    }
+  }
+}
+
+// One session per workgroup; the blocks are walked last to first and every block's parameter gradients leave as soon as the block is done
+// (one slab per session and block): both blocks' accumulators at once would not fit the register file next to the data path.
+template <int HEADS, int NT>
+__global__ __launch_bounds__(64 * NT) void enc32_bwd_kernel(Enc32Args a) {
+  constexpr int CG = 2 / HEADS, ROWS = NT * 16;
+  const int LAYERS = a.layers;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;
+  float* Xl = Ws + LAYERS * EB;                  // [LAYERS][ROWS][32]: the input rows of every block (live across the blocks' reductions below)
+  float* Ks = Xl + LAYERS * ROWS * D;
+  float* Vs = Ks + ROWS * LDR;
+  float* Qs = Vs + ROWS * LDR;
+  float* dAs = Qs + ROWS * LDR;
+  float* LSEs = dAs + ROWS * LDR;
+  float* DLs = LSEs + HEADS * ROWS;
+  float* Ts = DLs + HEADS * ROWS;                // [NT][16][LDR]
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, j = lane >> 4;
+  const int wave = tid >> 6, row = 16 * wave + i;
+  float* T = Ts + wave * 16 * LDR;
+  enc32_stage(a, Ws, tid, 64 * NT);
+  __syncthreads();
+  const float scl = 1.0f / sqrtf((float)(D / HEADS));
+  const float sc2 = LOG2E * scl;
+  f32x4 gW[5][2][2];
+  float gv[9][2];                                // bq bk bv b1 b2 g1 be1 g2 be2 (column shares, summed over j at the end of a block)
+  float* R = Ks;                                 // cross-wave reduction of a block's gradients (the activation tiles are dead then)
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const int n = min(a.len[b], a.T);
+    const size_t row0 = a.off ? (size_t)a.off[b] : (size_t)b * a.T;
+    const size_t base = (row0 + row) * D;
+    const bool rok = row < n;
+    float* slab = a.slabs + (size_t)b * LAYERS * ENC32_SLAB;
+    if (n <= 0) {
+      if (!a.off && row < a.T) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(a.dX + base + 16 * g + 4 * j) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      for (int e = tid * 4; e < LAYERS * ENC32_SLAB; e += 64 * NT * 4) *reinterpret_cast<f32x4*>(slab + e) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
+    {   // forward recompute: the input rows of every block
+      f32x4 x[2], q[2], at[2], c[2], xh1[2], f[2], xh2[2];
+      float rstd1, rstd2, lse2[HEADS];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) x[g] = rok ? *reinterpret_cast<const f32x4*>(a.X + base + 16 * g + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int l = 0; l < LAYERS; ++l) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(Xl + ((size_t)l * ROWS + row) * D + 16 * g + 4 * j) = x[g];
+        if (l + 1 < LAYERS) enc32_block_fwd<HEADS, NT, false>(Ws + l * EB, Ks, Vs, nullptr, n, row, i, j, x, q, at, c, xh1, rstd1, f, xh2, rstd2, lse2);
+      }
+    }
+    f32x4 dy[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) dy[g] = row == n - 1 ? *reinterpret_cast<const f32x4*>(a.dout + (size_t)b * a.ldd + 16 * g + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int l = LAYERS - 1; l >= 0; --l) {
+      const float* Wb = Ws + l * EB;
+      const float* xrow = Xl + ((size_t)l * ROWS + row) * D + 4 * j;
+      f32x4 q[2], at[2], dz1[2], da[2];
+      float lse2[HEADS];
+#pragma unroll
+      for (int w = 0; w < 5; ++w)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn) gW[w][m][nn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < 9; ++w) gv[w][0] = gv[w][1] = 0.f;
+      {
+        f32x4 x[2], c[2], xh1[2], f[2], xh2[2];
+        float rstd1, rstd2;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) x[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+        enc32_block_fwd<HEADS, NT, true>(Wb, Ks, Vs, Qs, n, row, i, j, x, q, at, c, xh1, rstd1, f, xh2, rstd2, lse2);
+        // LayerNorm-2 backward
+        f32x4 t[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[g][r] = dy[g][r] * xh2[g][r];
+        colsum32(T, i, j, t, gv[7]);
+        colsum32(T, i, j, dy, gv[8]);
+        ln32_bwd(dy, Wb, EV_G2, j, xh2, rstd2);             // dy = dz2
+        // feed-forward backward; the residual c receives dz2 too
+        wgrad32<true>(T, i, j, dy, f, gW[4], gv[4]);
+        f32x4 df[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        linT32(Wb + 4 * WMAT, i, j, dy, df);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) df[g][r] = f[g][r] > 0.f ? df[g][r] : 0.f;
+        wgrad32<true>(T, i, j, df, c, gW[3], gv[3]);
+        linT32(Wb + 3 * WMAT, i, j, df, dy);                 // dy = dc = dz2 + df W1
+        // LayerNorm-1 backward
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t[g][r] = dy[g][r] * xh1[g][r];
+        colsum32(T, i, j, t, gv[5]);
+        colsum32(T, i, j, dy, gv[6]);
+        ln32_bwd(dy, Wb, EV_G1, j, xh1, rstd1);              // dy = dz1 = d(attention output) = residual gradient into x
+        dz1[0] = dy[0]; dz1[1] = dy[1];
+        da[0] = dy[0]; da[1] = dy[1];
+      }
+      // attention backward, pass 1 (this wave's 16 queries -> dQ)
+      f32x4 dq[2];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(dAs + row * LDR + 16 * g + 4 * j) = da[g];
+#pragma unroll
+      for (int h = 0; h < HEADS; ++h) {
+        float dl = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < CG; ++gq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dl += da[h * CG + gq][r] * at[h * CG + gq][r];
+        dl = row_sum(dl);
+        if (j == 0) {
+          LSEs[h * ROWS + row] = lse2[h];
+          DLs[h * ROWS + row] = dl;
+        }
+        f32x4 ds[NT];
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+          f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int gq = 0; gq < CG; ++gq) {
+            const int g = h * CG + gq;
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + i) * LDR + 16 * g + 4 * j);
+            const f32x4 vf = *reinterpret_cast<const f32x4*>(Vs + (16 * kt + i) * LDR + 16 * g + 4 * j);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              st = mfma16(kf[s], q[g][s], st);
+              dp = mfma16(vf[s], da[g][s], dp);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * kt + 4 * j + r;
+            const float p = key < n ? __builtin_amdgcn_exp2f(st[r] * sc2 - lse2[h]) : 0.f;
+            ds[kt][r] = p * (dp[r] - dl) * scl;
+          }
+        }
+#pragma unroll
+        for (int gq = 0; gq < CG; ++gq) {
+          const int ct = h * CG + gq;
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(Ks[(16 * kt + 4 * j + s) * LDR + 16 * ct + i], ds[kt][s], acc);
+          dq[ct] = acc;
+        }
+      }
+      {
+        f32x4 xin[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) xin[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+        wgrad32<true>(T, i, j, dq, xin, gW[0], gv[0]);
+        linT32(Wb + 0 * WMAT, i, j, dq, dz1);
+      }
+      __syncthreads();
+      // pass 2 (this wave's 16 keys -> dK, dV)
+      f32x4 dk[2], dv[2];
+      {
+        f32x4 k[2], v[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          k[g] = *reinterpret_cast<const f32x4*>(Ks + row * LDR + 16 * g + 4 * j);
+          v[g] = *reinterpret_cast<const f32x4*>(Vs + row * LDR + 16 * g + 4 * j);
+        }
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+          f32x4 adk[CG], adv[CG];
+#pragma unroll
+          for (int gq = 0; gq < CG; ++gq) adk[gq] = adv[gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int qt = 0; qt < NT; ++qt) {
+            f32x4 st = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gq = 0; gq < CG; ++gq) {
+              const int g = h * CG + gq;
+              const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + (16 * qt + i) * LDR + 16 * g + 4 * j);
+              const f32x4 of = *reinterpret_cast<const f32x4*>(dAs + (16 * qt + i) * LDR + 16 * g + 4 * j);
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                st = mfma16(qf[s], k[g][s], st);
+                dp = mfma16(of[s], v[g][s], dp);
+              }
+            }
+            const f32x4 ls = *reinterpret_cast<const f32x4*>(LSEs + h * ROWS + 16 * qt + 4 * j);
+            const f32x4 dl = *reinterpret_cast<const f32x4*>(DLs + h * ROWS + 16 * qt + 4 * j);
+            f32x4 p, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[r] = rok ? __builtin_amdgcn_exp2f(st[r] * sc2 - ls[r]) : 0.f;      // a key past the history is masked
+              ds[r] = p[r] * (dp[r] - dl[r]) * scl;
+            }
+#pragma unroll
+            for (int gq = 0; gq < CG; ++gq) {
+              const int ct = h * CG + gq;
+#pragma unroll
+              for (int s = 0; s < 4; ++s) {
+                adv[gq] = mfma16(dAs[(16 * qt + 4 * j + s) * LDR + 16 * ct + i], p[s], adv[gq]);
+                adk[gq] = mfma16(Qs[(16 * qt + 4 * j + s) * LDR + 16 * ct + i], ds[s], adk[gq]);
+              }
+            }
+          }
+#pragma unroll
+          for (int gq = 0; gq < CG; ++gq) {
+            dk[h * CG + gq] = adk[gq];
+            dv[h * CG + gq] = adv[gq];
+          }
+        }
+      }
+      {
+        f32x4 xin[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) xin[g] = *reinterpret_cast<const f32x4*>(xrow + 16 * g);
+        wgrad32<true>(T, i, j, dk, xin, gW[1], gv[1]);
+        wgrad32<true>(T, i, j, dv, xin, gW[2], gv[2]);
+      }
+      linT32(Wb + 1 * WMAT, i, j, dk, dz1);
+      linT32(Wb + 2 * WMAT, i, j, dv, dz1);
+      dy[0] = dz1[0];
+      dy[1] = dz1[1];
+      // ---- this block's parameter gradients: waves summed in order through LDS (over the dead activation tiles), one slab
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < 9; ++w)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) gv[w][mt] = row_sum(gv[w][mt]);
+      for (int w = 0; w < NT; ++w) {
+        if (wave == w) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float* p = R + m * 1024 + (16 * mt + 4 * j + r) * 32 + 16 * nt + i;
+                  *p = (w == 0 ? 0.f : *p) + gW[m][mt][nt][r];
+                }
+          if (j == 0) {
+#pragma unroll
+            for (int v = 0; v < 9; ++v)
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt) {
+                float* p = R + 5 * 1024 + v * 32 + 16 * mt + i;
+                *p = (w == 0 ? 0.f : *p) + gv[v][mt];
+              }
+          }
+        }
+        __syncthreads();
+      }
+      for (int e = tid * 4; e < ENC32_SLAB; e += 64 * NT * 4) *reinterpret_cast<f32x4*>(slab + l * ENC32_SLAB + e) = *reinterpret_cast<const f32x4*>(R + e);
+      // (the next block's forward recompute starts with a barrier before it rewrites the K / V / Q tiles this reduction sat on)
+    }
+    // rows past the history carry no gradient (queries of rows >= n fed nothing that reached the output); padded layout: zeros there
+    if (rok || (!a.off && row < a.T)) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g) *reinterpret_cast<f32x4*>(a.dX + base + 16 * g + 4 * j) = rok ? dy[g] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+}
+
+size_t enc32_fwd_smem(int nt, int layers) { return sizeof(float) * ((size_t)layers * EB + 2 * (size_t)nt * 16 * LDR); }
+size_t enc32_bwd_smem(int nt, int heads, int layers) {
+  const size_t rows = (size_t)nt * 16;
+  return sizeof(float) * ((size_t)layers * EB + 4 * rows * LDR + 2 * heads * rows + (size_t)nt * 16 * LDR + (size_t)layers * rows * D);
+}
+
 size_t fwd_smem(int nt) { return sizeof(float) * (WS_FLOATS + 2 * (size_t)nt * 16 * LDR); }
 size_t bwd_smem(int nt, int heads, int layers) {
   const size_t rows = (size_t)nt * 16;
@@ -724,6 +1158,96 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
     if (!grads[p]) continue;
     if (isw[p]) redq_push(q, slabs + off[p], TW32_SLAB, grid, 32, 32, grads[p], 32, accumulate[p]);
     else redq_push(q, slabs + off[p], TW32_SLAB, grid, 1, 32, grads[p], 32, accumulate[p]);
+  }
+  return 0;
+}
+
+// ---- BERT4Rec at width 32 (enc32_* kernels above) ------------------------------------------------------------------------------
+constexpr int ENC32_MAXB = 2048;      // one slab per session and block: larger batches take the kernel-per-op encoder (they are not launch-bound)
+bool enc32_supported(int T, int dm, int heads, int layers, int train) {
+  static const int on = [] { const char* e = getenv("INTEL_ENC32"); return (e && e[0] == '0') ? 0 : 1; }();
+  (void)train;
+  return on && dm == 32 && (heads == 1 || heads == 2) && T >= 1 && T <= 32 && layers >= 1 && layers <= ENC32_MAXL;
+}
+bool enc32_batch_ok(int B, int train) { return !train || B <= ENC32_MAXB;
+}
+size_t enc32_slab_floats(int B, int layers) { return (size_t)(B < ENC32_MAXB ? B : ENC32_MAXB) * layers * ENC32_SLAB; }
+
+static void enc32_fill(Enc32Args& a, const Enc32Block* blk, int layers) {
+  for (int l = 0; l < layers; ++l) {
+    const Enc32Block& k = blk[l];
+    const float* W[5] = {k.Wq, k.Wk, k.Wv, k.W1, k.W2};
+    const float* V[9] = {k.bq, k.bk, k.bv, k.b1, k.b2, k.g1, k.be1, k.g2, k.be2};
+    for (int i = 0; i < 5; ++i) a.W[l][i] = W[i];
+    for (int i = 0; i < 9; ++i) a.V[l][i] = V[i];
+  }
+}
+
+int launch_enc32_fwd(const float* X, const int* off, const int* len, int B, int T, int heads, int layers, const Enc32Block* blk, float* out, int ldo,
+                     hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(enc32_supported(T, 32, heads, layers, 0), "enc32_fwd: unsupported shape T=%d heads=%d layers=%d", T, heads, layers);
+  Enc32Args a{};
+  a.X = X; a.off = off; a.len = len; a.B = B; a.T = T; a.layers = layers; a.out = out; a.ldo = ldo;
+  enc32_fill(a, blk, layers);
+  const int nt = T <= 16 ? 1 : 2;
+  const size_t smem = enc32_fwd_smem(nt, layers);
+  const int grid = B < 2048 ? B : 2048;
+  const double rows = (double)B * T * 0.5;
+  const double flops = layers * (rows * 2.0 * D * D * 5 + 4.0 * rows * T * D * 0.5);
+  const double bytes = rows * D * 4 + (double)B * D * 4;
+#define E32F(H_, NT_)                                                                                                \
+  do {                                                                                                               \
+    allow_lds((enc32_fwd_kernel<H_, NT_>), smem);                                                                    \
+    LAUNCH_S(B * T, D, layers, flops, bytes, (enc32_fwd_kernel<H_, NT_>), dim3(grid), dim3(64 * NT_), smem, st, a);  \
+  } while (0)
+  if (heads == 1) { if (nt == 1) E32F(1, 1); else E32F(1, 2); }
+  else { if (nt == 1) E32F(2, 1); else E32F(2, 2); }
+#undef E32F
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
+// grads[l][14]: dWq dbq dWk dbk dWv dbv dg1 dbe1 dW1 db1 dW2 db2 dg2 dbe2 (the order of the INTEL_ENC_* slots; NULL = not wanted);
+// accumulate likewise.  The partial sums join the reduce queue (valid after its flush).
+int launch_enc32_bwd(const float* X, const int* off, const int* len, int B, int T, int heads, int layers, const Enc32Block* blk, const float* dout,
+                     int ldd, float* dX, float* const (*grads)[14], const int (*accumulate)[14], ReduceQueue* q, hipStream_t st) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(enc32_supported(T, 32, heads, layers, 1), "enc32_bwd: unsupported shape T=%d heads=%d layers=%d", T, heads, layers);
+  INTEL_CHECK_ARG(q, "enc32_bwd: needs the reduce queue");
+  INTEL_CHECK_ARG(B <= ENC32_MAXB, "enc32_bwd: batch %d > %d", B, ENC32_MAXB);
+  const int grid = B;
+  float* slabs = redq_alloc(q, (size_t)grid * layers * ENC32_SLAB);
+  INTEL_CHECK_ARG(slabs, "enc32_bwd: reduction arena exhausted");
+  Enc32Args a{};
+  a.X = X; a.off = off; a.len = len; a.B = B; a.T = T; a.layers = layers; a.dout = dout; a.ldd = ldd; a.dX = dX; a.slabs = slabs;
+  enc32_fill(a, blk, layers);
+  const int nt = T <= 16 ? 1 : 2;
+  size_t smem = enc32_bwd_smem(nt, heads, layers);
+  const size_t need = sizeof(float) * ((size_t)layers * EB + (size_t)layers * nt * 16 * D + ENC32_SLAB);      // the cross-wave reduction reuses the activation tiles (not the blocks' input rows)
+  if (smem < need) smem = need;
+  const double rows = (double)B * T * 0.5;
+  const double flops = layers * 2.0 * (rows * 2.0 * D * D * 5 + 4.0 * rows * T * D * 0.5);
+  const double bytes = rows * D * 4 * 2 + (double)B * D * 4;
+#define E32B(H_, NT_)                                                                                                  \
+  do {                                                                                                                 \
+    allow_lds((enc32_bwd_kernel<H_, NT_>), smem);                                                                      \
+    LAUNCH_S(B * T, D, layers, flops, bytes, (enc32_bwd_kernel<H_, NT_>), dim3(grid), dim3(64 * NT_), smem, st, a);    \
+  } while (0)
+  if (heads == 1) { if (nt == 1) E32B(1, 1); else E32B(1, 2); }
+  else { if (nt == 1) E32B(2, 1); else E32B(2, 2); }
+#undef E32B
+  INTEL_CHECK_LAUNCH();
+  // slab -> destination: slab order dWq dWk dWv dW1 dW2 | dbq dbk dbv db1 db2 dg1 dbe1 dg2 dbe2
+  static const int slot_of_w[5] = {0, 2, 4, 8, 10};                                   // index into the 14-entry INTEL_ENC_* order
+  static const int slot_of_v[9] = {1, 3, 5, 9, 11, 6, 7, 12, 13};
+  const size_t stride = (size_t)layers * ENC32_SLAB;
+  for (int l = 0; l < layers; ++l) {
+    const float* sl = slabs + (size_t)l * ENC32_SLAB;
+    for (int w = 0; w < 5; ++w)
+      if (grads[l][slot_of_w[w]]) redq_push(q, sl + w * 1024, stride, grid, 32, 32, grads[l][slot_of_w[w]], 32, accumulate[l][slot_of_w[w]]);
+    for (int v = 0; v < 9; ++v)
+      if (grads[l][slot_of_v[v]]) redq_push(q, sl + 5 * 1024 + v * 32, stride, grid, 1, 32, grads[l][slot_of_v[v]], 32, accumulate[l][slot_of_v[v]]);
   }
   return 0;
 }

@@ -206,7 +206,7 @@ def test_rccl_world1_runs_every_collective_branch(exchange, overlap, schedule):
     for bit)."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', False, overlap), nprocs=1, join=True)
+        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', False, overlap, '', schedule), nprocs=1, join=True)      # the same backward schedule: the comparison isolates the collectives (the two schedules round differently: chain launches only in the one-call form)
         mp.spawn(_run, args=(1, _free_port(), d, exchange, 'nccl', False, overlap, '_nccl', schedule), nprocs=1, join=True)
         one = torch.load(os.path.join(d, 'w1_r0.pt'))
         got = torch.load(os.path.join(d, 'w1_r0_nccl.pt'))

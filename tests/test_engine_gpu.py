@@ -511,7 +511,7 @@ def test_timeline_records_and_borrowed_stream():
     eng.train_step(batch)
     tl = json.loads(lib.intel_prof_timeline().decode())
     lib.intel_prof_enable(0)
-    assert len(tl) > 100 and all(r['t1'] >= r['t0'] for r in tl)
+    assert len(tl) > 40 and all(r['t1'] >= r['t0'] for r in tl)      # (60 launches at the reference's default widths since the one-kernel towers / encoders / chain launches)
     assert len({r['stream'] for r in tl}) >= 4                 # the caller's stream + three branches
     names = {r['name'].split('[')[0].strip('()').split('<')[0] for r in tl}
     assert {'bpr_loss_kernel', 'adam_rows_kernel', 'slab_reduce_batch_kernel'} <= names

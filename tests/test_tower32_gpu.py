@@ -40,3 +40,19 @@ def test_gate_variant_keeps_the_one_kernel_towers():
                  cross_attention=0, cal_diversity=0)
     worst, bad, desc = fuzz.one_case(random.Random(5), 7999, torch.device('cuda:0'), big=False, force=force)
     assert worst <= 1.0, (worst, bad, desc)
+
+
+E32 = dict(i_emb_size=16, im_emb_size=16, s_emb_size=32, u_emb_size=32, intent_emb_size=16, context_emb_size=16, cross_attn_qsize=32)
+
+
+@pytest.mark.parametrize('H,heads,layers,B,loss', [
+    (1, 1, 1, 3, 'IntBPRloss'), (5, 2, 2, 5, 'IntMSEloss'), (6, 1, 2, 17, 'IntListloss'), (16, 2, 1, 16, 'IntBPRloss'), (16, 2, 2, 9, 'IntMSEloss'),
+    (17, 1, 2, 7, 'IntBPRloss'), (20, 2, 2, 33, 'IntMSEloss'), (32, 2, 2, 4, 'IntListloss'), (32, 1, 1, 6, 'IntBPRloss'), (33, 2, 2, 5, 'IntBPRloss')])
+def test_one_kernel_bert4rec_encoder_matches_oracle_autograd(H, heads, layers, B, loss):
+    """The whole 32-wide BERT4Rec encoder in one kernel per direction (tower32.hip: enc32_*; models/sequential/BERT4Rec.py's blocks at the
+    reference's default widths: context 16 + intent 16, item id 16 + intent 16): histories of 1 .. 32 events (one and two 16-row tiles, tile
+    boundaries), 1 and 2 heads, 1 and 2 blocks, ragged lengths; 33 events fall back to the kernel-per-op encoder."""
+    force = dict(E32, L=20, B=B, I=30, num_heads=heads, num_layers=layers, encoder='BERT4Rec', history_max=H, model_num=3, loss=loss,
+                 cross_attention=1, cal_diversity=1)
+    worst, bad, desc = fuzz.one_case(random.Random(H * 100 + heads * 10 + layers), 7300 + H, torch.device('cuda:0'), big=False, force=force)
+    assert worst <= 1.0, (worst, bad, desc)
