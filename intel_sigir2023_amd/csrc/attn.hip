@@ -707,6 +707,7 @@ int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int*
   if (attn_seq_path(T, dk)) return launch_attn_seq_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
   INTEL_CHECK_ARG(!row_off || key_len, "attention: packed rows need the session lengths");
   dim3 grid(B * heads * cdiv(T, AT_QB));
+  if (attn_p3_supported(T, dk)) return launch_attn_p3_fwd(qkv, B, T, d, heads, key_len, out, lse, st, row_off);
   if (attn_bf16_products(T, dk)) {
     ATTN_DISPATCH_BF(dkt, {
       size_t smem = (size_t)2 * AT_KB * AttnSmem<DKT>::LD * sizeof(float);
@@ -747,6 +748,7 @@ int launch_attn_bwd(const float* qkv, const float* out, const float* dout, const
     const long long rows = (long long)B * T;
     LAUNCH_W(0.0, 8.0 * (double)rows * d, attn_dsum_kernel, dim3((unsigned)((rows * heads + 15) / 16)), dim3(256), 0, st, out, dout, T, d, heads, rows, dsum, key_len, row_off);
     INTEL_CHECK_LAUNCH();
+    if (attn_p3_supported(T, dk)) return launch_attn_p3_bwd(qkv, dout, lse, dsum, B, T, d, heads, key_len, dqkv, dS, ldS, st, row_off);
     if (attn_bf16_products(T, dk)) {
       ATTN_DISPATCH_BF(dkt, {
         size_t smem = (size_t)(2 * AT_KB * AttnSmem<DKT>::LD + 2 * AT_KB) * sizeof(float);

@@ -109,6 +109,12 @@ bool attn_seq_packed_supported(int T, int dk);
 bool attn_packed_supported(int T, int dk);
 int launch_attn_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,
                     hipStream_t st, const int* row_off = nullptr);
+// the general kernels with every product on the bf16 matrix pipe at fp32 accuracy (attn_p3.hip: three-plane operands split once at staging): fp32 mode,
+// T > 64, head dim 64 / 128; INTEL_ATTN_P3=0 keeps the exact-fp32 MFMA kernels of attn.hip
+bool attn_p3_supported(int T, int dk);
+int launch_attn_p3_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse, hipStream_t st, const int* row_off);
+int launch_attn_p3_bwd(const float* qkv, const float* dout, const float* lse, const float* dsum, int B, int T, int d, int heads, const int* key_len,
+                       float* dqkv, float* dS, int ldS, hipStream_t st, const int* row_off);
 // whole-sequence kernels (attn_seq.hip): T <= 64, head dim 64 / 128
 bool attn_seq_supported(int T, int dk);
 int launch_attn_seq_fwd(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out, float* lse,

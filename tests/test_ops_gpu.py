@@ -70,7 +70,10 @@ def _attn_ref(qkv, B, T, d, heads, key_len):
                                                 # whole-sequence kernels (T <= 64, head dim 64 / 128): every tile count, ragged pair counts
                                                 (5, 20, 128, 2, True), (3, 16, 64, 1, False), (7, 10, 128, 1, True), (3, 33, 128, 1, True),
                                                 (2, 48, 128, 2, True), (5, 64, 64, 1, True), (3, 50, 256, 2, False), (2, 20, 64, 1, False),
-                                                (9, 50, 128, 1, True), (6, 1, 64, 1, False)])
+                                                (9, 50, 128, 1, True), (6, 1, 64, 1, False),
+                                                # general kernels on the bf16 pipe (attn_p3.hip: T > 64, head dim 64 / 128): tile boundaries, one and several 64-row blocks
+                                                (2, 100, 128, 1, True), (3, 65, 256, 2, True), (2, 97, 128, 1, False), (1, 130, 64, 1, True),
+                                                (2, 128, 128, 2, False), (3, 129, 128, 1, True), (2, 96, 64, 1, True)])
 def test_attention_fwd_bwd(B, T, d, heads, masked):
     from intel_sigir2023_amd import ops
     dev = _dev()

@@ -25,6 +25,7 @@ CASES = [
     ({'INTEL_ATTN_FUSED_BWD': '0', 'INTEL_ENC_FUSED': '0'}, MODEL),    # whole-sequence attention backward as dK/dV kernel + dQ kernel
     ({'INTEL_ATTN_SEQ': '0', 'INTEL_ENC_FUSED': '0'}, MODEL),          # flash-style general attention for every shape
     ({'INTEL_ATTN_DS': '0'}, MODEL),                                   # general attention backward recomputes S / dP in the dQ pass
+    ({'INTEL_ATTN_P3': '0'}, MODEL),                                   # general attention (lists / histories > 64) on exact fp32 MFMAs instead of the three-plane bf16-pipe kernels (attn_p3.hip)
     ({'INTEL_BWD_WIDE': '0'}, MODEL),                                  # one-call backward runs its two branch sets one after the other
     ({'INTEL_FUSE_TAIL': '0'}, MODEL),                                 # towers' last LayerNorm as its own store / kernel
     ({'INTEL_GEMM_SMALL': '0'}, MODEL),                                # odd B-row products on the generic kernel
