@@ -20,13 +20,28 @@ namespace {
 
 #define AP_QB 64   // rows (queries, or keys in the dK/dV kernel) owned by a workgroup: 4 waves x 16
 #define AP_KB 32   // rows staged per iteration = the k depth of one transposed product
+#define LOG2E_F 1.4426950408889634f
+#ifndef AP_DKV_DUAL
+#define AP_DKV_DUAL 0      // the dK/dV kernel's products as two interleaved accumulator chains (0: one chain, one fragment set in flight)
+#endif
+#ifndef AP_DKV_PRE
+#define AP_DKV_PRE 0      // (measured: the prefetch registers cost a wave per SIMD, 252 -> 320 us at head dim 64)
+#endif
+#ifndef AP_DKV_OCC
+#define AP_DKV_OCC 3       // its waves per SIMD at head dim 64 (register budget 168)
+#endif
+#define LN2_F 0.6931471805599453f
 
 typedef short ap_s16x4 __attribute__((ext_vector_type(4)));
 typedef short ap_s16x8 __attribute__((ext_vector_type(8)));
 
 // One staged tile = three bf16 planes of [32 rows][dk], dk = 16 DKT in {64, 128}.  Byte offset of 16-byte chunk ch of row `row` inside a plane:
-// the chunk index is XORed with a function of the row such that (a) 16 consecutive rows read at the same chunk (row operands) and (b) 8 consecutive
-// rows read at a chunk pair (transposed operands, half a wave) fall into 16 different 16-byte bank groups.
+// the chunk index is XORed with a function of the row chosen for the lane groups the LDS really services together (MI355X_MICROARCH.md, LDS):
+//   (a) row operands, ds_read_b128, lane (p, g) reads row p at chunk 4c + g: the groups are lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32),
+//       i.e. rows {0-3, 12-15} at chunk 4c + g and rows {4-11} at chunk 4c + (g ^ 1) -- the first set maps to swizzles 0..7, the second to 8..15;
+//   (b) transposed operands, ds_read_b64_tr_b16, half a wave reads rows 0..7 (or 8..15) at a chunk PAIR: swz >> 1 differs over each of the two sets.
+// Both hold for swz(r) = 2 (r & 3) | (r >> 3) | 8 ((r >> 2) ^ (r >> 3)) at 256-byte rows (the 256-byte bank window is one row), and for the same
+// function of r >> 1 on three bits at 128-byte rows (two rows per window: the row's parity picks the half).
 template <int DKT>
 struct P3Tile {
   static constexpr int RB = DKT * 32;                 // bytes per row
@@ -34,7 +49,9 @@ struct P3Tile {
   static constexpr int PLANE = AP_KB * RB;
   static constexpr int BYTES = 3 * PLANE;
   __device__ __forceinline__ static int swz(int row) {
-    return DKT == 8 ? (((row & 7) << 1) | ((row >> 3) & 1)) : ((((row >> 1) & 3) << 1) | ((row >> 3) & 1));
+    if (DKT == 8) return ((row & 3) << 1) | ((row >> 3) & 1) | ((((row >> 2) ^ (row >> 3)) & 1) << 3);
+    const int u = (row >> 1) & 7;
+    return ((u & 1) << 1) | ((u >> 2) & 1) | ((((u >> 1) ^ (u >> 2)) & 1) << 2);
   }
   __device__ __forceinline__ static int off(int row, int ch) { return RB * row + 16 * (ch ^ swz(row)); }
 };
@@ -83,8 +100,21 @@ struct P3Stage {
 };
 
 // the lane's own row (query / key) as the B operand of the S-type products: dims 32c + 8g .. +7, three planes per 32-deep block
+struct Frag3 { bf16x8 h, m, l; };
+#define AP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+// Two independent six-product chains (planes::mma<3>'s order: smallest products first), interleaved: a v_mfma that accumulates into its
+// predecessor's result waits for that result's passes, so the two accumulators alternate.
+__device__ __forceinline__ void mma3x2(const Frag3& a1, const Frag3& b1, f32x4& c1, const Frag3& a2, const Frag3& b2, f32x4& c2) {
+  c1 = AP_MFMA(a1.m, b1.m, c1); c2 = AP_MFMA(a2.m, b2.m, c2);
+  c1 = AP_MFMA(a1.h, b1.l, c1); c2 = AP_MFMA(a2.h, b2.l, c2);
+  c1 = AP_MFMA(a1.l, b1.h, c1); c2 = AP_MFMA(a2.l, b2.h, c2);
+  c1 = AP_MFMA(a1.h, b1.m, c1); c2 = AP_MFMA(a2.h, b2.m, c2);
+  c1 = AP_MFMA(a1.m, b1.h, c1); c2 = AP_MFMA(a2.m, b2.h, c2);
+  c1 = AP_MFMA(a1.h, b1.h, c1); c2 = AP_MFMA(a2.h, b2.h, c2);
+}
+
 template <int DKT>
-__device__ __forceinline__ void own_row_planes(const float* __restrict__ rowp, bool ok, int g, bf16x8 (&h)[DKT / 2], bf16x8 (&m)[DKT / 2], bf16x8 (&l)[DKT / 2]) {
+__device__ __forceinline__ void own_row_planes(const float* __restrict__ rowp, bool ok, int g, Frag3 (&f)[DKT / 2]) {
 #pragma unroll
   for (int c = 0; c < DKT / 2; ++c) {
     f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
@@ -92,44 +122,103 @@ __device__ __forceinline__ void own_row_planes(const float* __restrict__ rowp, b
       a = *reinterpret_cast<const f32x4*>(rowp + 32 * c + 8 * g);
       b = *reinterpret_cast<const f32x4*>(rowp + 32 * c + 8 * g + 4);
     }
-    split8(a, b, h[c], m[c], l[c]);
+    split8(a, b, f[c].h, f[c].m, f[c].l);
   }
 }
 
-// S-type tile product: 16 staged rows (tile rows 16 t + (lane & 15): the A operand, k along the head dim) against the lane's own row planes.
-// roff = P3Tile::off(lane & 15, lane >> 4): chunk 4c + g of the row is roff ^ 64c (the low two chunk bits belong to g), tile t adds 16 rows
+// row fragment: staged row 16 t + (lane & 15), dims 32c + 8g .. +7, three planes.  roff = P3Tile::off(lane & 15, lane >> 4): chunk 4c + g of the
+// row is roff ^ 64c (the low two chunk bits belong to g)
 template <int DKT>
-__device__ __forceinline__ f32x4 row_mma(const unsigned char* tile, int roff, int t, const bf16x8 (&bh)[DKT / 2], const bf16x8 (&bm)[DKT / 2],
-                                         const bf16x8 (&bl)[DKT / 2], f32x4 acc) {
+__device__ __forceinline__ Frag3 row_frag(const unsigned char* tile, int roff, int t, int c) {
   using TL = P3Tile<DKT>;
+  const unsigned char* p = tile + (roff ^ (64 * c)) + t * 16 * TL::RB;
+  return Frag3{*reinterpret_cast<const bf16x8*>(p), *reinterpret_cast<const bf16x8*>(p + TL::PLANE), *reinterpret_cast<const bf16x8*>(p + 2 * TL::PLANE)};
+}
+// S-type tile products of TWO 16-row tiles (tile rows: the A operand, k along the head dim) against B operands held in registers, 32 dims per step;
+// the fragments of step c + 1 are requested before the products of step c
+template <int DKT, bool PRE = true>
+__device__ __forceinline__ void row_mma2(const unsigned char* tile1, int t1, const Frag3 (&b1)[DKT / 2], f32x4& acc1, const unsigned char* tile2, int t2,
+                                         const Frag3 (&b2)[DKT / 2], f32x4& acc2, int roff) {
+  Frag3 a1 = row_frag<DKT>(tile1, roff, t1, 0), a2 = row_frag<DKT>(tile2, roff, t2, 0);
 #pragma unroll
   for (int c = 0; c < DKT / 2; ++c) {
-    const unsigned char* p = tile + (roff ^ (64 * c)) + t * 16 * TL::RB;
-    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(p);
-    const bf16x8 am = *reinterpret_cast<const bf16x8*>(p + TL::PLANE);
-    const bf16x8 al = *reinterpret_cast<const bf16x8*>(p + 2 * TL::PLANE);
-    acc = planes::mma<3>(ah, am, al, bh[c], bm[c], bl[c], acc);
+    Frag3 n1 = a1, n2 = a2;
+    if (PRE && c + 1 < DKT / 2) {
+      n1 = row_frag<DKT>(tile1, roff, t1, c + 1);
+      n2 = row_frag<DKT>(tile2, roff, t2, c + 1);
+    }
+    mma3x2(a1, b1[c], acc1, a2, b2[c], acc2);
+    if (!PRE && c + 1 < DKT / 2) {
+      n1 = row_frag<DKT>(tile1, roff, t1, c + 1);
+      n2 = row_frag<DKT>(tile2, roff, t2, c + 1);
+    }
+    a1 = n1; a2 = n2;
   }
-  return acc;
 }
 
-// transposed fragment of one plane: dims 16 dt + (lane & 15) on the accumulator rows, k = the 32 staged rows (slot (g, s): row 4g + s, s < 4; 16 + 4g + s - 4)
+// transposed fragment: dims 16 dt + (lane & 15) on the accumulator rows, k = the 32 staged rows (slot (g, s): row 4g + s for s < 4, 16 + 4g + s - 4 above)
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* plane, int off_lo, int off_hi) {
   const ap_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ap_s16x4*)(plane + off_lo));
   const ap_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ap_s16x4*)(plane + off_hi));
-  return __builtin_bit_cast(bf16x8, ap_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
-// acc[dt] += (tile^T)[dims of tile dt][32 rows] * b[32 rows][the lane's column]; tlo / thi: the lane's read addresses for dt = 0 (dt: ^ 32 dt)
 template <int DKT>
-__device__ __forceinline__ void tr_mma(f32x4 (&acc)[DKT], const unsigned char* tile, int tlo, int thi, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+__device__ __forceinline__ Frag3 tr_frag3(const unsigned char* tile, int tlo, int thi, int dt) {      // tlo / thi: the lane's addresses for dt = 0 (dt: ^ 32 dt)
   using TL = P3Tile<DKT>;
+  const int lo = tlo ^ (32 * dt), hi = thi ^ (32 * dt);
+  return Frag3{tr_frag(tile, lo, hi), tr_frag(tile + TL::PLANE, lo, hi), tr_frag(tile + 2 * TL::PLANE, lo, hi)};
+}
+// acc1[dt] += (tile1^T)[dims of tile dt][32 rows] * b1[32 rows][the lane's column], acc2[dt] likewise from tile2 / b2: two chains per dim tile
+template <int DKT, bool PRE = true>
+__device__ __forceinline__ void tr_mma2(f32x4 (&acc1)[DKT], const unsigned char* tile1, const Frag3& b1, f32x4 (&acc2)[DKT], const unsigned char* tile2,
+                                        const Frag3& b2, int tlo, int thi) {
+  Frag3 a1 = tr_frag3<DKT>(tile1, tlo, thi, 0), a2 = tr_frag3<DKT>(tile2, tlo, thi, 0);
 #pragma unroll
   for (int dt = 0; dt < DKT; ++dt) {
-    const int lo = tlo ^ (32 * dt), hi = thi ^ (32 * dt);
-    const bf16x8 ah = tr_frag(tile, lo, hi);
-    const bf16x8 am = tr_frag(tile + TL::PLANE, lo, hi);
-    const bf16x8 al = tr_frag(tile + 2 * TL::PLANE, lo, hi);
-    acc[dt] = planes::mma<3>(ah, am, al, bh, bm, bl, acc[dt]);
+    Frag3 n1 = a1, n2 = a2;
+    if (PRE && dt + 1 < DKT) {
+      n1 = tr_frag3<DKT>(tile1, tlo, thi, dt + 1);
+      n2 = tr_frag3<DKT>(tile2, tlo, thi, dt + 1);
+    }
+    mma3x2(a1, b1, acc1[dt], a2, b2, acc2[dt]);
+    if (!PRE && dt + 1 < DKT) {
+      n1 = tr_frag3<DKT>(tile1, tlo, thi, dt + 1);
+      n2 = tr_frag3<DKT>(tile2, tlo, thi, dt + 1);
+    }
+    a1 = n1; a2 = n2;
+  }
+}
+// single-chain forms (fewer fragment registers: one set in flight)
+template <int DKT>
+__device__ __forceinline__ f32x4 row_mma1(const unsigned char* tile, int t, const Frag3 (&b)[DKT / 2], f32x4 acc, int roff) {
+#pragma unroll
+  for (int c = 0; c < DKT / 2; ++c) {
+    const Frag3 a = row_frag<DKT>(tile, roff, t, c);
+    acc = planes::mma<3>(a.h, a.m, a.l, b[c].h, b[c].m, b[c].l, acc);
+  }
+  return acc;
+}
+template <int DKT>
+__device__ __forceinline__ void tr_mma1(f32x4 (&acc)[DKT], const unsigned char* tile, const Frag3& b, int tlo, int thi) {
+#pragma unroll
+  for (int dt = 0; dt < DKT; ++dt) {
+    const Frag3 a = tr_frag3<DKT>(tile, tlo, thi, dt);
+    acc[dt] = planes::mma<3>(a.h, a.m, a.l, b.h, b.m, b.l, acc[dt]);
+  }
+}
+// one tile, one B operand: the dim tiles go in pairs
+template <int DKT>
+__device__ __forceinline__ void tr_mma(f32x4 (&acc)[DKT], const unsigned char* tile, const Frag3& b, int tlo, int thi) {
+  Frag3 a1 = tr_frag3<DKT>(tile, tlo, thi, 0), a2 = tr_frag3<DKT>(tile, tlo, thi, 1);
+#pragma unroll
+  for (int dt = 0; dt < DKT; dt += 2) {
+    Frag3 n1 = a1, n2 = a2;
+    if (dt + 2 < DKT) {
+      n1 = tr_frag3<DKT>(tile, tlo, thi, dt + 2);
+      n2 = tr_frag3<DKT>(tile, tlo, thi, dt + 3);
+    }
+    mma3x2(a1, b, acc[dt], a2, b, acc[dt + 1]);
+    a1 = n1; a2 = n2;
   }
 }
 // the lane's addresses of the transposed reads for dim tile 0: lane 4q + pp of a 16-lane group names row q and columns 4pp .. 4pp+3 of its block
@@ -181,8 +270,8 @@ __global__ __launch_bounds__(256, DKT == 8 ? 2 : 3) void attn_fwd_p3_kernel(cons
   if (blk.y * AP_QB >= nrow) return;
   const float* base = qkv + row0 * ldg;
   const int q = blk.y * AP_QB + wave * 16 + p;
-  bf16x8 qh[DKT / 2], qm[DKT / 2], ql[DKT / 2];
-  own_row_planes<DKT>(base + (size_t)q * ldg + h * dk, q < nrow, g, qh, qm, ql);
+  Frag3 qf[DKT / 2];
+  own_row_planes<DKT>(base + (size_t)q * ldg + h * dk, q < nrow, g, qf);
   f32x4 oT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -190,6 +279,7 @@ __global__ __launch_bounds__(256, DKT == 8 ? 2 : 3) void attn_fwd_p3_kernel(cons
   const int roff = TL::off(p, g);
   int tlo, thi;
   tr_addr<DKT>(lane, tlo, thi);
+  const float scale2 = scale * LOG2E_F;
 
   P3Stage<DKT> kreg, vreg;
   kreg.load(base, ldg, d + h * dk, 0, nrow, tid);
@@ -204,31 +294,27 @@ __global__ __launch_bounds__(256, DKT == 8 ? 2 : 3) void attn_fwd_p3_kernel(cons
       vreg.load(base, ldg, 2 * d + h * dk, kb + AP_KB, nrow, tid);
     }
     if (blk.y * AP_QB + wave * 16 >= nrow) continue;      // a wave whose 16 queries are all past the list only helps staging
-    f32x4 st[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-      st[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (kb + kt * 16 < nkeys) st[kt] = row_mma<DKT>(Ks, roff, kt, qh, qm, ql, st[kt]);
-    }
+    f32x4 st[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    row_mma2<DKT>(Ks, 0, qf, st[0], Ks, 1, qf, st[1], roff);      // (a second tile past the keys is zero rows / masked below)
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kb + kt * 16 + 4 * g + r;
-        const float v = key < nkeys ? st[kt][r] * scale : -INFINITY;
+        const float v = key < nkeys ? st[kt][r] * scale2 : -INFINITY;      // base-2 logits (v_exp_f32 is 2^x)
         st[kt][r] = v;
         mx = fmaxf(mx, v);
       }
     mx = planes::gmax16(mx);
     const float m_new = fmaxf(m_run, mx);        // finite: this block holds >= 1 valid key
-    const float corr = (m_run == -INFINITY) ? 0.f : expf(m_run - m_new);
+    const float corr = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = expf(st[kt][r] - m_new);   // exp(-inf) = 0 for masked keys
+        const float e = __builtin_amdgcn_exp2f(st[kt][r] - m_new);   // 2^(-inf) = 0 for masked keys
         st[kt][r] = e;
         ps += e;
       }
@@ -237,14 +323,14 @@ __global__ __launch_bounds__(256, DKT == 8 ? 2 : 3) void attn_fwd_p3_kernel(cons
     m_run = m_new;
 #pragma unroll
     for (int i = 0; i < DKT; ++i) oT[i] *= corr;
-    bf16x8 ph, pm, pl;
-    split8(st[0], st[1], ph, pm, pl);
-    tr_mma<DKT>(oT, Vs, tlo, thi, ph, pm, pl);
+    Frag3 pf;
+    split8(st[0], st[1], pf.h, pf.m, pf.l);
+    tr_mma<DKT>(oT, Vs, pf, tlo, thi);
   }
   if (q < nrow) {
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     dim_store<DKT>(out + (row0 + q) * d + h * dk, oT, g, inv);
-    if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
+    if (lane < 16) lse[((size_t)b * heads + h) * T + q] = l_run > 0.f ? m_run * LN2_F + logf(l_run) : INFINITY;      // natural-log statistic, as attn.hip stores it
   }
 }
 
@@ -252,7 +338,7 @@ __global__ __launch_bounds__(256, DKT == 8 ? 2 : 3) void attn_fwd_p3_kernel(cons
 // backward, dK / dV (+ the dS tiles of the dQ kernel): wave owns 16 keys, sweeps query blocks (attn_bwd_dkv_kernel's structure)
 // ------------------------------------------------------------------------------------------
 template <int DKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p3_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, DKT == 8 ? 2 : AP_DKV_OCC) void attn_bwd_dkv_p3_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                  const float* __restrict__ lse, const float* __restrict__ dsum, int T, int d, int heads,
                                                                  const int* __restrict__ key_len, float scale, float* __restrict__ dqkv,
                                                                  float* __restrict__ dS, int ldS, const int* __restrict__ row_off) {
@@ -274,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p3_kernel(const float* __
   const float* base = qkv + row0 * ldg;
   const int key = blk.y * AP_QB + wave * 16 + p;
   const bool kok = key < nrow;
-  bf16x8 kh[DKT / 2], km[DKT / 2], kl[DKT / 2], vh[DKT / 2], vm[DKT / 2], vl[DKT / 2];
-  own_row_planes<DKT>(base + (size_t)key * ldg + d + h * dk, kok, g, kh, km, kl);
-  own_row_planes<DKT>(base + (size_t)key * ldg + 2 * d + h * dk, kok, g, vh, vm, vl);
+  Frag3 kf[DKT / 2], vf[DKT / 2];
+  own_row_planes<DKT>(base + (size_t)key * ldg + d + h * dk, kok, g, kf);
+  own_row_planes<DKT>(base + (size_t)key * ldg + 2 * d + h * dk, kok, g, vf);
   f32x4 dkT[DKT], dvT[DKT];
 #pragma unroll
   for (int i = 0; i < DKT; ++i) {
@@ -288,49 +374,67 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_p3_kernel(const float* __
   const int roff = TL::off(p, g);
   int tlo, thi;
   tr_addr<DKT>(lane, tlo, thi);
+  const float scale2 = scale * LOG2E_F;
   const float* dob = dout + row0 * d;
+  // head dim 64: the next block's Q / dO rows and statistics are requested before this block's products (with the products on the bf16 pipe a
+  // block's MFMAs no longer cover the load latency of the next); head dim 128 has no registers left for that (K / V planes: 96)
+  constexpr bool PRE = AP_DKV_PRE && DKT == 4;
+  P3Stage<DKT> qreg, oreg;
+  float lreg = INFINITY, dreg = 0.f;
+  auto load_block = [&](int qb) {
+    qreg.load(base, ldg, h * dk, qb, nrow, tid);
+    oreg.load(dob, d, h * dk, qb, nrow, tid);
+    const int qq = qb + tid;
+    const bool ok = tid < AP_KB && qq < nrow;
+    lreg = ok ? lse[((size_t)b * heads + h) * T + qq] * LOG2E_F : INFINITY;      // base-2 statistics: p = exp2(s * scale * log2 e - lse * log2 e)
+    dreg = ok ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
+  };
+  if (PRE) load_block(0);
   for (int qb = 0; qb < nrow; qb += AP_KB) {
     __syncthreads();
-    {
-      P3Stage<DKT> qreg, oreg;
-      qreg.load(base, ldg, h * dk, qb, nrow, tid);
-      oreg.load(dob, d, h * dk, qb, nrow, tid);
-      const int qq = qb + tid;
-      const bool ok = tid < AP_KB && qq < nrow;
-      const float lreg = ok ? lse[((size_t)b * heads + h) * T + qq] : INFINITY;
-      const float dreg = ok ? dsum[((size_t)b * heads + h) * T + qq] : 0.f;
-      qreg.store(Qs, tid);
-      oreg.store(Os, tid);
-      if (tid < AP_KB) {
-        Ls[tid] = lreg;
-        Ds[tid] = dreg;
-      }
+    if (!PRE) load_block(qb);
+    qreg.store(Qs, tid);
+    oreg.store(Os, tid);
+    if (tid < AP_KB) {
+      Ls[tid] = lreg;
+      Ds[tid] = dreg;
     }
     __syncthreads();
+    if (PRE && qb + AP_KB < nrow) load_block(qb + AP_KB);
     if (!wave_live) continue;
     f32x4 pr[2], ds[2];
+    float* dSp = dS ? dS + ((size_t)blk.bh * T + qb) * ldS + key : nullptr;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = sa;
-      if (qb + qt * 16 < nrow) {
-        sa = row_mma<DKT>(Qs, roff, qt, kh, km, kl, sa);     // S[query][key]
-        dp = row_mma<DKT>(Os, roff, qt, vh, vm, vl, dp);     // dP[query][key]
+      if (qb + qt * 16 < nrow) {     // S[query][key], dP[query][key]
+#if AP_DKV_DUAL
+        row_mma2<DKT, false>(Qs, qt, kf, sa, Os, qt, vf, dp, roff);
+#else
+        sa = row_mma1<DKT>(Qs, qt, kf, sa, roff);
+        dp = row_mma1<DKT>(Os, qt, vf, dp, roff);
+#endif
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = qt * 16 + 4 * g + r;
-        const float pv = key_live ? expf(sa[r] * scale - Ls[ql]) : 0.f;      // (rows past the list: Ls = inf -> 0)
+        const float pv = key_live ? __builtin_amdgcn_exp2f(sa[r] * scale2 - Ls[ql]) : 0.f;      // (rows past the list: Ls = inf -> 0)
         pr[qt][r] = pv;
         ds[qt][r] = pv * (dp[r] - Ds[ql]) * scale;
         // the dS tile for the dQ = dS K kernel (row = query, ldS floats per row); keys >= nkeys / queries >= T are never read
-        if (dS && qb + ql < nrow && kok) dS[((size_t)blk.bh * T + qb + ql) * ldS + key] = ds[qt][r];
+        if (dS && qb + ql < nrow && kok) dSp[ql * ldS] = ds[qt][r];
       }
     }
-    bf16x8 bh, bm, bl;
-    split8(pr[0], pr[1], bh, bm, bl);
-    tr_mma<DKT>(dvT, Os, tlo, thi, bh, bm, bl);      // dV^T[dim][key] += dO^T P
-    split8(ds[0], ds[1], bh, bm, bl);
-    tr_mma<DKT>(dkT, Qs, tlo, thi, bh, bm, bl);      // dK^T[dim][key] += Q^T dS
+    Frag3 pf, df;
+    split8(pr[0], pr[1], pf.h, pf.m, pf.l);
+    split8(ds[0], ds[1], df.h, df.m, df.l);
+    // dV^T[dim][key] += dO^T P, dK^T[dim][key] += Q^T dS
+#if AP_DKV_DUAL
+    tr_mma2<DKT, false>(dvT, Os, pf, dkT, Qs, df, tlo, thi);
+#else
+    tr_mma1<DKT>(dvT, Os, pf, tlo, thi);
+    tr_mma1<DKT>(dkT, Qs, df, tlo, thi);
+#endif
   }
   if (kok) {
     float* drow = dqkv + (row0 + key) * ldg + h * dk;
@@ -384,9 +488,9 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_p3_kernel(const float* 
 #pragma unroll
       for (int r = 0; r < 4; ++r) dsT[kt][r] = key0 + r < nkeys ? dsT[kt][r] : 0.f;      // masked / padding keys: nothing was stored
     }
-    bf16x8 bh, bm, bl;
-    split8(dsT[0], dsT[1], bh, bm, bl);
-    tr_mma<DKT>(dqT, Ks, tlo, thi, bh, bm, bl);      // dQ^T[dim][query] += K^T dS^T
+    Frag3 df;
+    split8(dsT[0], dsT[1], df.h, df.m, df.l);
+    tr_mma<DKT>(dqT, Ks, df, tlo, thi);      // dQ^T[dim][query] += K^T dS^T
   }
   if (qok) dim_store<DKT>(dqkv + (row0 + q) * ldg + h * dk, dqT, g, 1.f);
 }
