@@ -36,6 +36,11 @@ timeout 300 python tools/step_timeline.py f32 eval full tmall_pub 512 > $out/tim
 timeout 300 python tools/gpu_bound_probe.py tmall_pub 512 30 > $out/gpu_bound_pub.txt 2>&1 < /dev/null
 timeout 300 python tools/gpu_bound_probe.py tmall 4096 20 > $out/gpu_bound_tmall.txt 2>&1 < /dev/null
 timeout 900 python tools/ab_bench.py "--workload tmall_pub --steps 300 --warmup 30" INTEL_TOWER32=1,0 INTEL_HEAD_FUSED=1,0 > $out/ab_pub.txt 2>&1 < /dev/null
+timeout 600 python tools/ab_bench.py "--workload tmall_pub_mse --loss IntMSEloss --steps 300 --warmup 30 --no_bf16_line" INTEL_ENC32=1,0,1,0 > $out/ab_mse_enc32.txt 2>&1 < /dev/null
+# the general attention kernels on the bf16 pipe (attn_p3.hip) against the exact-fp32 ones: steps and kernels
+timeout 600 python tools/ab_bench.py "--workload lifedata --batch 2048 --steps 30 --warmup 5 --no_bf16_line" INTEL_ATTN_P3=1,0,1,0 > $out/ab_attn_p3_lifedata.txt 2>&1 < /dev/null
+timeout 600 python tools/ab_bench.py "--workload stress --batch 1024 --steps 12 --warmup 3 --no_bf16_line" INTEL_ATTN_P3=1,0,1,0 > $out/ab_attn_p3_stress.txt 2>&1 < /dev/null
+( timeout 300 python tools/attn_bench.py long; INTEL_ATTN_P3=0 timeout 300 python tools/attn_bench.py long ) > $out/attn_bench_long.txt 2>&1 < /dev/null
 if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload tmall_pub --steps 300 --warmup 30 --no_cpu_baseline > $out/bench_tmall_pub_long.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload tmall_pub_mse --loss IntMSEloss --steps 300 --warmup 30 --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_pub_mse.json 2>/dev/null < /dev/null

@@ -66,7 +66,7 @@ if fb and wb:
 fl, wl = one('fetch_lazy/**/*counter_collection.csv'), one('write_lazy/**/*counter_collection.csv')
 if fl and wl:
     subprocess.run([sys.executable, 'tools/pmc_summary.py', fl, wl, '4', os.path.join(dst, '%s_pmc_traffic_lazy_adam.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
-for name in ('gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt'):
+for name in ('gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_enc32.txt', 'ab_attn_p3_lifedata.txt', 'ab_attn_p3_stress.txt', 'attn_bench_long.txt'):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, name)))
