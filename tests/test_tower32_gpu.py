@@ -66,3 +66,26 @@ def test_one_kernel_encoder_batch_limit(B):
                  cross_attention=1, cal_diversity=0)
     worst, bad, desc = fuzz.one_case(random.Random(B), 7400 + (B & 1), torch.device('cuda:0'), big=False, force=force)
     assert worst <= 1.0, (worst, bad, desc)
+
+
+def test_one_kernel_encoder_inference_beyond_its_grid():
+    """Inference has no batch limit on the one-kernel encoder (no gradient slabs): its 2 048 workgroups walk the sessions with a stride.  A batch of 2 100
+    sessions must give, session by session, exactly what its two halves give (sessions are independent; published IntEL-MSE widths, small tables)."""
+    from intel_sigir2023_amd import parallel, synth
+    from intel_sigir2023_amd.model import IntEL
+    dev = torch.device('cuda:0')
+    over = dict(items=5000, users=500)
+    torch.manual_seed(3)
+    args = synth.make_args('tmall_pub_mse', dev)
+    corpus, _ = synth.make_corpus('tmall_pub_mse', **over)
+    model = IntEL(args, corpus).to(dev)
+    model.eval()
+    batch = synth.make_batch('tmall_pub_mse', 2100, dev, seed=5, ragged=True, corpus_over=over)
+    with torch.no_grad():
+        whole = {k: v.clone() for k, v in model(batch).items() if torch.is_tensor(v)}
+        parts = []
+        for r in range(2):
+            parts.append({k: v.clone() for k, v in model(parallel.shard_batch(batch, r, 2)).items() if torch.is_tensor(v)})
+    for k, v in whole.items():
+        if v.dim() >= 1 and v.shape[0] == 2100:
+            assert torch.equal(v, torch.cat([p[k] for p in parts])), k
