@@ -90,7 +90,12 @@ struct P3Stage {
     for (int n = 0; n < NCK; ++n) {
       const int i = tid + n * 256, r = i / NCH, ch = i - r * NCH;
       bf16x8 h, m, l;
+#if AP_ABLATE & 2
+      for (int e = 0; e < 4; ++e) { h[e] = (__bf16)v[n][0][e]; h[4 + e] = (__bf16)v[n][1][e]; }
+      m = h; l = h;
+#else
       split8(v[n][0], v[n][1], h, m, l);
+#endif
       unsigned char* d = tile + TL::off(r, ch);
       *reinterpret_cast<bf16x8*>(d) = h;
       *reinterpret_cast<bf16x8*>(d + TL::PLANE) = m;
@@ -102,9 +107,23 @@ struct P3Stage {
 // the lane's own row (query / key) as the B operand of the S-type products: dims 32c + 8g .. +7, three planes per 32-deep block
 struct Frag3 { bf16x8 h, m, l; };
 #define AP_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#ifndef AP_ABLATE
+#define AP_ABLATE 0      // measurement builds (tools/): 1 = one plane product instead of six (results wrong); 2 = no staging split (hi plane only)
+#endif
+__device__ __forceinline__ f32x4 ap_mma3(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh, const bf16x8& bm, const bf16x8& bl, f32x4 c) {
+#if AP_ABLATE & 1
+  return AP_MFMA(ah, bh, c);
+#else
+  return planes::mma<3>(ah, am, al, bh, bm, bl, c);
+#endif
+}
 // Two independent six-product chains (planes::mma<3>'s order: smallest products first), interleaved: a v_mfma that accumulates into its
 // predecessor's result waits for that result's passes, so the two accumulators alternate.
 __device__ __forceinline__ void mma3x2(const Frag3& a1, const Frag3& b1, f32x4& c1, const Frag3& a2, const Frag3& b2, f32x4& c2) {
+#if AP_ABLATE & 1
+  c1 = AP_MFMA(a1.h, b1.h, c1); c2 = AP_MFMA(a2.h, b2.h, c2);
+  return;
+#endif
   c1 = AP_MFMA(a1.m, b1.m, c1); c2 = AP_MFMA(a2.m, b2.m, c2);
   c1 = AP_MFMA(a1.h, b1.l, c1); c2 = AP_MFMA(a2.h, b2.l, c2);
   c1 = AP_MFMA(a1.l, b1.h, c1); c2 = AP_MFMA(a2.l, b2.h, c2);
@@ -194,7 +213,7 @@ __device__ __forceinline__ f32x4 row_mma1(const unsigned char* tile, int t, cons
 #pragma unroll
   for (int c = 0; c < DKT / 2; ++c) {
     const Frag3 a = row_frag<DKT>(tile, roff, t, c);
-    acc = planes::mma<3>(a.h, a.m, a.l, b[c].h, b[c].m, b[c].l, acc);
+    acc = ap_mma3(a.h, a.m, a.l, b[c].h, b[c].m, b[c].l, acc);
   }
   return acc;
 }
@@ -203,7 +222,7 @@ __device__ __forceinline__ void tr_mma1(f32x4 (&acc)[DKT], const unsigned char* 
 #pragma unroll
   for (int dt = 0; dt < DKT; ++dt) {
     const Frag3 a = tr_frag3<DKT>(tile, tlo, thi, dt);
-    acc[dt] = planes::mma<3>(a.h, a.m, a.l, b.h, b.m, b.l, acc[dt]);
+    acc[dt] = ap_mma3(a.h, a.m, a.l, b.h, b.m, b.l, acc[dt]);
   }
 }
 // one tile, one B operand: the dim tiles go in pairs
