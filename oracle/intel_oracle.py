@@ -185,6 +185,15 @@ def mha(x, sd, prefix, heads, key_mask=None, bf16_products=True):
     return o.transpose(1, 2).reshape(B, T, D)
 
 
+def _nudged(pre, taps, key, layer):
+    """Test hook (tools/fuzz_parity.py): taps['__nudge__'][key][layer] is a CONSTANT tensor added to the pre-ReLU activations -- it picks a side
+    for entries that sit on the kink of the relu (|pre| at rounding-noise level), where both one-sided derivatives are legitimate."""
+    n = taps.get('__nudge__')
+    if n is not None and key in n and n[key].get(layer) is not None:
+        return pre + n[key][layer]
+    return pre
+
+
 def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0, taps=None):
     """models/IntEL/IntEL.py:182-188 / 191-197: the SAME weights are applied ``layers`` times,
     attention is unmasked (padded rows act as keys and queries).  keep: per-layer 0/1 tensors of the
@@ -198,6 +207,7 @@ def tied_tower(h, sd, attn, w1, w2, ln, heads, layers, keep=None, p=0.0, taps=No
         h = mha(h, sd, attn, heads, bf16_products=(h.shape[1] <= 64 and D_ in (64, 128) and dk_ in (32, 64, 128)) or (h.shape[1] > 64 and dk_ in (64, 128)))
         h = _lin(h, sd, w1)
         if taps is not None:
+            h = _nudged(h, taps, w1, l)
             taps.setdefault(w1, []).append(h.detach())
         h = _lin(torch.relu(h), sd, w2)
         if keep is not None:
@@ -221,6 +231,7 @@ def bert4rec(seq, lengths, sd, prefix, heads=2, layers=2, taps=None):
         ctx = F.layer_norm(ctx + x, (D,), sd[p + '.layer_norm1.weight'], sd[p + '.layer_norm1.bias'], 1e-5)
         pre = _lin(ctx, sd, p + '.linear1')
         if taps is not None:
+            pre = _nudged(pre, taps, p + '.linear1', 0)
             taps.setdefault(p + '.linear1', []).append(pre.detach())
         y = _lin(torch.relu(pre), sd, p + '.linear2')
         x = F.layer_norm(y + ctx, (D,), sd[p + '.layer_norm2.weight'], sd[p + '.layer_norm2.bias'], 1e-5)

@@ -18,7 +18,7 @@ from oracle import intel_oracle as O
 from tests.helpers import relu_flip_forgiven_error
 
 
-def one_case(rng, idx, dev, big=None, force=None):
+def one_case(rng, idx, dev, big=None, force=None, dry=False):
     """big: None = decided per case (about one case in 25), True / False = forced.  A 'big' case is the reference's own tower widths
     (16/16/32/32, script/IntEL.sh:15,21) at lists of 50 / 90 with more than 32 768 candidate rows per batch: the far side of the
     row-count thresholds of the short-list attention backward and the batched small weight gradients."""
@@ -50,6 +50,8 @@ def one_case(rng, idx, dev, big=None, force=None):
     if force:
         over.update({k: force[k] for k in ('cross_attention', 'cal_diversity') if k in force})
         loss_name = force.get('loss', loss_name)
+    if dry:      # only advance the generator (re-running single cases of a sweep: `--only`)
+        return None
     torch.manual_seed(100 + idx)
     args = synth.make_args(name, dev, **over)
     corpus, c = synth.make_corpus(name)
@@ -75,23 +77,73 @@ def one_case(rng, idx, dev, big=None, force=None):
         rl = O.int_mse_loss(ref, ref_batch, cfg)
     rl[0].backward()
     desc = '%s B=%d L=%d I=%d %s' % (loss_name, B, L, I, {k: v for k, v in list(flags.items()) + list(over.items())})
-    worst = 0.0
-    for k in ('weights', 'ens_score', 'intents'):
-        err = float((out[k].detach().cpu() - ref[k].detach()).abs().max()) / max(1.0, float(ref[k].detach().abs().max()))
-        worst = max(worst, err / 3e-5)
-    lerr = abs(float(loss) - float(rl[0]))
-    worst = max(worst, lerr / 1e-5)
     named = dict(model.named_parameters())
-    bad = None
-    for k, p in named.items():
-        g = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
-        r = sd[k].grad if sd[k].grad is not None else torch.zeros(p.shape)
-        tol = 1e-6 + 2e-4 * float(r.abs().max())            # the fixture tests' tolerance
-        err = float((g - r).abs().max())
-        if err > tol:      # the relu-flip exemption (tests/helpers.py: one row of a first-linear gradient, only when the oracle's pre-activation touches zero)
-            err = relu_flip_forgiven_error(k, g, r, tol, taps)
-        if err / tol > worst:
-            worst, bad = err / tol, k
+
+    def compare(ref, rl, sd, taps, forgive):
+        worst, bad = 0.0, None
+        for k in ('weights', 'ens_score', 'intents'):
+            err = float((out[k].detach().cpu() - ref[k].detach()).abs().max()) / max(1.0, float(ref[k].detach().abs().max()))
+            worst = max(worst, err / 3e-5)
+        worst = max(worst, abs(float(loss.detach()) - float(rl[0].detach())) / 1e-5)
+        for k, p in named.items():
+            g = p.grad.cpu() if p.grad is not None else torch.zeros(p.shape)
+            r = sd[k].grad if sd[k].grad is not None else torch.zeros(p.shape)
+            tol = 1e-6 + 2e-4 * float(r.abs().max())            # the fixture tests' tolerance
+            err = float((g - r).abs().max())
+            if err > tol and forgive:      # the relu-flip exemption (tests/helpers.py: one row of a first-linear gradient, only when the oracle's pre-activation touches zero)
+                err = relu_flip_forgiven_error(k, g, r, tol, taps)
+            if err / tol > worst:
+                worst, bad = err / tol, k
+        return worst, bad
+
+    def oracle_losses(ref):
+        if loss_name == 'IntBPRloss':
+            return O.int_bpr_loss(ref, ref_batch, cfg, noise.cpu())
+        if loss_name == 'IntListloss':
+            return O.int_list_loss(ref, ref_batch, cfg)
+        return O.int_mse_loss(ref, ref_batch, cfg)
+
+    worst, bad = compare(ref, rl, sd, taps, True)
+    if worst > 1.0:
+        # A hidden unit whose pre-activation is ZERO at rounding-noise level in the oracle sits on the kink of the relu: both one-sided derivatives
+        # are legitimate, the two implementations may take different ones entry by entry, and at a handful of rows per batch the difference reaches
+        # every upstream parameter.  Decide it properly: for every such ENTRY (|pre| < 1e-5 max(1, max|pre|) of a feed-forward block's first linear)
+        # the ORACLE is re-run with the entry pushed to either side (a constant added before the relu: oracle._nudged; outputs move by less than their
+        # tolerance) and the kernels' gradients must match ONE assignment at the PLAIN tolerances -- no exemption at all.  <= 8 entries (256 runs).
+        entries = []
+        for key, pres in taps.items():
+            if key == '__nudge__' or (key + '.bias') not in named:
+                continue
+            # only the hidden units whose OWN gradient row is off (a unit on the kink that both sides resolved alike needs no decision)
+            g, r = named[key + '.bias'].grad.cpu(), sd[key + '.bias'].grad
+            gw, rw = named[key + '.weight'].grad.cpu(), sd[key + '.weight'].grad
+            off = ((g - r).abs() > 1e-6 + 2e-4 * float(r.abs().max())) | ((gw - rw).abs().max(dim=1)[0] > 1e-6 + 2e-4 * float(rw.abs().max()))
+            big = max(1.0, max(float(t.abs().max()) for t in pres))
+            for li, t in enumerate(pres):
+                idx = torch.nonzero((t.abs() < 1e-5 * big) & off.reshape(*([1] * (t.dim() - 1)), -1))
+                for e in idx.tolist():
+                    entries.append((key, li, tuple(e), 4e-5 * big, t.shape))
+        if len(entries) > 8:
+            desc += '  [%d entries on the relu kink: not decided]' % len(entries)
+        elif entries:
+            import itertools
+            best, bestbad = 1e30, None
+            for signs in itertools.product((1.0, -1.0), repeat=len(entries)):
+                nudge = {}
+                for (key, li, e, dlt, shape), sg in zip(entries, signs):
+                    t = nudge.setdefault(key, {}).setdefault(li, torch.zeros(shape))
+                    t[e] = sg * dlt
+                sd2 = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+                ref2 = O.forward(sd2, ref_batch, cfg, taps={'__nudge__': nudge})
+                rl2 = oracle_losses(ref2)
+                rl2[0].backward()
+                w2, b2 = compare(ref2, rl2, sd2, None, False)
+                if w2 < best:
+                    best, bestbad = w2, b2
+                if w2 <= 1.0:
+                    desc += '  [relu kink: %d entries of %s decided, %.2f of tolerance]' % (len(entries), sorted(set(k for k, *_ in entries)), w2)
+                    return w2, None, desc
+            desc += '  [relu kink: %d entries of %s, no assignment matched (best %.2f at %s)]' % (len(entries), sorted(set(k for k, *_ in entries)), best, bestbad)
     return worst, bad, desc
 
 
@@ -101,7 +153,13 @@ def main():
     rng = random.Random(seed)
     dev = torch.device('cuda:0')
     fails = 0
+    only = None
+    if '--only' in sys.argv:      # fuzz_parity.py N seed --only 56,136: the same cases as the full sweep draws, only these are run
+        only = set(int(x) for x in sys.argv[sys.argv.index('--only') + 1].split(','))
     for i in range(n):
+        if only is not None and i not in only:
+            one_case(rng, i, dev, dry=True)
+            continue
         try:
             worst, bad, desc = one_case(rng, i, dev)
         except Exception as ex:      # an unsupported shape must fail loudly, not silently
