@@ -161,7 +161,7 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
 // padded [B, T]; out[b * ldo + c]: row len-1 of the last block.  INTEL_ENC32=0 turns the path off.
 struct Enc32Block { const float *Wq, *bq, *Wk, *bk, *Wv, *bv, *g1, *be1, *W1, *b1, *W2, *b2, *g2, *be2; };
 bool enc32_supported(int T, int dm, int heads, int layers, int train);
-bool enc32_batch_ok(int B, int train);      // training: one slab per session and block, batches of <= 2048 sessions
+bool enc32_batch_ok(int B, int train);      // training: one slab per session and block, batches of <= 1024 sessions
 size_t enc32_slab_floats(int B, int layers);
 int launch_enc32_fwd(const float* X, const int* off, const int* len, int B, int T, int heads, int layers, const Enc32Block* blk, float* out, int ldo,
                      hipStream_t st);

@@ -1163,7 +1163,9 @@ int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int head
 }
 
 // ---- BERT4Rec at width 32 (enc32_* kernels above) ------------------------------------------------------------------------------
-constexpr int ENC32_MAXB = 2048;      // one slab per session and block: larger batches take the kernel-per-op encoder (they are not launch-bound)
+constexpr int ENC32_MAXB = 1024;      // one slab per session and block: larger batches take the kernel-per-op encoder.  Measured on the published IntEL-MSE
+                                       // configuration (ms per step with / without this kernel family): 256 sessions 0.72 / 1.03, 512: 0.72 / 0.79, 768: 0.77 / 0.84, 1024: 0.89 / 0.91,
+                                       // 1536: 1.24 / 0.97, 2048: 1.45 / 1.10 -- one workgroup and one 21.6 KB slab per session stop paying where the step stops being launch-bound
 bool enc32_supported(int T, int dm, int heads, int layers, int train) {
   static const int on = [] { const char* e = getenv("INTEL_ENC32"); return (e && e[0] == '0') ? 0 : 1; }();
   (void)train;
