@@ -1227,8 +1227,12 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   // kernels while a chain launch holds whole CUs (measured same-box, round 4, both directions on: Tmall shape 1024 / 2048 / 4096 sessions
   // -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress 1024 +-0): they stop at 768 sessions per step.  The FORWARD chains run at any batch
   // size (evaluation +2 ... +7 %, the training forward at the headline +0.5 %).  INTEL_HEAD_FUSED=2 forces the backward chains on too.
+  // With BOTH towers on the one-kernel 32-wide path (tower32.hip) there are no tower launches to hide the head's under: the backward chains pay
+  // up to 4096 sessions (published hyper-parameters, same-box: GRU4Rec encoders 1024 sessions +4 %, 4096 +-0, 8192 -5 %; BERT4Rec encoders
+  // 1024 / 2048 / 4096: +2 / +4 / +5.5 %).
   static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
-  if (train == 1 && y.B > 768 && !force) return false;
+  const bool tw32_both = D.layers > 0 && tower32_supported(y.L, y.tw[0].d, D.heads, D.layers, 1) && tower32_supported(y.L, y.tw[1].d, D.heads, D.layers, 1);
+  if (train == 1 && y.B > (tw32_both ? 4096 : 768) && !force) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
   const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
