@@ -234,7 +234,7 @@ def main():
     ap.add_argument('--cal_diversity', type=int, default=-1, help='-1: the workload default')
     ap.add_argument('--zipf', type=int, default=0, help='1: Zipf(1.05) item popularity instead of uniform')
     ap.add_argument('--dtype', type=str, default='f32', help='f32: the parity mode (headline); bf16: single bf16 product per linear')
-    ap.add_argument('--adam', type=str, default='auto', help='auto: lazy when a step touches at most 1/8 of the item-id table (engine.py), dense otherwise; lazy: the item-id table\'s dense Adam in its lazy form (rows replayed when they are next read; the whole table '
+    ap.add_argument('--adam', type=str, default='auto', help='auto: lazy when a step touches at most 1/4 of the item-id table (engine.py), dense otherwise; lazy: the item-id table\'s dense Adam in its lazy form (rows replayed when they are next read; the whole table '
                     'is settled INSIDE the timed region after the last step); dense: one sweep over the whole table every step')
     ap.add_argument('--nbatches', type=int, default=8, help='distinct resident batches cycled by the timed loop')
     ap.add_argument('--eval_steps', type=int, default=-1, help='evaluation steps timed after the training loop (-1: max(3, steps/2); 0: none)')

@@ -74,9 +74,9 @@ class IntELEngine(object):
         # reads model.iid_embeddings.weight or eng.m / eng.v directly calls eng.flush() first.  Opt-in: lazy_table=True or
         # INTEL_ADAM_LAZY=1 (bench.py and the runner's engine path switch it on)
         # 'auto' (what bench.py and the runner pass): decided at the first step from the batch shape -- lazy when a step touches at
-        # most 1/8 of the rows of a table of at least 128 MB (the 10 M-item stress table at batch 256: 1 %, the dense sweep is 2.75 of its 5.7 ms step,
-        # 43 k -> 69 k sessions/s; Tmall at batch 1024: 7 %, +7 %), dense otherwise (Tmall at batch 4096 touches 29 %: the sweep
-        # hides under the backward's tail and the lazy form only saves its traffic -- measured equal within 1 %, fp32 and bf16)
+        # most 1/4 of the rows of a table of at least 128 MB (the 10 M-item stress table at batch 256: 1 %, the dense sweep is 2.75 of its 5.7 ms step,
+        # 43 k -> 69 k sessions/s; Tmall shape, lazy against dense, round 4: 1536 sessions (11 % of the rows) +7 %, 2048 +5 %, 2560 +3.5 %, 3072 (22 %) +1 %,
+        # 3584 +-0, 4096 (29 %) -0.6 %: the sweep hides under the backward's tail there and the lazy form only saves its traffic), dense otherwise
         if lazy_table is None:
             lazy_table = {'0': False, '1': True}.get(os.environ.get('INTEL_ADAM_LAZY', '0'), 'auto')
         self._lazy = None
@@ -348,7 +348,7 @@ class IntELEngine(object):
         if self._lazy_auto:             # same decision on every rank: the shape is global (_check_global_shape)
             self._lazy_auto = False
             w = model.iid_embeddings.weight       # ... and the table is large enough for its sweep to matter (>= 128 MB: >= 0.15 ms per step)
-            if (ib.B * world) * (ib.L + ib.Hi) * 8 <= w.shape[0] and w.numel() * 4 >= (128 << 20):
+            if (ib.B * world) * (ib.L + ib.Hi) * 4 <= w.shape[0] and w.numel() * 4 >= (128 << 20):
                 self._lazy_init()
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         params = [p.detach() for _, _, p in model.slot_items()]
