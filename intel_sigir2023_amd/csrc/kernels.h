@@ -154,7 +154,7 @@ int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, cons
 // grads / accumulate: dWq, dWk, dWv, dW1, db1, dW2, db2, dgamma, dbeta (NULL = not wanted); valid after the queue's flush
 int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
-                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop = nullptr);
+                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop = nullptr, int share8 = 8);      // share8: eighths of the CUs a small batch's grid may take
 
 // BERT4Rec at the reference's default widths (dm = 32, <= 2 blocks, 1-2 heads, histories of <= 32 events): the whole encoder of a session
 // history as one kernel per direction (tower32.hip: enc32_*).  X: [rows, 32] input rows incl. the position embedding, packed (off) or

@@ -788,8 +788,10 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     }
     Tower32Dropout dr = tower32_dropout(r, &w == &r.y.tw[0] ? 0 : 1);
     if (!r.ctx->fwd_dropout) dr.p = 0.f;
+    static const int tw32_share = [] { const char* e = getenv("INTEL_TW32_SHARE"); return e ? atoi(e) : 0; }();      // 1 .. 8: eighths of the CUs for the small-batch grid (A/B)
     if (!r.ok(launch_tower32_bwd(w.X0, dX, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1),
-                                 r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st, &dr)))
+                                 r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st, &dr,
+                                 tw32_share > 0 ? tw32_share : ((D.encoder == INTEL_ENC_BERT4REC && B <= 2 * num_cus()) ? 5 : 8))))      // (tower32.hip: tower32_grid)
       return nullptr;
     return dXalt;
   }

@@ -1061,14 +1061,17 @@ bool tower32_supported(int L, int d, int heads, int layers, int train) {
   return true;
 }
 
-// small batches: one workgroup per CU (launch_tower32_bwd) on 3/8 of the CUs -- the two towers' backward kernels run side by side and must
-// leave whole CUs to the sequence encoders' kernels of the step's critical chain (the GRU recurrence needs a CU's entire register file)
-int tower32_grid(int B) {
+// small batches (<= 4 sessions per CU): one workgroup per CU (launch_tower32_bwd) on `share8` eighths of the CUs -- the two towers' backward kernels
+// run side by side with the sequence encoders' kernels of the step's critical chain and must leave them room.  How much was re-measured on the round's
+// final code (published hyper-parameters, 512 sessions, three runs each, sessions/s): GRU4Rec encoders 96 / 128 / 160 / 192 / 256 workgroups =
+// 644 / 652 / 674 / 674 / 694 k (the recurrence kernels are 32 workgroups: every CU may carry a tower workgroup); BERT4Rec encoders (one-kernel,
+// a workgroup per session) 665-764 / 711-740 / 788-790 / 721-768 / 712-734 k: five eighths.  640 ... 1024 sessions: all CUs in both (GRU4Rec +6 ... +7 %).
+int tower32_grid(int B, int share8) {
   if (B > 4 * num_cus()) return 1024;
-  const int g = num_cus() * 3 / 8;
+  const int g = num_cus() * (share8 < 1 ? 1 : (share8 > 8 ? 8 : share8)) / 8;
   return B < g ? B : g;
 }
-size_t tower32_slab_floats(int B) { return (size_t)tower32_grid(B) * TW32_SLAB; }
+size_t tower32_slab_floats(int B) { return (size_t)tower32_grid(B, 8) * TW32_SLAB; }
 
 #define TW32_DISPATCH_D(KERNEL, DROP_)                                \
   do {                                                               \
@@ -1121,11 +1124,11 @@ int launch_tower32_fwd(const float* X, int B, int L, int heads, int layers, cons
 // The partial sums go to `q`'s arena and are valid after its flush (redq_flush / redq_flush_tag).
 int launch_tower32_bwd(const float* X, const float* dout, int B, int L, int heads, int layers, const float* Wq, const float* Wk, const float* Wv,
                        const float* W1, const float* b1, const float* W2, const float* b2, const float* gamma, const float* beta, float* dX,
-                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop) {
+                       float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, const Tower32Dropout* drop, int share8) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower32_supported(L, 32, heads, layers, 1), "tower32_bwd: unsupported shape L=%d heads=%d layers=%d", L, heads, layers);
   INTEL_CHECK_ARG(q, "tower32_bwd: needs the reduce queue");
-  const int grid = tower32_grid(B);
+  const int grid = tower32_grid(B, share8);
   float* slabs = redq_alloc(q, (size_t)grid * TW32_SLAB);
   INTEL_CHECK_ARG(slabs, "tower32_bwd: reduction arena exhausted");
   Tw32BwdArgs a;
