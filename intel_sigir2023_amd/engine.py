@@ -265,8 +265,27 @@ class IntELEngine(object):
             self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
+    def _param_cache(self):
+        """(slot items, detached parameters, parameter-pointer array, gradient-pointer array), built once: the engine owns the flat buckets
+        the parameters and gradients are views of (_flatten), so the pointers are the same every step.  Re-validated by the address of the
+        first and the last parameter (a .to() / re-flatten moves all of them)."""
+        c = getattr(self, '_pcache', None)
+        items = c[0] if c is not None else self.model.slot_items()
+        key = (items[0][2].data_ptr(), items[-1][2].data_ptr(), len(self.grad_by_slot))
+        if c is None or c[4] != key:
+            items = self.model.slot_items()
+            params = [p.detach() for _, _, p in items]
+            for t in params:
+                L.require_gpu(t)
+            parr = self.model._param_array({s: t.contiguous() for (s, _, _), t in zip(items, params)})
+            garr = self.model._param_array(self.grad_by_slot)
+            key = (items[0][2].data_ptr(), items[-1][2].data_ptr(), len(self.grad_by_slot))
+            c = self._pcache = (items, params, parr, garr, key)
+        return c[0], c[1], c[2], c[3]
+
     # ---- flat parameter / gradient / moment buckets -------------------------------------------------
     def _flatten(self):
+        self._pcache = None
         items = self.model.slot_items()
         # three flat buckets: the item-id table (its all-reduce is the big one and is overlapped with the second
         # half of the backward pass), every other decayed parameter, the biases (weight_decay 0)
@@ -351,9 +370,9 @@ class IntELEngine(object):
             if (ib.B * world) * (ib.L + ib.Hi) * 4 <= w.shape[0] and w.numel() * 4 >= (128 << 20):
                 self._lazy_init()
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
-        params = [p.detach() for _, _, p in model.slot_items()]
+        items, params, parr, garr = self._param_cache()
         sort_ev = self._sort_scatter_ids(ib, keep)
-        weights, ens, intents = model.run_forward(ib, keep, params, train=True)
+        weights, ens, intents = model.run_forward(ib, keep, params, train=True, items=items, parr=parr)
         model._generation = getattr(model, '_generation', 0) + 1
         st = L.stream_ptr(dev)
         nb = lib.intel_loss_workspace_bytes(B, Lmax, K)
@@ -453,7 +472,7 @@ class IntELEngine(object):
             side = self._table_stream()
             lib.intel_set_table_stream(model._context(), C.c_void_p(side.cuda_stream))
             try:
-                model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+                model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, items=items, parr=parr, garr=garr)
             finally:
                 lib.intel_set_table_stream(model._context(), None)
             # exchange observability (bench.py --gpus N: `exchange` object): HIP events around the table exchange (+ its Adam sweep) on the
@@ -498,7 +517,7 @@ class IntELEngine(object):
             # layers, session-history encoder: matrix work that touches neither the table nor its gradient)
             cur = torch.cuda.current_stream(dev)
             side = self._table_stream()         # a context stream (idle in phase 2), not a fifth stream of our own
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=1)
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, items=items, parr=parr, garr=garr, phase=1)
             sparse = dp and self._sparse_exchange(keep, world)
             sharded = dp and self._sharded()
             work = parallel.allreduce_sum_async(self.gflat['iid']) if (dp and not sparse and not sharded) else None
@@ -514,14 +533,14 @@ class IntELEngine(object):
                     if sparse:
                         self._exchange_touched_rows(keep, L.stream_ptr(dev))
                     adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=work is not None)
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, phase=2)
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, items=items, parr=parr, garr=garr, phase=2)
             if dp:
                 parallel.allreduce_sum_([self.gflat['decay'], self.gflat['nodecay']])
             adam('decay', self.l2, st)
             adam('nodecay', 0.0, st)
             cur.wait_stream(side)
         else:
-            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot)
+            model.run_backward(ib, keep, params, d_w, d_ens, d_int, grad_tensors=self.grad_by_slot, items=items, parr=parr, garr=garr)
             sharded = dp and self._sharded()
             if dp:
                 parallel.allreduce_sum_(([] if sharded else [self.gflat['iid']]) + [self.gflat['decay'], self.gflat['nodecay']])
@@ -583,8 +602,8 @@ class IntELEngine(object):
         model = self.model
         self.flush()                # lazy table Adam: settle the table once per evaluation phase (no-op when nothing is pending)
         ib, keep = model.prepare_batch(batch)
-        params = [p.detach() for _, _, p in model.slot_items()]
-        weights, ens, intents = model.run_forward(ib, keep, params, train=False)
+        items, params, parr, _ = self._param_cache()
+        weights, ens, intents = model.run_forward(ib, keep, params, train=False, items=items, parr=parr)
         model._generation = getattr(model, '_generation', 0) + 1
         ndcg = self._buf('ndcg', (ib.B,), torch.float32)
         ranking = batch['ranking'] if batch['ranking'].dtype == torch.int32 else batch['ranking'].to(torch.int32)
