@@ -33,6 +33,8 @@ timeout 300 python tools/step_timeline.py f32 eval full > $out/timeline_f32_eval
 INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_pub -- python3 bench.py --workload tmall_pub --steps 20 --warmup 5 --eval_steps 0 $PMCARGS > $out/stats1s_pub.log 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py f32 train full tmall_pub 512 > $out/timeline_pub_f32_train.txt 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py f32 eval full tmall_pub 512 > $out/timeline_pub_f32_eval.txt 2>&1 < /dev/null
+INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_pub_mse -- python3 bench.py --workload tmall_pub_mse --loss IntMSEloss --steps 20 --warmup 5 --eval_steps 0 $PMCARGS > $out/stats1s_pub_mse.log 2>&1 < /dev/null
+timeout 300 python tools/step_timeline.py f32 train full tmall_pub_mse 512 > $out/timeline_pub_mse_f32_train.txt 2>&1 < /dev/null
 timeout 300 python tools/gpu_bound_probe.py tmall_pub 512 30 > $out/gpu_bound_pub.txt 2>&1 < /dev/null
 timeout 300 python tools/gpu_bound_probe.py tmall 4096 20 > $out/gpu_bound_tmall.txt 2>&1 < /dev/null
 timeout 900 python tools/ab_bench.py "--workload tmall_pub --steps 300 --warmup 30" INTEL_TOWER32=1,0 INTEL_HEAD_FUSED=1,0 > $out/ab_pub.txt 2>&1 < /dev/null

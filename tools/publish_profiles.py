@@ -47,7 +47,7 @@ def one(pattern):
     return fs[0] if fs else None
 
 
-for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'), ('stats1s_pub', 'bench_tmall_pub_kernel_stats.csv'),
+for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'), ('stats1s_pub', 'bench_tmall_pub_kernel_stats.csv'), ('stats1s_pub_mse', 'bench_tmall_pub_mse_kernel_stats.csv'),
                  ('stats_eval', 'bench_tmall_eval_kernel_stats.csv'), ('stats1s_bf16', 'bench_tmall_bf16_kernel_stats.csv')):
     f = one('%s/**/*kernel_stats.csv' % sub)
     if f:
@@ -70,7 +70,7 @@ for name in ('gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_e
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, name)))
-for t in ('f32_train', 'bf16_train', 'f32_eval', 'pub_f32_train', 'pub_f32_eval'):
+for t in ('f32_train', 'bf16_train', 'f32_eval', 'pub_f32_train', 'pub_f32_eval', 'pub_mse_f32_train'):
     f = os.path.join(src, 'timeline_%s.txt' % t)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_timeline_%s.txt' % (rnd, t)))
