@@ -1519,25 +1519,36 @@ void forward_impl(Run& r, const IntelOut* out) {
     y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train ? 2 : 0) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
   fork_streams(r, 3);
   hipEvent_t ev_pack = r.ctx->ev_x[0];
+  bool raw_only = false;
   {
     IntelCtx* c = r.ctx;
     const int shape[5] = {y.B, y.L, y.H, y.Hi, (r.train && c->drop_p > 0.f) ? 1 : 0};
     const bool reuse = c->params_unchanged && c->pack_ok && c->pack_ws == (const void*)y.ARENA && memcmp(shape, c->pack_shape, sizeof(shape)) == 0 &&
                        c->pack_train == (r.train != 0);      // the set of images depends on the mode (one-kernel tower layer)
     c->pack_ok = false;
+    // When NONE of the four branches reads a packed image -- both towers on the one-kernel 32-wide path, both encoders on the one-kernel BERT4Rec
+    // path, the small input linears on their raw-weight kernels: the reference's default widths -- only the session head needs the images: the packing
+    // launches go to the score tower's stream (the shortest branch) and the caller's stream waits for them in front of the head instead of in front
+    // of its own encoder branch (published IntEL-MSE configuration: the images were ~60 us at the head of every branch).  INTEL_PACK_SIDE=0: off.
+    static const int pack_side_on = [] { const char* e = getenv("INTEL_PACK_SIDE"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool towers_raw = pack_side_on && c->streams == 1 && D.layers > 0 && D.cross_attention && !reuse && smallk_supported(D.d_s, K) &&
+                            tower32_supported(L, y.tw[0].d, D.heads, D.layers, r.train) && tower32_supported(L, y.tw[1].d, D.heads, D.layers, r.train);
+    raw_only = towers_raw && D.encoder == INTEL_ENC_BERT4REC && c->enc32[0] && c->enc32[1] && smallk_supported(D.d_int, I) && bt.his_item_idx != nullptr;
+    // (measured and dropped: splitting the packing where only the ENCODERS need images -- GRU4Rec at the published hyper-parameters: no change)
+    Run pk = branch(r, raw_only ? 2 : -1, 0);
     if (!reuse) {
-      pack_all(r);
-      if (r.rc) return;
+      pack_all(pk);
+      if (!r.ok(pk.rc)) return;
       c->pack_train = r.train != 0;
     }
     c->pack_ws = (const void*)y.ARENA;       // the layout is a pure function of the shape and the workspace base
     memcpy(c->pack_shape, shape, sizeof(shape));
     c->pack_ok = true;
-    if (c->streams == 1) r.ok((int)hipEventRecord(ev_pack, r.st));
+    if (c->streams == 1) r.ok((int)hipEventRecord(ev_pack, pk.st));
   }
   hipStream_t main_st = r.st;
   auto wait_pack = [&](Run& b) {
-    if (r.ctx->streams == 1 && b.st != main_st) b.ok((int)hipStreamWaitEvent(b.st, ev_pack, 0));
+    if (r.ctx->streams == 1 && b.st != main_st && !raw_only) b.ok((int)hipStreamWaitEvent(b.st, ev_pack, 0));
   };
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
@@ -1616,6 +1627,7 @@ void forward_impl(Run& r, const IntelOut* out) {
   // the intent prediction needs the two encoders only (main + side 0): it and the intent-side projections of the pooling run
   // while the towers (side 1, side 2) are still busy; each pooling waits for its own tower
   wait_side(r, 0, r.st);
+  if (raw_only) r.ok((int)hipStreamWaitEvent(r.st, ev_pack, 0));      // the head's chains / products read the packed images
   if (r.rc) return;
   if (head_fused_ok(D, y, r.train ? 2 : 0)) {
     // the session head as two chain launches around the two pooling kernels (chain.hip)

@@ -47,6 +47,7 @@ CASES = [
     ({'INTEL_TOWER32': '0'}, MODEL),                                   # 32-wide towers on the kernel-per-op pipeline instead of the one-kernel tower (tower32.hip)
     ({'INTEL_HEAD_FUSED': '0'}, MODEL),                                # session head as one launch per link instead of the chain launches (chain.hip)
     ({'INTEL_HEAD_FUSED': '0'}, ENGINE),
+    ({'INTEL_PACK_SIDE': '0'}, MODEL),                                 # weight packing on the caller's stream even where no branch reads a packed image
     ({'INTEL_ENC32': '0'}, MODEL),                                     # 32-wide BERT4Rec encoders on the kernel-per-op pipeline instead of the one-kernel encoder (tower32.hip: enc32_*)
     ({'INTEL_WGRAD_TR': '0'}, BF16),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
