@@ -469,7 +469,6 @@ template <int DKT>
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_p3_kernel(const float* __restrict__ qkv, const float* __restrict__ dS, int ldS, int T, int d,
                                                                    int heads, const int* __restrict__ key_len, float* __restrict__ dqkv,
                                                                    const int* __restrict__ row_off) {
-  using TL = P3Tile<DKT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_p3[];
   unsigned char* Ks = smem_p3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, g = lane >> 4;
