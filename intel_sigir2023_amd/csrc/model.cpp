@@ -1234,7 +1234,8 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   // 1024 / 2048 / 4096: +2 / +4 / +5.5 %).
   static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
   const bool tw32_both = D.layers > 0 && tower32_supported(y.L, y.tw[0].d, D.heads, D.layers, 1) && tower32_supported(y.L, y.tw[1].d, D.heads, D.layers, 1);
-  if (train == 1 && y.B > (tw32_both ? 4096 : 768) && !force) return false;
+  const int bwd_limit = !tw32_both ? 768 : (D.encoder == INTEL_ENC_BERT4REC ? (1 << 30) : 4096);      // (BERT4Rec encoders: still +5 / +4 / +1.3 % at 6144 / 8192 / 16 384 sessions)
+  if (train == 1 && y.B > bwd_limit && !force) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
   const size_t Ip = rup(D.intent_num, 16) + 4, Pp = rup(y.Pin, 16) + 4, Fp = rup(y.F, 16) + 4, dd = y.tw[0].d + y.tw[1].d + 8;
