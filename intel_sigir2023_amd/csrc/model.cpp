@@ -1516,8 +1516,12 @@ void forward_impl(Run& r, const IntelOut* out) {
   const int B = y.B, L = y.L, M = y.M, I = D.intent_num, K = D.model_num;
   // the side branches start with work that needs no packed weights (history packing, embedding gathers): they fork BEFORE the
   // packing launches of the main stream and wait for them (ev_pack) in front of their first matrix product
-  for (int e = 0; e < 2; ++e)      // GRU4Rec with the fused session head: the output projections are links of the head's chains
-    y.enc[e].gru.ext_proj = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train ? 2 : 0) && gru_ext_proj_supported(y.enc[e].dm, D.gru_hidden);
+  {   // GRU4Rec with the fused session head: the output projections are links of the head's chains -- of BOTH encoders or of neither (the
+      // chains take them over only as a pair: an encoder left alone with the flag would have its projection computed by nobody)
+    const bool both = D.encoder == INTEL_ENC_GRU4REC && head_fused_ok(D, y, r.train ? 2 : 0) && gru_ext_proj_supported(y.enc[0].dm, D.gru_hidden) &&
+                      gru_ext_proj_supported(y.enc[1].dm, D.gru_hidden);
+    for (int e = 0; e < 2; ++e) y.enc[e].gru.ext_proj = both;
+  }
   fork_streams(r, 3);
   hipEvent_t ev_pack = r.ctx->ev_x[0];
   bool raw_only = false;

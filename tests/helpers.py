@@ -97,3 +97,43 @@ def relu_flip_forgiven_error(name, got, ref, tol, taps, max_units=1):
     keep = torch.ones_like(rows, dtype=torch.bool)
     keep[over] = False
     return float(rows[keep].max()) if bool(keep.any()) else 0.0
+
+
+def kernel_base(name):
+    """'(tw32_bwd_kernel<HEADS, NT, DROP>)[4096x50x32]' -> 'tw32_bwd_kernel' (the launch macros record the kernel's source text)."""
+    return name.split('[')[0].strip('() ').split('<')[0].split('::')[-1].strip('() ')
+
+
+class KernelTrace(object):
+    """Which kernels ran?  ``with KernelTrace() as kt: <calls through the C ABI>`` brackets every launch with the library's
+    built-in profiler (csrc/prof.cpp: intel_prof_enable / intel_prof_timeline) and leaves the set of kernel base names in
+    ``kt.names``.  The parity tests of a kernel FAMILY assert with it that the family's kernels really ran (and the superseded
+    ones did not): dispatch is decided by shape / batch predicates in csrc/model.cpp, and a predicate that silently routes a
+    case to the kernel-per-op pipeline would otherwise leave every test green."""
+
+    def __enter__(self):
+        from intel_sigir2023_amd import _lib
+        self._lib = _lib.lib()
+        self._lib.intel_prof_timeline()          # drop older records
+        self._lib.intel_prof_enable(1)
+        self.names = set()
+        self.count = {}
+        self.records = []
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        self.records = json.loads(self._lib.intel_prof_timeline().decode())
+        self._lib.intel_prof_enable(0)
+        self.count = {}
+        for r in self.records:
+            k = kernel_base(r['name'])
+            self.count[k] = self.count.get(k, 0) + 1
+        self.names = set(self.count)
+        return False
+
+    def check(self, present=(), absent=(), what=''):
+        missing = [k for k in present if k not in self.names]
+        extra = [k for k in absent if k in self.names]
+        assert not missing and not extra, 'dispatch%s: expected kernels that did not run %s, superseded kernels that ran %s; ran: %s' % (
+            (' (' + what + ')') if what else '', missing, extra, sorted(self.names))

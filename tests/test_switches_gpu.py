@@ -18,43 +18,46 @@ ENGINE = ['tests/test_engine_gpu.py', '-k', 'synthetic_workloads or adam']
 BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode's forward / gradient parity against its emulating oracle
 
 CASES = [
-    ({'INTEL_GEMM_B3': '0'}, MODEL),                                   # fp32-MFMA row GEMMs (LDS-DMA form)
-    ({'INTEL_GEMM_B3': '0', 'INTEL_GLDS': '0'}, MODEL),                # ... register-prefetch form
-    ({'INTEL_WGRAD_B3': '0'}, MODEL),                                  # fp32-MFMA weight gradients (LDS-DMA form)
-    ({'INTEL_WGRAD_B3': '0', 'INTEL_WGRAD_DMA': '0'}, MODEL),          # ... register-prefetch form
-    ({'INTEL_ATTN_FUSED_BWD': '0', 'INTEL_ENC_FUSED': '0'}, MODEL),    # whole-sequence attention backward as dK/dV kernel + dQ kernel
-    ({'INTEL_ATTN_SEQ': '0', 'INTEL_ENC_FUSED': '0'}, MODEL),          # flash-style general attention for every shape
-    ({'INTEL_ATTN_DS': '0'}, MODEL),                                   # general attention backward recomputes S / dP in the dQ pass
-    ({'INTEL_ATTN_P3': '0'}, MODEL),                                   # general attention (lists / histories > 64) on exact fp32 MFMAs instead of the three-plane bf16-pipe kernels (attn_p3.hip)
-    ({'INTEL_BWD_WIDE': '0'}, MODEL),                                  # one-call backward runs its two branch sets one after the other
-    ({'INTEL_FUSE_TAIL': '0'}, MODEL),                                 # towers' last LayerNorm as its own store / kernel
-    ({'INTEL_GEMM_SMALL': '0'}, MODEL),                                # odd B-row products on the generic kernel
-    ({'INTEL_STREAMS': '0'}, MODEL),                                   # whole step on the caller's stream
-    ({'INTEL_POS_GRAD_PACKED': '0'}, MODEL),                           # position-embedding gradient through the LDS-atomic kernel
-    ({'INTEL_PACK_HISTORY': '0'}, MODEL),                              # encoders on the padded [B, H] rows
-    ({'INTEL_GEMM_XCD': '0'}, MODEL),                                  # row-GEMM grids not rounded to the XCD count
-    ({'INTEL_FUSE_TOWER_D64': '0'}, MODEL),                            # fp32 training keeps the 64-wide tower on the kernel-per-op pipeline
-    ({'INTEL_ENC_FUSED_BWD': '0'}, MODEL),                             # kernel-per-op encoder backward on the fused forward's stash
-    ({'INTEL_WGRAD_SLABS': '64', 'INTEL_WGRAD_CORESIDENT': '0'}, MODEL),
-    ({'INTEL_MODEL_OP': '1'}, MODEL),                                  # IntEL.forward through torch.ops.intel_mi355x.intel_forward
-    ({'INTEL_STREAMS': '0'}, ENGINE),                                  # ... the engine's table sweep still has to wait for the backward
-    ({'INTEL_BWD_WIDE': '0'}, ENGINE),
-    ({'INTEL_ADAM_ROWS': '0'}, ENGINE),                                # dense Adam kernel over the item-id table
-    ({'INTEL_OVERLAP_TABLE': '0'}, ENGINE),                            # table sweep on the main stream
-    ({'INTEL_BWD_SCHEDULE': 'phased'}, ENGINE),                        # two-call backward
-    ({'INTEL_SCATTER_SORTED': '1'}, ENGINE),                           # always the sorted embedding scatter
-    ({'INTEL_BPR_NOISE': 'tensor'}, ENGINE),                           # BPR tie-breaking noise as a torch.rand tensor
-    ({'INTEL_TOWER32': '0'}, MODEL),                                   # 32-wide towers on the kernel-per-op pipeline instead of the one-kernel tower (tower32.hip)
-    ({'INTEL_HEAD_FUSED': '0'}, MODEL),                                # session head as one launch per link instead of the chain launches (chain.hip)
-    ({'INTEL_HEAD_FUSED': '0'}, ENGINE),
-    ({'INTEL_PACK_SIDE': '0'}, MODEL),                                 # weight packing on the caller's stream even where no branch reads a packed image
-    ({'INTEL_ENC32': '0'}, MODEL),                                     # 32-wide BERT4Rec encoders on the kernel-per-op pipeline instead of the one-kernel encoder (tower32.hip: enc32_*)
-    ({'INTEL_WGRAD_TR': '0'}, BF16),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
+    ({'INTEL_GEMM_B3': '0'}, MODEL, [], ['gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel']),                                   # fp32-MFMA row GEMMs (LDS-DMA form)
+    ({'INTEL_GEMM_B3': '0', 'INTEL_GLDS': '0'}, MODEL, [], ['gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'gemm_rows_w8g_kernel']),                # ... register-prefetch form
+    ({'INTEL_WGRAD_B3': '0'}, MODEL, ['wgrad_dma_kernel'], ['wgrad_b3_kernel', 'wgrad_b3_batch_kernel']),                                  # fp32-MFMA weight gradients (LDS-DMA form)
+    ({'INTEL_WGRAD_B3': '0', 'INTEL_WGRAD_DMA': '0'}, MODEL, ['wgrad_pipe_kernel'], ['wgrad_b3_kernel', 'wgrad_b3_batch_kernel', 'wgrad_dma_kernel']),          # ... register-prefetch form
+    ({'INTEL_ATTN_FUSED_BWD': '0', 'INTEL_ENC_FUSED': '0'}, MODEL, ['attn_seq_bwd_kv_kernel', 'attn_seq_bwd_q_kernel'], ['attn_seq_bwd_fused_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel']),    # whole-sequence attention backward as dK/dV kernel + dQ kernel
+    ({'INTEL_ATTN_SEQ': '0', 'INTEL_ENC_FUSED': '0'}, MODEL, ['attn_fwd_kernel'], ['attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'attn_seq_bwd_kv_kernel', 'enc_block_fwd_kernel']),          # flash-style general attention for every shape
+    ({'INTEL_ATTN_DS': '0'}, MODEL, [], ['attn_bwd_dq_ds_kernel', 'attn_bwd_dq_ds_p3_kernel']),                                   # general attention backward recomputes S / dP in the dQ pass
+    ({'INTEL_ATTN_P3': '0'}, MODEL, ['attn_fwd_kernel', 'attn_bwd_dkv_kernel'], ['attn_fwd_p3_kernel', 'attn_bwd_dkv_p3_kernel', 'attn_bwd_dq_ds_p3_kernel']),                                   # general attention (lists / histories > 64) on exact fp32 MFMAs instead of the three-plane bf16-pipe kernels (attn_p3.hip)
+    ({'INTEL_BWD_WIDE': '0'}, MODEL, [], []),                                  # one-call backward runs its two branch sets one after the other
+    ({'INTEL_FUSE_TAIL': '0'}, MODEL, [], ['xatt_pool_ln_bwd_reg_kernel']),                                 # towers' last LayerNorm as its own store / kernel
+    ({'INTEL_GEMM_SMALL': '0'}, MODEL, ['gemm_rows_kernel'], ['gemm_rows_small_kernel']),                                # odd B-row products on the generic kernel
+    ({'INTEL_STREAMS': '0'}, MODEL, [], []),                                   # whole step on the caller's stream
+    ({'INTEL_POS_GRAD_PACKED': '0'}, MODEL, ['pos_grad_kernel'], ['pos_grad_packed_kernel']),                           # position-embedding gradient through the LDS-atomic kernel
+    ({'INTEL_PACK_HISTORY': '0'}, MODEL, [], ['his_pack_kernel', 'enc_block_fwd_kernel']),                              # encoders on the padded [B, H] rows
+    ({'INTEL_GEMM_XCD': '0'}, MODEL, [], []),                                  # row-GEMM grids not rounded to the XCD count
+    ({'INTEL_FUSE_TOWER_D64': '0'}, MODEL, [], ['tower_fwd_fused_kernel']),                            # fp32 training keeps the 64-wide tower on the kernel-per-op pipeline
+    ({'INTEL_ENC_FUSED_BWD': '0'}, MODEL, ['enc_block_fwd_kernel'], ['enc_block_bwd_kernel', 'enc_last_bwd_kernel']),                             # kernel-per-op encoder backward on the fused forward's stash
+    ({'INTEL_WGRAD_SLABS': '64', 'INTEL_WGRAD_CORESIDENT': '0'}, MODEL, [], []),
+    ({'INTEL_MODEL_OP': '1'}, MODEL, [], []),                                  # IntEL.forward through torch.ops.intel_mi355x.intel_forward
+    ({'INTEL_STREAMS': '0'}, ENGINE, [], []),                                  # ... the engine's table sweep still has to wait for the backward
+    ({'INTEL_BWD_WIDE': '0'}, ENGINE, [], []),
+    ({'INTEL_ADAM_ROWS': '0'}, ENGINE, [], ['adam_rows_kernel']),                                # dense Adam kernel over the item-id table
+    ({'INTEL_OVERLAP_TABLE': '0'}, ENGINE, [], []),                            # table sweep on the main stream
+    ({'INTEL_BWD_SCHEDULE': 'phased'}, ENGINE, [], []),                        # two-call backward
+    ({'INTEL_SCATTER_SORTED': '1'}, ENGINE, ['scatter_add_sorted_kernel'], []),                           # always the sorted embedding scatter
+    ({'INTEL_BPR_NOISE': 'tensor'}, ENGINE, [], []),                           # BPR tie-breaking noise as a torch.rand tensor
+    ({'INTEL_TOWER32': '0'}, MODEL, [], ['tw32_fwd_kernel', 'tw32_bwd_kernel']),                                   # 32-wide towers on the kernel-per-op pipeline instead of the one-kernel tower (tower32.hip)
+    ({'INTEL_HEAD_FUSED': '0'}, MODEL, [], ['chain_kernel']),                                # session head as one launch per link instead of the chain launches (chain.hip)
+    ({'INTEL_HEAD_FUSED': '0'}, ENGINE, [], ['chain_kernel']),
+    ({'INTEL_PACK_SIDE': '0'}, MODEL, [], []),                                 # weight packing on the caller's stream even where no branch reads a packed image
+    ({'INTEL_ENC32': '0'}, MODEL, [], ['enc32_fwd_kernel', 'enc32_bwd_kernel']),                                     # 32-wide BERT4Rec encoders on the kernel-per-op pipeline instead of the one-kernel encoder (tower32.hip: enc32_*)
+    ({'INTEL_WGRAD_TR': '0'}, BF16, [], ['wgrad_tr_kernel']),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
 
 
-@pytest.mark.parametrize('env,target', CASES, ids=[','.join('%s=%s' % kv for kv in e.items()) for e, _ in CASES])
-def test_parity_set_with_switch(env, target):
+@pytest.mark.parametrize('env,target,expect,forbid', CASES, ids=[','.join('%s=%s' % kv for kv in c[0].items()) for c in CASES])
+def test_parity_set_with_switch(env, target, expect, forbid):
+    """expect / forbid: kernels the child session must / must not launch with the switch set (tests/conftest.py: the dispatch check) -- a switch that no
+    longer selects its code path fails here instead of re-testing the default path."""
+    env = dict(env, INTEL_EXPECT_KERNELS=','.join(expect), INTEL_FORBID_KERNELS=','.join(forbid))
     r = subprocess.run([sys.executable, '-m', 'pytest'] + target + ['-m', 'gpu', '-x', '-q', '-p', 'no:cacheprovider'], cwd=ROOT,
                        env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]

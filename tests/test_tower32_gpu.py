@@ -18,6 +18,14 @@ _spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.pa
 fuzz = importlib.util.module_from_spec(_spec)
 _spec.loader.exec_module(fuzz)
 
+
+def _check(tr, present, absent, what):
+    from tests.helpers import KernelTrace
+    kt = KernelTrace.__new__(KernelTrace)
+    kt.names = tr['names']
+    kt.check(present, absent, what)
+
+
 W32 = dict(i_emb_size=16, im_emb_size=16, s_emb_size=32, u_emb_size=32, intent_emb_size=32, context_emb_size=64, cross_attn_qsize=32)
 
 
@@ -30,16 +38,26 @@ def test_reference_widths_match_oracle_autograd(L, heads, layers, B, encoder, lo
     assert torch.cuda.is_available(), 'GPU tests need an MI355X'
     force = dict(W32, L=L, B=B, I=30, num_heads=heads, num_layers=layers, encoder=encoder, history_max=20, model_num=3, loss=loss,
                  cross_attention=1, cal_diversity=1)
-    worst, bad, desc = fuzz.one_case(random.Random(L * 100 + heads * 10 + layers), 7000 + L, torch.device('cuda:0'), big=False, force=force)
+    tr = {}
+    worst, bad, desc = fuzz.one_case(random.Random(L * 100 + heads * 10 + layers), 7000 + L, torch.device('cuda:0'), big=False, force=force, trace=tr)
     assert worst <= 1.0, (worst, bad, desc)
+    # ... and it was the one-kernel tower + the chain launches that produced these numbers (training lists of 97 .. 128 candidates: kernel-per-op pipeline)
+    if L <= 96:
+        _check(tr, ['tw32_fwd_kernel', 'tw32_bwd_kernel', 'chain_kernel'], ['tower_fwd_fused_kernel'], desc)
+        assert tr['count']['tw32_fwd_kernel'] == 2 and tr['count']['tw32_bwd_kernel'] == 2, tr['count']      # both towers
+    else:
+        _check(tr, ['chain_kernel'], ['tw32_fwd_kernel', 'tw32_bwd_kernel'], desc)
+    _check(tr, ['gru_seq_fwd_kernel', 'gru_seq_bwd_kernel'] if encoder == 'GRU4Rec' else [], ['enc32_fwd_kernel', 'enc32_bwd_kernel'], desc)
 
 
 def test_gate_variant_keeps_the_one_kernel_towers():
     """--cross_attention 0 (IntEL.py:206-209): the chains do not apply, the 32-wide towers still do."""
     force = dict(W32, L=50, B=9, I=30, num_heads=2, num_layers=2, encoder='GRU4Rec', history_max=20, model_num=3, loss='IntBPRloss',
                  cross_attention=0, cal_diversity=0)
-    worst, bad, desc = fuzz.one_case(random.Random(5), 7999, torch.device('cuda:0'), big=False, force=force)
+    tr = {}
+    worst, bad, desc = fuzz.one_case(random.Random(5), 7999, torch.device('cuda:0'), big=False, force=force, trace=tr)
     assert worst <= 1.0, (worst, bad, desc)
+    _check(tr, ['tw32_fwd_kernel', 'tw32_bwd_kernel', 'gate_fwd_kernel', 'gate_bwd_kernel'], ['chain_kernel'], desc)
 
 
 E32 = dict(i_emb_size=16, im_emb_size=16, s_emb_size=32, u_emb_size=32, intent_emb_size=16, context_emb_size=16, cross_attn_qsize=32)
@@ -54,8 +72,13 @@ def test_one_kernel_bert4rec_encoder_matches_oracle_autograd(H, heads, layers, B
     boundaries), 1 and 2 heads, 1 and 2 blocks, ragged lengths; 33 events fall back to the kernel-per-op encoder."""
     force = dict(E32, L=20, B=B, I=30, num_heads=heads, num_layers=layers, encoder='BERT4Rec', history_max=H, model_num=3, loss=loss,
                  cross_attention=1, cal_diversity=1)
-    worst, bad, desc = fuzz.one_case(random.Random(H * 100 + heads * 10 + layers), 7300 + H, torch.device('cuda:0'), big=False, force=force)
+    tr = {}
+    worst, bad, desc = fuzz.one_case(random.Random(H * 100 + heads * 10 + layers), 7300 + H, torch.device('cuda:0'), big=False, force=force, trace=tr)
     assert worst <= 1.0, (worst, bad, desc)
+    if H <= 32:
+        _check(tr, ['enc32_fwd_kernel', 'enc32_bwd_kernel', 'tw32_fwd_kernel', 'tw32_bwd_kernel'], ['enc_block_fwd_kernel', 'attn_lastq_fwd_kernel', 'attn_seq_fwd_kernel'], desc)
+    else:
+        _check(tr, ['tw32_fwd_kernel', 'tw32_bwd_kernel'], ['enc32_fwd_kernel', 'enc32_bwd_kernel'], desc)
 
 
 @pytest.mark.parametrize('B', [1024, 1025])
@@ -64,8 +87,13 @@ def test_one_kernel_encoder_batch_limit(B):
     the kernel-per-op encoder above; both sides of the limit against the oracle."""
     force = dict(E32, L=4, B=B, I=10, num_heads=2, num_layers=2, encoder='BERT4Rec', history_max=20, model_num=2, loss='IntBPRloss',
                  cross_attention=1, cal_diversity=0)
-    worst, bad, desc = fuzz.one_case(random.Random(B), 7400 + (B & 1), torch.device('cuda:0'), big=False, force=force)
+    tr = {}
+    worst, bad, desc = fuzz.one_case(random.Random(B), 7400 + (B & 1), torch.device('cuda:0'), big=False, force=force, trace=tr)
     assert worst <= 1.0, (worst, bad, desc)
+    if B <= 1024:
+        _check(tr, ['enc32_fwd_kernel', 'enc32_bwd_kernel'], [], desc)
+    else:
+        _check(tr, [], ['enc32_fwd_kernel', 'enc32_bwd_kernel'], desc)
 
 
 def test_one_kernel_encoder_inference_beyond_its_grid():

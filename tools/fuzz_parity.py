@@ -18,7 +18,7 @@ from oracle import intel_oracle as O
 from tests.helpers import relu_flip_forgiven_error
 
 
-def one_case(rng, idx, dev, big=None, force=None, dry=False):
+def one_case(rng, idx, dev, big=None, force=None, dry=False, trace=None):
     """big: None = decided per case (about one case in 25), True / False = forced.  A 'big' case is the reference's own tower widths
     (16/16/32/32, script/IntEL.sh:15,21) at lists of 50 / 90 with more than 32 768 candidate rows per batch: the far side of the
     row-count thresholds of the short-list attention backward and the batched small weight gradients."""
@@ -64,9 +64,18 @@ def one_case(rng, idx, dev, big=None, force=None, dry=False):
     noise = torch.rand(B, L, L, device=dev)
     batch['bpr_noise'] = noise
     crit = getattr(LS, loss_name)(args)
-    out = model(batch)
-    loss, ens, itl = crit(out, batch)
-    loss.backward()
+    if trace is not None:      # tests: which kernels did this case run (tests/helpers.py: KernelTrace)
+        from tests.helpers import KernelTrace
+        with KernelTrace() as kt:
+            out = model(batch)
+            loss, ens, itl = crit(out, batch)
+            loss.backward()
+        trace['names'] = kt.names
+        trace['count'] = kt.count
+    else:
+        out = model(batch)
+        loss, ens, itl = crit(out, batch)
+        loss.backward()
     taps = {}
     ref = O.forward(sd, ref_batch, cfg, taps=taps)
     if loss_name == 'IntBPRloss':
