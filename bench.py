@@ -21,7 +21,7 @@ HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15      # FLOP/s dense bf16 MFMA
 B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel')
-FUSED_KERNELS = ('tower_fwd_fused_kernel',)
+FUSED_KERNELS = ('tower_fwd_fused_kernel', 'tower_bwd_fused_kernel')
 MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
                 'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_kv_kernel',
                 'attn_seq_bwd_q_kernel', 'attn_seq_bwd_fused_kernel', 'attn_bwd_dq_ds_kernel', 'tw32_fwd_kernel', 'tw32_bwd_kernel')      # exact fp32 MFMAs (v_mfma_f32_16x16x4_f32)
@@ -223,6 +223,45 @@ def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_sh
     return roof, prof
 
 
+def short_line(workload, B, over, steps, warmup, dev):
+    """One short training measurement of another workload (fresh model + engine, 4 resident batches, the workload's own optimizer settings and
+    table-Adam policy), same brackets as the headline's timed block."""
+    import gc
+    import torch
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    w = synth.WORKLOADS[workload]
+    over = dict(over)
+    loss_name = over.pop('loss', 'IntBPRloss')
+    args_ns = synth.make_args(workload, dev, **over)
+    corpus, cinfo = synth.make_corpus(workload)
+    torch.manual_seed(0)
+    model = IntEL(args_ns, corpus).to(dev)
+    lr, l2 = w.get('optim', (1e-3, 1e-4))
+    eng = IntELEngine(model, loss_name, args_ns, lr=lr, l2=l2, lazy_table='auto')
+    batches = [synth.make_batch(workload, B, dev, seed=50 + i) for i in range(4)]
+    for bt in batches:
+        bt['_intel'] = model.prepare_batch(bt)
+        bt['_intel'][1]['ranking_i32'] = bt['ranking']
+    for i in range(warmup):
+        eng.train_step(batches[i % 4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        eng.train_step(batches[i % 4])
+    eng.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = {'workload': workload, 'batch': B, 'loss': loss_name, 'cal_diversity': int(args_ns.cal_diversity), 'steps': steps, 'warmup': warmup,
+           'value': round(B * steps / max(el, 1e-9), 1), 'unit': 'sessions/s', 'ms_per_step': round(1e3 * el / max(1, steps), 4),
+           'table_adam': 'lazy' if eng._lazy is not None else 'dense'}
+    del eng, model, batches
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,6 +281,8 @@ def main():
     ap.add_argument('--no_bf16_line', action='store_true', help='skip the bf16-mode measurement appended to the fp32 line at N=1')
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
+    ap.add_argument('--no_workloads', action='store_true', help='skip the short driver-timed lines of the other workloads (tmall_pub, lifedata, stress) appended at N=1')
+    ap.add_argument('--spread_blocks', type=int, default=2, help='extra timed blocks of --steps steps after the one that defines `value` (value_spread)')
     ap.add_argument('--cpu_budget', type=float, default=24.0)
     ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
     ap.add_argument('--encoder', type=str, default='', help='override the sequence encoder: BERT4Rec | GRU4Rec')
@@ -304,6 +345,20 @@ def main():
     el = time.perf_counter() - t0
     el = parallel.allreduce_max_float(el, dev)
     last_loss = float(loss[0]) if (a.steps + a.warmup) > 0 else float('nan')
+    # the same timed block again (same brackets): `value` stays the FIRST block -- the driver's --steps -- and the spread shows what one sample is worth
+    block_values = [world * B * a.steps / max(el, 1e-9)]
+    for _ in range(max(0, a.spread_blocks) if a.steps > 0 else 0):
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        for i in range(a.steps):
+            one_step(i)
+        eng.flush()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        block_values.append(world * B * a.steps / max(parallel.allreduce_max_float(time.perf_counter() - tb, dev), 1e-9))
 
     # ---- eval throughput (forward + on-device NDCG@3), not part of `value`
     model.eval()
@@ -362,7 +417,8 @@ def main():
             ('fp32 storage and accumulation; the large products run as three-plane bf16 splits (hi+mid+lo, six plane products) on the bf16 '
              'MFMA pipe = fp32 accuracy, same parity thresholds as the fp32-MFMA kernels')
     res = {
-        'metric': 'train sessions/sec, IntEL fwd+BPR loss+bwd+Adam, synthetic Tmall-shape list=%d K=%d d=64' % (Lmax, f['model_num']),
+        'metric': 'train sessions/sec, IntEL fwd+%s+bwd+Adam, synthetic %s list=%d K=%d, item / score tower %d / %d wide'
+                  % (a.loss, {'tmall': 'Tmall-shape', 'lifedata': 'LifeData-shape'}.get(a.workload, a.workload), Lmax, f['model_num'], f['i_emb_size'] + f['im_emb_size'], f['s_emb_size']),
         'value': round(world * B * a.steps / max(el, 1e-9), 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(1e3 * el / max(1, a.steps), 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
@@ -377,6 +433,8 @@ def main():
                                   'the last step') if eng._lazy is not None else 'dense sweep over the whole table every step'},
         'eval_sessions_per_s': round(world * B * ev_steps / ev_el, 1), 'ndcg3_random_init': round(ndcg3, 5),
         'loss_last_step': round(last_loss, 6),
+        'value_spread': {'blocks': [round(v, 1) for v in block_values], 'min': round(min(block_values), 1), 'max': round(max(block_values), 1),
+                         'note': '`value` is the first block (the driver\'s --steps); the others repeat it with the same brackets in the same process'},
     }
     if exchange is not None:      # data parallel: what the gradient exchange cost and how much of it was NOT hidden (slowest rank, 5 extra steps)
         res['exchange'] = exchange
@@ -417,6 +475,27 @@ def main():
             res['kernel_table'] = {k: '%d launches/step, %.4f ms/step, avg %.1f us' % (v['launches'] // psteps, v['ms'] / psteps, 1e3 * v['ms'] / max(1, v['launches']))
                                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])}
         res['kernel_launches_per_step'] = round(sum(v['launches'] for v in prof.values()) / psteps, 1)
+        # the STEP against its own floor: algorithmic bytes (SURVEY 8-d per-session figure x sessions + the optimizer's streams) and the HBM bytes the
+        # PMC passes counted for a step, both over the measured step time; fp32-equivalent flops of every matrix product of the step
+        n_tab = model.iid_embeddings.weight.numel()
+        n_all = sum(p.numel() for p in model.parameters())
+        adam_b = (24.0 * n_tab if eng._lazy is None else 0.0) + 32.0 * (n_all - n_tab)
+        alg_b = float(bytes_train) * B + adam_b
+        step_s = el / max(1, a.steps)
+        sr = {'algorithmic_GB_per_step': round(alg_b / 1e9, 3), 'pmc_GB_per_step': None, 'traffic_ratio': None,
+              'hbm_frac_algorithmic': round(alg_b / step_s / HBM_PEAK, 4), 'hbm_frac_pmc': None,
+              'fp32_equivalent_TFLOPs': round(sum(v['flops'] for v in prof.values()) / psteps / step_s / 1e12, 1),
+              'note': 'algorithmic = %d B/session x %d sessions + %.2f GB of Adam streams (dense table sweep: 24 B/parameter, other parameters 32)' % (bytes_train, B, adam_b / 1e9)}
+        try:
+            if exact and world == 1:
+                jj = json.load(open(os.path.join(ROOT, src.split(' ')[0])))
+                sr['pmc_GB_per_step'] = jj['hbm_GB_per_train_step']
+                sr['traffic_ratio'] = round(jj['hbm_GB_per_train_step'] * 1e9 / alg_b, 2)
+                sr['hbm_frac_pmc'] = round(jj['hbm_GB_per_train_step'] * 1e9 / step_s / HBM_PEAK, 4)
+                sr['pmc_source'] = src.split(' ')[0]
+        except Exception:
+            pass
+        res['step_roofline'] = sr
         res['eval_kernel_launches_per_step'] = round(sum(v['launches'] for v in eprof.values()) / psteps, 1)
     if world == 1 and not bf16 and not a.no_bf16_line:
         # the same workload in the bf16 arithmetic mode (BASELINE.json configs[1] names it), measured in the same run on the same
@@ -449,11 +528,41 @@ def main():
             _, nd_bf = eng_bf.eval_step(batches[i % nbatches], k=3)
         torch.cuda.synchronize()
         ev_bf = time.perf_counter() - t1
+        bf_roof = None
+        if not a.no_roofline:
+            lib = _lib.lib()
+            lib.intel_set_concurrency(model_bf._context(), 0)
+            ovb, eng_bf.overlap_table_update = eng_bf.overlap_table_update, False
+            model_bf.train()
+            lib.intel_prof_enable(1)
+            for i in range(3):
+                eng_bf.train_step(batches[i % nbatches])
+            pbf = json.loads(lib.intel_prof_collect().decode())
+            lib.intel_prof_enable(0)
+            eng_bf.overlap_table_update = ovb
+            lib.intel_set_concurrency(model_bf._context(), 1)
+            pmc_bf, src_bf = None, None
+            try:
+                import glob
+                src_bf = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic_bf16.json')))[-1]
+                pmc_bf = json.load(open(os.path.join(ROOT, src_bf))).get('kernels')
+            except Exception:
+                pass
+            bf_roof, bf_prof = price_dominant_kernel(pbf, 3, pmc_bf, src_bf, a.workload == 'tmall' and B == 4096, 1.0)
+            bf_roof['kernel_ms_per_step'] = {k: round(v['ms'] / 3, 4) for k, v in sorted(bf_prof.items(), key=lambda kv: -kv[1]['ms'])[:8]}
         res['bf16_mode'] = {'value': round(B * a.steps / max(el_bf, 1e-9), 1), 'unit': 'sessions/s', 'ms_per_step': round(1e3 * el_bf / max(1, a.steps), 4),
                             'eval_sessions_per_s': round(B * max(1, ev_steps) / ev_bf, 1), 'ndcg3_random_init': round(float(nd_bf.float().nan_to_num(0).mean()), 5),
                             'loss_last_step': round(float(lb[0]), 6) if a.steps else None,
-                            'note': 'python bench.py --dtype bf16 gives this mode its own full line (roofline, kernel table); not `value`'}
+                            'roofline': bf_roof,
+                            'note': 'python bench.py --dtype bf16 gives this mode its own full line (kernel table, eval roofline); not `value`'}
         del eng_bf, model_bf
+        gc.collect()
+        torch.cuda.empty_cache()
+    if world == 1 and not bf16 and a.workload == 'tmall' and not a.no_workloads:
+        # the other workloads of BASELINE.json / the published scripts, each as a short timed block in THIS process, so that their numbers are
+        # driver-timed too (own full lines: python bench.py --workload W [--batch B]); never part of `value`
+        res['workloads'] = [short_line(wl, bb, oo, min(20, max(1, a.steps)), min(5, a.warmup), dev)
+                            for wl, bb, oo in (('tmall_pub', 512, {}), ('tmall_pub_mse', 512, {'loss': 'IntMSEloss'}), ('lifedata', 2048, {}), ('stress', 256, {}))]
     if world == 1 and not a.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(args_ns, corpus, cinfo, a.workload, a.loss, a.cpu_budget)
     print(json.dumps(res))

@@ -140,6 +140,18 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
                            float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16 = 0);
 
+// ---- the middle of one tower layer's backward in one kernel (tower_bwd.hip): dZ -> dQKV, with dW1 / db1 / dW2 / db2 accumulated in the workgroup ----
+// L <= 64, d in {64, 128}, head dim in {64, 128}; needs the forward's A (attention output) and LSE stashes and the layer input X; the q/k/v weight
+// gradient and dX = dQKV Wqkv + dZ stay on the GEMM kernels.  INTEL_FUSE_TOWER_BWD=0 turns the path off, =1 forces it wherever supported.
+bool tower_bwd_fused_supported(int L, int d, int heads);
+bool tower_bwd_fused_wanted(int d);      // the policy (INTEL_FUSE_TOWER_BWD unset): bf16 mode both widths, fp32 the 64-wide tower (tower_bwd.hip)
+size_t tower_bwd_slab_floats(int B, int d);      // arena floats one launch takes from the reduce queue
+// W*_b3: three-plane images (launch_pack_b3) of the packed forward [d -> 3d] / [d -> d] weights and of the TRANSPOSED feed-forward weights;
+// accumulate[4]: dW2, db2, dW1, db1 (valid after the queue's flush; NULL = not wanted); a16 / dqkv16 (bf16 mode): A read / dQKV written as bf16 arrays
+int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, const float* dZ, int B, int L, int d, int heads, const void* Wqkv_b3,
+                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const float* b1, float* dQKV, float* dW2, float* db2, float* dW1,
+                           float* db1, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16 = 0, int dqkv16 = 0);
+
 // ---- the whole tied tower at the reference's own 32-wide shapes, one kernel per direction (tower32.hip) ---------------------------
 // d = 32, 1-2 heads, L <= 128, any number of tied layers; raw (unpacked) reference weights W [32, 32], vectors [32].  No activation stash:
 // the backward recomputes the forward from the tower input.  INTEL_TOWER32=0 turns the path off.

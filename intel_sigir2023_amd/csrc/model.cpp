@@ -48,6 +48,7 @@ struct TowerBufs {
   float *pWqkv, *pW1, *pW2, *pWqkvT, *pW1T, *pW2T;
   float* b3WqkvT;           // bf16 three-plane image of pWqkvT (K = 3d > 128: GEMM on the bf16 pipe)
   float *b3Wqkv, *b3W1, *b3W2;   // images of the forward weights for the one-kernel tower layer (tower.hip)
+  float *b3W1T, *b3W2T;          // ... and of the transposed feed-forward weights for the one-kernel middle of its backward (tower_bwd.hip)
   float *pXq, *pXqT, *pXk, *pXkT, *pXv, *pXvT;
   // --cross_attention 0
   float *MH, *MV, *pM0, *pM2, *pM2T, *pM0T;
@@ -146,6 +147,7 @@ struct IntelCtx {
   int pack_shape[5] = {0, 0, 0, 0, 0};      // B, L, H, Hi, dropout layout
   bool enc32[2] = {false, false};      // this forward ran encoder e as the one-kernel 32-wide BERT4Rec encoder (tower32.hip: enc32_*): no stash
   bool tw32[2] = {false, false};       // this forward ran tower t as the one-kernel 32-wide tower (tower32.hip): no stash, the backward recomputes
+  bool tw_bwdf[2] = {false, false};    // this forward left tower t's backward to the one-kernel middle (tower_bwd.hip): only A and the log-sum-exp are stashed
   bool tw_qkv16[2] = {false, false};   // this forward stored tower t's q/k/v stash as bf16 (bf16 mode; the backward reads it and writes dQKV the same way)
   int enc_rows[2];             // rows of encoder e: B * T, or the packed total
 };
@@ -182,6 +184,8 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     w.b3Wqkv = ar.f(packed_b3_bytes(d, 3 * d) / 4);
     w.b3W1 = ar.f(packed_b3_bytes(d, d) / 4);
     w.b3W2 = ar.f(packed_b3_bytes(d, d) / 4);
+    w.b3W1T = ar.f(packed_b3_bytes(d, d) / 4);
+    w.b3W2T = ar.f(packed_b3_bytes(d, d) / 4);
     w.pW1T = ar.f(packed_floats(d, d));
     w.pW2T = ar.f(packed_floats(d, d));
     if (D.cross_attention) {
@@ -400,6 +404,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
+    a += (size_t)D.layers * (rup_sz(tower_bwd_slab_floats(B, d_i), 64) + rup_sz(tower_bwd_slab_floats(B, d_s), 64));      // ... of the one-kernel backward middles (tower_bwd.hip)
     if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
                                 rup_sz((size_t)d_i * d_i + (size_t)d_s * d_s + (size_t)(d_i + d_s) * I + (size_t)I * y.Pin + I, 64) + 64 +
@@ -597,10 +602,16 @@ void pack_all(Run& r) {
     TowerBufs& w = y.tw[t];
     if (!(D.layers > 0 && tower32_supported(y.L, w.d, D.heads, D.layers, r.train)))      // (tower32.hip reads the raw weights)
       RUN(launch_pack_b3(w.pWqkvT, 3 * rup(w.d, 16), w.d, w.b3WqkvT, r.st));
-    if (tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train, w.d)) {
+    const bool bwdf = r.train && D.layers > 0 && tower_bwd_fused_supported(y.L, w.d, D.heads) && tower_bwd_fused_wanted(w.d);      // (tower_fwd decides with the same predicate + no dropout)
+    const bool fwdf = tower_fused_supported(y.L, w.d, D.heads) && tower_fused_wanted(r.train, w.d);
+    if (fwdf || bwdf) {
       RUN(launch_pack_b3(w.pWqkv, w.d, 3 * w.d, w.b3Wqkv, r.st));
       RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
-      RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
+    }
+    if (fwdf) RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
+    if (bwdf) {
+      RUN(launch_pack_b3(w.pW1T, w.d, w.d, w.b3W1T, r.st));
+      RUN(launch_pack_b3(w.pW2T, w.d, w.d, w.b3W2T, r.st));
     }
   }
   if (D.encoder == INTEL_ENC_BERT4REC) {
@@ -711,6 +722,7 @@ void tower_fwd(Run& r, TowerBufs& w) {
   r.ctx->tw32[tw_i] = D.layers > 0 && tower32_supported(L, d, D.heads, D.layers, r.train);
   if (r.ctx->tw32[tw_i]) {
     r.ctx->tw_qkv16[tw_i] = false;
+    r.ctx->tw_bwdf[tw_i] = false;
     Tower32Dropout dr = tower32_dropout(r, tw_i);
     RUN(launch_tower32_fwd(X, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1), r.P(pb + T_W2),
                            r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), w.layer[D.layers - 1].Xout, r.st, &dr));
@@ -724,11 +736,15 @@ void tower_fwd(Run& r, TowerBufs& w) {
   // bf16 mode: q/k/v (and, in the backward, their gradients) live in HBM as bf16 arrays -- every consumer rounds them to bf16
   // before its product anyway (attention backward, the q/k/v data- and weight-gradient products)
   r.ctx->tw_qkv16[tw_i] = fused && r.train && gemm_planes() == 1;
+  // the backward's middle in one kernel (tower_bwd.hip): it recomputes q/k/v and the relu output, so the one-kernel forward stashes A and the log-sum-exp only
+  r.ctx->tw_bwdf[tw_i] = r.train && D.layers > 0 && tower_bwd_fused_supported(L, d, D.heads) && tower_bwd_fused_wanted(d) && !(r.ctx->drop_p > 0.f);
+  const bool slim = r.ctx->tw_bwdf[tw_i];
   for (int l = 0; fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only
     RUN(launch_tower_fwd_fused(X, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2, r.P(pb + T_B1), r.P(pb + T_B2), r.P(pb + T_LNG),
-                               r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, b.QKV, b.A, b.LSE, b.R1, b.XH, b.RSTD, r.st, r.ctx->tw_qkv16[tw_i]));
+                               r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, slim ? nullptr : b.QKV, b.A, b.LSE, slim ? nullptr : b.R1, b.XH, b.RSTD, r.st,
+                               r.ctx->tw_qkv16[tw_i]));
     X = b.Xout;
   }
   for (int l = 0; !fused && l < D.layers; ++l) {
@@ -819,6 +835,19 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     // bf16 mode: the stashes read only by matrix products (A, R1 -- R1 also as a sign test) and the gradients consumed only by
     // matrix products (dF1, dA, dQKV) are bf16 arrays; dZ stays fp32 (it is also the residual gradient)
     const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
+    if (r.ctx->tw_bwdf[&w == &r.y.tw[0] ? 0 : 1]) {
+      // dZ -> dQKV in one kernel, dW2 / db2 / dW1 / db1 accumulated in its workgroups (tower_bwd.hip); q/k/v weight gradient and dX below as before
+      static const int slots[4] = {T_W2, T_B2, T_W1, T_B1};
+      float* g[4];
+      int acc[4];
+      for (int k = 0; k < 4; ++k) {
+        g[k] = r.G(pb + slots[k]);
+        acc[k] = r.acc(pb + slots[k]);
+      }
+      if (!r.ok(launch_tower_bwd_fused(Xin, b.A, b.LSE, dZ, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2T, w.b3W1T, r.P(pb + T_B1), r.T->dQKV, g[0], g[1], g[2], g[3],
+                                       acc, r.ctx->rq, r.st, h16, h16)))
+        return nullptr;
+    } else {
     wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2, h16 ? 2 : 0);
     if (r.ctx->fwd_dropout) wgrad_batch_begin();
     GemmEpilogue em;
@@ -831,6 +860,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     lin(r, r.T->dF1, d, M, d, w.pW1T, d, r.T->dA, d, e0);
     if (r.rc) return nullptr;
     if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st, nullptr, h16))) return nullptr;
+    }
     {
       const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
       wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs, h16);

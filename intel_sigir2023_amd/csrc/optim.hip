@@ -1,4 +1,6 @@
 // Fused Adam (dense, coupled L2) and on-device NDCG@k.
+#include <stdio.h>
+
 #include "../../include/intel_hip.h"
 #include "kernels.h"
 #include "session.h"
@@ -12,15 +14,35 @@
 struct AdamArgs {
   float* p; float* g; float* m; float* v; long long n;
   float step_size, beta1, beta2, eps, wd, inv_bc2_sqrt, grad_scale; int zero_grad;
+  float omb1, omb2;      // 1 - beta1, 1 - beta2 as torch forms them: in DOUBLE from the decimal betas, then rounded to float (adam_scalars)
 };
+
+// The step's scalars the way torch.optim.Adam's single-tensor path forms them (python doubles: bias_correction = 1 - beta ** step, step_size =
+// lr / bias_correction1, lerp weight 1 - beta1, addcmul value 1 - beta2; each becomes a float only where a tensor op consumes it).  The C ABI
+// carries lr and the betas as floats: (double)0.999f is 0.99900001287..., and 1.f - 0.999f is 1.3e-5 off float(0.001) -- a systematic 6e-6 on
+// sqrt(v) that tests/test_trajectory_gpu.py sees against the reference at t = 1.  The decimal value the caller meant is recovered by printing
+// the float with 7 significant digits (exact for every hyper-parameter given with <= 7 digits; any other float is reproduced to its own precision).
+static double adam_decimal(float x) {
+  char buf[48];
+  snprintf(buf, sizeof(buf), "%.7g", (double)x);
+  return strtod(buf, nullptr);
+}
+static void adam_scalars(float lr, float beta1, float beta2, int step, float* step_size, float* inv_bc2_sqrt, float* omb1, float* omb2) {
+  const double b1 = adam_decimal(beta1), b2 = adam_decimal(beta2);
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  *step_size = (float)(adam_decimal(lr) / bc1);
+  *inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  *omb1 = (float)(1.0 - b1);
+  *omb2 = (float)(1.0 - b2);
+}
 
 // The roundings are pinned (explicit fused multiply-adds, no contraction left to the compiler): the dense sweeps and the lazy
 // replay below must produce the same bits from the same inputs whatever code surrounds the inlined body.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
 #pragma clang fp contract(off)
   g = __builtin_fmaf(g, a.grad_scale, a.wd * p);
-  m = __builtin_fmaf(g - m, 1.f - a.beta1, m);
-  const float g2 = ((1.f - a.beta2) * g) * g;
+  m = __builtin_fmaf(g - m, a.omb1, m);
+  const float g2 = (a.omb2 * g) * g;
   v = __builtin_fmaf(v, a.beta2, g2);
   const float denom = __builtin_fmaf(sqrtf(v), a.inv_bc2_sqrt, a.eps);
   p = __builtin_fmaf(-a.step_size, m / denom, p);
@@ -98,10 +120,7 @@ int launch_adam_rows(float* p, float* g, float* m, float* v, long long rows, int
                     reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adam: tensors must be 16-byte aligned");
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = rows * d;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.step_size = (float)((double)lr / bc1);
-  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  adam_scalars(lr, beta1, beta2, step, &a.step_size, &a.inv_bc2_sqrt, &a.omb1, &a.omb2);
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = 1;
   long long blocks = ((a.n >> 2) + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
@@ -146,10 +165,7 @@ __global__ __launch_bounds__(256) void adam_pair_kernel(AdamArgs a, AdamArgs b, 
 static void adam_fill(AdamArgs& a, float* p, float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, float wd,
                       int step, float grad_scale, int zero_grad) {
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.step_size = (float)((double)lr / bc1);
-  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  adam_scalars(lr, beta1, beta2, step, &a.step_size, &a.inv_bc2_sqrt, &a.omb1, &a.omb2);
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
 }
 
@@ -178,10 +194,7 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
                     reinterpret_cast<uintptr_t>(v)) & 15) == 0, "adam: tensors must be 16-byte aligned");
   AdamArgs a;
   a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  a.step_size = (float)((double)lr / bc1);
-  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  adam_scalars(lr, beta1, beta2, step, &a.step_size, &a.inv_bc2_sqrt, &a.omb1, &a.omb2);
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = wd; a.grad_scale = grad_scale; a.zero_grad = zero_grad;
   long long blocks = ((n >> 2) + 255) / 256;
   blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);     // grid-stride: 256 CUs x 8
@@ -201,14 +214,14 @@ int launch_adam(float* p, float* g, float* m, float* v, long long n, float lr, f
 struct LazyArgs {
   float* p; float* g; float* m; float* v; int* last; float* sched; unsigned char* flags;
   long long rows; int d, base, step;
-  float beta1, beta2, eps, wd, grad_scale, zero, step_size, inv_bc2_sqrt;
+  float beta1, beta2, eps, wd, grad_scale, zero, step_size, inv_bc2_sqrt, omb1, omb2;
 };
 
 __device__ __forceinline__ AdamArgs lazy_consts(const LazyArgs& a) {
   AdamArgs c;
   c.p = c.g = c.m = c.v = nullptr; c.n = 0; c.zero_grad = 0;
   c.beta1 = a.beta1; c.beta2 = a.beta2; c.eps = a.eps; c.wd = a.wd; c.grad_scale = a.grad_scale;
-  c.step_size = a.step_size; c.inv_bc2_sqrt = a.inv_bc2_sqrt;
+  c.step_size = a.step_size; c.inv_bc2_sqrt = a.inv_bc2_sqrt; c.omb1 = a.omb1; c.omb2 = a.omb2;
   return c;
 }
 
@@ -378,6 +391,10 @@ static int lazy_fill(LazyArgs& a, const IntelLazyTable& t) {
   a.rows = t.rows; a.d = t.d; a.base = t.base; a.step = 0;
   a.beta1 = t.beta1; a.beta2 = t.beta2; a.eps = t.eps; a.wd = t.weight_decay; a.grad_scale = 1.f; a.zero = 0.f;
   a.step_size = 0.f; a.inv_bc2_sqrt = 0.f;
+  {
+    float u0, u1;
+    adam_scalars(1.f, t.beta1, t.beta2, 1, &u0, &u1, &a.omb1, &a.omb2);
+  }
   return 0;
 }
 
@@ -392,11 +409,8 @@ int launch_adam_lazy_step(const IntelLazyTable& t, float* g, unsigned char* row_
   if (int rc = lazy_fill(a, t)) return rc;
   INTEL_CHECK_ARG(g && row_flags && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "adam_lazy: gradient / row flags missing or misaligned");
   INTEL_CHECK_ARG(step > t.base && step - t.base <= t.cap, "adam_lazy: step %d outside the schedule window (%d, %d]", step, t.base, t.base + t.cap);
-  const double bc1 = 1.0 - pow((double)t.beta1, (double)step);
-  const double bc2 = 1.0 - pow((double)t.beta2, (double)step);
   a.g = g; a.flags = row_flags; a.step = step;
-  a.step_size = (float)((double)lr / bc1);
-  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  adam_scalars(lr, t.beta1, t.beta2, step, &a.step_size, &a.inv_bc2_sqrt, &a.omb1, &a.omb2);
   LAUNCH_W(0.0, (double)t.rows, adam_lazy_rows_kernel, dim3(lazy_grid(t.rows, t.d >> 2)), dim3(256), 0, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;

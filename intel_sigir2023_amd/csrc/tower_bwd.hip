@@ -1,0 +1,684 @@
+// The MIDDLE of one tied tower layer's backward (models/IntEL/IntEL.py:182-188 / 191-197, torch autograd of
+//
+//     h = MHA(x, x, x);  f = relu(W1 h + b1);  z = W2 f + b2;  y = LayerNorm(z + x)
+//
+// ) as ONE kernel per layer: from dZ (the gradient behind the LayerNorm) to dQKV (the gradient of the fused q/k/v projection), with the
+// weight gradients of both feed-forward linears accumulated in the workgroup.  A workgroup owns one session at a time (persistent over
+// sessions, lists of up to 64 candidates, widths 64 / 128); nothing between dZ and dQKV touches HBM:
+//
+//   P0  A (the forward's attention-output stash) and dZ tiles  global -> three bf16 planes each in LDS
+//   P1  R1 = relu(A W1^T + b1)                       recomputed on the bf16 pipe (six plane products = fp32 accuracy) -> planes
+//   P2  dW2 += dZ^T R1, db2 += colsum dZ             (operands k-contiguous along the ROWS: ds_read_b64_tr_b16 from the row-major planes)
+//       dF1 = (dZ W2) * [R1 > 0]                     -> planes, over R1
+//   P3  dW1 += dF1^T A, db1 += colsum dF1;  dA = dF1 W1 -> fp32 rows;  delta = rowsum(dA * A) per head
+//   P4  X tile -> planes;  [Q | K | V] = X Wqkv^T    recomputed -> fp32 rows
+//   P5  attention backward per head on exact fp32 MFMAs (bf16 mode: single bf16 MFMAs):
+//         pass 1, wave = (16 keys, half of the queries): S and dP once, P from the forward's log-sum-exp, dS -> LDS, partial dV = P^T dA and
+//                 dK = dS^T Q in registers; the two query halves are summed through the dead Q / dA columns
+//         pass 2, wave = (16 queries, half of the head dim): dQ = dS K
+//       dQ / dK / dV leave as rows of dQKV [B L, 3 D]
+//
+// What stays outside: the LayerNorm backward in front (fused into the pooling backward for the last layer: session.hip), and behind it the
+// q/k/v weight gradient dQKV^T X and dX = dQKV Wqkv + dZ (gemm.hip; at D = 128 the 192 KB of accumulators of dWqkv do not fit beside the
+// 128 KB of dW1 / dW2).  HBM per session and layer: A, dZ, X in, dQKV out = 24 L D bytes, against 100 L D of the kernel-per-op middle
+// (R1, dF1 twice, dA twice, QKV, A twice, dZ three times ...); the forward stashes A and the log-sum-exp only.
+// Padded rows (row >= L) are zero rows of A / dZ / X: they add nothing to any gradient; their keys are masked, their queries get P = 0.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+#include "planes.h"
+
+namespace {
+
+using namespace planes;
+
+struct TowerBwdArgs {
+  const float* X;        // [B*L, D] layer input
+  const float* A;        // [B*L, D] attention output (forward stash; bf16 array when a16)
+  const float* LSE;      // [B*heads*L] natural-log softmax normalisers of the forward
+  const float* dZ;       // [B*L, D] gradient behind the LayerNorm
+  int B, L;
+  int a16, dqkv16;       // bf16 mode: A is read / dQKV is written as a bf16 array of the same shape
+  const uint4* Wqkv;     // three-plane images (launch_pack_b3): [D -> 3D] forward weights,
+  const uint4* W1;       //   [D -> D] forward W1 (R1 = A W1^T),
+  const uint4* W2T;      //   W2 transposed (dR1 = dZ W2),
+  const uint4* W1T;      //   W1 transposed (dA = dF1 W1)
+  const float* b1;
+  float* dQKV;           // [B*L, 3D]
+  float* slabs;          // per workgroup: dW2 [D, D] | db2 [D] | dW1 [D, D] | db1 [D]
+  unsigned long long* dbg;   // INTEL_TOWER_DBG=1 (debug builds): per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
+};
+
+template <int D, int NP>
+struct BwdCfg {
+  static constexpr int NW = 8, NT = 512;
+  static constexpr int KB = D / 32, CTW = D / 16;
+  static constexpr int RS = NW / CTW, RT = 4 / RS;          // row splits of a linear over the waves, row tiles per wave
+  static constexpr int WPN = NW / CTW, KTL = CTW / WPN;      // weight gradient: waves per 16-row block of dW, 16-column tiles per wave
+  static constexpr int LDP = D + 8, PLANE = 64 * LDP;        // bf16 plane pitch / elements
+  static constexpr int LQ = D + 4;                            // fp32 row pitch
+  static constexpr int DSP = 68;                              // dS [64 queries][64 keys] pitch
+  static constexpr size_t P3 = (size_t)NP * PLANE * 2;
+  static constexpr size_t F = (size_t)64 * LQ * 4;
+  static constexpr size_t DS = (size_t)64 * DSP * 4;
+  static constexpr size_t R12 = 2 * P3 > 3 * F ? 2 * P3 : 3 * F;      // P(A) | P(R1 -> dF1), later fp32 Q | K | V
+  static constexpr size_t R3 = P3 > F + DS ? P3 : F + DS;             // P(dZ), later fp32 dA + dS
+  static constexpr size_t STAT = (size_t)(2 * 64 + 2 * 64 + 8 * 64) * 4;      // lse2 [2][64], delta [2][64], dpart [8][64]
+  static constexpr size_t SMEM = R12 + R3 + STAT;
+  static constexpr int NJ = 64 * (D / 4) / NT;                // float4 per thread per 64-row tile
+  static constexpr size_t SLAB = (size_t)2 * D * (D + 1);
+};
+
+typedef short tb_s16x4 __attribute__((ext_vector_type(4)));
+typedef short tb_s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// The operand of a product whose reduction runs over the ROWS of a row-major plane image: lane (p, j) gets column ct*16 + p at the eight rows
+// 32 kb + 8 j + {0, 2, 4, 6, 1, 3, 5, 7} from two transposing reads (ds_read_b64_tr_b16: lane 4q + pp of a 16-lane group names row q, columns
+// 4pp .. 4pp+3 of the group's 4 x 16 block and receives column p of its four rows).  Both operands of a product use the same row order.  The 32 lanes
+// one LDS cycle services touch rows {0, 2, .. 14} + half of a 32-row block: with a pitch of D + 8 bf16 (68 / 36 dwords) they cover all 64 banks once.
+template <int LDP>
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* plane, int kb, int ct, int p, int j) {
+  const int q = p >> 2, pp = p & 3;
+  const __bf16* a0 = plane + (32 * kb + 8 * j + 2 * q) * LDP + ct * 16 + 4 * pp;
+  const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0));
+  const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0 + LDP));
+  return __builtin_bit_cast(bf16x8, tb_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
+__device__ __forceinline__ float sum8(const bf16x8& v) {
+  return (((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3])) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
+}
+
+// the first k-block's weight fragments of a column tile's image (issued ahead of the phase that uses them: one L2 round trip off the phase)
+template <int NP>
+__device__ __forceinline__ void wload(const uint4* img, uint4 (&w)[NP]) {
+#pragma unroll
+  for (int q = 0; q < NP; ++q) w[q] = img[q * 64];
+}
+
+// acc[rt] (lane (p, j): row (rt0 + rt) * 16 + p, columns ct * 16 + 4j .. 4j+3) += planes[row][:] . W[column][:]; img = the image of column tile ct (+ lane),
+// w0 = its first k-block's fragments (wload); NEXT: the first fragments of the image `nimg` are fetched under the last k-block into wn
+template <int D, int NP, int RT, bool NEXT>
+__device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const uint4 (&w0)[NP], int rt0, int p, int j, f32x4 (&acc)[RT], const uint4* nimg,
+                                    uint4 (&wn)[NP]) {
+  constexpr int KB = D / 32, LDP = D + 8, PLANE = 64 * LDP;
+  const __bf16* frag = pl + (rt0 * 16 + p) * LDP + 8 * j;
+  uint4 bw[2][NP];
+#pragma unroll
+  for (int q = 0; q < NP; ++q) bw[0][q] = w0[q];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+    if (kb + 1 < KB) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) bw[(kb + 1) & 1][q] = img[((kb + 1) * 3 + q) * 64];
+    } else if (NEXT) {
+      wload<NP>(nimg, wn);
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
+      const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
+      const bf16x8 am = NP == 3 ? *reinterpret_cast<const bf16x8*>(fp + PLANE) : ah;
+      const bf16x8 al = NP == 3 ? *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE) : ah;
+      acc[rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw[kb & 1][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][NP == 3 ? 1 : 0]),
+                        __builtin_bit_cast(bf16x8, bw[kb & 1][NP == 3 ? 2 : 0]), ah, am, al, acc[rt]);
+    }
+  }
+}
+
+// acc[kt] (lane (p, j): dW[nt * 16 + 4j + r][(kt0 + kt) * 16 + p]) += sum over the 64 rows of Y[row][nt * 16 + .] X[row][(kt0 + kt) * 16 + .];
+// dbp += this lane's share of colsum(Y[:, nt * 16 + p]) (rows 8j .. 8j+7 of every 32-row block)
+template <int D, int NP, int KTL>
+__device__ __forceinline__ void wgrad(const __bf16* Y, const __bf16* X, int nt, int kt0, int p, int j, f32x4 (&acc)[KTL], float& dbp) {
+  constexpr int LDP = D + 8, PLANE = 64 * LDP;
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const bf16x8 yh = tr_frag<LDP>(Y, kb, nt, p, j);
+    const bf16x8 ym = NP == 3 ? tr_frag<LDP>(Y + PLANE, kb, nt, p, j) : yh;
+    const bf16x8 yl = NP == 3 ? tr_frag<LDP>(Y + 2 * PLANE, kb, nt, p, j) : yh;
+    dbp += NP == 3 ? (sum8(yl) + sum8(ym)) + sum8(yh) : sum8(yh);
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt) {
+      const bf16x8 xh = tr_frag<LDP>(X, kb, kt0 + kt, p, j);
+      const bf16x8 xm = NP == 3 ? tr_frag<LDP>(X + PLANE, kb, kt0 + kt, p, j) : xh;
+      const bf16x8 xl = NP == 3 ? tr_frag<LDP>(X + 2 * PLANE, kb, kt0 + kt, p, j) : xh;
+      acc[kt] = mma<NP>(yh, ym, yl, xh, xm, xl, acc[kt]);
+    }
+  }
+}
+
+// 16-deep group of an attention product: four exact fp32 MFMAs, or (bf16 mode) one bf16 MFMA of the rounded operands (same element order)
+template <int NP>
+__device__ __forceinline__ f32x4 amma(const f32x4& a, const f32x4& b, f32x4 c) {
+  if (NP == 1) return mma4_bf16(to_bf16x4(a), to_bf16x4(b), c);
+  return mma4(a, b, c);
+}
+
+// IO16 (bf16 mode only): A is read and dQKV written as bf16 arrays
+template <int D, int DK, int NP, bool IO16>
+__global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a) {
+  using C = BwdCfg<D, NP>;
+  constexpr int NT = C::NT, CTW = C::CTW, RT = C::RT, WPN = C::WPN, KTL = C::KTL, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, DSP = C::DSP, NJ = C::NJ;
+  constexpr int HEADS = D / DK, DQ = DK / 64, KBT = 4;
+  // the next session's A / dZ tiles are requested under the last attention pass where the registers allow it; the 128-wide fp32 form (64 registers of
+  // weight-gradient accumulators per wave) has none to spare there -- a spilled register's reload would queue behind the tile loads (vmcnt is in
+  // order) -- and requests them in front of the dQKV copy-out instead
+  constexpr bool EARLY = NP == 1 || D == 64;
+  constexpr bool WPF = EARLY;      // ... likewise the next phase's first weight fragments under the current phase's last k-block
+  static_assert(DK == 64 || DK == 128, "head dim 64 / 128");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* pA = reinterpret_cast<__bf16*>(smem_raw);                          // P(A); later P(X)
+  __bf16* pR = reinterpret_cast<__bf16*>(smem_raw + C::P3);                  // P(R1) -> P(dF1)
+  __bf16* pZ = reinterpret_cast<__bf16*>(smem_raw + C::R12);                 // P(dZ)
+  float* fQ = reinterpret_cast<float*>(smem_raw);                            // fp32 rows Q | K | V over P(X) / P(dF1)
+  float* fK = fQ + 64 * LQ;
+  float* fV = fK + 64 * LQ;
+  float* fdA = reinterpret_cast<float*>(smem_raw + C::R12);                  // fp32 rows dA over P(dZ)
+  float* dSb = fdA + 64 * LQ;
+  float* lse2 = reinterpret_cast<float*>(smem_raw + C::R12 + C::R3);
+  float* delta = lse2 + 2 * 64;
+  float* dpart = delta + 2 * 64;
+  const int tid = threadIdx.x, lane0 = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, NTL = (L + 15) >> 4;
+  const float scale = 1.0f / sqrtf((float)DK);
+  const float c2 = scale * 1.4426950408889634f;
+  // linears: wave = column tile ct, row tiles rt0 .. rt0 + RT - 1
+  const int ct = wave % CTW, rt0 = (wave / CTW) * RT;
+  // weight gradients: wave = rows nt * 16 .. of dW, column tiles kt0 .. kt0 + KTL - 1
+  const int wnt = wave / WPN, wkt0 = (wave % WPN) * KTL;
+  // tile staging: float4 #i of a 64-row tile = (row i / (D/4), 4 * (i % (D/4)))
+  // (recomputed from a laundered thread id wherever a tile is loaded / stored: hoisted, the 64-bit addresses of three arrays x NJ pieces would be spilled)
+  auto tile_rc = [&](int jj, int& row, int& colx) {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+    const int i = t + NT * jj;
+    row = i / (D / 4);
+    colx = (i - row * (D / 4)) * 4;
+  };
+  // A tile's loads are issued long before their values are needed, so nothing here may LOOK at a loaded value (a select on it would make the wave
+  // wait for the load where it is issued): rows are clamped to the list, the raw 16 (bf16 arrays: 8) bytes stay in registers, and padding rows are
+  // zeroed / bf16 values widened when the tile is stored to LDS
+  auto load_tile = [&](const float* src, int b, auto is16, f32x4 (&v)[NJ]) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      int tr, tc;
+      tile_rc(jj, tr, tc);
+      const int row = min(tr, L - 1);
+      const size_t off = ((size_t)b * L + row) * D + tc;
+      if constexpr (decltype(is16)::value) {
+        const f32x2 u = *reinterpret_cast<const f32x2*>(reinterpret_cast<const __bf16*>(src) + off);
+        v[jj][0] = u[0];
+        v[jj][1] = u[1];
+      } else {
+        v[jj] = *reinterpret_cast<const f32x4*>(src + off);
+      }
+    }
+  };
+  auto store_tile = [&](__bf16* dst, auto is16, const f32x4 (&v)[NJ]) {
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      int tr, tc;
+      tile_rc(jj, tr, tc);
+      f32x4 x = v[jj];
+      if constexpr (decltype(is16)::value) {
+        const bf16x4 h = __builtin_bit_cast(bf16x4, f32x2{v[jj][0], v[jj][1]});
+        x = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      }
+      if (tr >= L) x = f32x4{0.f, 0.f, 0.f, 0.f};
+      store4<NP, PLANE>(dst + tr * LDP + tc, x);
+    }
+  };
+
+  f32x4 accW2[KTL], accW1[KTL];
+#pragma unroll
+  for (int kt = 0; kt < KTL; ++kt) accW2[kt] = accW1[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db2p = 0.f, db1p = 0.f;
+  unsigned long long tstamp = 0;
+  const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
+  auto mark = [&](int ph) {
+    if (probe) {
+      const unsigned long long now = clock64();
+      if (ph >= 0) a.dbg[ph] += now - tstamp;
+      tstamp = now;
+    }
+  };
+  mark(-1);
+  // the session's A / dZ tiles and log-sum-exp travel during the previous session's last phase
+  f32x4 va[NJ], vz[NJ];
+  float lsev = 0.f;
+  auto load_session = [&](int b) {
+    load_tile(a.A, b, std::integral_constant<bool, IO16>{}, va);
+    load_tile(a.dZ, b, std::false_type{}, vz);
+    if (tid < 64 * HEADS) {
+      const int h = tid >> 6, q = min(tid & 63, L - 1);
+      lsev = a.LSE[((size_t)b * HEADS + h) * L + q];
+    }
+  };
+  if ((int)blockIdx.x < a.B) load_session(blockIdx.x);
+
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    // The LDS / image addresses of a session's phases are a few hundred distinct values of (lane, wave); hoisted out of the session loop they would
+    // all be spilled.  Laundering the lane id once per session keeps every address a couple of VALU instructions next to its use.
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int j = lane >> 4, p = lane & 15;
+    const int col = ct * 16 + 4 * j;                    // this lane's four columns in every linear's epilogue
+    const size_t wtile = ((size_t)ct * KBT * 3) * 64 + lane;
+    // ---- P0: A and dZ -> planes; the forward's log-sum-exp (base 2; +inf for padded queries: P = 0)
+    uint4 wf[NP];
+    wload<NP>(launder(a.W1) + wtile, wf);
+    {
+      if (tid < 64 * HEADS) lse2[tid] = (tid & 63) < L ? lsev * 1.4426950408889634f : INFINITY;
+      store_tile(pA, std::integral_constant<bool, IO16>{}, va);
+      store_tile(pZ, std::false_type{}, vz);
+    }
+    lds_barrier();
+    mark(0);
+    // ---- P1: R1 = relu(A W1^T + b1) -> planes
+    {
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + col);
+      uint4 wn[NP];
+      lin<D, NP, RT, WPF>(pA, a.W1 + wtile, wf, rt0, p, j, acc, launder(a.W2T) + wtile, wn);
+      if (WPF) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4 x = acc[rt] + bias;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
+        store4<NP, PLANE>(pR + ((rt0 + rt) * 16 + p) * LDP + col, x);
+      }
+    }
+    lds_barrier();
+    mark(1);
+    // ---- P2: dW2 += dZ^T R1, db2;  dF1 = (dZ W2) * [R1 > 0] -> planes over R1
+    {
+      float dbp = 0.f;
+      if (!WPF) wload<NP>(launder(a.W2T) + wtile, wf);
+      wgrad<D, NP, KTL>(pZ, pR, wnt, wkt0, p, j, accW2, dbp);
+      if (wkt0 == 0) db2p += dbp;
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 wn[NP];
+      lin<D, NP, RT, WPF>(pZ, a.W2T + wtile, wf, rt0, p, j, acc, launder(a.W1T) + wtile, wn);
+      if (WPF) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+      }
+      lds_barrier();      // every transposed read of R1 is done
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        __bf16* dst = pR + ((rt0 + rt) * 16 + p) * LDP + col;
+        const bf16x4 hv = *reinterpret_cast<const bf16x4*>(dst);      // high plane of R1: > 0 exactly where R1 > 0
+        f32x4 x = acc[rt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = (float)hv[r] > 0.f ? x[r] : 0.f;
+        store4<NP, PLANE>(dst, x);
+      }
+    }
+    lds_barrier();
+    mark(2);
+    // ---- P3: dW1 += dF1^T A, db1;  dA = dF1 W1 -> fp32 rows (over dZ);  delta partials;  the X tile of P4 travels meanwhile
+    {
+      f32x4 vx[NJ];
+      load_tile(a.X, b, std::false_type{}, vx);
+      float dbp = 0.f;
+      if (!WPF) wload<NP>(launder(a.W1T) + wtile, wf);
+      wgrad<D, NP, KTL>(pR, pA, wnt, wkt0, p, j, accW1, dbp);
+      if (wkt0 == 0) db1p += dbp;
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      uint4 wn[NP];
+      lin<D, NP, RT, WPF>(pR, a.W1T + wtile, wf, rt0, p, j, acc, launder(a.Wqkv) + wtile, wn);
+      if (WPF) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int row = (rt0 + rt) * 16 + p;
+        const __bf16* src = pA + row * LDP + col;
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(src);
+        f32x4 av = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        if (NP == 3) {
+          const bf16x4 m = *reinterpret_cast<const bf16x4*>(src + PLANE), l = *reinterpret_cast<const bf16x4*>(src + 2 * PLANE);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) av[r] = ((float)l[r] + (float)m[r]) + av[r];      // exact: A = hi + mid + lo
+        }
+        float part = (acc[rt][0] * av[0] + acc[rt][1] * av[1]) + (acc[rt][2] * av[2] + acc[rt][3] * av[3]);
+        part = gsum16(part);
+        if (j == 0) dpart[ct * 64 + row] = part;
+      }
+      lds_barrier();      // every read of P(A), P(dF1), P(dZ) is done
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fdA + ((rt0 + rt) * 16 + p) * LQ + col) = acc[rt];
+      store_tile(pA, std::false_type{}, vx);      // P(X)
+    }
+    lds_barrier();
+    mark(3);
+    // ---- P4: delta[h][q] = sum of its column tiles' partials (fixed order);  [Q | K | V] = X Wqkv^T -> fp32 rows
+    {
+      if (tid < 64 * HEADS) {
+        const int h = tid >> 6, q = tid & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < DK / 16; ++c) s += dpart[(h * (DK / 16) + c) * 64 + q];
+        delta[h * 64 + q] = s;
+      }
+      if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
+      f32x4 acc[3][RT];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4* img = a.Wqkv + ((size_t)(c * CTW + ct) * KBT * 3) * 64 + lane;
+        uint4 wn[NP];
+        if (c < 2) lin<D, NP, RT, true>(pA, img, wf, rt0, p, j, acc[c], img + ((size_t)CTW * KBT * 3) * 64, wn);
+        else lin<D, NP, RT, false>(pA, img, wf, rt0, p, j, acc[c], img, wn);
+        if (c < 2) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+        }
+      }
+      lds_barrier();      // every read of P(X) is done
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fQ + c * 64 * LQ + ((rt0 + rt) * 16 + p) * LQ + col) = acc[c][rt];
+    }
+    lds_barrier();
+    mark(4);
+    // ---- P5: attention backward, head by head.  dQ is left in the dead V rows, dK in the dead Q rows, dV in the dead dA rows (fp32), and the
+    // three matrices leave together as whole rows of dQKV at the end
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      const int hc = h * DK;
+      const int kt = wave & 3, qh = wave >> 2;
+      f32x4 dk[DQ * 4], dv[DQ * 4];
+#pragma unroll
+      for (int i = 0; i < DQ * 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < NTL) {      // (wave-uniform; a key tile of padding only has nothing to add)
+        f32x4 st[2], dp[2];
+        st[0] = st[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* Kp = fK + (kt * 16 + p) * LQ + hc + 4 * j;
+        const float* Vp = fV + (kt * 16 + p) * LQ + hc + 4 * j;
+#pragma unroll
+        for (int g = 0; g < DK / 16; ++g) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(Kp + 16 * g);
+          const f32x4 vf = *reinterpret_cast<const f32x4*>(Vp + 16 * g);
+#pragma unroll
+          for (int qi = 0; qi < 2; ++qi) {
+            const int qt = 2 * qh + qi;
+            if (qt < NTL) {
+              const f32x4 qf = *reinterpret_cast<const f32x4*>(fQ + (qt * 16 + p) * LQ + hc + 4 * j + 16 * g);
+              const f32x4 df = *reinterpret_cast<const f32x4*>(fdA + (qt * 16 + p) * LQ + hc + 4 * j + 16 * g);
+              st[qi] = amma<NP>(qf, kf, st[qi]);      // S[query qt*16 + 4j + r][key kt*16 + p]
+              dp[qi] = amma<NP>(df, vf, dp[qi]);      // dP, same layout
+            }
+          }
+        }
+        const bool keyok = kt * 16 + p < L;
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          const int q0 = (2 * qh + qi) * 16 + 4 * j;
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + h * 64 + q0);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + h * 64 + q0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][r], c2, -l4[r])) : 0.f;
+            const float ds = pv * (dp[qi][r] - d4[r]) * scale;
+            st[qi][r] = pv;
+            dp[qi][r] = ds;
+            dSb[(q0 + r) * DSP + kt * 16 + p] = ds;
+          }
+        }
+        // dV[key][dim] += P^T dA, dK[key][dim] += dS^T Q: the row operand read as one b128 along the head dim feeds four MFMAs whose
+        // output row i means dim 4 i + t (tower.hip, phase 2)
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          const int qt = 2 * qh + qi;
+          if (qt >= NTL) continue;
+#pragma unroll
+          for (int dq = 0; dq < DQ; ++dq) {
+            {
+              f32x4 vv[4];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const f32x4*>(fdA + (qt * 16 + 4 * j + s) * LQ + hc + dq * 64 + 4 * p);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) dv[dq * 4 + t] = amma<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, st[qi], dv[dq * 4 + t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (register budget: one operand block at a time)
+            {
+              f32x4 ww[4];
+#pragma unroll
+              for (int s = 0; s < 4; ++s) ww[s] = *reinterpret_cast<const f32x4*>(fQ + (qt * 16 + 4 * j + s) * LQ + hc + dq * 64 + 4 * p);
+#pragma unroll
+              for (int t = 0; t < 4; ++t) dk[dq * 4 + t] = amma<NP>(f32x4{ww[0][t], ww[1][t], ww[2][t], ww[3][t]}, dp[qi], dk[dq * 4 + t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      lds_barrier();      // dS complete; this head's reads of Q / dA / V done
+      mark(5);
+      if (qh == 1 && kt < NTL) {      // park the second query half's partials in the head's dead Q / dA columns (rows = keys)
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int off = (kt * 16 + p) * LQ + hc + dq * 64 + 16 * j + 4 * r;
+            *reinterpret_cast<f32x4*>(fQ + off) = f32x4{dk[dq * 4 + 0][r], dk[dq * 4 + 1][r], dk[dq * 4 + 2][r], dk[dq * 4 + 3][r]};
+            *reinterpret_cast<f32x4*>(fdA + off) = f32x4{dv[dq * 4 + 0][r], dv[dq * 4 + 1][r], dv[dq * 4 + 2][r], dv[dq * 4 + 3][r]};
+          }
+      }
+      lds_barrier();      // the parked partials are visible
+      mark(6);
+      if (qh == 0 && kt < NTL) {      // dK / dV of this key tile = both halves, left where the partials were parked
+#pragma unroll
+        for (int dq = 0; dq < DQ; ++dq)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int off = (kt * 16 + p) * LQ + hc + dq * 64 + 16 * j + 4 * r;
+            const f32x4 k4 = f32x4{dk[dq * 4 + 0][r], dk[dq * 4 + 1][r], dk[dq * 4 + 2][r], dk[dq * 4 + 3][r]} + *reinterpret_cast<const f32x4*>(fQ + off);
+            const f32x4 v4 = f32x4{dv[dq * 4 + 0][r], dv[dq * 4 + 1][r], dv[dq * 4 + 2][r], dv[dq * 4 + 3][r]} + *reinterpret_cast<const f32x4*>(fdA + off);
+            *reinterpret_cast<f32x4*>(fQ + off) = k4;
+            *reinterpret_cast<f32x4*>(fdA + off) = v4;
+          }
+      }
+      if (EARLY && h == HEADS - 1) load_session(min(b + (int)gridDim.x, a.B - 1));      // the next session's tiles travel under the last pass (the last session re-reads itself: no stale registers to keep)
+      {   // pass 2: dQ = dS K -> the dead V rows; wave = (query tile, half of the head dim: DK = 128 a 64-dim block, DK = 64 the dims 4 i + {2 sub, 2 sub + 1})
+        const int qt = wave & 3, sub = wave >> 2;
+        if (qt < NTL) {
+          const int q = qt * 16 + p;
+          if constexpr (DK == 128) {
+            f32x4 o[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+              if (k2 < NTL) {
+                const f32x4 ds4 = *reinterpret_cast<const f32x4*>(dSb + q * DSP + k2 * 16 + 4 * j);
+                f32x4 vv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const f32x4*>(fK + (k2 * 16 + 4 * j + s) * LQ + hc + sub * 64 + 4 * p);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = amma<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, ds4, o[t]);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<f32x4*>(fV + q * LQ + hc + sub * 64 + 16 * j + 4 * r) = f32x4{o[0][r], o[1][r], o[2][r], o[3][r]};
+          } else {
+            f32x4 o[2];
+            o[0] = o[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+              if (k2 < NTL) {
+                const f32x4 ds4 = *reinterpret_cast<const f32x4*>(dSb + q * DSP + k2 * 16 + 4 * j);
+                f32x2 vv[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) vv[s] = *reinterpret_cast<const f32x2*>(fK + (k2 * 16 + 4 * j + s) * LQ + hc + 4 * p + 2 * sub);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) o[t] = amma<NP>(f32x4{vv[0][t], vv[1][t], vv[2][t], vv[3][t]}, ds4, o[t]);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(fV + q * LQ + hc + 16 * j + 4 * r + 2 * sub) = f32x2{o[0][r], o[1][r]};
+          }
+        }
+      }
+      lds_barrier();      // pass 2's reads of dS / K done (the next head's pass 1 rewrites dS); dQ / dK / dV of this head complete
+      mark(7);
+    }
+    if (!EARLY) load_session(min(b + (int)gridDim.x, a.B - 1));
+    // ---- dQKV rows: [dQ | dK | dV] from the V / Q / dA regions, 16 bytes per lane along the row
+    for (int i = tid; i < L * (D / 4); i += NT) {
+      const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(fV + row * LQ + c4);
+      const f32x4 k4 = *reinterpret_cast<const f32x4*>(fQ + row * LQ + c4);
+      const f32x4 v4 = *reinterpret_cast<const f32x4*>(fdA + row * LQ + c4);
+      const size_t g = ((size_t)b * L + row) * (3 * D) + c4;
+      if constexpr (IO16) {
+        __bf16* o16 = reinterpret_cast<__bf16*>(a.dQKV);
+        *reinterpret_cast<bf16x4*>(o16 + g) = bf16x4{(__bf16)q4[0], (__bf16)q4[1], (__bf16)q4[2], (__bf16)q4[3]};
+        *reinterpret_cast<bf16x4*>(o16 + g + D) = bf16x4{(__bf16)k4[0], (__bf16)k4[1], (__bf16)k4[2], (__bf16)k4[3]};
+        *reinterpret_cast<bf16x4*>(o16 + g + 2 * D) = bf16x4{(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
+      } else {
+        *reinterpret_cast<f32x4*>(a.dQKV + g) = q4;
+        *reinterpret_cast<f32x4*>(a.dQKV + g + D) = k4;
+        *reinterpret_cast<f32x4*>(a.dQKV + g + 2 * D) = v4;
+      }
+    }
+    lds_barrier();      // the next session's tiles go over the regions the copy still read
+  }
+  const int j = lane0 >> 4, p = lane0 & 15;
+  // ---- the workgroup's weight-gradient slab: dW2 [D, D] | db2 [D] | dW1 [D, D] | db1 [D]
+  float* slab = a.slabs + (size_t)blockIdx.x * C::SLAB;
+#pragma unroll
+  for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = (size_t)(wnt * 16 + 4 * j + r) * D + (wkt0 + kt) * 16 + p;
+      slab[o] = accW2[kt][r];
+      slab[(size_t)D * (D + 1) + o] = accW1[kt][r];
+    }
+  db2p = gsum16(db2p);
+  db1p = gsum16(db1p);
+  if (wkt0 == 0 && j == 0) {
+    slab[(size_t)D * D + wnt * 16 + p] = db2p;
+    slab[(size_t)D * (D + 1) + (size_t)D * D + wnt * 16 + p] = db1p;
+  }
+}
+
+// INTEL_FUSE_TOWER_BWD: 0 = never, 1 = wherever the shape is supported, unset = where it is the faster step (tower_bwd_fused_wanted)
+int bwd_mode() {
+  static const int m = [] { const char* e = getenv("INTEL_FUSE_TOWER_BWD"); return !e || !e[0] || e[0] == 'a' ? 2 : (e[0] == '0' ? 0 : 1); }();
+  return m;
+}
+
+// one workgroup per CU (the LDS tile of a session takes more than half a CU's); INTEL_TOWER_BWD_CUS=n: at most n of them (A/B: a tower that is
+// not on the step's critical chain may leave CUs to the branches that are)
+int bwd_grid(int B) {
+  static const int cap = [] { const char* e = getenv("INTEL_TOWER_BWD_CUS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 30; }();
+  int g = num_cus();
+  if (g > cap) g = cap;
+  return B < g ? B : g;
+}
+
+template <int D, int DK, int NP, bool IO16>
+int launch_one(const TowerBwdArgs& a, hipStream_t st) {
+  using C = BwdCfg<D, NP>;
+  static_assert(C::SMEM <= 160 * 1024, "LDS budget");
+  allow_lds((tower_bwd_fused_kernel<D, DK, NP, IO16>), C::SMEM);
+  const int grid = bwd_grid(a.B);
+  // algorithmic work per session: six D x D linears (R1, dR1, dA, q / k / v) + two weight gradients, five attention products
+  const double flops = (double)a.B * (16.0 * a.L * D * D + 10.0 * (double)a.L * a.L * D);
+  const double bytes = (double)a.B * a.L * D * ((a.a16 ? 2.0 : 4.0) + 8.0 + (a.dqkv16 ? 6.0 : 12.0));
+  static const int dbg_on = INTEL_DEBUG_ENV("INTEL_TOWER_DBG", 0);      // phase clocks: debug builds only (common.h)
+  TowerBwdArgs aa = a;
+  static unsigned long long* dbg_buf = nullptr;
+  if (dbg_on) {
+    if (!dbg_buf) (void)hipMalloc(&dbg_buf, 8 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dbg_buf, 0, 8 * sizeof(unsigned long long), st);
+    aa.dbg = dbg_buf;
+  }
+  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_bwd_fused_kernel<D, DK, NP, IO16>), dim3(grid), dim3(C::NT), C::SMEM, st, aa);
+  INTEL_CHECK_LAUNCH();
+  if (dbg_on) {          // tools/tower_probe.py
+    unsigned long long h[8];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, dbg_buf, sizeof(h), hipMemcpyDeviceToHost);
+    const int iters = (a.B + grid - 1) / grid;
+    fprintf(stderr, "tower_bwd D=%d dk=%d np=%d grid=%d iters=%d  cycles/session: load %llu  r1 %llu  dw2+df1 %llu  dw1+da %llu  qkv %llu  attn-kv %llu  pair %llu  attn-q %llu\n",
+            D, DK, NP, grid, iters, h[0] / iters, h[1] / iters, h[2] / iters, h[3] / iters, h[4] / iters, h[5] / iters, h[6] / iters, h[7] / iters);
+  }
+  return 0;
+}
+
+template <int D, int DK>
+int launch_np(const TowerBwdArgs& a, hipStream_t st) {
+  if (gemm_planes() == 1) return a.a16 ? launch_one<D, DK, 1, true>(a, st) : launch_one<D, DK, 1, false>(a, st);
+  return launch_one<D, DK, 3, false>(a, st);
+}
+
+}  // namespace
+
+bool tower_bwd_fused_supported(int L, int d, int heads) {
+  if (bwd_mode() == 0 || L < 1 || L > 64 || heads < 1 || d % heads != 0) return false;
+  const int dk = d / heads;
+  return (d == 128 && (dk == 128 || dk == 64)) || (d == 64 && dk == 64);
+}
+
+// Policy (same-box A/B at the headline): bf16 mode -- both widths (one plane: no spill, the kernel is 35 / 20 k cycles per
+// session against ~52 / 26 k of the kernels it replaces); fp32 -- the 64-wide tower (36 k against 38 k, and 0.6 GB less HBM traffic); the 128-wide fp32
+// form carries 64 registers of weight-gradient accumulators per wave next to six-plane operands, spills, and loses (103 - 115 k cycles against 76 k).
+bool tower_bwd_fused_wanted(int d) {
+  const int m = bwd_mode();
+  if (m != 2) return m == 1;
+  return gemm_planes() == 1 || d == 64;
+}
+
+size_t tower_bwd_slab_floats(int B, int d) { return (size_t)bwd_grid(B) * 2 * d * (d + 1); }
+
+int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, const float* dZ, int B, int L, int d, int heads, const void* Wqkv_b3,
+                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const float* b1, float* dQKV, float* dW2, float* db2, float* dW1,
+                           float* db1, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16, int dqkv16) {
+  if (B <= 0) return 0;
+  INTEL_CHECK_ARG(tower_bwd_fused_supported(L, d, heads), "tower_bwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
+  INTEL_CHECK_ARG(q != nullptr, "tower_bwd_fused: needs the reduce queue");
+  INTEL_CHECK_ARG(!(a16 || dqkv16) || gemm_planes() == 1, "tower_bwd_fused: bf16 operands need the bf16 mode");
+  INTEL_CHECK_ARG((a16 != 0) == (dqkv16 != 0), "tower_bwd_fused: A and dQKV are bf16 arrays together or not at all");
+  const size_t slab = (size_t)2 * d * (d + 1);
+  const int grid = bwd_grid(B);
+  float* slabs = redq_alloc(q, (size_t)grid * slab);
+  INTEL_CHECK_ARG(slabs != nullptr, "tower_bwd_fused: reduce arena exhausted");
+  TowerBwdArgs a;
+  a.X = X; a.A = A; a.LSE = LSE; a.dZ = dZ; a.B = B; a.L = L; a.a16 = a16 ? 1 : 0; a.dqkv16 = dqkv16 ? 1 : 0;
+  a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3);
+  a.W2T = reinterpret_cast<const uint4*>(W2T_b3); a.W1T = reinterpret_cast<const uint4*>(W1T_b3);
+  a.b1 = b1; a.dQKV = dQKV; a.slabs = slabs; a.dbg = nullptr;
+  const int dk = d / heads;
+  int rc;
+  if (d == 128 && dk == 128) rc = launch_np<128, 128>(a, st);
+  else if (d == 128) rc = launch_np<128, 64>(a, st);
+  else rc = launch_np<64, 64>(a, st);
+  if (rc) return rc;
+  const size_t dd = (size_t)d * d;
+  if (dW2) redq_push(q, slabs, slab, grid, d, d, dW2, d, accumulate[0]);
+  if (db2) redq_push(q, slabs + dd, slab, grid, 1, d, db2, d, accumulate[1]);
+  if (dW1) redq_push(q, slabs + dd + d, slab, grid, d, d, dW1, d, accumulate[2]);
+  if (db1) redq_push(q, slabs + 2 * dd + d, slab, grid, 1, d, db1, d, accumulate[3]);
+  return 0;
+}

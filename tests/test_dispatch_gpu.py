@@ -1,0 +1,109 @@
+"""Which kernel family serves which shape under the DEFAULT policy, asserted from the library's own launch records
+(tests/helpers.py: KernelTrace over csrc/prof.cpp).  Dispatch is decided by shape / batch predicates in csrc/model.cpp
+(tower_fused_supported / tower_fused_wanted, tower_bwd_fused_*, enc_fused_supported, attn_p3_supported, head_fused_ok, ...):
+every case below checks parity against the oracle's autograd AND that the kernels the case exists for really produced the
+numbers -- flipping a predicate turns these red instead of silently re-testing the kernel-per-op pipeline."""
+import importlib.util
+import os
+import random
+
+os.environ.setdefault('INTEL_GRU_ORDER_MIN_B', '1')
+
+import pytest
+import torch
+
+from tests.helpers import KernelTrace
+
+pytestmark = pytest.mark.gpu
+
+_spec = importlib.util.spec_from_file_location('fuzz_parity', os.path.join(os.path.dirname(__file__), '..', 'tools', 'fuzz_parity.py'))
+fuzz = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(fuzz)
+
+# the benchmarked widths: item tower 64 + 64 = 128, score tower 64, encoders 64 + 64 = 128
+W64 = dict(i_emb_size=64, im_emb_size=64, s_emb_size=64, u_emb_size=64, intent_emb_size=64, context_emb_size=64, cross_attn_qsize=64)
+
+
+def _run(force, idx):
+    tr = {}
+    worst, bad, desc = fuzz.one_case(random.Random(idx), idx, torch.device('cuda:0'), big=False, force=force, trace=tr)
+    assert worst <= 1.0, (worst, bad, desc)
+    kt = KernelTrace.__new__(KernelTrace)
+    kt.names, kt.count = tr['names'], tr['count']
+    return kt, desc
+
+
+@pytest.mark.parametrize('L,B', [(50, 17), (64, 5), (20, 33)])
+def test_headline_widths_short_lists(L, B):
+    """Tmall-shape widths, lists <= 64, histories <= 32, fp32: the 64-wide score tower as one-kernel layers in both directions (tower.hip forward, the
+    fused middle of the backward: tower_bwd.hip), the 128-wide item tower on the kernel-per-op pipeline (policy: tower_fused_wanted,
+    tower_bwd_fused_wanted), fused BERT4Rec blocks, forward chain launches, the pooling with the folded LayerNorm tail, weight gradients / row
+    GEMMs on the bf16 pipe."""
+    kt, desc = _run(dict(W64, L=L, B=B, I=30, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=20, model_num=3, loss='IntBPRloss',
+                         cross_attention=1, cal_diversity=0), 9100 + L)
+    kt.check(['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'enc_block_fwd_kernel', 'enc_last_fwd_kernel',
+              'enc_block_bwd_kernel', 'enc_last_bwd_kernel', 'chain_kernel', 'xatt_pool_fwd_reg_kernel', 'xatt_pool_ln_bwd_reg_kernel', 'wgrad_b3_kernel',
+              'gemm_rows_b3k_kernel'],
+             ['attn_fwd_kernel', 'tw32_fwd_kernel', 'enc32_fwd_kernel', 'gru_seq_fwd_kernel'], desc)
+    assert kt.count['tower_fwd_fused_kernel'] == 1 and kt.count['tower_bwd_fused_kernel'] == 1 and kt.count['attn_seq_bwd_fused_kernel'] == 1, kt.count
+
+
+def test_headline_widths_two_layers_two_heads():
+    kt, desc = _run(dict(W64, L=50, B=9, I=30, num_heads=2, num_layers=2, encoder='BERT4Rec', history_max=20, model_num=3, loss='IntListloss',
+                         cross_attention=1, cal_diversity=1), 9200)
+    # fp32: the 128-wide item tower stays on the kernel-per-op pipeline by policy; the 64-wide score tower has heads of 32 (one-kernel forward, but the
+    # backward middle needs head dims of 64 / 128): no tower_bwd_fused_kernel at all, two whole-sequence attention backward launches per tower
+    kt.check(['tower_fwd_fused_kernel', 'attn_seq_bwd_fused_kernel'], ['tw32_bwd_kernel', 'tower_bwd_fused_kernel'], desc)
+
+
+def test_long_lists_take_the_plane_attention_kernels():
+    """LifeData shape (lists of 100): general attention on the bf16 pipe at fp32 accuracy (attn_p3.hip), no one-kernel tower layer."""
+    kt, desc = _run(dict(W64, L=100, B=5, I=10, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=20, model_num=5, loss='IntBPRloss',
+                         cross_attention=1, cal_diversity=0), 9300)
+    kt.check(['attn_fwd_p3_kernel', 'attn_bwd_dkv_p3_kernel', 'attn_bwd_dq_ds_p3_kernel', 'enc_block_fwd_kernel'],
+             ['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'attn_seq_fwd_kernel', 'attn_fwd_kernel'], desc)
+
+
+def test_long_histories_leave_the_fused_encoder():
+    kt, desc = _run(dict(W64, L=20, B=5, I=10, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=70, model_num=3, loss='IntBPRloss',
+                         cross_attention=1, cal_diversity=0), 9400)
+    kt.check(['attn_fwd_p3_kernel', 'attn_lastq_fwd_kernel'], ['enc_block_fwd_kernel', 'enc_block_bwd_kernel'], desc)
+
+
+def test_gru4rec_recurrence_kernels():
+    kt, desc = _run(dict(W64, L=50, B=19, I=30, num_heads=1, num_layers=1, encoder='GRU4Rec', history_max=20, model_num=3, loss='IntBPRloss',
+                         cross_attention=1, cal_diversity=0), 9500)
+    kt.check(['gru_seq_fwd_kernel', 'gru_seq_bwd_kernel', 'tower_bwd_fused_kernel'], ['gru_gate_fwd_kernel', 'enc_block_fwd_kernel'], desc)
+    assert kt.count['tower_bwd_fused_kernel'] == 1, kt.count
+
+
+def test_gru_output_projection_with_one_chain_capable_width():
+    """context_emb_size 8 makes encoder 0 24 wide (not a multiple of 16) and encoder 1 32 wide.  The head's chains take over
+    the GRU output projections only as a pair: with one width unsuitable BOTH encoders must compute their own projection (csrc/model.cpp:
+    forward_impl) -- outputs, loss and every gradient against the oracle."""
+    kt, desc = _run(dict(i_emb_size=16, im_emb_size=16, s_emb_size=32, u_emb_size=32, intent_emb_size=16, context_emb_size=8, cross_attn_qsize=32,
+                         L=20, B=7, I=30, num_heads=1, num_layers=1, encoder='GRU4Rec', history_max=20, model_num=3, loss='IntBPRloss',
+                         cross_attention=1, cal_diversity=1), 9600)
+    kt.check(['gru_seq_fwd_kernel', 'chain_kernel'], [], desc)
+
+
+def test_bf16_mode_kernels():
+    """--dtype bf16: the one-kernel tower layers in both directions at one plane, the transposing-read weight gradient."""
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.model import IntEL
+    dev = torch.device('cuda:0')
+    torch.manual_seed(1)
+    over = dict(items=5000, users=500)
+    args = synth.make_args('tmall', dev, dtype='bf16')
+    corpus, _ = synth.make_corpus('tmall', **over)
+    model = IntEL(args, corpus).to(dev).train()
+    batch = synth.make_batch('tmall', 64, dev, seed=2, ragged=True, corpus_over=over)
+    with KernelTrace() as kt:
+        out = model(batch)
+        loss, _, _ = LS.IntListloss(args)(out, batch)
+        loss.backward()
+    assert bool(torch.isfinite(loss))
+    kt.check(['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'wgrad_tr_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel'],
+             ['attn_seq_bwd_fused_kernel', 'attn_seq_fwd_kernel'], 'bf16 mode, Tmall shape')
+    assert kt.count['tower_fwd_fused_kernel'] == 2 and kt.count['tower_bwd_fused_kernel'] == 2, kt.count

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 MODEL = ['tests/test_model_gpu.py', '-k', 'forward or grads']
 ENGINE = ['tests/test_engine_gpu.py', '-k', 'synthetic_workloads or adam']
+FUZZ = ['tests/test_model_gpu.py', 'tests/test_fuzz_gpu.py', '-k', 'forward or grads or random_configs']      # + random shapes (1 - 2 heads, 1 - 2 tied layers)
 BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode's forward / gradient parity against its emulating oracle
 
 CASES = [
@@ -49,7 +50,10 @@ CASES = [
     ({'INTEL_HEAD_FUSED': '0'}, ENGINE, [], ['chain_kernel']),
     ({'INTEL_PACK_SIDE': '0'}, MODEL, [], []),                                 # weight packing on the caller's stream even where no branch reads a packed image
     ({'INTEL_ENC32': '0'}, MODEL, [], ['enc32_fwd_kernel', 'enc32_bwd_kernel']),                                     # 32-wide BERT4Rec encoders on the kernel-per-op pipeline instead of the one-kernel encoder (tower32.hip: enc32_*)
-    ({'INTEL_WGRAD_TR': '0'}, BF16, [], ['wgrad_tr_kernel']),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
+    ({'INTEL_WGRAD_TR': '0'}, BF16, [], ['wgrad_tr_kernel']),
+    ({'INTEL_FUSE_TOWER_BWD': '1'}, FUZZ, ['tower_bwd_fused_kernel'], []),       # the one-kernel backward middle also for the 128-wide fp32 tower (default: 64-wide only)
+    ({'INTEL_FUSE_TOWER_BWD': '0'}, MODEL, [], ['tower_bwd_fused_kernel']),      # kernel-per-op middle of the tower backward everywhere
+    ({'INTEL_FUSE_TOWER_BWD': '0'}, BF16, [], ['tower_bwd_fused_kernel']),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
 
 

@@ -12,7 +12,7 @@ for combo in itertools.product(*[v for _, v in axes]):
     env = dict(os.environ)
     for (k, _), v in zip(axes, combo):
         env[k] = v
-    r = subprocess.run([sys.executable, 'bench.py', '--no_cpu_baseline', '--no_feed'] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    r = subprocess.run([sys.executable, 'bench.py', '--no_cpu_baseline', '--no_feed', '--no_workloads', '--spread_blocks', '0', '--no_bf16_line'] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
     try:
         d = json.loads(r.stdout.strip().splitlines()[-1])
         top = list(d.get('kernel_ms_per_step', {}).items())[:6]
