@@ -2710,7 +2710,7 @@ static int redq_flush_impl(ReduceQueue* q, int tag, hipStream_t st) {
       if (first < 0) first = b;
       if (eff[b] > rmax) rmax = eff[b];
     }
-    if (first >= 0 && all_same) {
+    if (first >= 0 && all_same && f.accumulate) {      // (a later job that OVERWRITES its destination is not an addend of the chain: it keeps a round of its own)
       const int h = head[first] >= 0 ? head[first] : first;
       head[a] = h;
       eff[a] = eff[h];

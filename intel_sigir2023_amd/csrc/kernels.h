@@ -144,13 +144,17 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
 // L <= 64, d in {64, 128}, head dim in {64, 128}; needs the forward's A (attention output) and LSE stashes and the layer input X; the q/k/v weight
 // gradient and dX = dQKV Wqkv + dZ stay on the GEMM kernels.  INTEL_FUSE_TOWER_BWD=0 turns the path off, =1 forces it wherever supported.
 bool tower_bwd_fused_supported(int L, int d, int heads);
-bool tower_bwd_fused_wanted(int d);      // the policy (INTEL_FUSE_TOWER_BWD unset): bf16 mode both widths, fp32 the 64-wide tower (tower_bwd.hip)
+bool tower_bwd_fused_wanted(int d);      // the policy (INTEL_FUSE_TOWER_BWD unset): bf16 mode only (tower_bwd.hip)
 size_t tower_bwd_slab_floats(int B, int d);      // arena floats one launch takes from the reduce queue
-// W*_b3: three-plane images (launch_pack_b3) of the packed forward [d -> 3d] / [d -> d] weights and of the TRANSPOSED feed-forward weights;
-// accumulate[4]: dW2, db2, dW1, db1 (valid after the queue's flush; NULL = not wanted); a16 / dqkv16 (bf16 mode): A read / dQKV written as bf16 arrays
+// What one launch covers beyond dQKV (by width and arithmetic mode): bit 0 = dX = dQKV Wqkv + dZ too, bit 1 = the q/k/v weight gradients too (dQKV is
+// then not written at all).  64-wide: 3; 128-wide: 1 in bf16 mode, 0 in fp32 (six-plane operands + 64 accumulator registers leave no room).
+int tower_bwd_fused_scope(int d);
+// W*_b3: three-plane images (launch_pack_b3) of the packed forward [d -> 3d] / [d -> d] weights, of the TRANSPOSED feed-forward weights and (scope
+// bit 0) of the stacked transposed q/k/v weights [3d -> d]; grads / accumulate [7]: dW2, db2, dW1, db1, dWq, dWk, dWv (valid after the queue's flush;
+// NULL = not wanted; the last three only with scope bit 1); a16 / dqkv16 (bf16 mode): A read / dQKV written as bf16 arrays
 int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, const float* dZ, int B, int L, int d, int heads, const void* Wqkv_b3,
-                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const float* b1, float* dQKV, float* dW2, float* db2, float* dW1,
-                           float* db1, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16 = 0, int dqkv16 = 0);
+                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const void* WqkvT_b3, const float* b1, float* dQKV, float* dX,
+                           float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16 = 0, int dqkv16 = 0);
 
 // ---- the whole tied tower at the reference's own 32-wide shapes, one kernel per direction (tower32.hip) ---------------------------
 // d = 32, 1-2 heads, L <= 128, any number of tied layers; raw (unpacked) reference weights W [32, 32], vectors [32].  No activation stash:

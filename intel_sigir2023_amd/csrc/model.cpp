@@ -804,7 +804,7 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     }
     Tower32Dropout dr = tower32_dropout(r, &w == &r.y.tw[0] ? 0 : 1);
     if (!r.ctx->fwd_dropout) dr.p = 0.f;
-    static const int tw32_share = [] { const char* e = getenv("INTEL_TW32_SHARE"); return e ? atoi(e) : 0; }();      // 1 .. 8: eighths of the CUs for the small-batch grid (A/B)
+    static const int tw32_share = INTEL_DEBUG_ENV("INTEL_TW32_SHARE", 0);      // 1 .. 8: eighths of the CUs for the small-batch grid (A/B probe: debug builds only, common.h)
     if (!r.ok(launch_tower32_bwd(w.X0, dX, B, L, D.heads, D.layers, r.P(pb + T_WQ), r.P(pb + T_WK), r.P(pb + T_WV), r.P(pb + T_W1), r.P(pb + T_B1),
                                  r.P(pb + T_W2), r.P(pb + T_B2), r.P(pb + T_LNG), r.P(pb + T_LNB), dXalt, g, acc, r.ctx->rq, r.st, &dr,
                                  tw32_share > 0 ? tw32_share : ((D.encoder == INTEL_ENC_BERT4REC && B <= 2 * num_cus()) ? 5 : 8))))      // (tower32.hip: tower32_grid)
@@ -836,17 +836,35 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     // matrix products (dF1, dA, dQKV) are bf16 arrays; dZ stays fp32 (it is also the residual gradient)
     const int h16 = r.ctx->tw_qkv16[&w == &r.y.tw[0] ? 0 : 1] ? 1 : 0;
     if (r.ctx->tw_bwdf[&w == &r.y.tw[0] ? 0 : 1]) {
-      // dZ -> dQKV in one kernel, dW2 / db2 / dW1 / db1 accumulated in its workgroups (tower_bwd.hip); q/k/v weight gradient and dX below as before
-      static const int slots[4] = {T_W2, T_B2, T_W1, T_B1};
-      float* g[4];
-      int acc[4];
-      for (int k = 0; k < 4; ++k) {
-        g[k] = r.G(pb + slots[k]);
-        acc[k] = r.acc(pb + slots[k]);
+      // dZ -> dQKV in one kernel, dW2 / db2 / dW1 / db1 accumulated in its workgroups (tower_bwd.hip).  By width / mode the same launch also
+      // produces dX = dQKV Wqkv + dZ (scope bit 0) and the q/k/v weight gradients (bit 1); what it leaves is done below as before
+      const int scope = tower_bwd_fused_scope(d);
+      static const int slots[7] = {T_W2, T_B2, T_W1, T_B1, T_WQ, T_WK, T_WV};
+      float* g[7];
+      int acc[7];
+      for (int k = 0; k < 7; ++k) {
+        const bool mine = k < 4 || (scope & 2);
+        g[k] = mine ? r.G(pb + slots[k]) : nullptr;
+        acc[k] = mine ? r.acc(pb + slots[k]) : 0;
       }
-      if (!r.ok(launch_tower_bwd_fused(Xin, b.A, b.LSE, dZ, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2T, w.b3W1T, r.P(pb + T_B1), r.T->dQKV, g[0], g[1], g[2], g[3],
-                                       acc, r.ctx->rq, r.st, h16, h16)))
+      if (!r.ok(launch_tower_bwd_fused(Xin, b.A, b.LSE, dZ, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2T, w.b3W1T, w.b3WqkvT, r.P(pb + T_B1), r.T->dQKV,
+                                       (scope & 1) ? dXalt : nullptr, g, acc, r.ctx->rq, r.st, h16, h16)))
         return nullptr;
+      if (!(scope & 2)) {
+        const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
+        wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs, h16);
+      }
+      if (!(scope & 1)) {
+        GemmEpilogue er;
+        er.res = dZ; er.ldres = d;
+        er.b3 = w.b3WqkvT;
+        er.a_bf16 = h16;
+        lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);
+      }
+      if (r.rc) return nullptr;
+      if (!r.ok(wgrad_batch_flush(r.st))) return nullptr;
+      float* t = dX; dX = dXalt; dXalt = t;
+      continue;
     } else {
     wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2, h16 ? 2 : 0);
     if (r.ctx->fwd_dropout) wgrad_batch_begin();
@@ -1250,7 +1268,8 @@ float* bert_bwd(Run& r, int e) {
 // buffer a later launch reads (the stash, the operands of the deferred weight-gradient products) is written as before.
 // INTEL_HEAD_FUSED=0 keeps the kernel-per-op head.
 static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
-  static const int on = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '0') ? 0 : 1; }();
+  static const int mode = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }();      // parsed once: 0 off, 2 backward chains forced on
+  const int on = mode != 0;
   if (!on || !D.cross_attention || D.pool_mean || D.weight_norm != 0 || D.model_num > 16) return false;
   if (D.dtype != INTEL_DTYPE_F32) return false;      // bf16 mode rounds the operands of the 64 / 128-deep B-row products (oracle.forward_bf16): kernel-per-op head
   // train: 0 = inference forward, 1 = training BACKWARD, 2 = training FORWARD -- the forward chains write the kernel-per-op path's stash, so
@@ -1262,7 +1281,7 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   // With BOTH towers on the one-kernel 32-wide path (tower32.hip) there are no tower launches to hide the head's under: the backward chains pay
   // up to 4096 sessions (published hyper-parameters, same-box: GRU4Rec encoders 1024 sessions +4 %, 4096 +-0, 8192 -5 %; BERT4Rec encoders
   // 1024 / 2048 / 4096: +2 / +4 / +5.5 %).
-  static const int force = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return (e && e[0] == '2') ? 1 : 0; }();
+  const int force = mode == 2;
   const bool tw32_both = D.layers > 0 && tower32_supported(y.L, y.tw[0].d, D.heads, D.layers, 1) && tower32_supported(y.L, y.tw[1].d, D.heads, D.layers, 1);
   const int bwd_limit = !tw32_both ? 768 : (D.encoder == INTEL_ENC_BERT4REC ? (1 << 30) : 4096);      // (BERT4Rec encoders: still +5 / +4 / +1.3 % at 6144 / 8192 / 16 384 sessions)
   if (train == 1 && y.B > bwd_limit && !force) return false;

@@ -10,10 +10,11 @@
 //   P1  R1 = relu(A W1^T + b1)                       recomputed on the bf16 pipe (six plane products = fp32 accuracy) -> planes
 //   P2  dW2 += dZ^T R1, db2 += colsum dZ             (operands k-contiguous along the ROWS: ds_read_b64_tr_b16 from the row-major planes)
 //       dF1 = (dZ W2) * [R1 > 0]                     -> planes, over R1
-//   P3  dW1 += dF1^T A, db1 += colsum dF1;  dA = dF1 W1 -> fp32 rows;  delta = rowsum(dA * A) per head
+//   P3  dW1 += dF1^T A, db1 += colsum dF1;  dA = dF1 W1 -> fp32 rows
 //   P4  X tile -> planes;  [Q | K | V] = X Wqkv^T    recomputed -> fp32 rows
 //   P5  attention backward per head on exact fp32 MFMAs (bf16 mode: single bf16 MFMAs):
-//         pass 1, wave = (16 keys, half of the queries): S and dP once, P from the forward's log-sum-exp, dS -> LDS, partial dV = P^T dA and
+//         pass 1, wave = (16 keys, half of the queries): S and dP once, P from the forward's log-sum-exp, delta = rowsum(P * dP) summed over the key tiles
+//                 through LDS, dS -> LDS, partial dV = P^T dA and
 //                 dK = dS^T Q in registers; the two query halves are summed through the dead Q / dA columns
 //         pass 2, wave = (16 queries, half of the head dim): dQ = dS K
 //       dQ / dK / dV leave as rows of dQKV [B L, 3 D]
@@ -46,9 +47,11 @@ struct TowerBwdArgs {
   const uint4* W1;       //   [D -> D] forward W1 (R1 = A W1^T),
   const uint4* W2T;      //   W2 transposed (dR1 = dZ W2),
   const uint4* W1T;      //   W1 transposed (dA = dF1 W1)
+  const uint4* WqkvT;    //   [3D -> D] the stacked q/k/v weights transposed (dX = dQKV Wqkv), k extent 3D
   const float* b1;
-  float* dQKV;           // [B*L, 3D]
-  float* slabs;          // per workgroup: dW2 [D, D] | db2 [D] | dW1 [D, D] | db1 [D]
+  float* dQKV;           // [B*L, 3D] (not written where the kernel consumes it itself: TowerBwdScope)
+  float* dX;             // [B*L, D] = dQKV Wqkv + dZ (scope bit 0)
+  float* slabs;          // per workgroup: dW2 [D, D] | db2 [D] | dW1 [D, D] | db1 [D] (| dWq | dWk | dWv [D, D] each: scope bit 1)
   unsigned long long* dbg;   // INTEL_TOWER_DBG=1 (debug builds): per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
 };
 
@@ -66,10 +69,14 @@ struct BwdCfg {
   static constexpr size_t DS = (size_t)64 * DSP * 4;
   static constexpr size_t R12 = 2 * P3 > 3 * F ? 2 * P3 : 3 * F;      // P(A) | P(R1 -> dF1), later fp32 Q | K | V
   static constexpr size_t R3 = P3 > F + DS ? P3 : F + DS;             // P(dZ), later fp32 dA + dS
-  static constexpr size_t STAT = (size_t)(2 * 64 + 2 * 64 + 8 * 64) * 4;      // lse2 [2][64], delta [2][64], dpart [8][64]
-  static constexpr size_t SMEM = R12 + R3 + STAT;
+  static constexpr size_t STAT = (size_t)(2 * 64 + 4 * 64) * 4;      // lse2 [2][64], dpart [4][64]
+  // scope of the kernel beyond dQKV: FULLX = dX = dQKV Wqkv + dZ too, FULLW = the q/k/v weight gradients too (their 3 D^2 accumulators fit the registers
+  // at D = 64 only; six-plane operands at D = 128 leave no room for either)
+  static constexpr bool FULLX = D == 64 || NP == 1, FULLW = D == 64;
+  static constexpr size_t R4 = (FULLX && NP == 3) ? 2 * P3 : 0;      // P(X) | P(dQ / dK / dV); one plane: over the dead K rows / dS instead
+  static constexpr size_t SMEM = R12 + R3 + STAT + R4;
   static constexpr int NJ = 64 * (D / 4) / NT;                // float4 per thread per 64-row tile
-  static constexpr size_t SLAB = (size_t)2 * D * (D + 1);
+  static constexpr size_t SLAB = (size_t)2 * D * (D + 1) + (FULLW ? (size_t)3 * D * D : 0);
 };
 
 typedef short tb_s16x4 __attribute__((ext_vector_type(4)));
@@ -180,8 +187,10 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
   float* fdA = reinterpret_cast<float*>(smem_raw + C::R12);                  // fp32 rows dA over P(dZ)
   float* dSb = fdA + 64 * LQ;
   float* lse2 = reinterpret_cast<float*>(smem_raw + C::R12 + C::R3);
-  float* delta = lse2 + 2 * 64;
-  float* dpart = delta + 2 * 64;
+  float* dpart = lse2 + 2 * 64;      // [4 key tiles][64 queries]: shares of delta
+  constexpr bool FULLX = C::FULLX, FULLW = C::FULLW;
+  __bf16* pX2 = NP == 1 ? reinterpret_cast<__bf16*>(fK) : reinterpret_cast<__bf16*>(smem_raw + C::R12 + C::R3 + C::STAT);      // P(X) of the tail
+  __bf16* pD = NP == 1 ? reinterpret_cast<__bf16*>(dSb) : pX2 + NP * PLANE;                                                      // P(dQ), P(dK), P(dV) in turn
   const int tid = threadIdx.x, lane0 = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int L = a.L, NTL = (L + 15) >> 4;
@@ -238,6 +247,11 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
 #pragma unroll
   for (int kt = 0; kt < KTL; ++kt) accW2[kt] = accW1[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db2p = 0.f, db1p = 0.f;
+  f32x4 accWqkv[FULLW ? 3 : 1][KTL];
+#pragma unroll
+  for (int c = 0; c < (FULLW ? 3 : 1); ++c)
+#pragma unroll
+    for (int kt = 0; kt < KTL; ++kt) accWqkv[c][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
   unsigned long long tstamp = 0;
   const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
   auto mark = [&](int ph) {
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     }
     lds_barrier();
     mark(2);
-    // ---- P3: dW1 += dF1^T A, db1;  dA = dF1 W1 -> fp32 rows (over dZ);  delta partials;  the X tile of P4 travels meanwhile
+    // ---- P3: dW1 += dF1^T A, db1;  dA = dF1 W1 -> fp32 rows (over dZ);  the X tile of P4 travels meanwhile
     {
       f32x4 vx[NJ];
       load_tile(a.X, b, std::false_type{}, vx);
@@ -346,21 +360,6 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
 #pragma unroll
         for (int q = 0; q < NP; ++q) wf[q] = wn[q];
       }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        const int row = (rt0 + rt) * 16 + p;
-        const __bf16* src = pA + row * LDP + col;
-        const bf16x4 h = *reinterpret_cast<const bf16x4*>(src);
-        f32x4 av = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        if (NP == 3) {
-          const bf16x4 m = *reinterpret_cast<const bf16x4*>(src + PLANE), l = *reinterpret_cast<const bf16x4*>(src + 2 * PLANE);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) av[r] = ((float)l[r] + (float)m[r]) + av[r];      // exact: A = hi + mid + lo
-        }
-        float part = (acc[rt][0] * av[0] + acc[rt][1] * av[1]) + (acc[rt][2] * av[2] + acc[rt][3] * av[3]);
-        part = gsum16(part);
-        if (j == 0) dpart[ct * 64 + row] = part;
-      }
       lds_barrier();      // every read of P(A), P(dF1), P(dZ) is done
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fdA + ((rt0 + rt) * 16 + p) * LQ + col) = acc[rt];
@@ -368,15 +367,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     }
     lds_barrier();
     mark(3);
-    // ---- P4: delta[h][q] = sum of its column tiles' partials (fixed order);  [Q | K | V] = X Wqkv^T -> fp32 rows
+    // ---- P4: [Q | K | V] = X Wqkv^T -> fp32 rows
     {
-      if (tid < 64 * HEADS) {
-        const int h = tid >> 6, q = tid & 63;
-        float s = 0.f;
-#pragma unroll
-        for (int c = 0; c < DK / 16; ++c) s += dpart[(h * (DK / 16) + c) * 64 + q];
-        delta[h * 64 + q] = s;
-      }
       if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
       f32x4 acc[3][RT];
 #pragma unroll
@@ -409,9 +401,9 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       f32x4 dk[DQ * 4], dv[DQ * 4];
 #pragma unroll
       for (int i = 0; i < DQ * 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 st[2], dp[2];
+      st[0] = st[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (kt < NTL) {      // (wave-uniform; a key tile of padding only has nothing to add)
-        f32x4 st[2], dp[2];
-        st[0] = st[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* Kp = fK + (kt * 16 + p) * LQ + hc + 4 * j;
         const float* Vp = fV + (kt * 16 + p) * LQ + hc + 4 * j;
 #pragma unroll
@@ -429,17 +421,35 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
             }
           }
         }
+        // P from the forward's log-sum-exp; this key tile's share of delta[q] = sum_k P[q][k] dP[q][k] (the SAME P and dP the products below use: the rows
+        // of dS then sum to zero exactly, whatever the arithmetic mode rounded on the way) -- summed over the 16 keys = the 16 lanes of a DPP row
         const bool keyok = kt * 16 + p < L;
 #pragma unroll
         for (int qi = 0; qi < 2; ++qi) {
           const int q0 = (2 * qh + qi) * 16 + 4 * j;
           const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + h * 64 + q0);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(delta + h * 64 + q0);
+          f32x4 part;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[qi][r], c2, -l4[r])) : 0.f;
-            const float ds = pv * (dp[qi][r] - d4[r]) * scale;
             st[qi][r] = pv;
+            part[r] = row16_sum(pv * dp[qi][r]);
+          }
+          if (p == 0) *reinterpret_cast<f32x4*>(dpart + kt * 64 + q0) = part;
+        }
+      }
+      lds_barrier();      // the key tiles' shares of delta
+      if (kt < NTL) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+          const int q0 = (2 * qh + qi) * 16 + 4 * j;
+          f32x4 d4 = *reinterpret_cast<const f32x4*>(dpart + q0);
+#pragma unroll
+          for (int k2 = 1; k2 < 4; ++k2)
+            if (k2 < NTL) d4 += *reinterpret_cast<const f32x4*>(dpart + k2 * 64 + q0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ds = st[qi][r] * (dp[qi][r] - d4[r]) * scale;
             dp[qi][r] = ds;
             dSb[(q0 + r) * DSP + kt * 16 + p] = ds;
           }
@@ -543,22 +553,71 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       mark(7);
     }
     if (!EARLY) load_session(min(b + (int)gridDim.x, a.B - 1));
-    // ---- dQKV rows: [dQ | dK | dV] from the V / Q / dA regions, 16 bytes per lane along the row
-    for (int i = tid; i < L * (D / 4); i += NT) {
-      const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(fV + row * LQ + c4);
-      const f32x4 k4 = *reinterpret_cast<const f32x4*>(fQ + row * LQ + c4);
-      const f32x4 v4 = *reinterpret_cast<const f32x4*>(fdA + row * LQ + c4);
-      const size_t g = ((size_t)b * L + row) * (3 * D) + c4;
-      if constexpr (IO16) {
-        __bf16* o16 = reinterpret_cast<__bf16*>(a.dQKV);
-        *reinterpret_cast<bf16x4*>(o16 + g) = bf16x4{(__bf16)q4[0], (__bf16)q4[1], (__bf16)q4[2], (__bf16)q4[3]};
-        *reinterpret_cast<bf16x4*>(o16 + g + D) = bf16x4{(__bf16)k4[0], (__bf16)k4[1], (__bf16)k4[2], (__bf16)k4[3]};
-        *reinterpret_cast<bf16x4*>(o16 + g + 2 * D) = bf16x4{(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
-      } else {
-        *reinterpret_cast<f32x4*>(a.dQKV + g) = q4;
-        *reinterpret_cast<f32x4*>(a.dQKV + g + D) = k4;
-        *reinterpret_cast<f32x4*>(a.dQKV + g + 2 * D) = v4;
+    if constexpr (!FULLW) {
+      // ---- dQKV rows: [dQ | dK | dV] from the V / Q / dA regions, 16 bytes per lane along the row
+      for (int i = tid; i < L * (D / 4); i += NT) {
+        const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(fV + row * LQ + c4);
+        const f32x4 k4 = *reinterpret_cast<const f32x4*>(fQ + row * LQ + c4);
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(fdA + row * LQ + c4);
+        const size_t g = ((size_t)b * L + row) * (3 * D) + c4;
+        if constexpr (IO16) {
+          __bf16* o16 = reinterpret_cast<__bf16*>(a.dQKV);
+          *reinterpret_cast<bf16x4*>(o16 + g) = bf16x4{(__bf16)q4[0], (__bf16)q4[1], (__bf16)q4[2], (__bf16)q4[3]};
+          *reinterpret_cast<bf16x4*>(o16 + g + D) = bf16x4{(__bf16)k4[0], (__bf16)k4[1], (__bf16)k4[2], (__bf16)k4[3]};
+          *reinterpret_cast<bf16x4*>(o16 + g + 2 * D) = bf16x4{(__bf16)v4[0], (__bf16)v4[1], (__bf16)v4[2], (__bf16)v4[3]};
+        } else {
+          *reinterpret_cast<f32x4*>(a.dQKV + g) = q4;
+          *reinterpret_cast<f32x4*>(a.dQKV + g + D) = k4;
+          *reinterpret_cast<f32x4*>(a.dQKV + g + 2 * D) = v4;
+        }
+      }
+    }
+    if constexpr (FULLX) {
+      // ---- tail: dX = dQ Wq + dK Wk + dV Wv + dZ, and (FULLW) dWq / dWk / dWv += dQ^T X, dK^T X, dV^T X.  The three gradients sit as fp32 rows in
+      // the V / Q / dA regions (zero in padded rows); each goes through planes in turn, X once
+      constexpr int KBT3 = 4 * ((3 * D + 127) / 128), KB = D / 32;
+      const uint4* imgT = launder(a.WqkvT) + ((size_t)ct * KBT3 * 3) * 64 + lane;
+      uint4 wq[NP];
+      wload<NP>(imgT, wq);
+      if constexpr (FULLW) {
+        f32x4 vx[NJ];
+        load_tile(a.X, b, std::false_type{}, vx);
+        store_tile(pX2, std::false_type{}, vx);
+      }
+      f32x4 accX[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) accX[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float* src = c == 0 ? fV : (c == 1 ? fQ : fdA);
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          int tr, tc;
+          tile_rc(jj, tr, tc);
+          store4<NP, PLANE>(pD + tr * LDP + tc, *reinterpret_cast<const f32x4*>(src + tr * LQ + tc));
+        }
+        lds_barrier();
+        uint4 wn[NP];
+        if (c < 2) lin<D, NP, RT, true>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
+        else lin<D, NP, RT, false>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
+        if (c < 2) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) wq[q] = wn[q];
+        }
+        if constexpr (FULLW) {
+          float nodb = 0.f;
+          wgrad<D, NP, KTL>(pD, pX2, wnt, wkt0, p, j, accWqkv[c], nodb);
+        }
+        lds_barrier();      // the next gradient's planes go over these; after the last one the three fp32 regions are free
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fQ + ((rt0 + rt) * 16 + p) * LQ + col) = accX[rt];
+      lds_barrier();
+      for (int i = tid; i < L * (D / 4); i += NT) {
+        const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+        const size_t g = ((size_t)b * L + row) * D + c4;
+        *reinterpret_cast<f32x4*>(a.dX + g) = *reinterpret_cast<const f32x4*>(fQ + row * LQ + c4) + *reinterpret_cast<const f32x4*>(a.dZ + g);
       }
     }
     lds_barrier();      // the next session's tiles go over the regions the copy still read
@@ -574,6 +633,15 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       slab[o] = accW2[kt][r];
       slab[(size_t)D * (D + 1) + o] = accW1[kt][r];
     }
+  if constexpr (FULLW) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int kt = 0; kt < KTL; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          slab[(size_t)2 * D * (D + 1) + (size_t)c * D * D + (size_t)(wnt * 16 + 4 * j + r) * D + (wkt0 + kt) * 16 + p] = accWqkv[c][kt][r];
+  }
   db2p = gsum16(db2p);
   db1p = gsum16(db1p);
   if (wkt0 == 0 && j == 0) {
@@ -604,8 +672,9 @@ int launch_one(const TowerBwdArgs& a, hipStream_t st) {
   allow_lds((tower_bwd_fused_kernel<D, DK, NP, IO16>), C::SMEM);
   const int grid = bwd_grid(a.B);
   // algorithmic work per session: six D x D linears (R1, dR1, dA, q / k / v) + two weight gradients, five attention products
-  const double flops = (double)a.B * (16.0 * a.L * D * D + 10.0 * (double)a.L * a.L * D);
-  const double bytes = (double)a.B * a.L * D * ((a.a16 ? 2.0 : 4.0) + 8.0 + (a.dqkv16 ? 6.0 : 12.0));
+  // (+ dX: three more linears, + the q/k/v weight gradients: three more weight gradients)
+  const double flops = (double)a.B * ((16.0 + (C::FULLX ? 6.0 : 0.0) + (C::FULLW ? 6.0 : 0.0)) * a.L * D * D + 10.0 * (double)a.L * a.L * D);
+  const double bytes = (double)a.B * a.L * D * ((a.a16 ? 2.0 : 4.0) + 8.0 + (C::FULLW ? 0.0 : (a.dqkv16 ? 6.0 : 12.0)) + (C::FULLX ? 4.0 : 0.0));
   static const int dbg_on = INTEL_DEBUG_ENV("INTEL_TOWER_DBG", 0);      // phase clocks: debug builds only (common.h)
   TowerBwdArgs aa = a;
   static unsigned long long* dbg_buf = nullptr;
@@ -641,26 +710,35 @@ bool tower_bwd_fused_supported(int L, int d, int heads) {
   return (d == 128 && (dk == 128 || dk == 64)) || (d == 64 && dk == 64);
 }
 
-// Policy (same-box A/B at the headline): bf16 mode -- both widths (one plane: no spill, the kernel is 35 / 20 k cycles per
-// session against ~52 / 26 k of the kernels it replaces); fp32 -- the 64-wide tower (36 k against 38 k, and 0.6 GB less HBM traffic); the 128-wide fp32
-// form carries 64 registers of weight-gradient accumulators per wave next to six-plane operands, spills, and loses (103 - 115 k cycles against 76 k).
+// Policy (same-box A/B at the headline).  bf16 mode: on for both widths (one plane, no spill; 35 / 20 k cycles per session
+// against ~52 / 26 k of the kernels it replaces; +2.3 ... +3.3 % sessions/s).  fp32: OFF -- the kernel's work is equal to (64-wide: 36 k cycles against
+// 38 k) or more than (128-wide: 103 - 115 k against 76 k; 64 accumulator registers per wave next to six-plane operands spill) what it replaces, and a
+// workgroup holds a whole CU (8 waves x 256 registers, > 80 KB of LDS), so the three other branches of the backward cannot share it: -1.5 ... -2 %
+// sessions/s for the 64-wide tower alone, -9 ... -15 % with the 128-wide one, at 5 GB less HBM traffic per step.  INTEL_FUSE_TOWER_BWD=1 forces it.
 bool tower_bwd_fused_wanted(int d) {
+  (void)d;
   const int m = bwd_mode();
   if (m != 2) return m == 1;
-  return gemm_planes() == 1 || d == 64;
+  return gemm_planes() == 1;
 }
 
-size_t tower_bwd_slab_floats(int B, int d) { return (size_t)bwd_grid(B) * 2 * d * (d + 1); }
+// what one launch covers beyond dQKV: bit 0 = dX = dQKV Wqkv + dZ, bit 1 = the q/k/v weight gradients (then dQKV itself is not written)
+int tower_bwd_fused_scope(int d) { return d == 64 ? 3 : (gemm_planes() == 1 ? 1 : 0); }
+
+size_t tower_bwd_slab_floats(int B, int d) { return (size_t)bwd_grid(B) * ((size_t)2 * d * (d + 1) + (d == 64 ? (size_t)3 * d * d : 0)); }
 
 int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, const float* dZ, int B, int L, int d, int heads, const void* Wqkv_b3,
-                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const float* b1, float* dQKV, float* dW2, float* db2, float* dW1,
-                           float* db1, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16, int dqkv16) {
+                           const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const void* WqkvT_b3, const float* b1, float* dQKV, float* dX,
+                           float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16, int dqkv16) {
+  float *dW2 = grads[0], *db2 = grads[1], *dW1 = grads[2], *db1 = grads[3];
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower_bwd_fused_supported(L, d, heads), "tower_bwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
   INTEL_CHECK_ARG(q != nullptr, "tower_bwd_fused: needs the reduce queue");
   INTEL_CHECK_ARG(!(a16 || dqkv16) || gemm_planes() == 1, "tower_bwd_fused: bf16 operands need the bf16 mode");
   INTEL_CHECK_ARG((a16 != 0) == (dqkv16 != 0), "tower_bwd_fused: A and dQKV are bf16 arrays together or not at all");
-  const size_t slab = (size_t)2 * d * (d + 1);
+  const int scope = tower_bwd_fused_scope(d);
+  INTEL_CHECK_ARG(!(scope & 1) || (dX && WqkvT_b3), "tower_bwd_fused: this shape computes dX in the kernel (needs dX and the transposed q/k/v image)");
+  const size_t slab = (size_t)2 * d * (d + 1) + ((scope & 2) ? (size_t)3 * d * d : 0);
   const int grid = bwd_grid(B);
   float* slabs = redq_alloc(q, (size_t)grid * slab);
   INTEL_CHECK_ARG(slabs != nullptr, "tower_bwd_fused: reduce arena exhausted");
@@ -668,6 +746,7 @@ int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, con
   a.X = X; a.A = A; a.LSE = LSE; a.dZ = dZ; a.B = B; a.L = L; a.a16 = a16 ? 1 : 0; a.dqkv16 = dqkv16 ? 1 : 0;
   a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3);
   a.W2T = reinterpret_cast<const uint4*>(W2T_b3); a.W1T = reinterpret_cast<const uint4*>(W1T_b3);
+  a.WqkvT = reinterpret_cast<const uint4*>(WqkvT_b3); a.dX = dX;
   a.b1 = b1; a.dQKV = dQKV; a.slabs = slabs; a.dbg = nullptr;
   const int dk = d / heads;
   int rc;
@@ -680,5 +759,8 @@ int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, con
   if (db2) redq_push(q, slabs + dd, slab, grid, 1, d, db2, d, accumulate[1]);
   if (dW1) redq_push(q, slabs + dd + d, slab, grid, d, d, dW1, d, accumulate[2]);
   if (db1) redq_push(q, slabs + 2 * dd + d, slab, grid, 1, d, db1, d, accumulate[3]);
+  if (scope & 2)
+    for (int c = 0; c < 3; ++c)
+      if (grads[4 + c]) redq_push(q, slabs + 2 * dd + 2 * d + (size_t)c * dd, slab, grid, d, d, grads[4 + c], d, accumulate[4 + c]);
   return 0;
 }

@@ -267,11 +267,14 @@ class IntELEngine(object):
 
     def _param_cache(self):
         """(slot items, detached parameters, parameter-pointer array, gradient-pointer array), built once: the engine owns the flat buckets
-        the parameters and gradients are views of (_flatten), so the pointers are the same every step.  Re-validated by the address of the
-        first and the last parameter (a .to() / re-flatten moves all of them)."""
+        the parameters and gradients are views of (_flatten), so the pointers are the same every step.  Re-validated by the address of EVERY
+        parameter and gradient tensor."""
         c = getattr(self, '_pcache', None)
         items = c[0] if c is not None else self.model.slot_items()
-        key = (items[0][2].data_ptr(), items[-1][2].data_ptr(), len(self.grad_by_slot))
+
+        def key_of(items):      # every parameter's and every gradient's address (~200 ints): a re-assigned middle parameter or a swapped gradient tensor rebuilds the arrays
+            return (tuple(p.data_ptr() for _, _, p in items), tuple((s, g.data_ptr()) for s, g in sorted(self.grad_by_slot.items())))
+        key = key_of(items)
         if c is None or c[4] != key:
             items = self.model.slot_items()
             params = [p.detach() for _, _, p in items]
@@ -279,8 +282,7 @@ class IntELEngine(object):
                 L.require_gpu(t)
             parr = self.model._param_array({s: t.contiguous() for (s, _, _), t in zip(items, params)})
             garr = self.model._param_array(self.grad_by_slot)
-            key = (items[0][2].data_ptr(), items[-1][2].data_ptr(), len(self.grad_by_slot))
-            c = self._pcache = (items, params, parr, garr, key)
+            c = self._pcache = (items, params, parr, garr, key_of(items))
         return c[0], c[1], c[2], c[3]
 
     # ---- flat parameter / gradient / moment buckets -------------------------------------------------

@@ -51,9 +51,9 @@ CASES = [
     ({'INTEL_PACK_SIDE': '0'}, MODEL, [], []),                                 # weight packing on the caller's stream even where no branch reads a packed image
     ({'INTEL_ENC32': '0'}, MODEL, [], ['enc32_fwd_kernel', 'enc32_bwd_kernel']),                                     # 32-wide BERT4Rec encoders on the kernel-per-op pipeline instead of the one-kernel encoder (tower32.hip: enc32_*)
     ({'INTEL_WGRAD_TR': '0'}, BF16, [], ['wgrad_tr_kernel']),
-    ({'INTEL_FUSE_TOWER_BWD': '1'}, FUZZ, ['tower_bwd_fused_kernel'], []),       # the one-kernel backward middle also for the 128-wide fp32 tower (default: 64-wide only)
-    ({'INTEL_FUSE_TOWER_BWD': '0'}, MODEL, [], ['tower_bwd_fused_kernel']),      # kernel-per-op middle of the tower backward everywhere
-    ({'INTEL_FUSE_TOWER_BWD': '0'}, BF16, [], ['tower_bwd_fused_kernel']),                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
+    ({'INTEL_FUSE_TOWER_BWD': '1'}, FUZZ, ['tower_bwd_fused_kernel'], []),       # the one-kernel tower backward in fp32 too (default: bf16 mode only): fixtures + random shapes
+    ({'INTEL_FUSE_TOWER_BWD': '1'}, ENGINE, ['tower_bwd_fused_kernel'], []),     # ... and through the engine's steps (tied layers, Adam)
+    ({'INTEL_FUSE_TOWER_BWD': '0'}, BF16, [], ['tower_bwd_fused_kernel']),       # bf16 mode on the kernel-per-op tower backward                                   # bf16 mode: 128 x 128 weight gradients through the transposed-staging kernel
 ]
 
 
