@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define INTEL_ABI_VERSION 4
+#define INTEL_ABI_VERSION 5
 
 enum {
   INTEL_OK = 0,
@@ -342,6 +342,14 @@ int intel_rows_take(float* table, int d, const int* idx, int n, float* out, int 
 /* table[idx[i],:] += rows[i,:] for idx[i] >= 0; idx must not repeat within one call (no atomics: called once per
  * source rank, in rank order, so that every replica sums in the same order). */
 int intel_rows_add(float* table, int d, const int* idx, int n, const float* rows, void* stream);
+/* ABI version 5.  The unique touched rows of a table from the row marks the backward leaves (intel_set_iid_grad_row_flags): idx[0 .. count) = the
+ * marked rows in ascending order, idx[count .. cap) = -1 -- a static shape (cap = the batch's id count, equal on every rank) without a sort and
+ * without a host-sized result, so the touched-rows exchange is enqueued like any other step.  scratch: intel_rows_compact_scratch_ints(rows) ints.
+ * intel_rows_mark sets flags[idx[i]] = 1 (idx[i] >= 0): the rows the OTHER ranks' buffers add into must be visited by the table's Adam sweep too.
+ * No reference counterpart (the reference is single-GPU: helpers/BaseRunner.py:279-290). */
+long long intel_rows_compact_scratch_ints(long long rows);
+int intel_rows_compact(const unsigned char* flags, long long rows, int* idx, int cap, int* scratch, void* stream);
+int intel_rows_mark(unsigned char* flags, const int* idx, int n, void* stream);
 
 /* ---- evaluation --------------------------------------------------------------------------- */
 /* Overall NDCG@k of BaseRunner.evaluate_method (helpers/BaseRunner.py:117-126) for a padded batch:

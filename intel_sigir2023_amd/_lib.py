@@ -37,7 +37,7 @@ def lib():
         except OSError as e:
             raise IntelHipError('cannot load %s: %s' % (LIB_PATH, e))
         _declare(_lib)
-        if _lib.intel_abi_version() != 4:
+        if _lib.intel_abi_version() != 5:
             raise IntelHipError('ABI version mismatch')
         sizes = (C.c_int * 4)()
         _lib.intel_abi_sizes(sizes)
@@ -133,7 +133,7 @@ EXPORTS = [
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_bpr_loss_seeded', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_pair', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
-    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_prof_timeline', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add',
+    'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_prof_timeline', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add', 'intel_rows_compact', 'intel_rows_compact_scratch_ints', 'intel_rows_mark',
     'intel_lazy_table_sizeof', 'intel_adam_lazy_step', 'intel_adam_lazy_catchup', 'intel_adam_lazy_flush', 'intel_set_lazy_table',
 ]
 
@@ -188,6 +188,9 @@ def _declare(l):
     sig('intel_op_workspace_bytes', sz, [i, i, i])
     sig('intel_rows_take', i, [vp, i, vp, i, vp, i, vp])
     sig('intel_rows_add', i, [vp, i, vp, i, vp, vp])
+    sig('intel_rows_compact', i, [vp, C.c_longlong, vp, i, vp, vp])
+    sig('intel_rows_compact_scratch_ints', C.c_longlong, [C.c_longlong])
+    sig('intel_rows_mark', i, [vp, vp, i, vp])
     sig('intel_feed_abi_sizes', None, [C.POINTER(C.c_int)])
     sig('intel_feed_collate', i, [C.POINTER(IntelFeedStore), vp, i, vp, C.c_ulonglong, C.POINTER(IntelFeedOut), vp])
     sig('intel_prof_enable', None, [i])

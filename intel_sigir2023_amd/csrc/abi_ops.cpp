@@ -87,6 +87,15 @@ extern "C" int intel_rows_add(float* table, int d, const int* idx, int n, const 
   INTEL_CHECK_ARG(table && idx && rows && d > 0 && n >= 0, "intel_rows_add: bad argument");
   return launch_rows_add(table, d, idx, n, rows, (hipStream_t)stream);
 }
+extern "C" long long intel_rows_compact_scratch_ints(long long rows) { return (long long)rows_compact_scratch_ints(rows); }
+extern "C" int intel_rows_compact(const unsigned char* flags, long long rows, int* idx, int cap, int* scratch, void* stream) {
+  INTEL_CHECK_ARG(flags && idx && scratch && rows > 0 && cap >= 0, "intel_rows_compact: bad argument");
+  return launch_rows_compact(flags, rows, idx, cap, scratch, (hipStream_t)stream);
+}
+extern "C" int intel_rows_mark(unsigned char* flags, const int* idx, int n, void* stream) {
+  INTEL_CHECK_ARG(flags && idx && n >= 0, "intel_rows_mark: bad argument");
+  return launch_rows_mark(flags, idx, n, (hipStream_t)stream);
+}
 
 extern "C" int intel_op_add_layernorm(const float* x, const float* r, int M, int N, const float* gamma,
                                       const float* beta, float* y, float* xhat, float* rstd, void* stream) {

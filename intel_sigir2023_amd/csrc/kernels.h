@@ -213,6 +213,10 @@ int launch_layernorm_bwd(const float* dy, int lddy, const float* xhat, int ldxh,
 // touched-row exchange of a gradient table (data parallel): see rowops.hip
 int launch_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, hipStream_t st);
 int launch_rows_add(float* table, int d, const int* idx, int n, const float* rows, hipStream_t st);
+// idx[0 .. count) = the rows marked in flags (ascending), the rest of idx[0 .. cap) = -1; scratch: rows_compact_scratch_ints(rows) ints
+size_t rows_compact_scratch_ints(long long rows);
+int launch_rows_compact(const unsigned char* flags, long long rows, int* idx, int cap, int* scratch, hipStream_t st);
+int launch_rows_mark(unsigned char* flags, const int* idx, int n, hipStream_t st);
 // softmax over rows of length N (in place allowed)
 int launch_softmax_rows(const float* x, int M, int N, float* y, hipStream_t st);
 // dx = y * (dy - sum(dy*y))

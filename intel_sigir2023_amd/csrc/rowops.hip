@@ -723,6 +723,80 @@ __global__ __launch_bounds__(256) void rows_add_kernel(float* __restrict__ table
     *dst = *dst + *reinterpret_cast<const f32x4*>(rows + (size_t)i * d + c);
   }
 }
+// The touched rows of a table from the row marks the embedding scatter leaves (one byte per row, intel_set_iid_grad_row_flags): idx[0 .. count) = the
+// marked rows in ascending order, idx[count .. cap) = -1.  Two launches over 4096-row chunks -- count (+ the -1 fill), then every chunk sums the
+// counts in front of it and compacts its own marks in order; no sort, no host-sized result (the data-parallel exchange needs a static shape: cap =
+// the batch's id count, the same on every rank).  Rows beyond cap (cannot happen for marks set by that batch) are dropped.
+#define RC_CHUNK 4096
+__global__ __launch_bounds__(256) void rows_compact_count_kernel(const unsigned char* __restrict__ flags, long long rows, int* __restrict__ counts,
+                                                                 int* __restrict__ idx, int cap) {
+  __shared__ int red[4];
+  const long long r0 = (long long)blockIdx.x * RC_CHUNK + threadIdx.x * 16;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) c += (r0 + k < rows && flags[r0 + k] != 0) ? 1 : 0;
+  c = wave_sum_i(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cap; i += gridDim.x * 256) idx[i] = -1;
+}
+__global__ __launch_bounds__(256) void rows_compact_write_kernel(const unsigned char* __restrict__ flags, long long rows, const int* __restrict__ counts,
+                                                                 int* __restrict__ idx, int cap) {
+  __shared__ int red[4], wbase[4], base_s;
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += counts[b];
+  before = wave_sum_i(before);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+  __syncthreads();
+  if (threadIdx.x == 0) base_s = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  const long long r0 = (long long)blockIdx.x * RC_CHUNK + threadIdx.x * 16;
+  unsigned m = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m |= (r0 + k < rows && flags[r0 + k] != 0) ? (1u << k) : 0u;
+  const int c = __popc(m);
+  // exclusive scan of c over the 256 threads: inside the wave by shuffles, across the four waves through LDS
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += v;
+  }
+  if ((threadIdx.x & 63) == 63) wbase[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int pos = base_s + incl - c;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) pos += wbase[w];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (m & (1u << k)) {
+      if (pos < cap) idx[pos] = (int)(r0 + k);
+      ++pos;
+    }
+}
+size_t rows_compact_scratch_ints(long long rows) { return (size_t)((rows + RC_CHUNK - 1) / RC_CHUNK) + 1; }
+int launch_rows_compact(const unsigned char* flags, long long rows, int* idx, int cap, int* scratch, hipStream_t st) {
+  if (cap <= 0) return 0;
+  INTEL_CHECK_ARG(rows > 0 && rows < (1LL << 31), "rows_compact: table of %lld rows unsupported", rows);
+  const int nblk = (int)((rows + RC_CHUNK - 1) / RC_CHUNK);
+  LAUNCH_W(0.0, (double)rows + 4.0 * cap, rows_compact_count_kernel, dim3(nblk), dim3(256), 0, st, flags, rows, scratch, idx, cap);
+  INTEL_CHECK_LAUNCH();
+  LAUNCH_W(0.0, (double)rows + 4.0 * cap, rows_compact_write_kernel, dim3(nblk), dim3(256), 0, st, flags, rows, scratch, idx, cap);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+// flags[idx[i]] = 1 for idx[i] >= 0 (the rows another rank's exchange buffer adds into: the table sweep must visit them too)
+__global__ __launch_bounds__(256) void rows_mark_kernel(unsigned char* __restrict__ flags, const int* __restrict__ idx, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n && idx[i] >= 0) flags[idx[i]] = 1;
+}
+int launch_rows_mark(unsigned char* flags, const int* idx, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  LAUNCH(rows_mark_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, flags, idx, n);
+  INTEL_CHECK_LAUNCH();
+  return 0;
+}
+
 int launch_rows_take(float* table, int d, const int* idx, int n, float* out, int zero_rows, hipStream_t st) {
   if (n <= 0) return 0;
   INTEL_CHECK_ARG(d % 4 == 0, "rows_take: row width %d must be a multiple of 4", d);

@@ -155,7 +155,7 @@ class IntELEngine(object):
         lib = L.lib()
         table = self.model.iid_embeddings.weight.grad
         d = table.shape[1]
-        idx = self._touched_idx(keep)
+        idx = self._touched_idx_dev(keep, stream_ptr)
         cap = idx.numel()
         rows = self._buf('xch_rows', (cap, d), torch.float32)
         L.check(lib.intel_rows_take(L.ptr(table), d, L.ptr(idx), cap, L.ptr(rows), 1, stream_ptr), 'intel_rows_take')
@@ -163,9 +163,24 @@ class IntELEngine(object):
         all_rows = parallel.allgather(rows)
         for r in range(all_idx.shape[0]):
             L.check(lib.intel_rows_add(L.ptr(table), d, L.ptr(all_idx[r]), cap, L.ptr(all_rows[r]), stream_ptr), 'intel_rows_add')
-        if self._iid_flags is not None:                   # rows of the other ranks (row 0 for the -1 padding: harmless)
-            self._iid_flags.index_fill_(0, all_idx.reshape(-1).clamp_min(0).long(), 1)
+        if self._iid_flags is not None:                   # the rows of the other ranks must be visited by the table's Adam sweep too
+            L.check(lib.intel_rows_mark(L.ptr(self._iid_flags), L.ptr(all_idx), all_idx.numel(), stream_ptr), 'intel_rows_mark')
         self._bufs['xch_keep'] = (all_idx, all_rows)      # alive until the kernels have run
+
+    def _touched_idx_dev(self, keep, stream_ptr):
+        """The rows of the item-id gradient table this rank's backward added into, as a static-shape index list (cap = the batch's id count, the
+        same on every rank; -1 padding): compacted ON THE DEVICE from the row marks the embedding scatter left (intel_rows_compact: two small
+        launches over the marks, ascending order) -- no sort, no concatenation, nothing sized on the host.  Without row marks (INTEL_ADAM_ROWS=0)
+        the list is derived from the batch's ids with torch (sort + first-of-run: _touched_idx)."""
+        if self._iid_flags is None:
+            return self._touched_idx(keep)
+        lib = L.lib()
+        cap = keep['i_id_s'].numel() + keep['his_item_id'].numel()
+        nrows = self.model.iid_embeddings.weight.shape[0]
+        idx = self._buf('xch_idx', (cap,), torch.int32)
+        scratch = self._buf('xch_scratch', (int(lib.intel_rows_compact_scratch_ints(nrows)),), torch.int32)
+        L.check(lib.intel_rows_compact(L.ptr(self._iid_flags), nrows, L.ptr(idx), cap, L.ptr(scratch), stream_ptr), 'intel_rows_compact')
+        return idx
 
     def _sharded(self):
         """INTEL_DP_EXCHANGE=sharded and no lazy table: the table's optimizer state is partitioned over the ranks."""
@@ -184,23 +199,17 @@ class IntELEngine(object):
         rows, d = self.model.iid_embeddings.weight.shape
         per = -(-rows // w)                                   # rows per rank
         n = per * d
-        g = self.gflat['iid']
-        pad = per * w * d - g.numel()
-        gfull = g if pad == 0 else torch.cat([g, g.new_zeros(pad)])
+        # the table's flat buckets (parameter, gradient, both moments) were allocated with room for per * w rows (_flatten): the collectives work on
+        # views of them -- no concatenation, no staging copy.  The padding rows stay zero under Adam (p = g = m = v = 0)
+        gfull, pfull = self.gflat['iid'][:w * n], self.flat['iid'][:w * n]
         gs = self._buf('shard_g', (n,), torch.float32)
         parallel.reduce_scatter_sum(gfull, gs)
-        lo = min(r * per, rows) * d
-        hi = min((r + 1) * per, rows) * d
-        if hi > lo:
-            b1, b2 = self.betas
-            L.check(lib.intel_adam_step(L.ptr(self.flat['iid'][lo:hi]), L.ptr(gs), L.ptr(self.m['iid'][lo:hi]), L.ptr(self.v['iid'][lo:hi]), hi - lo,
-                                        self.lr, b1, b2, self.eps, self.l2, self.step_count, 1.0, 0, stream_ptr), 'intel_adam_step')
-        ps = self._buf('shard_p', (n,), torch.float32)
-        ps.zero_()
-        ps[:hi - lo].copy_(self.flat['iid'][lo:hi])
-        allp = parallel.allgather(ps).reshape(-1)
-        self.flat['iid'].copy_(allp[:g.numel()])
-        g.zero_()                                             # the local gradient (every row) and the row marks are consumed
+        b1, b2 = self.betas
+        lo, hi = r * n, (r + 1) * n
+        L.check(lib.intel_adam_step(L.ptr(self.flat['iid'][lo:hi]), L.ptr(gs), L.ptr(self.m['iid'][lo:hi]), L.ptr(self.v['iid'][lo:hi]), n,
+                                    self.lr, b1, b2, self.eps, self.l2, self.step_count, 1.0, 0, stream_ptr), 'intel_adam_step')
+        parallel.allgather_inplace(pfull, r, n)               # every rank's updated rows into every replica's table, in place
+        gfull.zero_()                                         # the local gradient (every row) and the row marks are consumed
         if self._iid_flags is not None:
             self._iid_flags.zero_()
 
@@ -302,6 +311,9 @@ class IntELEngine(object):
         for gname, lst in groups.items():
             sizes = [((p.numel() + 63) // 64) * 64 for _, _, p in lst]      # 256-byte aligned slices
             total = sum(sizes)
+            if gname == 'iid' and lst and parallel.world_size() > 1:      # room for ceil(rows / world) * world rows: the sharded table update's collectives
+                rows_, d_ = lst[0][2].shape                                 # (reduce-scatter, in-place all-gather) then work on views of the buckets
+                total = max(total, ((-(-rows_ // parallel.world_size()) * parallel.world_size() * d_ + 63) // 64) * 64)
             flat = torch.zeros(total, dtype=torch.float32, device=self.device)
             gflat = torch.zeros(total, dtype=torch.float32, device=self.device)
             off = 0
@@ -364,8 +376,8 @@ class IntELEngine(object):
         ib, keep = model.prepare_batch(batch)
         if dp:
             self._check_global_shape(ib)
-            if self._sparse_exchange(keep, world):
-                self._touched_idx(keep)
+            if self._sparse_exchange(keep, world) and self._iid_flags is None:
+                self._touched_idx(keep)      # (torch fallback without row marks: derived from the batch's ids ahead of the forward pass)
         if self._lazy_auto:             # same decision on every rank: the shape is global (_check_global_shape)
             self._lazy_auto = False
             w = model.iid_embeddings.weight       # ... and the table is large enough for its sweep to matter (>= 128 MB: >= 0.15 ms per step)

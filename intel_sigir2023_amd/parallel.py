@@ -128,6 +128,20 @@ def allgather(t):
     return out
 
 
+def allgather_inplace(full, r, n):
+    """full[k * n:(k + 1) * n] <- rank k's full[k * n:(k + 1) * n] for every k (this rank's own chunk is already in place): the second half of a
+    ring all-reduce, written straight into the destination.  RCCL: one in-place all_gather_into_tensor; gloo (tests): all_gather into the chunks."""
+    if not active():
+        return
+    w = world_size()
+    assert full.numel() == w * n
+    mine = full[r * n:(r + 1) * n]
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(full, mine)
+    else:
+        dist.all_gather([full[k * n:(k + 1) * n] for k in range(w)], mine.clone())
+
+
 def allgather_object(obj):
     """List of every rank's picklable ``obj`` in rank order (evaluation records; off the hot path)."""
     if world_size() == 1:

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), 'libintel_hip.so does not export ' + name
     assert sorted(_lib.EXPORTS) == declared, (sorted(set(declared) ^ set(_lib.EXPORTS)))
-    assert lib.intel_abi_version() == 4
+    assert lib.intel_abi_version() == 5
 
 
 def test_struct_mirrors_match_header():

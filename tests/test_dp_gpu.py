@@ -216,3 +216,32 @@ def test_rccl_world1_runs_every_collective_branch(exchange, overlap, schedule):
         if 'k_linear.bias' in k:
             continue            # analytically-zero gradient: Adam direction is rounding noise
         assert float((v - got['sd'][k]).abs().max()) < 2e-6, k
+
+
+@pytest.mark.parametrize('rows,share', [(1, 1.0), (4095, 0.5), (4096, 0.0), (4097, 0.02), (1000003, 0.29), (10000000, 0.001)])
+def test_rows_compact_and_mark_kernels(rows, share):
+    """intel_rows_compact (the touched-rows list of the data-parallel table exchange, from the backward's row marks) against torch.nonzero:
+    ascending rows, -1 padding up to the static capacity, marks beyond the capacity dropped; intel_rows_mark sets the marks of an index
+    list (with -1 holes) and nothing else."""
+    from intel_sigir2023_amd import _lib as L
+    dev = torch.device('cuda:0')
+    lib = L.lib()
+    g = torch.Generator(device=dev).manual_seed(rows)
+    flags = (torch.rand(rows, device=dev, generator=g) < share).to(torch.uint8) * 7      # any non-zero byte is a mark
+    want = torch.nonzero(flags).flatten().to(torch.int32)
+    st = L.stream_ptr(dev)
+    scratch = torch.empty(int(lib.intel_rows_compact_scratch_ints(rows)), dtype=torch.int32, device=dev)
+    for cap in (int(want.numel()) + 5, max(1, int(want.numel()) // 2)):
+        idx = torch.full((cap,), 12345, dtype=torch.int32, device=dev)
+        L.check(lib.intel_rows_compact(L.ptr(flags), rows, L.ptr(idx), cap, L.ptr(scratch), st), 'intel_rows_compact')
+        torch.cuda.synchronize()
+        n = min(cap, int(want.numel()))
+        assert torch.equal(idx[:n], want[:n])
+        assert bool((idx[n:] == -1).all())
+    marks = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    lst = torch.cat([want[::3], torch.full((4,), -1, dtype=torch.int32, device=dev)])
+    L.check(lib.intel_rows_mark(L.ptr(marks), L.ptr(lst), lst.numel(), st), 'intel_rows_mark')
+    torch.cuda.synchronize()
+    ref = torch.zeros(rows, dtype=torch.uint8, device=dev)
+    ref[want[::3].long()] = 1
+    assert torch.equal(marks, ref)
