@@ -240,6 +240,7 @@ def short_line(workload, B, over, steps, warmup, dev):
     model = IntEL(args_ns, corpus).to(dev)
     lr, l2 = w.get('optim', (1e-3, 1e-4))
     eng = IntELEngine(model, loss_name, args_ns, lr=lr, l2=l2, lazy_table='auto')
+    eng.defer_table_wait = True
     batches = [synth.make_batch(workload, B, dev, seed=50 + i) for i in range(4)]
     for bt in batches:
         bt['_intel'] = model.prepare_batch(bt)
@@ -281,6 +282,7 @@ def main():
     ap.add_argument('--no_bf16_line', action='store_true', help='skip the bf16-mode measurement appended to the fp32 line at N=1')
     ap.add_argument('--no_roofline', action='store_true')
     ap.add_argument('--no_feed', action='store_true', help='skip the device-feed (batch assembly) throughput measurement')
+    ap.add_argument('--no_defer_table', action='store_true', help='every step waits for the item-id table sweep before it returns (default: the next forward starts under it)')
     ap.add_argument('--no_workloads', action='store_true', help='skip the short driver-timed lines of the other workloads (tmall_pub, lifedata, stress) appended at N=1')
     ap.add_argument('--spread_blocks', type=int, default=2, help='extra timed blocks of --steps steps after the one that defines `value` (value_spread)')
     ap.add_argument('--cpu_budget', type=float, default=24.0)
@@ -315,6 +317,7 @@ def main():
     lr, l2 = w.get('optim', (1e-3, 1e-4))
     lazy = {'lazy': True, 'dense': False}.get(a.adam, 'auto')
     eng = IntELEngine(model, a.loss, args_ns, lr=lr, l2=l2, lazy_table=lazy)
+    eng.defer_table_wait = not a.no_defer_table      # back-to-back steps: the next forward starts under the table's Adam sweep (engine.py)
     parallel.broadcast_(eng.param_buckets())
     B = a.batch or w.get('bench_batch', 4096)
     # distinct resident batches (inputs in HBM before the timed region): 8 x 73 MB of gathered item rows at the headline shape,
@@ -510,6 +513,7 @@ def main():
         torch.manual_seed(0)
         model_bf = IntEL(args_bf, corpus).to(dev)
         eng_bf = IntELEngine(model_bf, a.loss, args_bf, lr=lr, l2=l2, lazy_table=lazy)
+        eng_bf.defer_table_wait = not a.no_defer_table
         for i in range(a.warmup):
             eng_bf.train_step(batches[i % nbatches])
         torch.cuda.synchronize()

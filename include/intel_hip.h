@@ -191,6 +191,11 @@ void intel_set_table_stream(IntelCtx* ctx, void* stream);
  * wants work next to the context's branches (the table's optimizer sweep after intel_backward, which leaves all three idle)
  * should borrow one of these instead of creating its own.  Valid until intel_destroy. */
 void* intel_side_stream(IntelCtx* ctx, int i);
+/* ABI version 5.  One shot: the NEXT intel_forward makes the streams that READ the item-id table (the item tower's and the item-history encoder's
+ * gathers) wait for `event` (a hipEvent_t the caller recorded behind its optimizer's sweep of that table) -- the other two branches, which do not
+ * touch the table, start under the sweep.  NULL: off.  The caller orders every OTHER reader of the table itself.  No reference counterpart (the
+ * reference's step is one stream: helpers/BaseRunner.py:279-290). */
+void intel_set_table_wait_event(IntelCtx* ctx, void* event);
 
 /* A promise for the following intel_forward calls: the parameter VALUES equal those of the previous intel_forward on this
  * context.  The forward then reuses the packed weight images that call left in the workspace, provided the workspace

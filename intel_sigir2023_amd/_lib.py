@@ -129,7 +129,7 @@ ENC_STRIDE = 6 + ENC_BLOCK_STRIDE * ENC_MAX_BLOCKS
 P_COUNT = P_ENC0 + 2 * ENC_STRIDE
 
 EXPORTS = [
-    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_params_unchanged', 'intel_set_table_stream', 'intel_side_stream', 'intel_set_dropout', 'intel_set_iid_grad_row_flags', 'intel_workspace_bytes',
+    'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_params_unchanged', 'intel_set_table_stream', 'intel_set_table_wait_event', 'intel_side_stream', 'intel_set_dropout', 'intel_set_iid_grad_row_flags', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_bpr_loss_seeded', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_pair', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
     'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
@@ -154,6 +154,7 @@ def _declare(l):
     sig('intel_set_concurrency', None, [vp, i])
     sig('intel_set_params_unchanged', None, [vp, i])
     sig('intel_set_table_stream', None, [vp, vp])
+    sig('intel_set_table_wait_event', None, [vp, vp])
     sig('intel_side_stream', vp, [vp, i])
     sig('intel_set_dropout', i, [vp, f, C.c_ulonglong, vp])
     sig('intel_set_iid_grad_row_flags', i, [vp, vp])

@@ -655,10 +655,7 @@ template <int DKT>
 __global__ __launch_bounds__(256, 4) void attn_bwd_dq_ds_bf_kernel(DQDS_PARAMS) { attn_bwd_dq_ds_body<DKT, true>(qkv, dS, ldS, T, d, heads, key_len, dqkv, row_off); }
 
 static inline int attn_ds_pitch(int T) { return (T + 3) & ~3; }
-static inline bool attn_ds_scheme() {
-  static const int on = [] { const char* e = getenv("INTEL_ATTN_DS"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on != 0;
-}
+static inline bool attn_ds_scheme() { return true; }      // (the recompute form below stays for small problems only: launch_attn_bwd)
 
 static inline bool attn_seq_path(int T, int dk) { return attn_seq_supported(T, dk); }
 bool attn_packed_supported(int T, int dk) { return attn_seq_path(T, dk) ? attn_seq_packed_supported(T, dk) : true; }

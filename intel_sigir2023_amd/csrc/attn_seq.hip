@@ -22,8 +22,6 @@
 //     the dead Q / dO stages and become 16-query tiles for dQ = dS K: 5 tile products instead of the 7 of a recompute
 //     scheme, no dS / K round trip through HBM.  delta = rowsum(dO * O) = rowsum(P * dP) is summed over the key-tile
 //     waves through LDS, so the attention output O is not read at all.
-//     (attn_seq_bwd_kv_kernel + attn_seq_bwd_q_kernel, the two-kernel form with dS in global memory, stay behind
-//     INTEL_ATTN_FUSED_BWD=0.)
 #include <stdio.h>
 #include <stdlib.h>
 #include "kernels.h"
@@ -385,136 +383,7 @@ __device__ __forceinline__ void stage_seq2(float* dst0, const float* __restrict_
   }
 }
 
-// dK, dV of a 16-key tile + the dS tile column for the dQ kernel.  dS layout: [BH][TP][TP], row = query.
-template <int DKT, int NT, int LS>
-__global__ __launch_bounds__(256, 2) void attn_seq_bwd_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                              const float* __restrict__ dout, const float* __restrict__ lse,
-                                                              int BH, int T, int d, int heads, const int* __restrict__ key_len,
-                                                              float c2, float scale, float* __restrict__ dqkv, float* __restrict__ dS) {
-  using C = SeqCfg<DKT, NT>;
-  constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP, NSTEPS = (NT - 1) * 4 + LS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Qs = smem;
-  float* Os = smem + C::ROWS * LD;
-  float* Ls = smem + 2 * C::ROWS * LD;
-  float* Ds = Ls + C::ROWS;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 4, p = lane & 15;
-  const int bh0 = blockIdx.x * C::PW, ldg = 3 * d;
-  const int slot = wave / NT, tile = wave - slot * NT, bh = bh0 + slot;
-  const bool live = slot < C::PW && bh < BH;
-  int b = live ? bh : 0, h = 0;
-  if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
-  const int key = tile * 16 + p;
-  const bool kok = live && key < T;
-  f32x4 kf[DKT], vf[DKT];
-  load_row_frags<DKT>(kf, qkv + ((size_t)b * T + key) * ldg + d + h * DK, kok, DK, lane);
-  load_row_frags<DKT>(vf, qkv + ((size_t)b * T + key) * ldg + 2 * d + h * DK, kok, DK, lane);
-  {
-    // stage Q and dO (permuted rows); delta[row] = sum_d dO * O rides along: the C4 lanes of a row are adjacent
-    f32x4 vq[C::ITERS], vo[C::ITERS];
-    float dot[C::ITERS];
-#pragma unroll
-    for (int it = 0; it < C::ITERS; ++it) {
-      int rl, c4, hcol;
-      size_t grow;
-      const bool ok = seq_src<DKT, NT, true>(tid + it * 256, bh0, BH, T, heads, rl, c4, grow, hcol);
-      const size_t gr = ok ? grow : 0;
-      const int hc = ok ? hcol : 0;
-      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-      const f32x4 tq = *reinterpret_cast<const f32x4*>(qkv + gr * ldg + hc);
-      const f32x4 to = *reinterpret_cast<const f32x4*>(dout + gr * d + hc);
-      const f32x4 w = *reinterpret_cast<const f32x4*>(out + gr * d + hc);
-      vq[it] = ok ? tq : zero;
-      vo[it] = ok ? to : zero;
-      dot[it] = ok ? (to[0] * w[0] + to[1] * w[1] + to[2] * w[2] + to[3] * w[3]) : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < C::ITERS; ++it) {
-      const int i = tid + it * 256;
-      const int rl = i / C::C4, c4 = i - rl * C::C4;
-      *reinterpret_cast<f32x4*>(Qs + rl * LD + c4 * 4) = vq[it];
-      *reinterpret_cast<f32x4*>(Os + rl * LD + c4 * 4) = vo[it];
-      float s = dot[it];
-#pragma unroll
-      for (int m = 1; m < C::C4; m <<= 1) s += __shfl_xor(s, m);
-      if (c4 == 0) Ds[rl] = s;
-    }
-    if (tid < C::ROWS) {
-      const int sl = tid / TP, r = tid - sl * TP, rho = perm16(r), bb = bh0 + sl;
-      Ls[tid] = (bb < BH && rho < T) ? -1.44269504088896340736f * lse[(size_t)bb * T + rho] : -INFINITY;   // -lse in base 2
-    }
-  }
-  __syncthreads();
-  if (!live) return;
-  const int nkeys = key_len ? min(key_len[b], T) : T;
-  const bool key_live = key < nkeys;             // masked keys get exactly zero gradient
-  const float* Qp = Qs + slot * TP * LD;
-  const float* Op = Os + slot * TP * LD;
-  const float* Lp = Ls + slot * TP;
-  const float* Dp = Ds + slot * TP;
-  float* dSp = dS + (size_t)bh * TP * TP;
-  f32x4 dkT[DKT], dvT[DKT];
-#pragma unroll
-  for (int i = 0; i < DKT; ++i) {
-    dkT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dvT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  {
-#pragma unroll
-    for (int qt = 0; qt < NT; ++qt) {
-      f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < DKT; ++g) {
-        const int off = (qt * 16 + p) * LD + g * 16 + 4 * j;
-        const f32x4 qa = *reinterpret_cast<const f32x4*>(Qp + off);
-        const f32x4 oa = *reinterpret_cast<const f32x4*>(Op + off);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          sa = mfma16(qa[s], kf[g][s], sa);     // S[query slot][key]
-          dp = mfma16(oa[s], vf[g][s], dp);     // dP[query slot][key]
-        }
-      }
-      f32x4 pr, ds;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rl = qt * 16 + 4 * j + r;     // staged slot of accumulator row 4j+r; its query is 4r+j
-        const int qg = qt * 16 + 4 * r + j;
-        const float pv = key_live ? __builtin_amdgcn_exp2f(__builtin_fmaf(sa[r], c2, Lp[rl])) : 0.f;
-        pr[r] = pv;
-        ds[r] = pv * (dp[r] - Dp[rl]) * scale;
-        if (qg < T && key < T) dSp[(size_t)qg * TP + key] = ds[r];
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (qt * 4 + s >= NSTEPS) continue;     // queries 4s..4s+3 of the tile are padding (compile-time)
-#pragma unroll
-        for (int dq = 0; dq < DQ; ++dq) {
-          const int off = (qt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p;
-          const f32x4 ov = *reinterpret_cast<const f32x4*>(Op + off);
-          const f32x4 qv = *reinterpret_cast<const f32x4*>(Qp + off);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            dvT[dq * 4 + t] = mfma16(ov[t], pr[s], dvT[dq * 4 + t]);   // dV^T[dim][key] += dO^T P
-            dkT[dq * 4 + t] = mfma16(qv[t], ds[s], dkT[dq * 4 + t]);   // dK^T[dim][key] += Q^T dS
-          }
-        }
-      }
-    }
-  }
-  if (kok) {
-    float* drow = dqkv + ((size_t)b * T + key) * ldg + h * DK;
-#pragma unroll
-    for (int dq = 0; dq < DQ; ++dq)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int col = dq * 64 + 16 * j + 4 * r;
-        *reinterpret_cast<f32x4*>(drow + d + col) = f32x4{dkT[dq * 4 + 0][r], dkT[dq * 4 + 1][r], dkT[dq * 4 + 2][r], dkT[dq * 4 + 3][r]};
-        *reinterpret_cast<f32x4*>(drow + 2 * d + col) = f32x4{dvT[dq * 4 + 0][r], dvT[dq * 4 + 1][r], dvT[dq * 4 + 2][r], dvT[dq * 4 + 3][r]};
-      }
-  }
-}
-
-// The whole backward of one item in ONE kernel: the dK/dV sweep above, then -- the staged Q / dO rows being dead -- every
+// The whole backward of one item in ONE kernel: the dK/dV sweep (wave = 16 keys), then -- the staged Q / dO rows being dead -- every
 // wave parks its 16 K rows (still in registers) and its dS column block in their LDS space and turns into a 16-QUERY
 // tile for dQ = dS K.  Neither dS nor K makes a round trip through HBM (bwd_kv + bwd_q: 0.6 GB per Tmall-shape step).
 // BF: the products as single bf16 MFMAs (bf16 mode); H16 (with BF): q/k/v and dO are read and dq/dk/dv written as bf16 arrays
@@ -765,64 +634,6 @@ __global__ __launch_bounds__(256, 2) void attn_seq_bwd_fused_kernel(const float*
 }
 
 
-// dQ[q][dim] = sum_key dS[q][key] K[key][dim]  (dS already carries 1/sqrt(dk))
-template <int DKT, int NT>
-__global__ __launch_bounds__(256, 3) void attn_seq_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dS,
-                                                             int BH, int T, int d, int heads, const int* __restrict__ key_len,
-                                                             float* __restrict__ dqkv) {
-  using C = SeqCfg<DKT, NT>;
-  constexpr int LD = C::LD, DK = C::DK, DQ = DKT / 4, TP = C::TP;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 4, p = lane & 15;
-  const int bh0 = blockIdx.x * C::PW, ldg = 3 * d;
-  const int slot = wave / NT, tile = wave - slot * NT, bh = bh0 + slot;
-  const bool live = slot < C::PW && bh < BH;
-  int b = live ? bh : 0, h = 0;
-  if (heads > 1) { b = (live ? bh : 0) / heads; h = (live ? bh : 0) - b * heads; }
-  const int q = tile * 16 + p;
-  const bool qok = live && q < T;
-  const int nkeys = live ? (key_len ? min(key_len[b], T) : T) : 0;
-  f32x4 dsT[NT];
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-    dsT[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (qok && kt * 16 < nkeys) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(dS + ((size_t)bh * TP + q) * TP + kt * 16 + 4 * j);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) dsT[kt][s] = (kt * 16 + 4 * j + s < nkeys) ? v[s] : 0.f;
-    }
-  }
-  stage_seq2<DKT, NT, false, false>(Ks, qkv, ldg, d, nullptr, nullptr, 0, 0, bh0, BH, T, heads, tid);
-  __syncthreads();
-  if (!live) return;
-  const float* Kp = Ks + slot * TP * LD;
-  f32x4 dqT[DKT];
-#pragma unroll
-  for (int i = 0; i < DKT; ++i) dqT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kt = 0; kt < NT; ++kt) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int dq = 0; dq < DQ; ++dq) {
-        const f32x4 kv = *reinterpret_cast<const f32x4*>(Kp + (kt * 16 + 4 * j + s) * LD + dq * 64 + 4 * p);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) dqT[dq * 4 + t] = mfma16(kv[t], dsT[kt][s], dqT[dq * 4 + t]);
-      }
-    __builtin_amdgcn_sched_barrier(0);       // keep the LDS reads of later tiles from being hoisted (register pressure)
-  }
-  if (qok) {
-    float* drow = dqkv + ((size_t)b * T + q) * ldg + h * DK;
-#pragma unroll
-    for (int dq = 0; dq < DQ; ++dq)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(drow + dq * 64 + 16 * j + 4 * r) =
-            f32x4{dqT[dq * 4 + 0][r], dqT[dq * 4 + 1][r], dqT[dq * 4 + 2][r], dqT[dq * 4 + 3][r]};
-  }
-}
-
 }  // namespace
 
 #define SEQ_DISPATCH3(DKT_RT, NT_RT, LS_RT, ...)                                        \
@@ -884,8 +695,7 @@ size_t attn_seq_bwd_scratch_floats(int B, int T, int heads) {
 
 // scratch: attn_seq_bwd_scratch_floats(B, T, heads) floats (the dS tiles)
 bool attn_seq_packed_supported(int T, int dk) {
-  static const int fused = [] { const char* e = getenv("INTEL_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
-  return fused && attn_seq_supported(T, dk);
+  return attn_seq_supported(T, dk);
 }
 
 bool attn_seq_h16_supported(int T, int dk) { return attn_seq_packed_supported(T, dk) && gemm_planes() == 1; }
@@ -897,8 +707,7 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
   const int dk = d / heads, dkt = dk / 16, BH = B * heads;
   const int nt = cdiv(T, 16), ls = cdiv(T - (nt - 1) * 16, 4);
   const float scale = 1.0f / sqrtf((float)dk);
-  static const int fused = [] { const char* e = getenv("INTEL_ATTN_FUSED_BWD"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (fused) {
+  {
     SEQ_DISPATCH3(dkt, nt, ls, {
       using C = SeqCfg<DKT, NT>;
       const size_t smem = (size_t)(C::ROWS * C::LD + C::OSZ + (1 + NT) * C::ROWS) * sizeof(float);
@@ -916,20 +725,4 @@ int launch_attn_seq_bwd(const float* qkv, const float* out, const float* dout, c
     INTEL_CHECK_LAUNCH();
     return 0;
   }
-  SEQ_DISPATCH3(dkt, nt, ls, {
-    using C = SeqCfg<DKT, NT>;
-    const size_t smem = (size_t)(2 * C::ROWS * C::LD + 2 * C::ROWS) * sizeof(float);
-    allow_lds((attn_seq_bwd_kv_kernel<DKT, NT, LS>), smem);
-    LAUNCH_S(BH, T, dk, 8.0 * B * T * (double)T * d, 28.0 * B * T * (double)d, (attn_seq_bwd_kv_kernel<DKT, NT, LS>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, out, dout, lse, BH, T, d, heads, key_len, scale * 1.44269504088896340736f, scale, dqkv, dS);
-  });
-  INTEL_CHECK_LAUNCH();
-  SEQ_DISPATCH3(dkt, nt, 4, {
-    using C = SeqCfg<DKT, NT>;
-    const size_t smem = (size_t)C::ROWS * C::LD * sizeof(float);
-    (void)LS;
-    allow_lds((attn_seq_bwd_q_kernel<DKT, NT>), smem);
-    LAUNCH_S(BH, T, dk, 2.0 * B * T * (double)T * d, 8.0 * B * T * (double)d, (attn_seq_bwd_q_kernel<DKT, NT>), dim3(cdiv(BH, C::PW)), dim3(256), smem, st, qkv, dS, BH, T, d, heads, key_len, dqkv);
-  });
-  INTEL_CHECK_LAUNCH();
-  return 0;
 }

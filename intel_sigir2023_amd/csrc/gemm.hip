@@ -1387,202 +1387,6 @@ static int launch_w8k(const GemmRowsArgs& a, hipStream_t st) {
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// gemm_rows_w8g: the w8 kernel with the A tile loaded DIRECT-TO-LDS (global_load_lds_dwordx4, LDS-DMA):
-// no prefetch registers, no ds_write pass, and -- what matters -- no compiler-placed vmcnt wait between
-// the loads and the MFMAs: the DMA of tile t+2 is issued right after the barrier that retires tile t
-// and is waited for by ONE explicit vmcnt(0) after the MFMAs of tile t+1.
-// An LDS-DMA writes wave-base + lane*16 linearly, so the tile rows are unpadded (K*4 bytes) and bank
-// conflicts are avoided by an XOR swizzle of the 16-byte chunk index with (row & 15), applied to the
-// per-lane SOURCE address when loading and to the chunk index when reading fragments (cdna guide,
-// rule 21: swizzle both sides or neither).  K in {64, 128}.
-// ------------------------------------------------------------------------------------------
-template <int RT, bool LN>
-__global__ __launch_bounds__(512, 4) void gemm_rows_w8g_kernel(GemmRowsArgs a) {
-  constexpr int RG = 4 / RT;
-  constexpr int CT = 8 / RG;
-  constexpr int BUF = GR_BM * GR_LDA;           // floats per buffer (also holds the padded LayerNorm tile)
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = wave / RG, rg = wave % RG;
-  const int KG = a.K >> 4;                      // 4 or 8
-  const int cpr = a.K >> 2;                     // 16-byte chunks per row: 16 or 32
-  const int ipw = cpr >> 3;                     // DMA instructions per wave per tile: 2 or 4
-  const int NT = (a.N + 15) >> 4;
-  const int nc = blockIdx.y * CT;
-  const int ntc = min(CT, NT - nc);
-  const bool active = ct < ntc;
-  const GemmEpilogue& ep = a.ep;
-  f32x4 bfr[8];
-#pragma unroll
-  for (int g = 0; g < 8; ++g)
-    bfr[g] = (g < KG && active) ? reinterpret_cast<const f32x4*>(a.Bp)[((size_t)(nc + ct) * KG + g) * 64 + lane] : f32x4{0.f, 0.f, 0.f, 0.f};
-  // DMA slots of this lane: instruction q = wave*ipw + j covers linear chunks [q*64, q*64+64)
-  int drow[4], dcol[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int lin = (wave * ipw + j) * 64 + lane;
-    const int R = lin / cpr, pch = lin - R * cpr;
-    drow[j] = R;
-    dcol[j] = (pch ^ (R & 15)) * 4;             // source column of the chunk that lands at physical chunk pch
-  }
-  const int ntiles = (a.M + GR_BM - 1) / GR_BM;
-  int t = blockIdx.x;
-  if (t >= ntiles) return;
-  auto dma_tile = [&](int tt, float* As) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < ipw && !(a.dbg & 4)) {
-        const int row = min(tt * GR_BM + drow[j], a.M - 1);
-        __builtin_amdgcn_global_load_lds(a.A + (size_t)row * a.lda + dcol[j], As + (wave * ipw + j) * 256, 16, 0, 0);
-      }
-    }
-  };
-  const float* auxp = ep.mask ? ep.mask : (ep.res ? ep.res : (ep.accumulate ? a.C : nullptr));
-  const int auxld = ep.mask ? ep.ldmask : (ep.res ? ep.ldres : a.ldc);
-  const int mode = ep.mask ? 1 : (ep.res ? 2 : (ep.accumulate ? 3 : 0));
-  const int col = (nc + ct) * 16 + 4 * (lane >> 4);
-  const bool colok = active && col < a.N;
-  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (!LN && ep.bias && colok) bias = *reinterpret_cast<const f32x4*>(ep.bias + col);
-  // fragment read offsets (floats) of this lane inside a buffer, without the k-group term
-  int frow[RT], fswz[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int r = (rg * RT + rt) * 16 + (lane & 15);
-    frow[rt] = r * a.K;
-    fswz[rt] = r & 15;
-  }
-  const int jl = lane >> 4;
-
-  dma_tile(t, smem);
-  if (t + (int)gridDim.x < ntiles) dma_tile(t + gridDim.x, smem + BUF);
-  __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): B fragments, bias and both first tiles
-  __syncthreads();
-  int buf = 0;
-  for (; t < ntiles; t += gridDim.x) {
-    float* As = smem + buf * BUF;
-    f32x4 acc[RT];
-#pragma unroll
-    for (int i = 0; i < RT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (active && !(a.dbg & 2)) {
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        if (g < KG) {
-          f32x4 af[RT];
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-            af[rt] = *reinterpret_cast<const f32x4*>(As + frow[rt] + (((g * 4 + jl) ^ fswz[rt]) << 2));
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt] = mfma16(bfr[g][s], af[rt][s], acc[rt]);
-        }
-      }
-    }
-    // the DMA into the OTHER buffer (tile t+S, issued one iteration ago) and the previous tile's stores
-    // have had a whole MFMA phase to finish: retire them before this tile's stores are issued
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_sched_barrier(0);
-    const int m0 = t * GR_BM;
-    if (a.dbg & 1) {
-      if (acc[0][0] == 12345.678f) a.C[0] = 1.f;       // ablation: keep the accumulators live, no stores
-    } else if (!LN) {
-      if (colok) {
-        f32x4 aux[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
-          aux[rt] = (mode && row < a.M) ? *reinterpret_cast<const f32x4*>(auxp + (size_t)row * auxld + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          const int row = m0 + (rg * RT + rt) * 16 + (lane & 15);
-          f32x4 x = acc[rt] + bias;
-          if (ep.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = fmaxf(x[r], 0.f);
-          }
-          if (mode == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) x[r] = aux[rt][r] > 0.f ? x[r] : 0.f;
-          } else {
-            x += aux[rt];
-          }
-          if (row < a.M) *reinterpret_cast<f32x4*>(a.C + (size_t)row * a.ldc + col) = x;
-        }
-      }
-    } else {
-      __syncthreads();                 // all waves are done reading this A buffer
-      float* Es = As;
-      if (active) {
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-          *reinterpret_cast<f32x4*>(Es + ((rg * RT + rt) * 16 + (lane & 15)) * GR_LDE + ct * 16 + 4 * (lane >> 4)) = acc[rt];
-      }
-      const int ncols = a.N;
-      const bool ok0 = lane < ncols, ok1 = lane + 64 < ncols;
-      float res0[8], res1[8];
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int row = m0 + wave * 8 + rr;
-        const bool rok = row < a.M && ep.res != nullptr;
-        res0[rr] = (rok && ok0) ? ep.res[(size_t)row * ep.ldres + lane] : 0.f;
-        res1[rr] = (rok && ok1) ? ep.res[(size_t)row * ep.ldres + lane + 64] : 0.f;
-      }
-      const float bias0 = (ep.bias && ok0) ? ep.bias[lane] : 0.f, bias1 = (ep.bias && ok1) ? ep.bias[lane + 64] : 0.f;
-      const float g0 = ok0 ? ep.gamma[lane] : 0.f, g1 = ok1 ? ep.gamma[lane + 64] : 0.f;
-      const float be0 = ok0 ? ep.beta[lane] : 0.f, be1 = ok1 ? ep.beta[lane + 64] : 0.f;
-      __syncthreads();
-      const float inv_n = 1.f / (float)a.N;
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const int r = wave * 8 + rr;
-        const int row = m0 + r;
-        float v0 = 0.f, v1 = 0.f;
-        if (ok0) { v0 = Es[r * GR_LDE + lane] + bias0; if (ep.relu) v0 = fmaxf(v0, 0.f); v0 += res0[rr]; }
-        if (ok1) { v1 = Es[r * GR_LDE + lane + 64] + bias1; if (ep.relu) v1 = fmaxf(v1, 0.f); v1 += res1[rr]; }
-        const float mean = wave_sum(v0 + v1) * inv_n;
-        const float d0 = ok0 ? v0 - mean : 0.f, d1 = ok1 ? v1 - mean : 0.f;
-        const float var = wave_sum(d0 * d0 + d1 * d1) * inv_n;
-        const float rs = 1.f / sqrtf(var + 1e-5f);
-        if (row < a.M) {
-          if (ep.rstd && lane == 0) ep.rstd[row] = rs;
-          if (ok0) {
-            const float xh = d0 * rs;
-            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane] = xh;
-            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane] = xh * g0 + be0;
-          }
-          if (ok1) {
-            const float xh = d1 * rs;
-            if (ep.xhat) ep.xhat[(size_t)row * ep.ldxhat + lane + 64] = xh;
-            if (!ep.no_out) a.C[(size_t)row * a.ldc + lane + 64] = xh * g1 + be1;
-          }
-        }
-      }
-    }
-    __syncthreads();                   // every wave is done with this buffer (fragments / LayerNorm tile)
-    if (t + 2 * (int)gridDim.x < ntiles) dma_tile(t + 2 * gridDim.x, As);
-    buf ^= 1;
-  }
-}
-
-template <int RT, bool LN>
-static int launch_w8g(const GemmRowsArgs& a, hipStream_t st) {
-  constexpr int CT = 8 / (4 / RT);
-  const int ntiles = cdiv(a.M, GR_BM), nchunks = cdiv(rup(a.N, 16) / 16, CT);
-  int gx = ntiles < 512 ? ntiles : 512;
-  if (gx * nchunks > 512) gx = cdiv(512, nchunks) < ntiles ? cdiv(512, nchunks) : ntiles;
-  size_t smem = (size_t)(2 * GR_BM * GR_LDA) * sizeof(float);
-  allow_lds((gemm_rows_w8g_kernel<RT, LN>), smem);
-  LAUNCH_S(a.M, a.N, a.K, 2.0 * a.M * a.N * a.K, gemm_algorithmic_bytes(a),
-           (gemm_rows_w8g_kernel<RT, LN>), dim3(gx, nchunks), dim3(512), smem, st, a);
-  INTEL_CHECK_LAUNCH();
-  return 0;
-}
-
 template <int RT, bool LN>
 static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   constexpr int CT = 8 / (4 / RT);
@@ -1592,8 +1396,7 @@ static int launch_b3(const GemmRowsArgs& a, hipStream_t st) {
   // several column chunks per row tile (N = 3d: the fused q/k/v projection): workgroup (x, y) has linear id x + y * gx and lands
   // on XCD id % 8, so with gx a multiple of 8 the chunks of one row tile -- which walk the same row tiles in step -- share an
   // XCD and its L2: the A tile comes from HBM once instead of once per chunk
-  static const int xcd_align = [] { const char* e = getenv("INTEL_GEMM_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (xcd_align && nchunks > 1 && gx >= 16) gx &= ~7;
+  if (nchunks > 1 && gx >= 16) gx &= ~7;
   const size_t smem = (size_t)3 * GR_BM * B3_LDP * sizeof(__bf16);      // >= the LayerNorm staging tile (64 x 132 floats)
   if (g_planes == 1) {          // bf16 mode (the LayerNorm epilogue tile still needs the full staging area)
     if (a.K == 128) {
@@ -1656,8 +1459,6 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
   const bool vecA = ((lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
   INTEL_CHECK_ARG(!(ep.gamma && (ep.mask || ep.accumulate)), "gemm_rows: LayerNorm epilogue cannot be combined with mask/accumulate");
   if (rup(K, 16) <= GR_KC && vecA && a.vec_ep && (N & 3) == 0 && !((ep.mask || ep.res) && ep.accumulate) && !(ep.mask && ep.res)) {
-    static int use_glds = -1;
-    if (use_glds < 0) { const char* e = getenv("INTEL_GLDS"); use_glds = (e && e[0] == '0') ? 0 : 1; }
     static int use_b3 = -1;
     if (use_b3 < 0) { const char* e = getenv("INTEL_GEMM_B3"); use_b3 = (e && e[0] == '0') ? 0 : 1; }
     if (use_b3 && (K == 128 || K == 64)) {         // bf16 matrix pipe, three-plane split (fp32 accuracy)
@@ -1673,16 +1474,6 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
       if (N > 64) return launch_b3<4, false>(a, st);
       if (N > 32) return launch_b3<2, false>(a, st);
       return launch_b3<1, false>(a, st);
-    }
-    if (use_glds && (K == 128 || K == 64)) {       // direct-to-LDS variant
-      if (ep.gamma) {
-        if (N > 64) return launch_w8g<4, true>(a, st);
-        if (N > 32) return launch_w8g<2, true>(a, st);
-        return launch_w8g<1, true>(a, st);
-      }
-      if (N > 64) return launch_w8g<4, false>(a, st);
-      if (N > 32) return launch_w8g<2, false>(a, st);
-      return launch_w8g<1, false>(a, st);
     }
     if (ep.gamma) {
       if (N > 64) return launch_w8<4, true>(a, st);
@@ -1714,8 +1505,7 @@ int launch_gemm_rows(const float* A, int lda, int M, int K, const float* Bp, int
     if (N > 32) return launch_w8k<2>(a, st);
     return launch_w8k<1>(a, st);
   }
-  static const int use_small = [] { const char* e = getenv("INTEL_GEMM_SMALL"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (use_small && !ep.gamma && M <= 16384) {      // B-row chains: 16-row workgroups (see gemm_rows_small_kernel)
+  if (!ep.gamma && M <= 16384) {      // B-row chains: 16-row workgroups (see gemm_rows_small_kernel)
     if (N <= 32) {
       LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)K * N + (double)M * N), gemm_rows_small_kernel<true>, dim3(cdiv(M, 16)), dim3(256), 0, st, a);
       INTEL_CHECK_LAUNCH();
@@ -1759,8 +1549,7 @@ static inline int wgrad_num_slabs(int M, int N = 128, int K = 128) {
   // several 128-column blocks of dY against a 128-wide X (the fused q/k/v weight gradient, N = 3d): all S x N/128 workgroups
   // should be resident at once (two per CU) -- no half-empty second wave, and the column blocks of one slab, which share an
   // XCD when S is a multiple of 8, read their common X tile through the same L2
-  static const int co = [] { const char* e = getenv("INTEL_WGRAD_CORESIDENT"); return (e && e[0] == '0') ? 0 : 1; }();
-  if (co && N > 128 && K > 64) {
+  if (N > 128 && K > 64) {
     const int ny = cdiv(N, 128), fit = ((2 * 256) / ny) & ~7;
     if (cap > fit) cap = fit;
   }
@@ -1894,135 +1683,6 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
     }
   }
   if (a.want_db && blockIdx.z == 0 && tid < nb) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
-}
-
-// ------------------------------------------------------------------------------------------
-// wgrad_dma_kernel<NTW,KTW>: the same slab product for the shapes that matter (M % 32 == 0, N and K multiples of
-// 32, 16-byte aligned operands) with nothing conditional in the inner loop -- a branch around an accumulating MFMA
-// makes the compiler bounce every accumulator between AGPRs and VGPRs.
-//   * the 32-row dY / X tiles are copied global -> LDS by the DMA path, two stages, one vmcnt(0) + one barrier
-//     per tile; rows are unpadded (a DMA instruction writes 1 KB linearly);
-//   * wave (wn, wk) owns NTW x KTW 16x16 tiles; the operand values of ALL its tiles come from ONE LDS read per
-//     operand per k-step: lane p reads the NTW consecutive dY columns NTW*p .. NTW*p+NTW-1 of its row and feeds them
-//     to the NTW tiles, so row p of tile i is output row NTW*p + i (same for X / columns): the tiles interleave and
-//     the epilogue stores KTW consecutive floats;
-//   * 128-wide rows read with b128 are conflict-free as they are; 64- and 32-wide rows swap their halves on odd
-//     rows (applied to the DMA source column and to the reads) so that the two rows a lane group touches use
-//     disjoint banks.
-// ------------------------------------------------------------------------------------------
-template <int W>
-struct WgVec;
-template <>
-struct WgVec<4> { using T = f32x4; };
-template <>
-struct WgVec<2> { using T = float __attribute__((ext_vector_type(2))); };
-template <>
-struct WgVec<1> { using T = float; };
-template <int W>
-__device__ __forceinline__ float wg_elem(const typename WgVec<W>::T& v, int i) { return v[i]; }
-template <>
-__device__ __forceinline__ float wg_elem<1>(const float& v, int) { return v; }
-
-template <int NTW, int KTW>
-__global__ __launch_bounds__(256, 2) void wgrad_dma_kernel(WgradArgs a) {
-  constexpr int NB = 32 * NTW, KB = 32 * KTW;
-  constexpr int YIW = WG_RT * NB / 4 / 64 / 4, XIW = WG_RT * KB / 4 / 64 / 4;      // DMA instructions per wave per tile
-  constexpr int BUF = WG_RT * (NB + KB);
-  constexpr int SWY = NB == 128 ? 0 : NB / 2, SWX = KB == 128 ? 0 : KB / 2;        // odd rows: halves swapped
-  using VY = typename WgVec<NTW>::T;
-  using VX = typename WgVec<KTW>::T;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.y * NB, k0 = blockIdx.z * KB;
-  const int ntiles = a.M / WG_RT, S = gridDim.x;
-  size_t yoff[YIW], xoff[XIW];
-#pragma unroll
-  for (int j = 0; j < YIW; ++j) {
-    const int lin = (wave * YIW + j) * 64 + lane;
-    const int row = lin / (NB / 4), c = (lin - row * (NB / 4)) * 4;
-    yoff[j] = (size_t)row * a.lddy + n0 + (c ^ ((row & 1) * SWY));
-  }
-#pragma unroll
-  for (int j = 0; j < XIW; ++j) {
-    const int lin = (wave * XIW + j) * 64 + lane;
-    const int row = lin / (KB / 4), c = (lin - row * (KB / 4)) * 4;
-    xoff[j] = (size_t)row * a.ldx + k0 + (c ^ ((row & 1) * SWX));
-  }
-  auto dma_tile = [&](int tt, float* stage) {
-    const float* yb = a.dY + (size_t)tt * WG_RT * a.lddy;
-    const float* xb = a.X + (size_t)tt * WG_RT * a.ldx;
-#pragma unroll
-    for (int j = 0; j < YIW; ++j) {
-      const float* src = yb + yoff[j];
-      float* dst = stage + (wave * YIW + j) * 256;
-      __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < XIW; ++j) {
-      const float* src = xb + xoff[j];
-      float* dst = stage + WG_RT * NB + (wave * XIW + j) * 256;
-      __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
-    }
-  };
-  int t = blockIdx.x;
-  if (t < ntiles) dma_tile(t, smem);
-  if (t + S < ntiles) dma_tile(t + S, smem + BUF);
-  f32x4 acc[NTW][KTW];
-#pragma unroll
-  for (int i = 0; i < NTW; ++i)
-#pragma unroll
-    for (int j = 0; j < KTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbacc = 0.f;
-  const bool do_db = a.want_db && blockIdx.z == 0 && tid < NB;
-  // read offsets of this lane inside a stage: row 4*ms + g, NTW (KTW) consecutive columns
-  const int ycol = (wn * 16 * NTW + NTW * p) ^ ((g & 1) * SWY), xcol = (wk * 16 * KTW + KTW * p) ^ ((g & 1) * SWX);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  int buf = 0;
-  for (; t < ntiles; t += S) {
-    const float* Ys = smem + buf * BUF;
-    const float* Xs = Ys + WG_RT * NB;
-    if (do_db) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < WG_RT; ++r) s += Ys[r * NB + (tid ^ ((r & 1) * SWY))];
-      dbacc += s;
-    }
-#pragma unroll
-    for (int ms = 0; ms < WG_RT / 4; ++ms) {
-      const int row = ms * 4 + g;
-      const VY av = *reinterpret_cast<const VY*>(Ys + row * NB + ycol);
-      const VX bv = *reinterpret_cast<const VX*>(Xs + row * KB + xcol);
-#pragma unroll
-      for (int i = 0; i < NTW; ++i)
-#pragma unroll
-        for (int j = 0; j < KTW; ++j) acc[i][j] = mfma16(wg_elem<NTW>(av, i), wg_elem<KTW>(bv, j), acc[i][j]);
-    }
-    // the copy of tile t+S into the other stage was issued one tile ago
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (t + 2 * S < ntiles) dma_tile(t + 2 * S, smem + buf * BUF);
-    buf ^= 1;
-  }
-  float* slab = a.slabs + (size_t)blockIdx.x * ((size_t)a.N * a.K + a.N);
-#pragma unroll
-  for (int i = 0; i < NTW; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wn * 16 * NTW + NTW * (4 * g + r) + i;
-      float* dst = slab + (size_t)n * a.K + k0 + wk * 16 * KTW + KTW * p;
-      if (KTW == 4) {
-        *reinterpret_cast<f32x4*>(dst) = f32x4{acc[i][0][r], acc[i][KTW > 1 ? 1 : 0][r], acc[i][KTW > 2 ? 2 : 0][r], acc[i][KTW > 3 ? 3 : 0][r]};
-      } else {
-#pragma unroll
-        for (int j = 0; j < KTW; ++j) dst[j] = acc[i][j][r];
-      }
-    }
-  if (do_db) slab[(size_t)a.N * a.K + n0 + tid] = dbacc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2865,7 +2525,6 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
   a.x_bf16 = (io16 >> 1) & 1;
   {
     // fast path: exact 32-row tiles, widths in 32-float steps, 16-byte aligned operands
-    static const int use_dma = [] { const char* e = getenv("INTEL_WGRAD_DMA"); return (e && e[0] == '0') ? 0 : 1; }();
     const bool aligned = ((lddy & 3) == 0) && ((ldx & 3) == 0) && ((reinterpret_cast<uintptr_t>(dY) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(X) & 15) == 0) && ((((size_t)N * K + N) & 3) == 0) &&
                          ((reinterpret_cast<uintptr_t>(slabs) & 15) == 0);
@@ -2951,21 +2610,6 @@ int launch_wgrad(const float* dY, int lddy, const float* X, int ldx, int M, int 
       goto reduce;
     }
     INTEL_CHECK_ARG(!a.dy_bf16 && !a.x_bf16, "wgrad: bf16-stored operands need the bf16-pipe kernel (aligned operands, N and K multiples of 32)");
-    if (use_dma && aligned && M % WG_RT == 0 && N % 32 == 0 && K % 32 == 0) {
-      const int ntw = N % 128 == 0 ? 4 : (N % 64 == 0 ? 2 : 1), ktw = K % 128 == 0 ? 4 : (K % 64 == 0 ? 2 : 1);
-      const dim3 grid(a.S, N / (32 * ntw), K / (32 * ktw));
-      const size_t smem = (size_t)2 * WG_RT * 32 * (ntw + ktw) * sizeof(float);
-#define WG_CASE(A_, B_)                                                                                              \
-  if (ntw == A_ && ktw == B_) {                                                                                      \
-    allow_lds((wgrad_dma_kernel<A_, B_>), smem);                                                                     \
-    LAUNCH_S(M, N, K, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)M * N + (double)K * N), (wgrad_dma_kernel<A_, B_>), grid, \
-             dim3(256), smem, st, a);                                                                                \
-  }
-      WG_CASE(4, 4) WG_CASE(4, 2) WG_CASE(4, 1) WG_CASE(2, 4) WG_CASE(2, 2) WG_CASE(2, 1) WG_CASE(1, 4) WG_CASE(1, 2) WG_CASE(1, 1)
-#undef WG_CASE
-      INTEL_CHECK_LAUNCH();
-      goto reduce;
-    }
   }
   {
   const int nbm = min(128, N), kbm = min(128, K);

@@ -126,6 +126,7 @@ struct IntelCtx {
   hipEvent_t ev_fork, ev_join[3];
   hipEvent_t ev_x[4];          // the wide backward schedule: cross-attention backward of tower 0 / 1 done, d(intent) chain done, item-id table gradient complete
   hipStream_t table_stream = nullptr;      // intel_set_table_stream
+  hipEvent_t table_wait_ev = nullptr;      // intel_set_table_wait_event: the NEXT forward's item-id gathers wait for it (one shot)
   hipEvent_t ev_tab = nullptr;             // ... made to wait on this event where the four-branch schedule is not taken (see backward_entry)
   int streams;      // 0 = not created, 1 = ready, -1 = disabled (INTEL_STREAMS=0)
   // weight-gradient / LayerNorm partial sums of a backward phase, reduced together when the phase ends
@@ -404,6 +405,7 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
+    if (scatter_add_lds_supported(D.class_num, D.d_im)) a += rup_sz(scatter_add_lds_slab_floats(M, D.class_num, D.d_im), 64);      // item-class table partials (rowops.hip)
     a += (size_t)D.layers * (rup_sz(tower_bwd_slab_floats(B, d_i), 64) + rup_sz(tower_bwd_slab_floats(B, d_s), 64));      // ... of the one-kernel backward middles (tower_bwd.hip)
     if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
@@ -694,10 +696,9 @@ void pack_fp32(Run& r) {
 // Training forward with cross attention: the output of a tower's last layer is consumed only by the pooling kernel, which can
 // rebuild it from the LayerNorm's x-hat stash (x = x-hat * gamma + beta).  Then the W2 GEMM does not store the output at all,
 // the pooling kernels read x-hat, and the pooling backward applies the LayerNorm backward to its gradient rows in registers:
-// one [B*L, d] write and three reads less per tower (INTEL_FUSE_TAIL=0 turns it off).
+// one [B*L, d] write and three reads less per tower.
 static bool tail_fusable(const IntelCtx* ctx, const IntelDesc& D, int L, int d, bool train) {
-  static const int on = [] { const char* e = getenv("INTEL_FUSE_TAIL"); return (e && e[0] == '0') ? 0 : 1; }();
-  return on && train && D.cross_attention && D.layers > 0 && !(ctx->drop_p > 0.f) && d <= 128 && xatt_ln_fused_supported(L, d);
+  return train && D.cross_attention && D.layers > 0 && !(ctx->drop_p > 0.f) && d <= 128 && xatt_ln_fused_supported(L, d);
 }
 
 // the training-mode dropout of tower t for the one-kernel 32-wide tower: the same draw as launch_dropout_mask below (stream id = tower *
@@ -1607,6 +1608,11 @@ void forward_impl(Run& r, const IntelOut* out) {
   // ===== four independent branches: the two sequence encoders (predict_intent, IntEL.py:126-155) and the
   // two tied self-attention towers (IntEL.py:170-197) run concurrently on four streams
   const bool lazy_gather = r.ctx->lazy.p != nullptr && r.ctx->lazy_upto > r.ctx->lazy.base && r.P(INTEL_P_IID_EMB) == r.ctx->lazy.p;
+  // The caller's optimizer may still be sweeping the item-id table on another stream (intel_set_table_wait_event): only the two branches that READ
+  // the table wait for it -- the session-history encoder and the score tower start at once, under the sweep (HBM-bound; they are matrix work)
+  auto wait_table = [&](Run& b) {
+    if (r.ctx->table_wait_ev) b.ok((int)hipStreamWaitEvent(b.st, r.ctx->table_wait_ev, 0));
+  };
   auto encoder_branch = [&](Run& r, int e) {
     EncBufs& n = y.enc[e];
     const int rows = r.ctx->enc_rows[e], dm = n.dm;
@@ -1629,6 +1635,7 @@ void forward_impl(Run& r, const IntelOut* out) {
                                   bt.his_item_idx ? nullptr : bt.his_item_int, I, n.pkVec, n.rowT, r.st));
       n.pos_done = pk && D.encoder == INTEL_ENC_BERT4REC && bt.his_item_idx != nullptr;
       const float* pos = n.pos_done ? r.P(enc_slot(e, INTEL_ENC_POS)) : nullptr;
+      wait_table(r);
       // lazy table Adam (intel_set_lazy_table): rows that are behind are replayed inside the gather
       if (lazy_gather)
         RUN(launch_gather_rows_lazy(r.ctx->lazy, r.ctx->lazy_upto, pk ? n.pkIds : bt.his_item_id, rows, n.E0, dm, 0, r.st, pos, n.rowT));
@@ -1657,6 +1664,7 @@ void forward_impl(Run& r, const IntelOut* out) {
     encoder_branch(r, 0);                        // session-history encoder on the caller's stream
     encoder_branch(b1, 1);
     // item tower
+    wait_table(b2);
     if (b2.ok(lazy_gather ? launch_gather_rows_lazy(r.ctx->lazy, r.ctx->lazy_upto, bt.i_id_s, M, ti.X0, ti.d, 0, b2.st, nullptr, nullptr)
                           : launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
         (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st)))) {
@@ -1828,8 +1836,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
   // The weight-gradient products and table scatters of the session head are LEAVES of the dependency graph: nothing in this
   // backward reads their results.  The one-call schedule keeps them off the critical chain (loss -> fusion weights -> cross
   // attention backward -> d(intent) -> encoders): they are collected here and launched once the chain has been enqueued.
-  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
-  const bool wide = phase == 0 && wide_on && ensure_streams(r.ctx);
+  const bool wide = phase == 0 && ensure_streams(r.ctx);
   struct Leaf { std::function<void(Run&)> f; bool shared; };      // shared: writes a slot other branches write too
   std::vector<Leaf> lv_main, lv_score;
   std::vector<Leaf>* defer = wide ? &lv_main : nullptr;
@@ -1976,7 +1983,9 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
     }
     if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB)) {
-      if (bt.cls_sort_ids && bt.cls_sort_rows && vecm)
+      if (scatter_add_lds_supported(D.class_num, D.d_im) && M >= 4096)      // a few hundred class rows: accumulated in LDS, no global atomics (rowops.hip)
+        RUN(launch_scatter_add_lds(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, D.class_num, r.G(INTEL_P_ITEM_EMB), 1, r.ctx->rq, r.st));
+      else if (bt.cls_sort_ids && bt.cls_sort_rows && vecm)
         RUN(launch_scatter_add_sorted(dX0, d, D.d_id, D.d_im, bt.cls_sort_ids, bt.cls_sort_rows, M, r.G(INTEL_P_ITEM_EMB), r.st));
       else
         RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));
@@ -2377,6 +2386,10 @@ extern "C" void* intel_side_stream(IntelCtx* ctx, int i) {
   return (void*)ctx->side[i];
 }
 
+extern "C" void intel_set_table_wait_event(IntelCtx* ctx, void* event) {
+  if (ctx) ctx->table_wait_ev = (hipEvent_t)event;
+}
+
 extern "C" void intel_set_table_stream(IntelCtx* ctx, void* stream) {
   if (ctx) ctx->table_stream = (hipStream_t)stream;
 }
@@ -2478,6 +2491,7 @@ extern "C" int intel_forward(IntelCtx* ctx, const void* const* params, const Int
   Run r{ctx, ctx->d, ctx->lay, params, nullptr, batch, (hipStream_t)stream, 0, &ctx->lay.tmp[0], train};
   gemm_set_planes(ctx->d.dtype == INTEL_DTYPE_BF16 ? 1 : 3);
   forward_impl(r, out);
+  ctx->table_wait_ev = nullptr;      // (one shot: the waits are enqueued)
   gemm_set_planes(3);
   ctx->fwd_done = (r.rc == 0) && train;
   ctx->fB = batch->B; ctx->fL = batch->L; ctx->fH = batch->H; ctx->fHi = batch->Hi;
@@ -2506,10 +2520,9 @@ static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelB
   wgrad_batch_reset();
   gemm_set_planes(3);
   // The caller's table stream (intel_set_table_stream) is promised the finished item-id table gradient.  The four-branch schedule
-  // hands it over as early as possible; every other way through a one-call backward (INTEL_STREAMS=0, INTEL_BWD_WIDE=0) does it
+  // hands it over as early as possible; every other way through a one-call backward (INTEL_STREAMS=0) does it
   // here, after everything: without this wait the caller's optimizer sweep raced the backward (found by the A/B switch tests)
-  static const bool wide_on = [] { const char* e = getenv("INTEL_BWD_WIDE"); return !(e && e[0] == '0'); }();
-  if (r.rc == 0 && phase == 0 && ctx->table_stream && !(wide_on && ctx->streams == 1)) {
+  if (r.rc == 0 && phase == 0 && ctx->table_stream && ctx->streams != 1) {
     if (!ctx->ev_tab && hipEventCreateWithFlags(&ctx->ev_tab, hipEventDisableTiming) != hipSuccess) {
       intel_set_error("intel_backward: event creation failed");
       return INTEL_E_STATE;

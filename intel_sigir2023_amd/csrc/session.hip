@@ -827,8 +827,7 @@ bool pos_grad_supported(int T, int dm) { return dm % 4 == 0 && (size_t)T * dm * 
 int launch_pos_grad(const float* dE, int dm, const int* row_t, const int* len, int T, int rows, float* dpos, hipStream_t st,
                     ReduceQueue* q, const int* off, int B) {
   if (rows <= 0) return 0;
-  static const bool packed_on = [] { const char* e = getenv("INTEL_POS_GRAD_PACKED"); return !(e && e[0] == '0'); }();
-  if (packed_on && off && row_t && B > 0 && dm >= 4 && dm <= 1024 && 1024 % dm == 0 && q) {
+  if (off && row_t && B > 0 && dm >= 4 && dm <= 1024 && 1024 % dm == 0 && q) {
     // four sessions per workgroup up to 512 workgroups (long histories at small batches: the loop over positions is the kernel's latency)
     const int S = (B + 3) / 4 < 1 ? 1 : ((B + 3) / 4 > 512 ? 512 : (B + 3) / 4);
     float* slabs = redq_alloc(q, (size_t)S * T * dm);

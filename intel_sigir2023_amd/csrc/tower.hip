@@ -697,8 +697,7 @@ bool tower_fused_wanted(int train, int d) {
   if (m != 2) return m == 1;
   // fp32 training: the 64-wide tower only (80 KB of LDS: two workgroups per CU; same step time as the kernel-per-op pipeline,
   // 0.4 GB less traffic); the 128-wide one (154 KB, one workgroup per CU) stays on the pipeline (-2.4 % otherwise)
-  static const int d64 = [] { const char* e = getenv("INTEL_FUSE_TOWER_D64"); return (e && e[0] == '0') ? 0 : 1; }();
-  return !train || gemm_planes() == 1 || (d64 && d == 64);
+  return !train || gemm_planes() == 1 || d == 64;
 }
 
 bool tower_fused_supported(int L, int d, int heads) {

@@ -659,7 +659,7 @@ int bwd_mode() {
 // one workgroup per CU (the LDS tile of a session takes more than half a CU's); INTEL_TOWER_BWD_CUS=n: at most n of them (A/B: a tower that is
 // not on the step's critical chain may leave CUs to the branches that are)
 int bwd_grid(int B) {
-  static const int cap = [] { const char* e = getenv("INTEL_TOWER_BWD_CUS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 30; }();
+  static const int cap = [] { const int v = INTEL_DEBUG_ENV("INTEL_TOWER_BWD_CUS", 0); return v > 0 ? v : 1 << 30; }();      // (A/B probe: debug builds only)
   int g = num_cus();
   if (g > cap) g = cap;
   return B < g ? B : g;

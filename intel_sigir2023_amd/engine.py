@@ -33,6 +33,11 @@ class IntELEngine(object):
         self.kl_weight, self.kl_temp = float(g('kl_weight', 0.5)), float(g('kl_temp', 2.0))
         self.cal_diversity, self.alpha = int(g('cal_diversity', 0)), float(g('diversity_alpha', 0.01))
         self.lr, self.l2, self.betas, self.eps = float(lr), float(l2), betas, float(eps)
+        self._table_ev = None          # event behind the item-id table's pending Adam sweep (train_step, one-GPU wide schedule)
+        # Opt-in for loops that call train_step back to back and touch the model only THROUGH the engine / the model's own methods (bench.py, runner.fit):
+        # a step then returns with the item-id table's sweep still running on its side stream and the next forward starts under it.  Code that reads
+        # model.iid_embeddings.weight (or eng.m / eng.v) directly on another stream must call eng.flush() first -- hence off by default.
+        self.defer_table_wait = os.environ.get('INTEL_DEFER_TABLE', '0') == '1'
         self.step_count = 0
         # BPR tie-breaking noise (BPRloss.py:26) drawn inside the loss kernel: one generator per engine, seeded from torch's
         # CPU generator (reproducible under torch.manual_seed) and -- data parallel -- made COMMON to all ranks once, here;
@@ -47,7 +52,6 @@ class IntELEngine(object):
         self._noise_gen.manual_seed(int(seed0.item()))
         self._dp_shape = None
         # two-phase backward + table all-reduce / Adam on a side stream (default); INTEL_OVERLAP_TABLE=0 runs the plain order
-        import os
         self.overlap_table_update = os.environ.get('INTEL_OVERLAP_TABLE', '1') != '0'
         # the one-call backward with its four branches on four streams, the table exchange (data parallel) and sweep underneath
         # its tail; INTEL_BWD_SCHEDULE=phased: the two-call order (table gradient first, its exchange under the second call)
@@ -61,6 +65,10 @@ class IntELEngine(object):
         L.require_gpu(next(model.parameters()))
         self._flatten()
         self._bufs = {}
+        # readers outside train_step (state_dict / load_state_dict / a plain model(batch) forward) are ordered behind a pending table sweep
+        self._sync_hooks = [self.model.register_state_dict_pre_hook(lambda *a, **k: self._table_sync()),
+                            self.model.register_load_state_dict_pre_hook(lambda *a, **k: self._table_sync()),
+                            self.model.register_forward_pre_hook(lambda *a, **k: self._table_sync())]
         # one byte per item-id gradient row: the backward marks the rows it adds into, the table's Adam sweep reads and
         # clears the gradient only there (the other ~95 % of the rows have g = 0): 6 instead of 8 streams over the table
         self._iid_flags = None
@@ -111,8 +119,16 @@ class IntELEngine(object):
         upto = self._lazy.base if settled else self.step_count
         L.check(L.lib().intel_set_lazy_table(self.model._context(), C.byref(self._lazy), upto), 'intel_set_lazy_table')
 
+    def _table_sync(self):
+        """Order the current stream behind the pending sweep of the item-id table (a step's tail left running: train_step).  Everything that reads the
+        table or its optimizer state outside the next training forward comes through here."""
+        if self._table_ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(self._table_ev)
+            self._table_ev = None
+
     def flush(self):
         """Lazy table Adam: every row of the item-id table (and its moments) brought up to the current step.  No-op otherwise."""
+        self._table_sync()
         if self._lazy is None or self._lazy_settled == self.step_count:
             return
         L.check(L.lib().intel_adam_lazy_flush(C.byref(self._lazy), self.step_count, L.stream_ptr(self.device)), 'intel_adam_lazy_flush')
@@ -330,9 +346,11 @@ class IntELEngine(object):
             self.v[gname] = torch.zeros_like(flat)
 
     def buckets(self):
+        self._table_sync()
         return [self.gflat['iid'], self.gflat['decay'], self.gflat['nodecay']]
 
     def param_buckets(self):
+        self._table_sync()
         return [self.flat['iid'], self.flat['decay'], self.flat['nodecay']]
 
     def _buf(self, name, shape, dtype):
@@ -386,6 +404,9 @@ class IntELEngine(object):
         B, Lmax, K, I = ib.B, ib.L, model.model_num, model.intent_num
         items, params, parr, garr = self._param_cache()
         sort_ev = self._sort_scatter_ids(ib, keep)
+        if self._table_ev is not None:      # the previous step's table sweep may still run: only the forward's item-id gathers wait for it
+            lib.intel_set_table_wait_event(model._context(), C.c_void_p(self._table_ev.cuda_event))
+            self._table_ev_keep, self._table_ev = self._table_ev, None
         weights, ens, intents = model.run_forward(ib, keep, params, train=True, items=items, parr=parr)
         model._generation = getattr(model, '_generation', 0) + 1
         st = L.stream_ptr(dev)
@@ -510,7 +531,8 @@ class IntELEngine(object):
                     if tx is not None:
                         tx['t1'].record(side)
                     adam('iid', self.l2, L.stream_ptr(dev), dense_reduced=dp and not sparse)
-                loss_total(L.stream_ptr(dev))
+                if dp or not self.defer_table_wait:
+                    loss_total(L.stream_ptr(dev))
                 if tx is not None:
                     tx['t2'].record(side)
             if tx is not None:
@@ -522,7 +544,15 @@ class IntELEngine(object):
             self._adam_dense_groups(st)
             if tx is not None:
                 tx['m'].record(cur)
-            cur.wait_stream(side)
+            if dp or not self.defer_table_wait:
+                cur.wait_stream(side)
+            else:
+                # The table's sweep (HBM-bound, ~0.3 ms at the 1 M-row table) is NOT waited for here: the next step's forward starts under it -- its
+                # session-history encoder and score tower never touch the table, the item tower's branch runs on this very side stream (stream order),
+                # and the item-history encoder's gather waits for the event below inside intel_forward.  Every other reader goes through _table_sync.
+                loss_total(st)
+                self._table_ev = torch.cuda.Event()
+                self._table_ev.record(side)
             if tx is not None:
                 self._exchange_pending = True
         elif self.overlap_table_update:

@@ -256,9 +256,14 @@ class BaseRunner(object):
                 # (save_model) and load_state_dict() settle the whole table through the engine's hooks
                 self.engine = IntELEngine(model, loss_name or type(criterion).__name__, self.args, lr=self.learning_rate, l2=self.l2,
                                           lazy_table={'0': False, '1': True}.get(os.environ.get('INTEL_ADAM_LAZY', 'auto'), 'auto'))
-            for batch in batches:
-                loss, _, _ = self.engine.train_step(batch)
-                losses.append(loss.detach())
+            self.engine.defer_table_wait = True      # back-to-back steps of one epoch: the next forward starts under the table's sweep (engine.py);
+            try:                                     # everything after the epoch reads the model through the engine's hooks / flush()
+                for batch in batches:
+                    loss, _, _ = self.engine.train_step(batch)
+                    losses.append(loss.detach())
+            finally:
+                self.engine.defer_table_wait = False
+                self.engine.flush()
         else:
             if model.optimizer is None:
                 model.optimizer, model.scheduler = self._build_optimizer(model)

@@ -516,3 +516,50 @@ def test_timeline_records_and_borrowed_stream():
     names = {r['name'].split('[')[0].strip('()').split('<')[0] for r in tl}
     assert {'bpr_loss_kernel', 'adam_rows_kernel', 'slab_reduce_batch_kernel'} <= names
     assert json.loads(lib.intel_prof_timeline().decode()) == []      # cleared
+
+
+@pytest.mark.parametrize('workload,lazy', [('tiny', False), ('tmall', False), ('tmall', True)])
+def test_next_forward_under_the_table_sweep_changes_nothing(workload, lazy):
+    """engine.defer_table_wait (bench.py, runner.fit): a step returns with the item-id table's Adam sweep still running on its side stream; the next
+    forward's item-id gathers wait for it inside intel_forward (intel_set_table_wait_event), the other branches start under it.  Eight steps over
+    three alternating batches, an evaluation and a state_dict in between: losses, evaluation outputs and final parameters equal the engine that
+    waits after every step (up to the order of the embedding scatter's float atomics)."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.engine import IntELEngine
+    from intel_sigir2023_amd.model import IntEL
+    dev = _dev()
+    over = dict(items=30000, users=2000) if workload != 'tiny' else None
+    res = []
+    for defer in (False, True):
+        torch.manual_seed(11)
+        args = synth.make_args(workload, dev)
+        corpus, _ = synth.make_corpus(workload, **(over or {}))
+        model = IntEL(args, corpus).to(dev)
+        eng = IntELEngine(model, 'IntBPRloss', args, lr=1e-3, l2=1e-4, lazy_table=lazy)
+        eng.defer_table_wait = defer
+        batches = [synth.make_batch(workload, 24, dev, seed=60 + i, ragged=True, corpus_over=over) for i in range(3)]
+        held = synth.make_batch(workload, 24, dev, seed=99, ragged=True, corpus_over=over)
+        losses, mid = [], None
+        for step in range(8):
+            l = eng.train_step(batches[step % 3], noise_seed=500 + step)
+            losses.append([float(x) for x in l])
+            if step == 4:
+                out, nd = eng.eval_step(held)
+                mid = ({k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, nd.clone(),
+                       {k: v.detach().clone() for k, v in model.state_dict().items()})
+        assert (eng._table_ev is not None) == defer          # the last step's sweep is still pending in the deferred engine ...
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}      # ... and state_dict() orders itself behind it
+        assert eng._table_ev is None
+        res.append((losses, mid, sd))
+    (l0, m0, s0), (l1, m1, s1) = res
+    for a, b in zip(l0, l1):
+        for x, y in zip(a, b):
+            assert abs(x - y) < 1e-6, (l0, l1)
+    for k in m0[0]:
+        assert float((m0[0][k] - m1[0][k]).abs().max()) < 1e-6, k
+    assert float((m0[1] - m1[1]).abs().max()) < 1e-6
+    for k in s0:
+        # (the attention key biases have no gradient: what they receive is rounding noise, and Adam divides noise by noise -- tests/test_trajectory_gpu.py)
+        tol = 1e-4 if k.endswith('k_linear.bias') else 1e-6
+        assert float((s0[k] - s1[k]).abs().max()) < tol, k
+        assert float((m0[2][k].cpu() - m1[2][k].cpu()).abs().max()) < tol, k

@@ -20,27 +20,16 @@ BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode
 
 CASES = [
     ({'INTEL_GEMM_B3': '0'}, MODEL, [], ['gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel']),                                   # fp32-MFMA row GEMMs (LDS-DMA form)
-    ({'INTEL_GEMM_B3': '0', 'INTEL_GLDS': '0'}, MODEL, [], ['gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'gemm_rows_w8g_kernel']),                # ... register-prefetch form
-    ({'INTEL_WGRAD_B3': '0'}, MODEL, ['wgrad_dma_kernel'], ['wgrad_b3_kernel', 'wgrad_b3_batch_kernel']),                                  # fp32-MFMA weight gradients (LDS-DMA form)
-    ({'INTEL_WGRAD_B3': '0', 'INTEL_WGRAD_DMA': '0'}, MODEL, ['wgrad_pipe_kernel'], ['wgrad_b3_kernel', 'wgrad_b3_batch_kernel', 'wgrad_dma_kernel']),          # ... register-prefetch form
-    ({'INTEL_ATTN_FUSED_BWD': '0', 'INTEL_ENC_FUSED': '0'}, MODEL, ['attn_seq_bwd_kv_kernel', 'attn_seq_bwd_q_kernel'], ['attn_seq_bwd_fused_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel']),    # whole-sequence attention backward as dK/dV kernel + dQ kernel
+    ({'INTEL_WGRAD_B3': '0'}, MODEL, ['wgrad_pipe_kernel'], ['wgrad_b3_kernel', 'wgrad_b3_batch_kernel']),                                  # fp32-MFMA weight gradients (LDS-DMA form)
     ({'INTEL_ATTN_SEQ': '0', 'INTEL_ENC_FUSED': '0'}, MODEL, ['attn_fwd_kernel'], ['attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'attn_seq_bwd_kv_kernel', 'enc_block_fwd_kernel']),          # flash-style general attention for every shape
-    ({'INTEL_ATTN_DS': '0'}, MODEL, [], ['attn_bwd_dq_ds_kernel', 'attn_bwd_dq_ds_p3_kernel']),                                   # general attention backward recomputes S / dP in the dQ pass
     ({'INTEL_ATTN_P3': '0'}, MODEL, ['attn_fwd_kernel', 'attn_bwd_dkv_kernel'], ['attn_fwd_p3_kernel', 'attn_bwd_dkv_p3_kernel', 'attn_bwd_dq_ds_p3_kernel']),                                   # general attention (lists / histories > 64) on exact fp32 MFMAs instead of the three-plane bf16-pipe kernels (attn_p3.hip)
-    ({'INTEL_BWD_WIDE': '0'}, MODEL, [], []),                                  # one-call backward runs its two branch sets one after the other
-    ({'INTEL_FUSE_TAIL': '0'}, MODEL, [], ['xatt_pool_ln_bwd_reg_kernel']),                                 # towers' last LayerNorm as its own store / kernel
-    ({'INTEL_GEMM_SMALL': '0'}, MODEL, ['gemm_rows_kernel'], ['gemm_rows_small_kernel']),                                # odd B-row products on the generic kernel
+    ({'INTEL_WGRAD_SLABS': '64'}, MODEL, [], []),                              # 64 partial slabs per weight gradient instead of 128
     ({'INTEL_STREAMS': '0'}, MODEL, [], []),                                   # whole step on the caller's stream
-    ({'INTEL_POS_GRAD_PACKED': '0'}, MODEL, ['pos_grad_kernel'], ['pos_grad_packed_kernel']),                           # position-embedding gradient through the LDS-atomic kernel
     ({'INTEL_PACK_HISTORY': '0'}, MODEL, [], ['his_pack_kernel', 'enc_block_fwd_kernel']),                              # encoders on the padded [B, H] rows
-    ({'INTEL_GEMM_XCD': '0'}, MODEL, [], []),                                  # row-GEMM grids not rounded to the XCD count
-    ({'INTEL_FUSE_TOWER_D64': '0'}, MODEL, [], ['tower_fwd_fused_kernel']),                            # fp32 training keeps the 64-wide tower on the kernel-per-op pipeline
-    ({'INTEL_ENC_FUSED_BWD': '0'}, MODEL, ['enc_block_fwd_kernel'], ['enc_block_bwd_kernel', 'enc_last_bwd_kernel']),                             # kernel-per-op encoder backward on the fused forward's stash
-    ({'INTEL_WGRAD_SLABS': '64', 'INTEL_WGRAD_CORESIDENT': '0'}, MODEL, [], []),
+    ({'INTEL_ENC_FUSED_BWD': '0'}, MODEL, [], ['enc_block_bwd_kernel', 'enc_last_bwd_kernel']),                             # kernel-per-op encoder backward on the fused forward's stash
     ({'INTEL_MODEL_OP': '1'}, MODEL, [], []),                                  # IntEL.forward through torch.ops.intel_mi355x.intel_forward
     ({'INTEL_STREAMS': '0'}, ENGINE, [], []),                                  # ... the engine's table sweep still has to wait for the backward
-    ({'INTEL_BWD_WIDE': '0'}, ENGINE, [], []),
-    ({'INTEL_ADAM_ROWS': '0'}, ENGINE, [], ['adam_rows_kernel']),                                # dense Adam kernel over the item-id table
+    ({'INTEL_ADAM_ROWS': '0'}, ENGINE, ['adam_kernel'], []),                                # dense Adam kernel over the item-id table
     ({'INTEL_OVERLAP_TABLE': '0'}, ENGINE, [], []),                            # table sweep on the main stream
     ({'INTEL_BWD_SCHEDULE': 'phased'}, ENGINE, [], []),                        # two-call backward
     ({'INTEL_SCATTER_SORTED': '1'}, ENGINE, ['scatter_add_sorted_kernel'], []),                           # always the sorted embedding scatter

@@ -3,12 +3,12 @@
 # branches), the PMC passes (each counter in its own run, kernel-trace only; training steps and evaluation steps
 # separately) and the other workloads.  Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py and a copy into
 # profiles/ follow in the build container.
-tag=${1:-r04}
+tag=${1:-r05}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err < /dev/null
-PMCARGS="--no_cpu_baseline --no_roofline --no_feed --no_bf16_line"
+PMCARGS="--no_cpu_baseline --no_roofline --no_feed --no_bf16_line --no_workloads --spread_blocks 0"
 INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats.log 2>&1 < /dev/null
 INTEL_STREAMS=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_eval -- python3 bench.py --steps 0 --warmup 0 --eval_steps 10 $PMCARGS > $out/stats_eval.log 2>&1 < /dev/null
@@ -24,6 +24,15 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ou
 # the lazy form of the table's Adam forced onto the headline shape (auto keeps the dense sweep there): traffic passes
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_lazy -- python3 bench.py --adam lazy --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch_lazy.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_lazy -- python3 bench.py --adam lazy --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write_lazy.log 2>&1 < /dev/null
+# round 5: the one-kernel tower backward (tower_bwd.hip).  bf16 mode takes it by default, fp32 does not: same-box A/B lines of both modes, the fp32
+# step's HBM traffic and kernel stats with the kernel FORCED on (what it saves in bytes and what it costs in time), the deferred table wait
+timeout 600 python tools/ab_bench.py "--steps 100 --warmup 10 --no_roofline --dtype bf16" INTEL_FUSE_TOWER_BWD=a,0,a,0 > $out/ab_tower_bwd_bf16.txt 2>&1 < /dev/null
+timeout 600 python tools/ab_bench.py "--steps 100 --warmup 10 --no_roofline" INTEL_FUSE_TOWER_BWD=a,1,a,1 > $out/ab_tower_bwd_f32.txt 2>&1 < /dev/null
+INTEL_FUSE_TOWER_BWD=1 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch_fusedbwd -- python3 bench.py --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/fetch_fusedbwd.log 2>&1 < /dev/null
+INTEL_FUSE_TOWER_BWD=1 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write_fusedbwd -- python3 bench.py --steps 3 --warmup 1 --eval_steps 0 $PMCARGS > $out/write_fusedbwd.log 2>&1 < /dev/null
+INTEL_FUSE_TOWER_BWD=1 INTEL_STREAMS=0 INTEL_OVERLAP_TABLE=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats1s_fusedbwd -- python3 bench.py --steps 10 --warmup 3 --eval_steps 0 $PMCARGS > $out/stats1s_fusedbwd.log 2>&1 < /dev/null
+INTEL_FUSE_TOWER_BWD=1 timeout 300 python tools/step_timeline.py f32 train full > $out/timeline_f32_train_fusedbwd.txt 2>&1 < /dev/null
+( for i in 1 2 3; do timeout 200 python bench.py --dtype bf16 --no_cpu_baseline --no_feed --no_workloads --spread_blocks 0 --no_roofline --steps 100 --warmup 10 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 next forward under the table sweep', d['value'], d['ms_per_step'])"; timeout 200 python bench.py --dtype bf16 --no_defer_table --no_cpu_baseline --no_feed --no_workloads --spread_blocks 0 --no_roofline --steps 100 --warmup 10 | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bf16 every step waits for the sweep    ', d['value'], d['ms_per_step'])"; done ) > $out/ab_defer_table.txt 2>&1 < /dev/null
 # the step as it overlaps (HIP-event timeline, branches on their streams)
 timeout 300 python tools/step_timeline.py f32 train full > $out/timeline_f32_train.txt 2>&1 < /dev/null
 timeout 300 python tools/step_timeline.py bf16 train full > $out/timeline_bf16_train.txt 2>&1 < /dev/null

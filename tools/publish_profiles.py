@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else 'r04'
+rnd = sys.argv[2] if len(sys.argv) > 2 else 'r05'
 src = os.path.join('gpurun_out', tag)
 dst = 'profiles'
 
