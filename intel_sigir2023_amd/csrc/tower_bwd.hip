@@ -67,8 +67,14 @@ struct BwdCfg {
   static constexpr size_t P3 = (size_t)NP * PLANE * 2;
   static constexpr size_t F = (size_t)64 * LQ * 4;
   static constexpr size_t DS = (size_t)64 * DSP * 4;
-  static constexpr size_t R12 = 2 * P3 > 3 * F ? 2 * P3 : 3 * F;      // P(A) | P(R1 -> dF1), later fp32 Q | K | V
-  static constexpr size_t R3 = P3 > F + DS ? P3 : F + DS;             // P(dZ), later fp32 dA + dS
+  // bf16 mode (NP = 1, "PA"): the attention operands live as bf16 images too (pitch D + 16: row reads and the accumulator-order transposing reads are
+  // conflict-free), every product of the attention backward is a v_mfma_f32_16x16x32_bf16 -- five slots of one image each + the dS image
+  static constexpr bool PA = NP == 1;
+  static constexpr int LDA = D + 16;
+  static constexpr size_t SLOT = (size_t)64 * LDA * 2;
+  static constexpr size_t DSI = (size_t)64 * 72 * 2;
+  static constexpr size_t R12 = PA ? 5 * SLOT : (2 * P3 > 3 * F ? 2 * P3 : 3 * F);      // P(A) | P(R1 -> dF1), later fp32 Q | K | V
+  static constexpr size_t R3 = PA ? DSI : (P3 > F + DS ? P3 : F + DS);                  // P(dZ), later fp32 dA + dS
   static constexpr size_t STAT = (size_t)(2 * 64 + 4 * 64) * 4;      // lse2 [2][64], dpart [4][64]
   // scope of the kernel beyond dQKV: FULLX = dX = dQKV Wqkv + dZ too, FULLW = the q/k/v weight gradients too (their 3 D^2 accumulators fit the registers
   // at D = 64 only; six-plane operands at D = 128 leave no room for either)
@@ -87,12 +93,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // 32 kb + 8 j + {0, 2, 4, 6, 1, 3, 5, 7} from two transposing reads (ds_read_b64_tr_b16: lane 4q + pp of a 16-lane group names row q, columns
 // 4pp .. 4pp+3 of the group's 4 x 16 block and receives column p of its four rows).  Both operands of a product use the same row order.  The 32 lanes
 // one LDS cycle services touch rows {0, 2, .. 14} + half of a 32-row block: with a pitch of D + 8 bf16 (68 / 36 dwords) they cover all 64 banks once.
-template <int LDP>
+// P8 = false: rows 32 kb + 8 j + {0, 2, 4, 6, 1, 3, 5, 7} (conflict-free at a pitch of D + 8 bf16: 68 / 36 dwords); P8 = true: rows 32 kb + 4 j + {0 .. 3}
+// and 32 kb + 16 + 4 j + {0 .. 3} -- the order in which an S-type accumulator pair (two 16-row tiles) holds its rows, so that probabilities / dS values go
+// from the accumulators straight into the other operand (conflict-free at a pitch of D + 16 bf16: 72 / 40 dwords: eight consecutive rows cover all banks)
+template <int LD, bool P8 = false>
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* plane, int kb, int ct, int p, int j) {
   const int q = p >> 2, pp = p & 3;
-  const __bf16* a0 = plane + (32 * kb + 8 * j + 2 * q) * LDP + ct * 16 + 4 * pp;
+  const __bf16* a0 = plane + (P8 ? (32 * kb + 4 * j + q) : (32 * kb + 8 * j + 2 * q)) * LD + ct * 16 + 4 * pp;
   const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0));
-  const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0 + LDP));
+  const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0 + (P8 ? 16 : 1) * LD));
   return __builtin_bit_cast(bf16x8, tb_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
@@ -109,10 +118,10 @@ __device__ __forceinline__ void wload(const uint4* img, uint4 (&w)[NP]) {
 
 // acc[rt] (lane (p, j): row (rt0 + rt) * 16 + p, columns ct * 16 + 4j .. 4j+3) += planes[row][:] . W[column][:]; img = the image of column tile ct (+ lane),
 // w0 = its first k-block's fragments (wload); NEXT: the first fragments of the image `nimg` are fetched under the last k-block into wn
-template <int D, int NP, int RT, bool NEXT>
+template <int D, int NP, int RT, bool NEXT, int LD = D + 8>
 __device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const uint4 (&w0)[NP], int rt0, int p, int j, f32x4 (&acc)[RT], const uint4* nimg,
                                     uint4 (&wn)[NP]) {
-  constexpr int KB = D / 32, LDP = D + 8, PLANE = 64 * LDP;
+  constexpr int KB = D / 32, LDP = LD, PLANE = 64 * (D + 8);
   const __bf16* frag = pl + (rt0 * 16 + p) * LDP + 8 * j;
   uint4 bw[2][NP];
 #pragma unroll
@@ -139,20 +148,20 @@ __device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const ui
 
 // acc[kt] (lane (p, j): dW[nt * 16 + 4j + r][(kt0 + kt) * 16 + p]) += sum over the 64 rows of Y[row][nt * 16 + .] X[row][(kt0 + kt) * 16 + .];
 // dbp += this lane's share of colsum(Y[:, nt * 16 + p]) (rows 8j .. 8j+7 of every 32-row block)
-template <int D, int NP, int KTL>
+template <int D, int NP, int KTL, int LDY = D + 8, int LDX = D + 8, bool P8 = false>
 __device__ __forceinline__ void wgrad(const __bf16* Y, const __bf16* X, int nt, int kt0, int p, int j, f32x4 (&acc)[KTL], float& dbp) {
-  constexpr int LDP = D + 8, PLANE = 64 * LDP;
+  constexpr int PLANE = 64 * (D + 8);
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
-    const bf16x8 yh = tr_frag<LDP>(Y, kb, nt, p, j);
-    const bf16x8 ym = NP == 3 ? tr_frag<LDP>(Y + PLANE, kb, nt, p, j) : yh;
-    const bf16x8 yl = NP == 3 ? tr_frag<LDP>(Y + 2 * PLANE, kb, nt, p, j) : yh;
+    const bf16x8 yh = tr_frag<LDY, P8>(Y, kb, nt, p, j);
+    const bf16x8 ym = NP == 3 ? tr_frag<LDY, P8>(Y + PLANE, kb, nt, p, j) : yh;
+    const bf16x8 yl = NP == 3 ? tr_frag<LDY, P8>(Y + 2 * PLANE, kb, nt, p, j) : yh;
     dbp += NP == 3 ? (sum8(yl) + sum8(ym)) + sum8(yh) : sum8(yh);
 #pragma unroll
     for (int kt = 0; kt < KTL; ++kt) {
-      const bf16x8 xh = tr_frag<LDP>(X, kb, kt0 + kt, p, j);
-      const bf16x8 xm = NP == 3 ? tr_frag<LDP>(X + PLANE, kb, kt0 + kt, p, j) : xh;
-      const bf16x8 xl = NP == 3 ? tr_frag<LDP>(X + 2 * PLANE, kb, kt0 + kt, p, j) : xh;
+      const bf16x8 xh = tr_frag<LDX, P8>(X, kb, kt0 + kt, p, j);
+      const bf16x8 xm = NP == 3 ? tr_frag<LDX, P8>(X + PLANE, kb, kt0 + kt, p, j) : xh;
+      const bf16x8 xl = NP == 3 ? tr_frag<LDX, P8>(X + 2 * PLANE, kb, kt0 + kt, p, j) : xh;
       acc[kt] = mma<NP>(yh, ym, yl, xh, xm, xl, acc[kt]);
     }
   }
@@ -179,8 +188,17 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
   static_assert(DK == 64 || DK == 128, "head dim 64 / 128");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* pA = reinterpret_cast<__bf16*>(smem_raw);                          // P(A); later P(X)
-  __bf16* pR = reinterpret_cast<__bf16*>(smem_raw + C::P3);                  // P(R1) -> P(dF1)
-  __bf16* pZ = reinterpret_cast<__bf16*>(smem_raw + C::R12);                 // P(dZ)
+  constexpr bool PA = C::PA;
+  constexpr int LDA = C::LDA;
+  __bf16* pR = reinterpret_cast<__bf16*>(smem_raw + (PA ? C::SLOT : C::P3));                // P(R1) -> P(dF1)
+  __bf16* pZ = reinterpret_cast<__bf16*>(smem_raw + (PA ? 2 * C::SLOT : C::R12));           // P(dZ)
+  // PA slots: S0 = P(A) -> P(X), S1 = P(R1 / dF1) -> K, S2 = P(dZ) -> dA -> dK, S3 = Q -> dQ, S4 = V -> dV; dS image behind them
+  __bf16* const S0 = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* const S1 = reinterpret_cast<__bf16*>(smem_raw + C::SLOT);
+  __bf16* const S2 = reinterpret_cast<__bf16*>(smem_raw + 2 * C::SLOT);
+  __bf16* const S3 = reinterpret_cast<__bf16*>(smem_raw + 3 * C::SLOT);
+  __bf16* const S4 = reinterpret_cast<__bf16*>(smem_raw + 4 * C::SLOT);
+  __bf16* const dSi = reinterpret_cast<__bf16*>(smem_raw + 5 * C::SLOT);
   float* fQ = reinterpret_cast<float*>(smem_raw);                            // fp32 rows Q | K | V over P(X) / P(dF1)
   float* fK = fQ + 64 * LQ;
   float* fV = fK + 64 * LQ;
@@ -228,7 +246,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       }
     }
   };
-  auto store_tile = [&](__bf16* dst, auto is16, const f32x4 (&v)[NJ]) {
+  auto store_tile = [&](__bf16* dst, auto is16, const f32x4 (&v)[NJ], auto pitch) {
+    constexpr int LDT = decltype(pitch)::value;
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       int tr, tc;
@@ -239,9 +258,11 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
         x = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
       }
       if (tr >= L) x = f32x4{0.f, 0.f, 0.f, 0.f};
-      store4<NP, PLANE>(dst + tr * LDP + tc, x);
+      store4<NP, PLANE>(dst + tr * LDT + tc, x);
     }
   };
+  using PitchP = std::integral_constant<int, LDP>;
+  using PitchA = std::integral_constant<int, LDA>;
 
   f32x4 accW2[KTL], accW1[KTL];
 #pragma unroll
@@ -288,8 +309,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     wload<NP>(launder(a.W1) + wtile, wf);
     {
       if (tid < 64 * HEADS) lse2[tid] = (tid & 63) < L ? lsev * 1.4426950408889634f : INFINITY;
-      store_tile(pA, std::integral_constant<bool, IO16>{}, va);
-      store_tile(pZ, std::false_type{}, vz);
+      store_tile(pA, std::integral_constant<bool, IO16>{}, va, PitchP{});
+      store_tile(pZ, std::false_type{}, vz, PitchP{});
     }
     lds_barrier();
     mark(0);
@@ -361,12 +382,222 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
         for (int q = 0; q < NP; ++q) wf[q] = wn[q];
       }
       lds_barrier();      // every read of P(A), P(dF1), P(dZ) is done
+      if constexpr (PA) {      // dA as a bf16 image (its consumers round it anyway) and X in the attention pitch: both stay for the tail
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fdA + ((rt0 + rt) * 16 + p) * LQ + col) = acc[rt];
-      store_tile(pA, std::false_type{}, vx);      // P(X)
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4& v = acc[rt];
+          *reinterpret_cast<bf16x4*>(S2 + ((rt0 + rt) * 16 + p) * LDA + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+        store_tile(S0, std::false_type{}, vx, PitchA{});
+      } else {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(fdA + ((rt0 + rt) * 16 + p) * LQ + col) = acc[rt];
+        store_tile(pA, std::false_type{}, vx, PitchP{});      // P(X)
+      }
     }
     lds_barrier();
     mark(3);
+    if constexpr (PA) {
+    // ======== bf16 mode: P4 / P5 / tail on bf16 images, every product a v_mfma_f32_16x16x32_bf16 ========
+    // ---- P4: [Q | K | V] = X Wqkv^T -> bf16 images (X stays in S0: nothing waits for its readers)
+    {
+      if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        f32x4 acc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4* img = a.Wqkv + ((size_t)(c * CTW + ct) * KBT * 3) * 64 + lane;
+        uint4 wn[NP];
+        if (c < 2) lin<D, NP, RT, true, LDA>(S0, img, wf, rt0, p, j, acc, img + ((size_t)CTW * KBT * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDA>(S0, img, wf, rt0, p, j, acc, img, wn);
+        if (c < 2) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+        }
+        __bf16* dst = c == 0 ? S3 : (c == 1 ? S1 : S4);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4& v = acc[rt];
+          *reinterpret_cast<bf16x4*>(dst + ((rt0 + rt) * 16 + p) * LDA + col) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+      }
+    }
+    lds_barrier();
+    mark(4);
+    // ---- P5: attention backward.  Pass 1: wave = (16 keys, half of the head's 16-dim tiles): S and dP for all queries (both halves compute them: a
+    // handful of MFMAs -- cheaper than summing partial dK / dV across waves), P, delta, dS; dV / dK of its dim tiles with the probabilities / dS
+    // values going from the accumulators straight into the B operand (tr_frag<.., true> delivers the A operand's rows in the accumulators' order).
+    // Pass 2: wave = (16 queries, half of the dim tiles): dQ = dS K.  Outputs over the dead inputs: dQ -> Q's slot, dK -> dA's, dV -> V's.
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) {
+      const int hc = h * DK;
+      constexpr int NDT = DK / 16, HDT = NDT / 2;
+      const int kt = wave & 3, dh = wave >> 2;
+      f32x4 st[4], dp[4], dv[HDT], dk[HDT];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) st[i] = dp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < HDT; ++i) dv[i] = dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kt < NTL) {
+#pragma unroll
+        for (int kb = 0; kb < DK / 32; ++kb) {
+          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(S1 + (kt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(S4 + (kt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {
+            if (qt < NTL) {
+              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(S3 + (qt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
+              const bf16x8 df = *reinterpret_cast<const bf16x8*>(S2 + (qt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
+              st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, st[qt], 0, 0, 0);      // S[query qt*16 + 4j + r][key kt*16 + p]
+              dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, dp[qt], 0, 0, 0);
+            }
+          }
+        }
+        const bool keyok = kt * 16 + p < L;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          const int q0 = qt * 16 + 4 * j;
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse2 + h * 64 + q0);
+          f32x4 part;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = keyok ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][r], c2, -l4[r])) : 0.f;
+            st[qt][r] = pv;
+            part[r] = row16_sum(pv * dp[qt][r]);
+          }
+          if (p == 0 && dh == 0) *reinterpret_cast<f32x4*>(dpart + kt * 64 + q0) = part;
+        }
+      }
+      lds_barrier();      // the key tiles' shares of delta
+      if (kt < NTL) {
+        // dS image: row = query, the 64 keys of a row stored in the order the pass-2 B operand wants them (key 32 a + 16 b + 4 c + r -> column 32 a + 8 c + 4 b + r)
+        const int key = kt * 16 + p;
+        const int kcol = 32 * (key >> 5) + 8 * ((key >> 2) & 3) + 4 * ((key >> 4) & 1) + (key & 3);
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          const int q0 = qt * 16 + 4 * j;
+          f32x4 d4 = *reinterpret_cast<const f32x4*>(dpart + q0);
+#pragma unroll
+          for (int k2 = 1; k2 < 4; ++k2)
+            if (k2 < NTL) d4 += *reinterpret_cast<const f32x4*>(dpart + k2 * 64 + q0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float ds = st[qt][r] * (dp[qt][r] - d4[r]) * scale;
+            dp[qt][r] = ds;
+            if (dh == 0) dSi[(q0 + r) * 72 + kcol] = (__bf16)ds;
+          }
+        }
+#pragma unroll
+        for (int kb2 = 0; kb2 < 2; ++kb2) {
+          if (2 * kb2 < NTL) {
+            const bf16x8 pb = bf16x8{(__bf16)st[2 * kb2][0], (__bf16)st[2 * kb2][1], (__bf16)st[2 * kb2][2], (__bf16)st[2 * kb2][3],
+                                     (__bf16)st[2 * kb2 + 1][0], (__bf16)st[2 * kb2 + 1][1], (__bf16)st[2 * kb2 + 1][2], (__bf16)st[2 * kb2 + 1][3]};
+            const bf16x8 db = bf16x8{(__bf16)dp[2 * kb2][0], (__bf16)dp[2 * kb2][1], (__bf16)dp[2 * kb2][2], (__bf16)dp[2 * kb2][3],
+                                     (__bf16)dp[2 * kb2 + 1][0], (__bf16)dp[2 * kb2 + 1][1], (__bf16)dp[2 * kb2 + 1][2], (__bf16)dp[2 * kb2 + 1][3]};
+#pragma unroll
+            for (int dt = 0; dt < HDT; ++dt) {
+              const int ctile = hc / 16 + dh * HDT + dt;
+              dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S2, kb2, ctile, p, j), pb, dv[dt], 0, 0, 0);      // dV[key][dim] += P^T dA
+              dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S3, kb2, ctile, p, j), db, dk[dt], 0, 0, 0);      // dK[key][dim] += dS^T Q
+            }
+          }
+        }
+      }
+      lds_barrier();      // dS complete; this head's reads of Q / dA / V done
+      mark(5);
+      if (kt < NTL) {
+#pragma unroll
+        for (int dt = 0; dt < HDT; ++dt) {
+          const int off = (kt * 16 + p) * LDA + hc + (dh * HDT + dt) * 16 + 4 * j;
+          *reinterpret_cast<bf16x4*>(S4 + off) = bf16x4{(__bf16)dv[dt][0], (__bf16)dv[dt][1], (__bf16)dv[dt][2], (__bf16)dv[dt][3]};
+          *reinterpret_cast<bf16x4*>(S2 + off) = bf16x4{(__bf16)dk[dt][0], (__bf16)dk[dt][1], (__bf16)dk[dt][2], (__bf16)dk[dt][3]};
+        }
+      }
+      mark(6);
+      if (h == HEADS - 1) load_session(min(b + (int)gridDim.x, a.B - 1));      // the next session's tiles travel under the last pass
+      {
+        const int qt = wave & 3;
+        if (qt < NTL) {
+          f32x4 o[HDT];
+#pragma unroll
+          for (int dt = 0; dt < HDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kb2 = 0; kb2 < 2; ++kb2) {
+            if (2 * kb2 < NTL) {
+              const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(dSi + (qt * 16 + p) * 72 + 32 * kb2 + 8 * j);
+#pragma unroll
+              for (int dt = 0; dt < HDT; ++dt)
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S1, kb2, hc / 16 + dh * HDT + dt, p, j), dsf, o[dt], 0, 0, 0);      // dQ[query][dim] += dS K
+            }
+          }
+#pragma unroll
+          for (int dt = 0; dt < HDT; ++dt)
+            *reinterpret_cast<bf16x4*>(S3 + (qt * 16 + p) * LDA + hc + (dh * HDT + dt) * 16 + 4 * j) = bf16x4{(__bf16)o[dt][0], (__bf16)o[dt][1], (__bf16)o[dt][2], (__bf16)o[dt][3]};
+        }
+      }
+      lds_barrier();      // pass 2's reads of dS / K done; dQ / dK / dV of this head complete
+      mark(7);
+    }
+    // ---- dQKV rows (only where the q/k/v weight gradient stays outside): [dQ | dK | dV] from their slots, 16 bytes of bf16 per lane along the row
+    if constexpr (!FULLW) {
+      for (int i = tid; i < L * (D / 8); i += NT) {
+        const int row = i / (D / 8), c8 = (i - row * (D / 8)) * 8;
+        const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(S3 + row * LDA + c8);
+        const bf16x8 k8 = *reinterpret_cast<const bf16x8*>(S2 + row * LDA + c8);
+        const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(S4 + row * LDA + c8);
+        const size_t g = ((size_t)b * L + row) * (3 * D) + c8;
+        if constexpr (IO16) {
+          __bf16* o16 = reinterpret_cast<__bf16*>(a.dQKV);
+          *reinterpret_cast<bf16x8*>(o16 + g) = q8;
+          *reinterpret_cast<bf16x8*>(o16 + g + D) = k8;
+          *reinterpret_cast<bf16x8*>(o16 + g + 2 * D) = v8;
+        } else {
+#pragma unroll
+          for (int hlf = 0; hlf < 2; ++hlf) {
+            *reinterpret_cast<f32x4*>(a.dQKV + g + 4 * hlf) = f32x4{(float)q8[4 * hlf], (float)q8[4 * hlf + 1], (float)q8[4 * hlf + 2], (float)q8[4 * hlf + 3]};
+            *reinterpret_cast<f32x4*>(a.dQKV + g + D + 4 * hlf) = f32x4{(float)k8[4 * hlf], (float)k8[4 * hlf + 1], (float)k8[4 * hlf + 2], (float)k8[4 * hlf + 3]};
+            *reinterpret_cast<f32x4*>(a.dQKV + g + 2 * D + 4 * hlf) = f32x4{(float)v8[4 * hlf], (float)v8[4 * hlf + 1], (float)v8[4 * hlf + 2], (float)v8[4 * hlf + 3]};
+          }
+        }
+      }
+    }
+    // ---- tail: dX = dQ Wq + dK Wk + dV Wv + dZ and (FULLW) dWq / dWk / dWv += dQ^T X, dK^T X, dV^T X straight from the images (X is still in S0)
+    {
+      constexpr int KBT3 = 4 * ((3 * D + 127) / 128), KB = D / 32;
+      const uint4* imgT = launder(a.WqkvT) + ((size_t)ct * KBT3 * 3) * 64 + lane;
+      uint4 wq[NP];
+      wload<NP>(imgT, wq);
+      f32x4 accX[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) accX[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const __bf16* src = c == 0 ? S3 : (c == 1 ? S2 : S4);
+        uint4 wn[NP];
+        if (c < 2) lin<D, NP, RT, true, LDA>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDA>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
+        if (c < 2) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) wq[q] = wn[q];
+        }
+        if constexpr (FULLW) {
+          float nodb = 0.f;
+          wgrad<D, NP, KTL, LDA, LDA, true>(src, S0, wnt, wkt0, p, j, accWqkv[c], nodb);
+        }
+      }
+      lds_barrier();      // every read of the three gradient images (and of K) is done: dX is staged as fp32 rows over the K / dK slots
+      float* stage = reinterpret_cast<float*>(S1);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *reinterpret_cast<f32x4*>(stage + ((rt0 + rt) * 16 + p) * LQ + col) = accX[rt];
+      lds_barrier();
+      for (int i = tid; i < L * (D / 4); i += NT) {
+        const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+        const size_t g = ((size_t)b * L + row) * D + c4;
+        *reinterpret_cast<f32x4*>(a.dX + g) = *reinterpret_cast<const f32x4*>(stage + row * LQ + c4) + *reinterpret_cast<const f32x4*>(a.dZ + g);
+      }
+    }
+    } else {
     // ---- P4: [Q | K | V] = X Wqkv^T -> fp32 rows
     {
       if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
@@ -583,7 +814,7 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       if constexpr (FULLW) {
         f32x4 vx[NJ];
         load_tile(a.X, b, std::false_type{}, vx);
-        store_tile(pX2, std::false_type{}, vx);
+        store_tile(pX2, std::false_type{}, vx, PitchP{});
       }
       f32x4 accX[RT];
 #pragma unroll
@@ -619,6 +850,7 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
         const size_t g = ((size_t)b * L + row) * D + c4;
         *reinterpret_cast<f32x4*>(a.dX + g) = *reinterpret_cast<const f32x4*>(fQ + row * LQ + c4) + *reinterpret_cast<const f32x4*>(a.dZ + g);
       }
+    }
     }
     lds_barrier();      // the next session's tiles go over the regions the copy still read
   }

@@ -48,7 +48,8 @@ def one(pattern):
 
 
 for sub, out in (('stats1s', 'bench_tmall_kernel_stats.csv'), ('stats', 'bench_tmall_kernel_stats_concurrent.csv'), ('stats1s_pub', 'bench_tmall_pub_kernel_stats.csv'), ('stats1s_pub_mse', 'bench_tmall_pub_mse_kernel_stats.csv'),
-                 ('stats_eval', 'bench_tmall_eval_kernel_stats.csv'), ('stats1s_bf16', 'bench_tmall_bf16_kernel_stats.csv')):
+                 ('stats_eval', 'bench_tmall_eval_kernel_stats.csv'), ('stats1s_bf16', 'bench_tmall_bf16_kernel_stats.csv'),
+                 ('stats1s_fusedbwd', 'bench_tmall_fused_tower_bwd_forced_kernel_stats.csv')):
     f = one('%s/**/*kernel_stats.csv' % sub)
     if f:
         shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, out)))
@@ -66,11 +67,14 @@ if fb and wb:
 fl, wl = one('fetch_lazy/**/*counter_collection.csv'), one('write_lazy/**/*counter_collection.csv')
 if fl and wl:
     subprocess.run([sys.executable, 'tools/pmc_summary.py', fl, wl, '4', os.path.join(dst, '%s_pmc_traffic_lazy_adam.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
-for name in ('gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_enc32.txt', 'ab_attn_p3_lifedata.txt', 'ab_attn_p3_stress.txt', 'attn_bench_long.txt'):
+ff, wf = one('fetch_fusedbwd/**/*counter_collection.csv'), one('write_fusedbwd/**/*counter_collection.csv')
+if ff and wf:
+    subprocess.run([sys.executable, 'tools/pmc_summary.py', ff, wf, '4', os.path.join(dst, '%s_pmc_traffic_fused_tower_bwd_forced.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
+for name in ('ab_tower_bwd_bf16.txt', 'ab_tower_bwd_f32.txt', 'ab_defer_table.txt', 'gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_enc32.txt', 'ab_attn_p3_lifedata.txt', 'ab_attn_p3_stress.txt', 'attn_bench_long.txt'):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, name)))
-for t in ('f32_train', 'bf16_train', 'f32_eval', 'pub_f32_train', 'pub_f32_eval', 'pub_mse_f32_train'):
+for t in ('f32_train_fusedbwd', 'f32_train', 'bf16_train', 'f32_eval', 'pub_f32_train', 'pub_f32_eval', 'pub_mse_f32_train'):
     f = os.path.join(src, 'timeline_%s.txt' % t)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_timeline_%s.txt' % (rnd, t)))
