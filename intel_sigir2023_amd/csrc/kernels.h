@@ -193,12 +193,6 @@ int launch_bcast_rows(const float* src, int lds, int d, int B, int T, float* dst
 // grad_table[idx[m], :] += src[m, col0:col0+d] (* (relu_src>0) if relu_src given) ; atomics
 int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const int* idx, int M, float* grad_table,
                             const float* relu_out, int ldr, int rcol0, hipStream_t st, unsigned char* row_flags = nullptr);
-// small tables (rows_t * d * 4 <= 144 KB: the item-class table): the whole table accumulated in LDS per workgroup, partial tables to the reduce queue --
-// no global atomics, fixed summation order; grad_table is valid after the queue's flush
-bool scatter_add_lds_supported(int rows_t, int d);
-size_t scatter_add_lds_slab_floats(int M, int rows_t, int d);
-int launch_scatter_add_lds(const float* src, int lds, int col0, int d, const int* idx, int M, int rows_t, float* grad_table, int accumulate,
-                           ReduceQueue* q, hipStream_t st);
 // the same with (id, source row) pairs sorted by id: runs of equal ids are summed in registers before the atomics
 // (row_off / len / T: the source rows are packed history rows, pair row b*T + t -> source row row_off[b] + t)
 int launch_scatter_add_sorted(const float* src, int lds, int col0, int d, const int* sorted_ids, const int* sorted_rows, int n,

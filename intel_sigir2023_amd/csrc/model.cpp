@@ -405,7 +405,6 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
-    if (scatter_add_lds_supported(D.class_num, D.d_im)) a += rup_sz(scatter_add_lds_slab_floats(M, D.class_num, D.d_im), 64);      // item-class table partials (rowops.hip)
     a += (size_t)D.layers * (rup_sz(tower_bwd_slab_floats(B, d_i), 64) + rup_sz(tower_bwd_slab_floats(B, d_s), 64));      // ... of the one-kernel backward middles (tower_bwd.hip)
     if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
@@ -1983,9 +1982,7 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         RUN(launch_scatter_add_rows(dX0, d, 0, D.d_id, bt.i_id_s, M, r.G(INTEL_P_IID_EMB), nullptr, 0, 0, r.st, r.ctx->iid_row_flags));
     }
     if (D.d_im > 0 && r.G(INTEL_P_ITEM_EMB)) {
-      if (scatter_add_lds_supported(D.class_num, D.d_im) && M >= 4096)      // a few hundred class rows: accumulated in LDS, no global atomics (rowops.hip)
-        RUN(launch_scatter_add_lds(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, D.class_num, r.G(INTEL_P_ITEM_EMB), 1, r.ctx->rq, r.st));
-      else if (bt.cls_sort_ids && bt.cls_sort_rows && vecm)
+      if (bt.cls_sort_ids && bt.cls_sort_rows && vecm)
         RUN(launch_scatter_add_sorted(dX0, d, D.d_id, D.d_im, bt.cls_sort_ids, bt.cls_sort_rows, M, r.G(INTEL_P_ITEM_EMB), r.st));
       else
         RUN(launch_scatter_add_rows(dX0, d, D.d_id, D.d_im, bt.i_class_c, M, r.G(INTEL_P_ITEM_EMB), nullptr, 0, 0, r.st));

@@ -106,55 +106,6 @@ int launch_scatter_add_rows(const float* src, int lds, int col0, int d, const in
   return 0;
 }
 
-// Small table (item_embeddings: 357 classes at Tmall shape, 204 800 gradient rows per step -- every global atomic of the kernel above lands on
-// one of a few hundred addresses and serialises at the memory side: 99 us on the item tower's chain).  Here a workgroup keeps the WHOLE table in LDS,
-// adds its share of the source rows with LDS atomics (ds_add_f32) and leaves one partial table per workgroup for the batched slab reduction:
-// no global atomic at all, and the sum's order is fixed by the reduction (bitwise reproducible, unlike the atomics).
-__global__ __launch_bounds__(256) void scatter_add_lds_kernel(const float* __restrict__ src, int lds, int col0, int d, const int* __restrict__ idx,
-                                                              int M, int rows_t, float* __restrict__ slabs) {
-  extern __shared__ __attribute__((aligned(16))) float tab[];
-  const int n = rows_t * d;
-  for (int i = threadIdx.x; i < n; i += 256) tab[i] = 0.f;
-  __syncthreads();
-  const int lpr = d >> 2;                          // lanes per source row (float4 each)
-  const int sub = threadIdx.x % lpr, rpb = 256 / lpr;
-  for (long long m = (long long)blockIdx.x * rpb + threadIdx.x / lpr; m < M; m += (long long)gridDim.x * rpb) {
-    const int row = idx[m];
-    if (row < 0 || row >= rows_t) continue;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)m * lds + col0 + 4 * sub);
-    float* dst = tab + row * d + 4 * sub;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) __hip_atomic_fetch_add(dst + c, v[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  __syncthreads();
-  float* out = slabs + (size_t)blockIdx.x * n;
-  for (int i = threadIdx.x * 4; i < n; i += 1024) *reinterpret_cast<f32x4*>(out + i) = *reinterpret_cast<const f32x4*>(tab + i);
-}
-static int scatter_lds_grid(int M) {
-  const int g = num_cus() / 2;      // half the chip: the kernel is short and runs beside the backward's other branches
-  const int need = (M + 255) / 256;
-  return need < g ? (need < 1 ? 1 : need) : g;
-}
-bool scatter_add_lds_supported(int rows_t, int d) { return d >= 16 && d <= 256 && 256 % (d >> 2) == 0 && d % 4 == 0 && (size_t)rows_t * d * 4 <= 144 * 1024 && (rows_t * d) % 4 == 0; }
-size_t scatter_add_lds_slab_floats(int M, int rows_t, int d) { return (size_t)scatter_lds_grid(M) * rows_t * d; }
-// grad_table (+)= the scatter-add; valid after the queue's flush
-int launch_scatter_add_lds(const float* src, int lds, int col0, int d, const int* idx, int M, int rows_t, float* grad_table, int accumulate,
-                           ReduceQueue* q, hipStream_t st) {
-  if (M <= 0) return 0;
-  INTEL_CHECK_ARG(q && scatter_add_lds_supported(rows_t, d), "scatter_add_lds: table of %d x %d unsupported", rows_t, d);
-  INTEL_CHECK_ARG((lds & 3) == 0 && (col0 & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0, "scatter_add_lds: misaligned source");
-  const int grid = scatter_lds_grid(M);
-  float* slabs = redq_alloc(q, (size_t)grid * rows_t * d);
-  INTEL_CHECK_ARG(slabs != nullptr, "scatter_add_lds: reduce arena exhausted");
-  const size_t smem = (size_t)rows_t * d * sizeof(float);
-  allow_lds(scatter_add_lds_kernel, smem);
-  LAUNCH_W(0.0, 4.0 * (double)M * d + 4.0 * M + 4.0 * (double)grid * rows_t * d, scatter_add_lds_kernel, dim3(grid), dim3(256), smem, st, src, lds, col0, d, idx, M,
-           rows_t, slabs);
-  INTEL_CHECK_LAUNCH();
-  redq_push(q, slabs, (size_t)rows_t * d, grid, rows_t, d, grad_table, d, accumulate);
-  return 0;
-}
-
 // The same with the (id, source row) pairs SORTED by id (the caller sorts the batch's ids once per step, off the critical
 // path): a group of d/4 lanes walks SS_CH consecutive pairs, sums runs of equal ids in registers and issues one row of float
 // atomics per run.  Distinct ids cost what they cost above; a popular id (Zipf item popularity: the top item of a 286 720-row

@@ -109,39 +109,62 @@ __device__ __forceinline__ float sum8(const bf16x8& v) {
   return (((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3])) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
 }
 
-// the first k-block's weight fragments of a column tile's image (issued ahead of the phase that uses them: one L2 round trip off the phase)
-template <int NP>
-__device__ __forceinline__ void wload(const uint4* img, uint4 (&w)[NP]) {
+// The weight fragments of a column tile's image that a linear holds BEFORE it starts: k-blocks 0 .. WN - 1 (issued one phase ahead: their L2 round trip is
+// off the phase).  fp32 mode (three planes, registers are scarce): the first k-block, the rest streams one k-block ahead of its MFMAs; bf16 mode (one
+// plane): ALL k-blocks -- a phase of 16 MFMAs per wave was four dependent L2 round trips long otherwise.
+template <int NP, int WN>
+struct WFrag { uint4 v[WN][NP]; };
+template <int NP, int WN>
+__device__ __forceinline__ void wload(const uint4* img, WFrag<NP, WN>& w) {
 #pragma unroll
-  for (int q = 0; q < NP; ++q) w[q] = img[q * 64];
+  for (int kb = 0; kb < WN; ++kb)
+#pragma unroll
+    for (int q = 0; q < NP; ++q) w.v[kb][q] = img[(kb * 3 + q) * 64];
 }
 
 // acc[rt] (lane (p, j): row (rt0 + rt) * 16 + p, columns ct * 16 + 4j .. 4j+3) += planes[row][:] . W[column][:]; img = the image of column tile ct (+ lane),
-// w0 = its first k-block's fragments (wload); NEXT: the first fragments of the image `nimg` are fetched under the last k-block into wn
-template <int D, int NP, int RT, bool NEXT, int LD = D + 8>
-__device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const uint4 (&w0)[NP], int rt0, int p, int j, f32x4 (&acc)[RT], const uint4* nimg,
-                                    uint4 (&wn)[NP]) {
+// w0 = its first WN k-blocks' fragments (wload); NEXT: the fragments of the image `nimg` are fetched meanwhile into wn (WN = all k-blocks: at the start of
+// this linear, otherwise under its last k-block)
+template <int D, int NP, int RT, bool NEXT, int LD = D + 8, int WN = 1>
+__device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const WFrag<NP, WN>& w0, int rt0, int p, int j, f32x4 (&acc)[RT], const uint4* nimg,
+                                    WFrag<NP, WN>& wn) {
   constexpr int KB = D / 32, LDP = LD, PLANE = 64 * (D + 8);
   const __bf16* frag = pl + (rt0 * 16 + p) * LDP + 8 * j;
+  if (NEXT && WN == KB) wload<NP, WN>(nimg, wn);
+  if constexpr (NP == 1 && WN == KB) {
+    // one plane, every weight fragment in registers: ALL activation fragments are requested before the first product (16 b128 reads in flight instead
+    // of a read -> wait -> MFMA chain per fragment: the phase was LDS-latency-bound)
+    bf16x8 af[KB][RT];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) af[kb][rt] = *reinterpret_cast<const bf16x8*>(frag + rt * 16 * LDP + kb * 32);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0.v[kb][0]), af[kb][rt], acc[rt], 0, 0, 0);
+    return;
+  }
   uint4 bw[2][NP];
 #pragma unroll
-  for (int q = 0; q < NP; ++q) bw[0][q] = w0[q];
-#pragma unroll
   for (int kb = 0; kb < KB; ++kb) {
-    if (kb + 1 < KB) {
+    if (kb + 1 >= WN && kb + 1 < KB) {
 #pragma unroll
       for (int q = 0; q < NP; ++q) bw[(kb + 1) & 1][q] = img[((kb + 1) * 3 + q) * 64];
-    } else if (NEXT) {
-      wload<NP>(nimg, wn);
     }
+    if (NEXT && WN != KB && kb == KB - 1) wload<NP, WN>(nimg, wn);
+    uint4 cw[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) cw[q] = kb < WN ? w0.v[kb < WN ? kb : 0][q] : bw[kb & 1][q];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const __bf16* fp = frag + rt * 16 * LDP + kb * 32;
       const bf16x8 ah = *reinterpret_cast<const bf16x8*>(fp);
       const bf16x8 am = NP == 3 ? *reinterpret_cast<const bf16x8*>(fp + PLANE) : ah;
       const bf16x8 al = NP == 3 ? *reinterpret_cast<const bf16x8*>(fp + 2 * PLANE) : ah;
-      acc[rt] = mma<NP>(__builtin_bit_cast(bf16x8, bw[kb & 1][0]), __builtin_bit_cast(bf16x8, bw[kb & 1][NP == 3 ? 1 : 0]),
-                        __builtin_bit_cast(bf16x8, bw[kb & 1][NP == 3 ? 2 : 0]), ah, am, al, acc[rt]);
+      acc[rt] = mma<NP>(__builtin_bit_cast(bf16x8, cw[0]), __builtin_bit_cast(bf16x8, cw[NP == 3 ? 1 : 0]), __builtin_bit_cast(bf16x8, cw[NP == 3 ? 2 : 0]), ah, am, al,
+                        acc[rt]);
     }
   }
 }
@@ -157,6 +180,14 @@ __device__ __forceinline__ void wgrad(const __bf16* Y, const __bf16* X, int nt, 
     const bf16x8 ym = NP == 3 ? tr_frag<LDY, P8>(Y + PLANE, kb, nt, p, j) : yh;
     const bf16x8 yl = NP == 3 ? tr_frag<LDY, P8>(Y + 2 * PLANE, kb, nt, p, j) : yh;
     dbp += NP == 3 ? (sum8(yl) + sum8(ym)) + sum8(yh) : sum8(yh);
+    if constexpr (NP == 1) {      // all of the k-block's X fragments in flight before the first product
+      bf16x8 xf[KTL];
+#pragma unroll
+      for (int kt = 0; kt < KTL; ++kt) xf[kt] = tr_frag<LDX, P8>(X, kb, kt0 + kt, p, j);
+#pragma unroll
+      for (int kt = 0; kt < KTL; ++kt) acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yh, xf[kt], acc[kt], 0, 0, 0);
+      continue;
+    }
 #pragma unroll
     for (int kt = 0; kt < KTL; ++kt) {
       const bf16x8 xh = tr_frag<LDX, P8>(X, kb, kt0 + kt, p, j);
@@ -190,6 +221,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
   __bf16* pA = reinterpret_cast<__bf16*>(smem_raw);                          // P(A); later P(X)
   constexpr bool PA = C::PA;
   constexpr int LDA = C::LDA;
+  constexpr int WN = NP == 1 ? C::KB : 1;      // k-blocks of a linear's weight fragments held ahead of it (lin)
+  using WF = WFrag<NP, WN>;
   __bf16* pR = reinterpret_cast<__bf16*>(smem_raw + (PA ? C::SLOT : C::P3));                // P(R1) -> P(dF1)
   __bf16* pZ = reinterpret_cast<__bf16*>(smem_raw + (PA ? 2 * C::SLOT : C::R12));           // P(dZ)
   // PA slots: S0 = P(A) -> P(X), S1 = P(R1 / dF1) -> K, S2 = P(dZ) -> dA -> dK, S3 = Q -> dQ, S4 = V -> dV; dS image behind them
@@ -305,8 +338,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     const int col = ct * 16 + 4 * j;                    // this lane's four columns in every linear's epilogue
     const size_t wtile = ((size_t)ct * KBT * 3) * 64 + lane;
     // ---- P0: A and dZ -> planes; the forward's log-sum-exp (base 2; +inf for padded queries: P = 0)
-    uint4 wf[NP];
-    wload<NP>(launder(a.W1) + wtile, wf);
+    WF wf;
+    wload<NP, WN>(launder(a.W1) + wtile, wf);
     {
       if (tid < 64 * HEADS) lse2[tid] = (tid & 63) < L ? lsev * 1.4426950408889634f : INFINITY;
       store_tile(pA, std::integral_constant<bool, IO16>{}, va, PitchP{});
@@ -320,11 +353,10 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
       const f32x4 bias = *reinterpret_cast<const f32x4*>(a.b1 + col);
-      uint4 wn[NP];
-      lin<D, NP, RT, WPF>(pA, a.W1 + wtile, wf, rt0, p, j, acc, launder(a.W2T) + wtile, wn);
+      WF wn;
+      lin<D, NP, RT, WPF, LDP, WN>(pA, a.W1 + wtile, wf, rt0, p, j, acc, launder(a.W2T) + wtile, wn);
       if (WPF) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+wf = wn;
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
@@ -339,17 +371,16 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     // ---- P2: dW2 += dZ^T R1, db2;  dF1 = (dZ W2) * [R1 > 0] -> planes over R1
     {
       float dbp = 0.f;
-      if (!WPF) wload<NP>(launder(a.W2T) + wtile, wf);
+      if (!WPF) wload<NP, WN>(launder(a.W2T) + wtile, wf);
       wgrad<D, NP, KTL>(pZ, pR, wnt, wkt0, p, j, accW2, dbp);
       if (wkt0 == 0) db2p += dbp;
       f32x4 acc[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      uint4 wn[NP];
-      lin<D, NP, RT, WPF>(pZ, a.W2T + wtile, wf, rt0, p, j, acc, launder(a.W1T) + wtile, wn);
+      WF wn;
+      lin<D, NP, RT, WPF, LDP, WN>(pZ, a.W2T + wtile, wf, rt0, p, j, acc, launder(a.W1T) + wtile, wn);
       if (WPF) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+wf = wn;
       }
       lds_barrier();      // every transposed read of R1 is done
 #pragma unroll
@@ -369,17 +400,16 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       f32x4 vx[NJ];
       load_tile(a.X, b, std::false_type{}, vx);
       float dbp = 0.f;
-      if (!WPF) wload<NP>(launder(a.W1T) + wtile, wf);
+      if (!WPF) wload<NP, WN>(launder(a.W1T) + wtile, wf);
       wgrad<D, NP, KTL>(pR, pA, wnt, wkt0, p, j, accW1, dbp);
       if (wkt0 == 0) db1p += dbp;
       f32x4 acc[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      uint4 wn[NP];
-      lin<D, NP, RT, WPF>(pR, a.W1T + wtile, wf, rt0, p, j, acc, launder(a.Wqkv) + wtile, wn);
+      WF wn;
+      lin<D, NP, RT, WPF, LDP, WN>(pR, a.W1T + wtile, wf, rt0, p, j, acc, launder(a.Wqkv) + wtile, wn);
       if (WPF) {
-#pragma unroll
-        for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+wf = wn;
       }
       lds_barrier();      // every read of P(A), P(dF1), P(dZ) is done
       if constexpr (PA) {      // dA as a bf16 image (its consumers round it anyway) and X in the attention pitch: both stay for the tail
@@ -401,19 +431,18 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     // ======== bf16 mode: P4 / P5 / tail on bf16 images, every product a v_mfma_f32_16x16x32_bf16 ========
     // ---- P4: [Q | K | V] = X Wqkv^T -> bf16 images (X stays in S0: nothing waits for its readers)
     {
-      if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
+      if (!WPF) wload<NP, WN>(launder(a.Wqkv) + wtile, wf);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         f32x4 acc[RT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const uint4* img = a.Wqkv + ((size_t)(c * CTW + ct) * KBT * 3) * 64 + lane;
-        uint4 wn[NP];
-        if (c < 2) lin<D, NP, RT, true, LDA>(S0, img, wf, rt0, p, j, acc, img + ((size_t)CTW * KBT * 3) * 64, wn);
-        else lin<D, NP, RT, false, LDA>(S0, img, wf, rt0, p, j, acc, img, wn);
+        WF wn;
+        if (c < 2) lin<D, NP, RT, true, LDA, WN>(S0, img, wf, rt0, p, j, acc, img + ((size_t)CTW * KBT * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDA, WN>(S0, img, wf, rt0, p, j, acc, img, wn);
         if (c < 2) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+wf = wn;
         }
         __bf16* dst = c == 0 ? S3 : (c == 1 ? S1 : S4);
 #pragma unroll
@@ -444,13 +473,18 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
         for (int kb = 0; kb < DK / 32; ++kb) {
           const bf16x8 kf = *reinterpret_cast<const bf16x8*>(S1 + (kt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
           const bf16x8 vf = *reinterpret_cast<const bf16x8*>(S4 + (kt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
+          bf16x8 qf[4], df[4];      // the k-block's ten fragments are requested together, then the eight products
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {
+            const int row = (qt < NTL ? qt : 0) * 16 + p;
+            qf[qt] = *reinterpret_cast<const bf16x8*>(S3 + row * LDA + hc + 32 * kb + 8 * j);
+            df[qt] = *reinterpret_cast<const bf16x8*>(S2 + row * LDA + hc + 32 * kb + 8 * j);
+          }
 #pragma unroll
           for (int qt = 0; qt < 4; ++qt) {
             if (qt < NTL) {
-              const bf16x8 qf = *reinterpret_cast<const bf16x8*>(S3 + (qt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
-              const bf16x8 df = *reinterpret_cast<const bf16x8*>(S2 + (qt * 16 + p) * LDA + hc + 32 * kb + 8 * j);
-              st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, st[qt], 0, 0, 0);      // S[query qt*16 + 4j + r][key kt*16 + p]
-              dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, dp[qt], 0, 0, 0);
+              st[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[qt], kf, st[qt], 0, 0, 0);      // S[query qt*16 + 4j + r][key kt*16 + p]
+              dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df[qt], vf, dp[qt], 0, 0, 0);
             }
           }
         }
@@ -495,11 +529,17 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
                                      (__bf16)st[2 * kb2 + 1][0], (__bf16)st[2 * kb2 + 1][1], (__bf16)st[2 * kb2 + 1][2], (__bf16)st[2 * kb2 + 1][3]};
             const bf16x8 db = bf16x8{(__bf16)dp[2 * kb2][0], (__bf16)dp[2 * kb2][1], (__bf16)dp[2 * kb2][2], (__bf16)dp[2 * kb2][3],
                                      (__bf16)dp[2 * kb2 + 1][0], (__bf16)dp[2 * kb2 + 1][1], (__bf16)dp[2 * kb2 + 1][2], (__bf16)dp[2 * kb2 + 1][3]};
+            bf16x8 fa[HDT], fq[HDT];
 #pragma unroll
             for (int dt = 0; dt < HDT; ++dt) {
               const int ctile = hc / 16 + dh * HDT + dt;
-              dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S2, kb2, ctile, p, j), pb, dv[dt], 0, 0, 0);      // dV[key][dim] += P^T dA
-              dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S3, kb2, ctile, p, j), db, dk[dt], 0, 0, 0);      // dK[key][dim] += dS^T Q
+              fa[dt] = tr_frag<LDA, true>(S2, kb2, ctile, p, j);
+              fq[dt] = tr_frag<LDA, true>(S3, kb2, ctile, p, j);
+            }
+#pragma unroll
+            for (int dt = 0; dt < HDT; ++dt) {
+              dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[dt], pb, dv[dt], 0, 0, 0);      // dV[key][dim] += P^T dA
+              dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[dt], db, dk[dt], 0, 0, 0);      // dK[key][dim] += dS^T Q
             }
           }
         }
@@ -526,9 +566,11 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
           for (int kb2 = 0; kb2 < 2; ++kb2) {
             if (2 * kb2 < NTL) {
               const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(dSi + (qt * 16 + p) * 72 + 32 * kb2 + 8 * j);
+              bf16x8 fk[HDT];
 #pragma unroll
-              for (int dt = 0; dt < HDT; ++dt)
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tr_frag<LDA, true>(S1, kb2, hc / 16 + dh * HDT + dt, p, j), dsf, o[dt], 0, 0, 0);      // dQ[query][dim] += dS K
+              for (int dt = 0; dt < HDT; ++dt) fk[dt] = tr_frag<LDA, true>(S1, kb2, hc / 16 + dh * HDT + dt, p, j);
+#pragma unroll
+              for (int dt = 0; dt < HDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[dt], dsf, o[dt], 0, 0, 0);      // dQ[query][dim] += dS K
             }
           }
 #pragma unroll
@@ -566,20 +608,19 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     {
       constexpr int KBT3 = 4 * ((3 * D + 127) / 128), KB = D / 32;
       const uint4* imgT = launder(a.WqkvT) + ((size_t)ct * KBT3 * 3) * 64 + lane;
-      uint4 wq[NP];
-      wload<NP>(imgT, wq);
+      WF wq;
+      wload<NP, WN>(imgT, wq);
       f32x4 accX[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) accX[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const __bf16* src = c == 0 ? S3 : (c == 1 ? S2 : S4);
-        uint4 wn[NP];
-        if (c < 2) lin<D, NP, RT, true, LDA>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
-        else lin<D, NP, RT, false, LDA>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
+        WF wn;
+        if (c < 2) lin<D, NP, RT, true, LDA, WN>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDA, WN>(src, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
         if (c < 2) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) wq[q] = wn[q];
+wq = wn;
         }
         if constexpr (FULLW) {
           float nodb = 0.f;
@@ -600,19 +641,18 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
     } else {
     // ---- P4: [Q | K | V] = X Wqkv^T -> fp32 rows
     {
-      if (!WPF) wload<NP>(launder(a.Wqkv) + wtile, wf);
+      if (!WPF) wload<NP, WN>(launder(a.Wqkv) + wtile, wf);
       f32x4 acc[3][RT];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[c][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const uint4* img = a.Wqkv + ((size_t)(c * CTW + ct) * KBT * 3) * 64 + lane;
-        uint4 wn[NP];
-        if (c < 2) lin<D, NP, RT, true>(pA, img, wf, rt0, p, j, acc[c], img + ((size_t)CTW * KBT * 3) * 64, wn);
-        else lin<D, NP, RT, false>(pA, img, wf, rt0, p, j, acc[c], img, wn);
+        WF wn;
+        if (c < 2) lin<D, NP, RT, true, LDP, WN>(pA, img, wf, rt0, p, j, acc[c], img + ((size_t)CTW * KBT * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDP, WN>(pA, img, wf, rt0, p, j, acc[c], img, wn);
         if (c < 2) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) wf[q] = wn[q];
+wf = wn;
         }
       }
       lds_barrier();      // every read of P(X) is done
@@ -809,8 +849,8 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
       // the V / Q / dA regions (zero in padded rows); each goes through planes in turn, X once
       constexpr int KBT3 = 4 * ((3 * D + 127) / 128), KB = D / 32;
       const uint4* imgT = launder(a.WqkvT) + ((size_t)ct * KBT3 * 3) * 64 + lane;
-      uint4 wq[NP];
-      wload<NP>(imgT, wq);
+      WF wq;
+      wload<NP, WN>(imgT, wq);
       if constexpr (FULLW) {
         f32x4 vx[NJ];
         load_tile(a.X, b, std::false_type{}, vx);
@@ -829,12 +869,11 @@ __global__ __launch_bounds__(512, 2) void tower_bwd_fused_kernel(TowerBwdArgs a)
           store4<NP, PLANE>(pD + tr * LDP + tc, *reinterpret_cast<const f32x4*>(src + tr * LQ + tc));
         }
         lds_barrier();
-        uint4 wn[NP];
-        if (c < 2) lin<D, NP, RT, true>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
-        else lin<D, NP, RT, false>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
+        WF wn;
+        if (c < 2) lin<D, NP, RT, true, LDP, WN>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT + ((size_t)(c + 1) * KB * 3) * 64, wn);
+        else lin<D, NP, RT, false, LDP, WN>(pD, imgT + ((size_t)c * KB * 3) * 64, wq, rt0, p, j, accX, imgT, wn);
         if (c < 2) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) wq[q] = wn[q];
+wq = wn;
         }
         if constexpr (FULLW) {
           float nodb = 0.f;
