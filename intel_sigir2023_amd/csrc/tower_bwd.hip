@@ -543,6 +543,15 @@ wf = wn;
             }
           }
         }
+      } else if (kt == NTL && (NTL & 1) && dh == 0) {
+        // an odd number of key tiles: pass 2 reads the dS image in 32-key blocks, so the absent tile's 16 columns must hold zeros (whatever the
+        // slot held before may be a NaN pattern, and NaN x K's zero rows is NaN)
+        const int key = kt * 16 + p;
+        const int kcol = 32 * (key >> 5) + 8 * ((key >> 2) & 3) + 4 * ((key >> 4) & 1) + (key & 3);
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dSi[(qt * 16 + 4 * j + r) * 72 + kcol] = (__bf16)0.f;
       }
       lds_barrier();      // dS complete; this head's reads of Q / dA / V done
       mark(5);

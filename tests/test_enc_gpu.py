@@ -20,17 +20,17 @@ def _dev():
     return torch.device('cuda:0')
 
 
-def _case(history_max, B, seed, train, dtype='f32'):
+def _case(history_max, B, seed, train, dtype='f32', L=12):
     from intel_sigir2023_amd import loss as LS
     from intel_sigir2023_amd import synth
     from intel_sigir2023_amd.model import IntEL
     from oracle import intel_oracle as O
     dev = _dev()
-    name = 'enc%d' % history_max
+    name = 'enc%d_%d' % (history_max, L)
     w = dict(synth.WORKLOADS['tmall'])
     w['flags'] = dict(w['flags'], history_max=history_max)
     w['corpus'] = dict(items=5000, users=500, classes=60, ctx=100, I=30)
-    w['batch'] = dict(L=12, H=history_max)
+    w['batch'] = dict(L=L, H=history_max)
     synth.WORKLOADS[name] = w
     torch.manual_seed(seed)
     args = synth.make_args(name, dev, cal_diversity=0, dtype=dtype)
@@ -140,3 +140,13 @@ def test_kernel_per_op_encoder_when_forced_off():
     r = subprocess.run([sys.executable, '-m', 'pytest', 'tests/test_enc_gpu.py', 'tests/test_pack_gpu.py', '-m', 'gpu', '-x', '-q', '-p', 'no:cacheprovider',
                         '-k', 'not forced_off'], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('L,seed', [(5, 30), (16, 31), (17, 32), (33, 33), (48, 34), (64, 35)])
+def test_training_step_at_every_key_tile_count(L, seed, dtype):
+    """Lists of 1 .. 4 key tiles of 16 (full and ragged last tile) through the towers' kernels of either mode -- in bf16 mode the one-kernel tower
+    backward (tower_bwd.hip), whose attention works on 32-key blocks: an odd tile count leaves half a block that must read as zeros (round 5: it
+    read whatever the LDS slot held, NaN patterns included, at lists of <= 16 and 33 .. 48).  bf16 mode on 96 sessions: its 5e-3 bar is about one
+    rounding flip in a SUM over sessions and list positions (33 sessions of 5 items: 5.5e-3 on an encoder weight, with either tower backward)."""
+    _case(20, 96 if dtype == 'bf16' else 33, seed, train=True, dtype=dtype, L=L)
