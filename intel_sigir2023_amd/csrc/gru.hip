@@ -136,6 +136,14 @@ __global__ void gru_gate_bwd_kernel(const float* __restrict__ dH, const float* _
 //   * the loop runs to the longest history of the workgroup's 16 sessions; shorter ones keep their state (forward) / pass the
 //     gradient through and write zero gate gradients (backward), as the per-step kernels do.
 // The same stashes as the per-step form (HP, GATES, GHN, HCUR; dGI, dGH), so the two forms mix freely (INTEL_GRU_SEQ=0: per step).
+// Round 5, three-plane form (gru_seq_fwd_pl / gru_seq_bwd_pl): the weight fragments are the A operand and the state / gate-gradient rows the B
+// operand, so the accumulator tile puts hidden units 16w+4g .. +3 of SESSION p on lane (p, g): every row access of a step is one 16-byte
+// vector per lane and tensor (3 loads + 5 stores forward, 5 loads + 6 stores backward, instead of 12 + 20 / 20 + 24 dwords) and the new rows go
+// to LDS as one 8-byte store per plane (instead of 12 / 36 two-byte stores); the LDS rows are double-buffered (one barrier per step); the
+// step's loads are issued at clamped row indices a step ahead (no select on a freshly loaded value).  The split planes of W_hh are pinned in
+// their 144 registers (gs_keep).  Per-step shader clocks at 512 sessions x 20 steps (debug build, INTEL_GRU_DBG=1): forward ~6 100 =
+// 3 000 LDS reads + MFMAs (the floor: 2 waves x 72 MFMAs x 16 cycles = 2 304 per SIMD), 1 300 gate arithmetic, 500 stash stores, 500 LDS writes,
+// 270 barrier; backward ~7 600 with ~2 500 of it waiting for the stash rows (with every request pointed at one hot row: 5 850).
 // ------------------------------------------------------------------------------------------
 #define GS_ROWS 16
 #define GS_H 128
@@ -183,55 +191,339 @@ __device__ __forceinline__ f32x4 gs_mma6(const gs_bf16x8& ah, const gs_bf16x8& a
   return c;
 }
 
-// PL: the step's product on the bf16 pipe as three-plane splits (six plane products: 72 MFMAs of 16 cycles per wave and step
-// instead of 96 of 32; the state / gate-gradient rows are kept in LDS as three bf16 planes, W_hh is split once into registers)
-// STASH: training (the backward reads GATES, GHN, HP); inference keeps only the final state
-template <bool PL, bool STASH = true>
-__global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
-                                                             const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
-                                                             float* __restrict__ HP, float* __restrict__ HCUR,
-                                                             float* __restrict__ GATES, float* __restrict__ GHN,
-                                                             const int* __restrict__ off, const int* __restrict__ order) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDP * 2 : GS_ROWS * GS_LDH * 4];
-  float* hs = reinterpret_cast<float*>(smem_raw);
-  __bf16* hp3 = reinterpret_cast<__bf16*>(smem_raw);
+typedef __bf16 gs_bf16x4 __attribute__((ext_vector_type(4)));
+#define GS_HBUF (3 * GS_ROWS * GS_LDP)      // bf16 elements of one state buffer (three planes)
+#define GS_QBUF (3 * GS_ROWS * GS_LDQ)      // ... of one gate-gradient buffer
+__device__ __forceinline__ void gs_split4(const f32x4& x, gs_bf16x4& h, gs_bf16x4& m, gs_bf16x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    __bf16 a, b, c;
+    gs_split(x[i], a, b, c);
+    h[i] = a; m[i] = b; l[i] = c;
+  }
+}
+
+// The split planes of W_hh must STAY in their 144 registers: left to itself the compiler keeps the 96 fp32 values instead and re-derives the planes
+// in every step (rematerialisation: ~460 conversion / mask / subtract instructions per wave and step -- more VALU time than the step's MFMAs)
+__device__ __forceinline__ void gs_keep(gs_bf16x8& v) { asm volatile("" : "+v"(v)); }
+
+#ifdef INTEL_DEBUG
+__device__ int g_gru_abl;                       // INTEL_GRU_ABL (debug builds): 1 = every stash / gate-input request goes to row 0 (cache-hot: what is memory latency?), 2 = no global stores
+__device__ unsigned long long g_gru_dbg[16];      // INTEL_GRU_DBG=1 (debug builds): per-phase shader clocks of workgroup 0's thread 0, summed over the steps
+#define GS_MARK(ph) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long now__ = clock64(); g_gru_dbg[ph] += now__ - tstamp__; tstamp__ = now__; } } while (0)
+#define GS_MARK0() unsigned long long tstamp__ = clock64()
+#else
+#define GS_MARK(ph) do { } while (0)
+#define GS_MARK0() do { } while (0)
+#endif
+
+// Forward recurrence, three-plane products.  Lane (p, g) of wave w: session slot p, hidden units 16w + 4g .. + 3.
+template <bool STASH>
+__device__ __forceinline__ void gru_seq_fwd_pl(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                               const int* __restrict__ len, int B, int T, float* __restrict__ HP, float* __restrict__ HCUR,
+                                               float* __restrict__ GATES, float* __restrict__ GHN, const int* __restrict__ off,
+                                               const int* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) __bf16 hp3[2 * GS_HBUF];
+  __shared__ int slen[GS_ROWS], sses[GS_ROWS];
   constexpr int PLANE = GS_ROWS * GS_LDP;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * GS_ROWS;
+  const int u0 = 16 * w + 4 * g;
+  for (int i = tid; i < GS_HBUF; i += 512) hp3[i] = (__bf16)0.f;      // buffer 0: h_0 = 0
+  if (tid < GS_ROWS) {
+    const int bsess = (b0 + tid < B) ? (order ? order[b0 + tid] : b0 + tid) : -1;
+    sses[tid] = bsess;
+    slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
+  }
+  // A fragments: gate q, W_hh[q*128 + 16w + p][32 j + 8 g + s], split once
+  gs_bf16x8 wq[3][4][3];
+  f32x4 bh[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    bh[q] = *reinterpret_cast<const f32x4*>(bhh + q * GS_H + u0);
+    const float* wrow = Whh + (size_t)(q * GS_H + 16 * w + p) * GS_H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g + 4);
+      const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      gs_split8(x, wq[q][j][0], wq[q][j][1], wq[q][j][2]);
+      gs_keep(wq[q][j][0]); gs_keep(wq[q][j][1]); gs_keep(wq[q][j][2]);
+    }
+  }
+  __syncthreads();
+  int tmax = 0;
+#pragma unroll
+  for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
+  const int ls = slen[p], bsess = sses[p];
+  const bool live = bsess >= 0;
+  const size_t rb = live ? (off ? (size_t)off[bsess] : (size_t)bsess * T) : 0;      // first row: b*T (padded [B, T] rows) or off[b] (packed)
+  // gate inputs of step t at a clamped row (a session without history reads row 0, which exists whenever the loop runs): the values of steps
+  // past the session's length are loaded and never looked at
+  auto ldgi = [&](int t, f32x4 (&v)[3]) {
+    const int tc = min(t, ls - 1);
+    const float* src = GI + (tc >= 0 ? rb + tc : 0) * (3 * GS_H) + u0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) v[q] = *reinterpret_cast<const f32x4*>(src + q * GS_H);
+  };
+  f32x4 h4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  int cur = 0;
+  GS_MARK0();
+  // One register set in flight: the top of step t takes the values requested at the top of step t-1 (the only wait of the step, for requests a whole
+  // step old) and requests step t+1's.  (Rotating two or three sets through an unrolled loop costs more than it hides: the compiler's wait-count
+  // bookkeeping merges the copies' states at the loop header and then waits for EVERYTHING in flight -- stores included -- at the top of each step.)
+  f32x4 gnext[3];
+  auto step = [&](int t) {
+    GS_MARK(0);
+    f32x4 gi[3] = {gnext[0], gnext[1], gnext[2]};
+    ldgi(t + 1, gnext);
+    __builtin_amdgcn_sched_barrier(0);      // the requests stay HERE: the scheduler sinks them below the MFMAs otherwise
+    f32x4 acc[3] = {bh[0], bh[1], bh[2]};
+    const __bf16* rd = hp3 + cur * GS_HBUF + p * GS_LDP + 8 * g;
+    // two passes over the state rows: the r and z columns first, the n columns second -- the sigmoids of r and z (half of the gate arithmetic) are
+    // issued between the k-blocks of the second pass and run on the vector ALU while the matrix pipe works (the fragments are read twice: LDS
+    // has the time, the registers for keeping all twelve do not exist).  They are computed for finished sessions too (never looked at).
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const gs_bf16x8 xh = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j);
+      const gs_bf16x8 xm = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + PLANE);
+      const gs_bf16x8 xl = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + 2 * PLANE);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[q] = gs_mma6(wq[q][j][0], wq[q][j][1], wq[q][j][2], xh, xm, xl, acc[q]);      // [unit][session]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 rg, zg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const gs_bf16x8 xh = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j);
+      const gs_bf16x8 xm = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + PLANE);
+      const gs_bf16x8 xl = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + 2 * PLANE);
+      acc[2] = gs_mma6(wq[2][j][0], wq[2][j][1], wq[2][j][2], xh, xm, xl, acc[2]);
+      rg[j] = sigm(gi[0][j] + acc[0][j]);
+      zg[j] = sigm(gi[1][j] + acc[1][j]);
+      asm volatile("" : "+v"(rg[j]), "+v"(zg[j]));      // (computed HERE: otherwise sunk into the branch below, behind the last MFMA)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const size_t row = rb + t;
+#ifdef INTEL_DEBUG
+    asm volatile("" :: "v"(acc[2]));
+    GS_MARK(1);
+#endif
+    if (t < ls) {
+      f32x4 ng;
+      const f32x4 ghn = acc[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ng[r] = gtanh(gi[2][r] + rg[r] * ghn[r]);
+        h4[r] = (1.f - zg[r]) * ng[r] + zg[r] * h4[r];
+      }
+      if (STASH) {
+        float* ga = GATES + row * (3 * GS_H) + u0;
+        *reinterpret_cast<f32x4*>(ga) = rg;
+        *reinterpret_cast<f32x4*>(ga + GS_H) = zg;
+        *reinterpret_cast<f32x4*>(ga + 2 * GS_H) = ng;
+        *reinterpret_cast<f32x4*>(GHN + row * GS_H + u0) = ghn;
+      }
+    }
+    GS_MARK(2);
+    if (STASH && live) {
+      if (t + 1 < (off ? ls : T)) *reinterpret_cast<f32x4*>(HP + (row + 1) * GS_H + u0) = h4;      // packed: row t+1 exists only below len
+      if (t == 0 && (off ? ls > 0 : true)) *reinterpret_cast<f32x4*>(HP + row * GS_H + u0) = f32x4{0.f, 0.f, 0.f, 0.f};      // h_0 = 0 (no fill launch)
+    }
+    GS_MARK(3);
+    gs_bf16x4 a, bq, c;
+    gs_split4(h4, a, bq, c);
+    __bf16* wr = hp3 + (cur ^ 1) * GS_HBUF + p * GS_LDP + u0;      // the other buffer: nobody reads it during this step
+    *reinterpret_cast<gs_bf16x4*>(wr) = a;
+    *reinterpret_cast<gs_bf16x4*>(wr + PLANE) = bq;
+    *reinterpret_cast<gs_bf16x4*>(wr + 2 * PLANE) = c;
+    cur ^= 1;
+    GS_MARK(4);
+    gs_lds_barrier();
+    GS_MARK(5);
+  };
+  if (tmax > 0) {
+    ldgi(0, gnext);
+    for (int t = 0; t < tmax; ++t) step(t);
+  }
+  if (live) {
+    *reinterpret_cast<f32x4*>(HCUR + (size_t)bsess * GS_H + u0) = h4;
+    // the steps the loop did not run (t >= the workgroup's longest history) keep the state: h_{t-1} stash for the weight gradient
+    // (padded rows only: packed histories have no rows past len)
+    for (int t = tmax; t + 1 < T && !off && STASH; ++t) *reinterpret_cast<f32x4*>(HP + ((size_t)bsess * T + t + 1) * GS_H + u0) = h4;
+    if (STASH && !off && tmax <= 0) *reinterpret_cast<f32x4*>(HP + (size_t)bsess * T * GS_H + u0) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+// Backward recurrence, three-plane products: dh_{t-1}[unit][session] = sum_k W_hh[k][unit] dGH_t[session][k], same lane roles.
+__device__ __forceinline__ void gru_seq_bwd_pl(const float* __restrict__ dH0, const float* __restrict__ HP, const float* __restrict__ GATES,
+                                               const float* __restrict__ GHN, const float* __restrict__ Whh, const int* __restrict__ len, int B,
+                                               int T, float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off,
+                                               const int* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) __bf16 dq3[2 * GS_QBUF];
+  __shared__ int slen[GS_ROWS], sses[GS_ROWS];
+  constexpr int PLANE = GS_ROWS * GS_LDQ;
+  const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b0 = blockIdx.x * GS_ROWS;
+  const int u0 = 16 * w + 4 * g;
+  if (tid < GS_ROWS) {
+    const int bsess = (b0 + tid < B) ? (order ? order[b0 + tid] : b0 + tid) : -1;
+    sses[tid] = bsess;
+    slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
+  }
+  // A fragments: W_hh[32 j + 8 g + s][16w + p]
+  gs_bf16x8 wq[12][3];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    float x[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) x[s] = Whh[(size_t)(32 * j + 8 * g + s) * GS_H + 16 * w + p];
+    gs_split8(x, wq[j][0], wq[j][1], wq[j][2]);
+    gs_keep(wq[j][0]); gs_keep(wq[j][1]); gs_keep(wq[j][2]);
+  }
+  __syncthreads();
+  int tmax = 0;
+#pragma unroll
+  for (int i = 0; i < GS_ROWS; ++i) tmax = max(tmax, slen[i]);
+  const int ls = slen[p], bsess = sses[p];
+  const bool live = bsess >= 0;
+  const size_t rb = live ? (off ? (size_t)off[bsess] : (size_t)bsess * T) : 0;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 dh4 = live ? *reinterpret_cast<const f32x4*>(dH0 + (size_t)bsess * GS_H + u0) : zero4;
+  // steps nobody in this workgroup reached: zero gate gradients (they feed the weight-gradient products over all B*T rows;
+  // packed histories have no such rows)
+  for (int t = T - 1; t >= tmax && !off && live; --t) {
+    const size_t row = (size_t)bsess * T + t;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      *reinterpret_cast<f32x4*>(dGI + row * (3 * GS_H) + q * GS_H + u0) = zero4;
+      *reinterpret_cast<f32x4*>(dGH + row * (3 * GS_H) + q * GS_H + u0) = zero4;
+    }
+  }
+  // the step's stash values (r, z, n, h_{t-1}, gh_n) at a clamped row, requested a whole step ahead and looked at only below the session's length
+  auto ldst = [&](int t, f32x4 (&v)[5]) {
+    const int tc = min(max(t, 0), ls - 1);
+#ifdef INTEL_DEBUG
+    const size_t row = (g_gru_abl & 1) ? 0 : (tc >= 0 ? rb + tc : 0);
+#else
+    const size_t row = tc >= 0 ? rb + tc : 0;
+#endif
+    const float* ga = GATES + row * (3 * GS_H) + u0;
+    v[0] = *reinterpret_cast<const f32x4*>(ga);
+    v[1] = *reinterpret_cast<const f32x4*>(ga + GS_H);
+    v[2] = *reinterpret_cast<const f32x4*>(ga + 2 * GS_H);
+    v[3] = *reinterpret_cast<const f32x4*>(HP + row * GS_H + u0);
+    v[4] = *reinterpret_cast<const f32x4*>(GHN + row * GS_H + u0);
+  };
+  int cur = 0;
+  GS_MARK0();
+  f32x4 snext[5];
+  auto step = [&](int t) {
+    GS_MARK(8);
+    f32x4 sv[5] = {snext[0], snext[1], snext[2], snext[3], snext[4]};      // (one set in flight: see the forward kernel)
+    f32x4 drp = zero4, dzp = zero4, dnp = zero4, dnr = zero4, dprev = dh4;
+    if (t < ls) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float rg = sv[0][r], zg = sv[1][r], ng = sv[2][r], hp = sv[3][r];
+        const float dn = dh4[r] * (1.f - zg);
+        const float dz = dh4[r] * (hp - ng);
+        dnp[r] = dn * (1.f - ng * ng);
+        dzp[r] = dz * zg * (1.f - zg);
+        const float dr = dnp[r] * sv[4][r];
+        drp[r] = dr * rg * (1.f - rg);
+        dnr[r] = dnp[r] * rg;
+        dprev[r] = dh4[r] * zg;
+      }
+    }
+#ifdef INTEL_DEBUG
+    asm volatile("" :: "v"(drp), "v"(dzp), "v"(dnp), "v"(dnr));
+#endif
+    GS_MARK(9);
+#ifdef INTEL_DEBUG
+    if (live && (!off || t < ls) && !(g_gru_abl & 2)) {
+#else
+    if (live && (!off || t < ls)) {       // packed: the row exists only below len
+#endif
+      float* dgi = dGI + (rb + t) * (3 * GS_H) + u0;
+      float* dgh = dGH + (rb + t) * (3 * GS_H) + u0;
+      *reinterpret_cast<f32x4*>(dgi) = drp;
+      *reinterpret_cast<f32x4*>(dgi + GS_H) = dzp;
+      *reinterpret_cast<f32x4*>(dgi + 2 * GS_H) = dnp;
+      *reinterpret_cast<f32x4*>(dgh) = drp;
+      *reinterpret_cast<f32x4*>(dgh + GS_H) = dzp;
+      *reinterpret_cast<f32x4*>(dgh + 2 * GS_H) = dnr;
+    }
+    GS_MARK(10);
+    __bf16* wr = dq3 + cur * GS_QBUF + p * GS_LDQ + u0;
+    {
+      gs_bf16x4 a, bq, c;
+      gs_split4(drp, a, bq, c);
+      *reinterpret_cast<gs_bf16x4*>(wr) = a; *reinterpret_cast<gs_bf16x4*>(wr + PLANE) = bq; *reinterpret_cast<gs_bf16x4*>(wr + 2 * PLANE) = c;
+      gs_split4(dzp, a, bq, c);
+      *reinterpret_cast<gs_bf16x4*>(wr + GS_H) = a; *reinterpret_cast<gs_bf16x4*>(wr + GS_H + PLANE) = bq; *reinterpret_cast<gs_bf16x4*>(wr + GS_H + 2 * PLANE) = c;
+      gs_split4(dnr, a, bq, c);
+      *reinterpret_cast<gs_bf16x4*>(wr + 2 * GS_H) = a; *reinterpret_cast<gs_bf16x4*>(wr + 2 * GS_H + PLANE) = bq; *reinterpret_cast<gs_bf16x4*>(wr + 2 * GS_H + 2 * PLANE) = c;
+    }
+    GS_MARK(11);
+    gs_lds_barrier();      // the only barrier of the step: the next step writes the other buffer
+    GS_MARK(12);
+    ldst(t - 1, snext);      // in flight under the step's MFMAs (requested at the top of the step instead, next to the step's stores: 64 -> 76 us per launch)
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[3] = {zero4, zero4, zero4};      // three chains of four k-blocks: a dependent MFMA does not wait for its predecessor
+    const __bf16* rd = dq3 + cur * GS_QBUF + p * GS_LDQ + 8 * g;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+      const gs_bf16x8 xh = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j);
+      const gs_bf16x8 xm = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + PLANE);
+      const gs_bf16x8 xl = *reinterpret_cast<const gs_bf16x8*>(rd + 32 * j + 2 * PLANE);
+      acc[j % 3] = gs_mma6(wq[j][0], wq[j][1], wq[j][2], xh, xm, xl, acc[j % 3]);
+    }
+    dh4 = dprev + ((acc[0] + acc[1]) + acc[2]);
+#ifdef INTEL_DEBUG
+    asm volatile("" :: "v"(dh4));
+#endif
+    GS_MARK(13);
+    cur ^= 1;
+  };
+  if (tmax > 0) {
+    ldst(tmax - 1, snext);
+    for (int t = tmax - 1; t >= 0; --t) step(t);
+  }
+}
+
+// Exact-fp32 form (INTEL_GRU_SEQ=1: v_mfma_f32_16x16x4_f32, 96 MFMAs of 32 cycles per wave and step): lane (p, g) of wave w holds hidden unit
+// 16w + p of sessions 4g .. 4g+3; two barriers per step.  Kept as the cross-check of the three-plane form.
+// STASH: training (the backward reads GATES, GHN, HP); inference keeps only the final state
+template <bool STASH>
+__device__ __forceinline__ void gru_seq_fwd_f32(const float* __restrict__ GI, const float* __restrict__ Whh, const float* __restrict__ bhh,
+                                                const int* __restrict__ len, int B, int T, float* __restrict__ HP, float* __restrict__ HCUR,
+                                                float* __restrict__ GATES, float* __restrict__ GHN, const int* __restrict__ off,
+                                                const int* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) float hs[GS_ROWS * GS_LDH];
   __shared__ int slen[GS_ROWS], sses[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GS_ROWS;
   const int unit = 16 * w + p;
-  if (PL) {
-    for (int i = tid; i < 3 * PLANE; i += 512) hp3[i] = (__bf16)0.f;      // h_0 = 0
-  } else {
-    for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;
-  }
+  for (int i = tid; i < GS_ROWS * GS_LDH; i += 512) hs[i] = 0.f;      // h_0 = 0
   // workgroup slot i is session order[b0 + i] (sessions of similar length together) or b0 + i
   if (tid < GS_ROWS) {
     const int bsess = (b0 + tid < B) ? (order ? order[b0 + tid] : b0 + tid) : -1;
     sses[tid] = bsess;
     slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
   }
-  // B fragments: gate q, W_hh[q*128 + unit][k]: fp32 MFMAs take k = 16 j + 4 g + s, the bf16 ones k = 32 j + 8 g + s
-  f32x4 wb[PL ? 1 : 3][PL ? 1 : 8];
-  gs_bf16x8 wq[PL ? 3 : 1][PL ? 4 : 1][3];
+  // B fragments: gate q, W_hh[q*128 + unit][k], k = 16 j + 4 g + s
+  f32x4 wb[3][8];
   float bh[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     bh[q] = bhh[q * GS_H + unit];
     const float* wrow = Whh + (size_t)(q * GS_H + unit) * GS_H;
-    if (PL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(wrow + 32 * j + 8 * g + 4);
-        const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        gs_split8(x, wq[PL ? q : 0][PL ? j : 0][0], wq[PL ? q : 0][PL ? j : 0][1], wq[PL ? q : 0][PL ? j : 0][2]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wb[PL ? 0 : q][PL ? 0 : j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j + 4 * g);
-    }
+    for (int j = 0; j < 8; ++j) wb[q][j] = *reinterpret_cast<const f32x4*>(wrow + 16 * j + 4 * g);
   }
   __syncthreads();
   int tmax = 0, lr[4];
@@ -247,7 +539,6 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   }
   float h[4] = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < tmax; ++t) {
-    // gate inputs of this step: in flight under the MFMAs
     float gi[4][3];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -258,24 +549,11 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     f32x4 acc[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) acc[q] = f32x4{bh[q], bh[q], bh[q], bh[q]};
-    if (PL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const __bf16* ap = hp3 + p * GS_LDP + 32 * j + 8 * g;
-        const gs_bf16x8 ah = *reinterpret_cast<const gs_bf16x8*>(ap);
-        const gs_bf16x8 am = *reinterpret_cast<const gs_bf16x8*>(ap + PLANE);
-        const gs_bf16x8 al = *reinterpret_cast<const gs_bf16x8*>(ap + 2 * PLANE);
+    for (int j = 0; j < 8; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(hs + p * GS_LDH + 16 * j + 4 * g);
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          acc[q] = gs_mma6(ah, am, al, wq[PL ? q : 0][PL ? j : 0][0], wq[PL ? q : 0][PL ? j : 0][1], wq[PL ? q : 0][PL ? j : 0][2], acc[q]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(hs + p * GS_LDH + 16 * j + 4 * g);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) acc[q] = gs_mma4(a, wb[PL ? 0 : q][PL ? 0 : j], acc[q]);
-      }
+      for (int q = 0; q < 3; ++q) acc[q] = gs_mma4(a, wb[q][j], acc[q]);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -298,16 +576,7 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
     }
     gs_lds_barrier();                     // every wave has read h_{t-1}
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (PL) {
-        __bf16 a, bq, c;
-        gs_split(h[r], a, bq, c);
-        __bf16* d = hp3 + (4 * g + r) * GS_LDP + unit;
-        d[0] = a; d[PLANE] = bq; d[2 * PLANE] = c;
-      } else {
-        hs[(4 * g + r) * GS_LDH + unit] = h[r];
-      }
-    }
+    for (int r = 0; r < 4; ++r) hs[(4 * g + r) * GS_LDH + unit] = h[r];
     gs_lds_barrier();
   }
 #pragma unroll
@@ -323,16 +592,22 @@ __global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __rest
   }
 }
 
-template <bool PL>
-__global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
-                                                             const float* __restrict__ GATES, const float* __restrict__ GHN,
-                                                             const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
-                                                             float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off,
-                                                             const int* __restrict__ order) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem_raw[PL ? 3 * GS_ROWS * GS_LDQ * 2 : GS_ROWS * GS_LDG * 4];
-  float* ds = reinterpret_cast<float*>(smem_raw);
-  __bf16* dq3 = reinterpret_cast<__bf16*>(smem_raw);
-  constexpr int PLANE = GS_ROWS * GS_LDQ;
+// PL: the three-plane form (default); otherwise the exact-fp32 form
+template <bool PL, bool STASH = true>
+__global__ __launch_bounds__(512, 1) void gru_seq_fwd_kernel(const float* __restrict__ GI, const float* __restrict__ Whh,
+                                                             const float* __restrict__ bhh, const int* __restrict__ len, int B, int T,
+                                                             float* __restrict__ HP, float* __restrict__ HCUR,
+                                                             float* __restrict__ GATES, float* __restrict__ GHN,
+                                                             const int* __restrict__ off, const int* __restrict__ order) {
+  if constexpr (PL) gru_seq_fwd_pl<STASH>(GI, Whh, bhh, len, B, T, HP, HCUR, GATES, GHN, off, order);
+  else gru_seq_fwd_f32<STASH>(GI, Whh, bhh, len, B, T, HP, HCUR, GATES, GHN, off, order);
+}
+
+__device__ __forceinline__ void gru_seq_bwd_f32(const float* __restrict__ dH0, const float* __restrict__ HP, const float* __restrict__ GATES,
+                                                const float* __restrict__ GHN, const float* __restrict__ Whh, const int* __restrict__ len, int B,
+                                                int T, float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off,
+                                                const int* __restrict__ order) {
+  __shared__ __attribute__((aligned(16))) float ds[GS_ROWS * GS_LDG];
   __shared__ int slen[GS_ROWS], sses[GS_ROWS];
   const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,26 +618,12 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
     sses[tid] = bsess;
     slen[tid] = bsess >= 0 ? min(len[bsess], T) : 0;
   }
-  if (PL) {
-    for (int i = tid; i < 3 * PLANE; i += 512) dq3[i] = (__bf16)0.f;      // the pad columns are never written again
-  }
-  // B fragments of dh_{t-1} += dGH_t W_hh: W_hh[k][unit], k = 16 j + 4 g + s (fp32 MFMAs) / 32 j + 8 g + s (bf16 ones)
-  f32x4 wb[PL ? 1 : 24];
-  gs_bf16x8 wq[PL ? 12 : 1][3];
-  if (PL) {
+  // B fragments of dh_{t-1} += dGH_t W_hh: W_hh[k][unit], k = 16 j + 4 g + s
+  f32x4 wb[24];
 #pragma unroll
-    for (int j = 0; j < 12; ++j) {
-      float x[8];
+  for (int j = 0; j < 24; ++j)
 #pragma unroll
-      for (int s = 0; s < 8; ++s) x[s] = Whh[(size_t)(32 * j + 8 * g + s) * GS_H + unit];
-      gs_split8(x, wq[PL ? j : 0][0], wq[PL ? j : 0][1], wq[PL ? j : 0][2]);
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 24; ++j)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) wb[PL ? 0 : j][s] = Whh[(size_t)(16 * j + 4 * g + s) * GS_H + unit];
-  }
+    for (int s = 0; s < 4; ++s) wb[j][s] = Whh[(size_t)(16 * j + 4 * g + s) * GS_H + unit];
   __syncthreads();
   int tmax = 0, lr[4];
 #pragma unroll
@@ -435,43 +696,31 @@ __global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __rest
         dgi[unit] = drp; dgi[GS_H + unit] = dzp; dgi[2 * GS_H + unit] = dnp;
         dgh[unit] = drp; dgh[GS_H + unit] = dzp; dgh[2 * GS_H + unit] = dnr;
       }
-      if (PL) {
-        const float v3[3] = {drp, dzp, dnr};
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          __bf16 a, bq, c;
-          gs_split(v3[q], a, bq, c);
-          __bf16* d = dq3 + (4 * g + r) * GS_LDQ + q * GS_H + unit;
-          d[0] = a; d[PLANE] = bq; d[2 * PLANE] = c;
-        }
-      } else {
-        float* dl = ds + (4 * g + r) * GS_LDG;
-        dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
-      }
+      float* dl = ds + (4 * g + r) * GS_LDG;
+      dl[unit] = drp; dl[GS_H + unit] = dzp; dl[2 * GS_H + unit] = dnr;
     }
     gs_lds_barrier();
     load_stash(t - 1);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (PL) {
 #pragma unroll
-      for (int j = 0; j < 12; ++j) {
-        const __bf16* ap = dq3 + p * GS_LDQ + 32 * j + 8 * g;
-        const gs_bf16x8 ah = *reinterpret_cast<const gs_bf16x8*>(ap);
-        const gs_bf16x8 am = *reinterpret_cast<const gs_bf16x8*>(ap + PLANE);
-        const gs_bf16x8 al = *reinterpret_cast<const gs_bf16x8*>(ap + 2 * PLANE);
-        acc = gs_mma6(ah, am, al, wq[PL ? j : 0][0], wq[PL ? j : 0][1], wq[PL ? j : 0][2], acc);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 24; ++j) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(ds + p * GS_LDG + 16 * j + 4 * g);
-        acc = gs_mma4(a, wb[PL ? 0 : j], acc);
-      }
+    for (int j = 0; j < 24; ++j) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ds + p * GS_LDG + 16 * j + 4 * g);
+      acc = gs_mma4(a, wb[j], acc);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) dh[r] = dprev[r] + acc[r];
     gs_lds_barrier();                     // the next step rewrites the gate-gradient rows
   }
+}
+
+template <bool PL>
+__global__ __launch_bounds__(512, 1) void gru_seq_bwd_kernel(const float* __restrict__ dH0, const float* __restrict__ HP,
+                                                             const float* __restrict__ GATES, const float* __restrict__ GHN,
+                                                             const float* __restrict__ Whh, const int* __restrict__ len, int B, int T,
+                                                             float* __restrict__ dGI, float* __restrict__ dGH, const int* __restrict__ off,
+                                                             const int* __restrict__ order) {
+  if constexpr (PL) gru_seq_bwd_pl(dH0, HP, GATES, GHN, Whh, len, B, T, dGI, dGH, off, order);
+  else gru_seq_bwd_f32(dH0, HP, GATES, GHN, Whh, len, B, T, dGI, dGH, off, order);
 }
 
 // INTEL_GRU_SEQ: 0 the per-step form, 1 the one-kernel recurrence with exact fp32 MFMAs, 2 (default) with three-plane bf16 products
@@ -502,6 +751,20 @@ int gru_fwd(GruBufs& g, const float* E0, int B, int T, int dm, int Hd, const int
     else
       LAUNCH((gru_seq_fwd_kernel<true, false>), dim3(cdiv(B, GS_ROWS)), dim3(512), 0, st, g.GI, Whh, bhh, len, B, T, g.HP, g.HCUR, g.GATES, g.GHN, off, order);
     INTEL_CHECK_LAUNCH();
+#ifdef INTEL_DEBUG
+    if (INTEL_DEBUG_ENV("INTEL_GRU_DBG", 0)) {
+      const int abl = INTEL_DEBUG_ENV("INTEL_GRU_ABL", 0);
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gru_abl), &abl, sizeof(abl));
+      unsigned long long h[16];
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gru_dbg), sizeof(h));
+      fprintf(stderr, "gru fwd [0-5] / previous bwd [8-13] phase clocks (sum over steps, B=%d T=%d):", B, T);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", h[i]);
+      fprintf(stderr, "\n");
+      unsigned long long z[16] = {0};
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gru_dbg), z, sizeof(z));
+    }
+#endif
     if (g.ext_proj) return 0;
     GemmEpilogue e0;
     return launch_gemm_rows(g.HCUR, Hd, B, Hd, g.pWout, dm, out + col0, ldo, e0, st);

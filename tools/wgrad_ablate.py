@@ -10,7 +10,10 @@ if bits != '0':
 dev = torch.device('cuda:0')
 lib = _lib.lib()
 st = _lib.stream_ptr(dev)
-for M, N, K in ((204800, 128, 128), (204800, 384, 128), (204800, 64, 64), (42752, 128, 128)):
+SHAPES = ((204800, 128, 128), (204800, 384, 128), (204800, 64, 64), (42752, 128, 128))
+if os.environ.get('WGRAD_SHAPES'):      # e.g. WGRAD_SHAPES=42566x128x128,42560x384x128
+    SHAPES = tuple(tuple(int(v) for v in t.split('x')) for t in os.environ['WGRAD_SHAPES'].split(','))
+for M, N, K in SHAPES:
     dy = torch.randn(M, N, device=dev); x = torch.randn(M, K, device=dev)
     dw = torch.empty(N, K, device=dev); db = torch.empty(N, device=dev)
     nb = lib.intel_op_workspace_bytes(M, N, K)
