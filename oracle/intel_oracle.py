@@ -173,7 +173,10 @@ def mha(x, sd, prefix, heads, key_mask=None, bf16_products=True):
     q = split(_lin(x, sd, prefix + '.q_linear'))
     k = split(_lin(x, sd, prefix + '.k_linear'))
     v = split(_lin(x, sd, prefix + '.v_linear'))
-    if _EMU['on'] and bf16_products:
+    if _EMU['on'] and bf16_products and dk in (64, 128):
+        # head widths 64 / 128 only: the whole-sequence kernels (lists of <= 64 rows, csrc/attn_seq.hip: attn_seq_supported) and the general
+        # kernels' bf16 form (longer lists, csrc/attn.hip: attn_bf16_products) exist for those; any other head width -- 2 heads on a 64-wide
+        # tower -- runs the exact-fp32 general kernels in bf16 mode too (q, k, v arrive rounded only in so far as their linears were)
         o = _BfAttention.apply(q, k, v, key_mask, 1.0 / dk ** 0.5, T > 64)
         return o.transpose(1, 2).reshape(B, T, D)
     s = torch.matmul(q, k.transpose(-1, -2)) / dk ** 0.5
