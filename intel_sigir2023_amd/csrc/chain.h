@@ -4,7 +4,7 @@
 #include "common.h"
 
 enum { CH_LOAD = 0, CH_LIN, CH_MASKCOPY, CH_SOFTMAX, CH_SOFTMAX_BWD, CH_ENS_FWD, CH_ENS_BWD, CH_WGRAD };
-enum { CH_RELU = 1, CH_ACCUM = 2, CH_GATHER = 4 };
+enum { CH_RELU = 1, CH_ACCUM = 2, CH_GATHER = 4, CH_BF16 = 8 };      // CH_BF16 (LIN, WGRAD; bf16 mode): both operands rounded to bf16 before the product
 
 struct ChainOp {
   int kind, level, flags;
@@ -52,6 +52,9 @@ struct ChainPlan {
   ChainArgs a;
   int lds = 0;
   bool ok = true;
+  bool bf16 = false;      // --dtype bf16: links whose FORWARD product the mode runs on the bf16 pipe round their operands (forward, data gradient, weight gradient)
+  // the mode's rule for a linear of K input features and N outputs (oracle.forward_bf16: _on_bf16_pipe; csrc/gemm.hip: launch_gemm_rows)
+  int bfl(int K, int N) const { return (bf16 && (K == 64 || K == 128) && N % 4 == 0) ? CH_BF16 : 0; }
   ChainPlan() { a.B = 0; a.nops = 0; a.nlevels = 0; a.ens = ChainEns{}; }
   ChainTile tile(int width) {
     const int w = rup(width, 16);
@@ -90,11 +93,11 @@ struct ChainPlan {
   // per-workgroup partial of dW [N, K] (+ db [N]) from the tiles dY[:, ycol : ycol + N] and X[:, xcol : xcol + K]; slab / dbslab point at
   // workgroup 0's partial, `stride` floats apart per workgroup; the matrix has row pitch ld and starts at column col0 of the slab rows
   void wgrad(int level, const ChainTile& dy, int ycol, int N, const ChainTile& x, int xcol, int K, float* slab, int ld, int col0, int stride,
-             float* dbslab = nullptr, bool accumulate = false) {
+             float* dbslab = nullptr, bool accumulate = false, int bf = 0) {
     ChainOp& o = add(CH_WGRAD, level);
     o.in_off = dy.off + ycol; o.in_ld = dy.ld; o.N = N; o.NT = rup(N, 16) / 16;
     o.aux_off = x.off + xcol; o.aux_ld = x.ld; o.K = K; o.KG = rup(K, 16) / 16;
-    o.gout = slab; o.gld = ld; o.gcol = col0; o.gstride = stride; o.gout2 = dbslab; o.flags = accumulate ? CH_ACCUM : 0;
+    o.gout = slab; o.gld = ld; o.gcol = col0; o.gstride = stride; o.gout2 = dbslab; o.flags = (accumulate ? CH_ACCUM : 0) | bf;
     if (ycol + o.NT * 16 > dy.width || xcol + o.KG * 16 > x.width) ok = false;
   }
 };

@@ -7,7 +7,8 @@
 //
 //   LOAD        global rows (optionally gathered through an id, optionally relu'd) -> tile
 //   LIN         tile x packed weight (launch_pack_b fragment order: one coalesced 16-byte load per lane and 16 x 16 block) on exact
-//               fp32 MFMAs, 16 sessions = the 16 rows of the MFMA tile; bias / relu / accumulate epilogue; tile (+ global copy)
+//               fp32 MFMAs, 16 sessions = the 16 rows of the MFMA tile; bias / relu / accumulate epilogue; tile (+ global copy).
+//               CH_BF16 (bf16 mode, links of 64 / 128 input features): both operands rounded to bf16 first, as on the bf16 pipe
 //   MASKCOPY    tile * (other tile > 0)  (relu backward)
 //   SOFTMAX(+BWD), ENS_FWD / ENS_BWD (IntEL.py:214-215: per-session weight vectors broadcast over the list, weighted score sum)
 //   WGRAD       the workgroup's share of a weight gradient dW = dY^T X (+ bias gradient) from two tiles: the 16 sessions are the MFMA's
@@ -54,8 +55,13 @@ __device__ __forceinline__ void op_load(const ChainOp& op, float* lds, int B, in
   }
 }
 
+// round-to-nearest-even to bf16 and back: a product of two such values is exact in fp32, so the exact-fp32 MFMA of rounded operands IS the
+// bf16 pipe's product with fp32 accumulation (bf16 mode, CH_BF16 links)
+__device__ __forceinline__ float bfr(float x) { return (float)(__bf16)x; }
+
 __device__ __forceinline__ void op_lin(const ChainOp& op, float* lds, int B, int b0, int mt, int lane) {
   const int i = lane & 15, j = lane >> 4;
+  const bool bf = (op.flags & CH_BF16) != 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const f32x4* P = reinterpret_cast<const f32x4*>(op.P) + (size_t)mt * op.KG * 64 + lane;
   const float* xin = lds + op.in_off + i * op.in_ld + 4 * j;
@@ -68,7 +74,7 @@ __device__ __forceinline__ void op_lin(const ChainOp& op, float* lds, int B, int
     for (int u = 0; u < 8; ++u) {
       const f32x4 x = *reinterpret_cast<const f32x4*>(xin + 16 * (g + u));
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma16(w[u][s], x[s], acc);
+      for (int s = 0; s < 4; ++s) acc = bf ? mfma16(bfr(w[u][s]), bfr(x[s]), acc) : mfma16(w[u][s], x[s], acc);
     }
   }
   {
@@ -80,7 +86,7 @@ __device__ __forceinline__ void op_lin(const ChainOp& op, float* lds, int B, int
       if (g + u >= op.KG) break;
       const f32x4 x = *reinterpret_cast<const f32x4*>(xin + 16 * (g + u));
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = mfma16(w[u][s], x[s], acc);
+      for (int s = 0; s < 4; ++s) acc = bf ? mfma16(bfr(w[u][s]), bfr(x[s]), acc) : mfma16(w[u][s], x[s], acc);
     }
   }
   const int col = 16 * mt + 4 * j;
@@ -235,8 +241,8 @@ __device__ __forceinline__ void op_wgrad(const ChainOp& op, const float* lds, in
   for (int s = 0; s < 4; ++s) {
     const float ya = lds[op.in_off + (4 * j + s) * op.in_ld + 16 * mt + i];
     const float xb = lds[op.aux_off + (4 * j + s) * op.aux_ld + 16 * nt + i];
-    acc = mfma16(ya, xb, acc);
-    cs += ya;
+    acc = (op.flags & CH_BF16) ? mfma16(bfr(ya), bfr(xb), acc) : mfma16(ya, xb, acc);
+    cs += ya;      // (the bias gradient sums the unrounded rows in either mode)
   }
   float* slab = op.gout + (size_t)blockIdx.x * op.gstride;
   const int k = 16 * nt + i;

@@ -1271,7 +1271,7 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   static const int mode = [] { const char* e = getenv("INTEL_HEAD_FUSED"); return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)); }();      // parsed once: 0 off, 2 backward chains forced on
   const int on = mode != 0;
   if (!on || !D.cross_attention || D.pool_mean || D.weight_norm != 0 || D.model_num > 16) return false;
-  if (D.dtype != INTEL_DTYPE_F32) return false;      // bf16 mode rounds the operands of the 64 / 128-deep B-row products (oracle.forward_bf16): kernel-per-op head
+  // (bf16 mode: the chains' links of 64 / 128 input features round their operands like the kernel-per-op head's products do -- chain.h: CH_BF16)
   // train: 0 = inference forward, 1 = training BACKWARD, 2 = training FORWARD -- the forward chains write the kernel-per-op path's stash, so
   // the two directions decide independently.  The BACKWARD chains pay where the step is launch-bound (the reference's hyper-parameters at
   // its batch of 512: +8.5 % sessions/s same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers'
@@ -1314,6 +1314,7 @@ static void head_fwd_a(Run& r, const IntelOut* out) {
   TowerBufs &ti = y.tw[0], &ts = y.tw[1];
   const int off_u = ti.d + ts.d, off_int = off_u + D.d_u, enc0 = D.d_c + D.d_u;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   ChainTile PRED = p.tile(Pin), LOG = p.tile(I), INT = p.tile(I), HU = p.tile(D.d_u), HI = p.tile(D.d_int);
   ChainTile QV[2] = {p.tile(ti.d), p.tile(ts.d)}, QK[2] = {p.tile(ti.d), p.tile(ts.d)};
   p.load(0, r.P(INTEL_P_CTX_EMB), D.d_c, 0, D.d_c, PRED, 0, 0, bt.context_mh, false, y.PREDIN, Pin, 0);
@@ -1326,24 +1327,24 @@ static void head_fwd_a(Run& r, const IntelOut* out) {
       EncBufs& n = y.enc[e];
       ChainTile HC = p.tile(D.gru_hidden);
       p.load(0, n.gru.HCUR, D.gru_hidden, 0, D.gru_hidden, HC, 0);
-      p.lin(1, HC, 0, D.gru_hidden, n.gru.pWout, n.dm, nullptr, PRED, n.predin_off, 0, y.PREDIN, Pin, n.predin_off);
+      p.lin(1, HC, 0, D.gru_hidden, n.gru.pWout, n.dm, nullptr, PRED, n.predin_off, p.bfl(D.gru_hidden, n.dm), y.PREDIN, Pin, n.predin_off);
     }
     lv = 2;
   } else {
     p.load(0, y.PREDIN, Pin, enc0, Pin - enc0, PRED, enc0, PRED.width - enc0);
   }
   p.load(0, r.P(INTEL_P_UID_EMB), D.d_u, 0, D.d_u, HU, 0, 0, bt.u_id_c, true, y.FEAT, F, off_u);      // relu(h_u), IntEL.py:178
-  p.lin(lv, PRED, 0, Pin, y.pPred, I, r.P(INTEL_P_PRED_B), LOG, 0);
+  p.lin(lv, PRED, 0, Pin, y.pPred, I, r.P(INTEL_P_PRED_B), LOG, 0, p.bfl(Pin, I));
   {
     ChainOp& o = p.add(CH_SOFTMAX, lv + 1);
     o.in_off = LOG.off; o.in_ld = LOG.ld; o.out_off = INT.off; o.out_ld = INT.ld; o.N = I; o.NP = INT.width;
     o.gout = y.INTENTS; o.gld = I; o.gcol = 0; o.gout2 = out->intents;
   }
-  p.lin(lv + 2, INT, 0, I, y.pInt, D.d_int, r.P(INTEL_P_INTENT_B), HI, 0, CH_RELU, y.FEAT, F, off_int);     // relu(h_intent), IntEL.py:212
+  p.lin(lv + 2, INT, 0, I, y.pInt, D.d_int, r.P(INTEL_P_INTENT_B), HI, 0, CH_RELU | p.bfl(I, D.d_int), y.FEAT, F, off_int);     // relu(h_intent), IntEL.py:212
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     p.lin(lv + 2, INT, 0, I, w.pXq, w.d, nullptr, QV[t], 0, 0, w.QV, w.d, 0);
-    p.lin(lv + 3, QV[t], 0, w.d, w.pXkT, w.d, nullptr, QK[t], 0, 0, w.QK, w.d, 0);
+    p.lin(lv + 3, QV[t], 0, w.d, w.pXkT, w.d, nullptr, QK[t], 0, p.bfl(w.d, w.d), w.QK, w.d, 0);
   }
   chain_run(r, p);
 }
@@ -1357,15 +1358,16 @@ static void head_fwd_b(Run& r, const IntelOut* out) {
   TowerBufs &ti = y.tw[0], &ts = y.tw[1];
   const int off_u = ti.d + ts.d, npad = D.d_u + D.d_int;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   ChainTile XB[2] = {p.tile(ti.d), p.tile(ts.d)}, FEAT = p.tile(F), WV = p.tile(16), WP = p.tile(16);
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     p.load(0, w.XBAR, w.d, 0, w.d, XB[t], 0);
-    p.lin(1, XB[t], 0, w.d, w.pXv, w.d, nullptr, FEAT, w.feat_off, 0, y.FEAT, F, w.feat_off);
+    p.lin(1, XB[t], 0, w.d, w.pXv, w.d, nullptr, FEAT, w.feat_off, p.bfl(w.d, w.d), y.FEAT, F, w.feat_off);
   }
   p.load(0, y.FEAT, F, off_u, npad, FEAT, off_u, FEAT.width - off_u);
-  p.lin(2, FEAT, 0, F, y.pWe, K, r.P(INTEL_P_WE_B), WV, 0, 0, y.WV, K, 0);
-  p.lin(2, FEAT, off_u, npad, y.pWePad, K, r.P(INTEL_P_WE_B), WP, 0, 0, y.WPAD, K, 0);
+  p.lin(2, FEAT, 0, F, y.pWe, K, r.P(INTEL_P_WE_B), WV, 0, p.bfl(F, K), y.WV, K, 0);
+  p.lin(2, FEAT, off_u, npad, y.pWePad, K, r.P(INTEL_P_WE_B), WP, 0, p.bfl(npad, K), y.WPAD, K, 0);
   {
     ChainOp& o = p.add(CH_ENS_FWD, 3);
     o.in_off = WV.off; o.in_ld = WV.ld; o.aux_off = WP.off; o.aux_ld = WP.ld;
@@ -1384,6 +1386,7 @@ static void head_bwd_a(Run& r, const float* d_weights, const float* d_ens) {
   TowerBufs &ti = y.tw[0], &ts = y.tw[1];
   const int off_u = ti.d + ts.d, off_int = off_u + D.d_u, npad = D.d_u + D.d_int;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   ChainTile DWV = p.tile(16), DWP = p.tile(16), DF = p.tile(F), MASK = p.tile(D.d_int), DH = p.tile(D.d_int), DI = p.tile(I);
   ChainTile G1[2] = {p.tile(ti.d), p.tile(ts.d)};
   {
@@ -1393,8 +1396,8 @@ static void head_bwd_a(Run& r, const float* d_weights, const float* d_ens) {
     p.a.ens.d_weights = d_weights; p.a.ens.d_ens = d_ens; p.a.ens.dwv = y.dWV; p.a.ens.dwpad = y.dWPAD;
   }
   p.load(0, y.FEAT, F, off_int, D.d_int, MASK, 0);
-  p.lin(1, DWV, 0, K, y.pWeT, F, nullptr, DF, 0, 0, y.dFEAT, F, 0);
-  p.lin(2, DWP, 0, K, y.pWePadT, npad, nullptr, DF, off_u, CH_ACCUM, y.dFEAT, F, off_u);      // padded rows only see [h_u | h_intent]
+  p.lin(1, DWV, 0, K, y.pWeT, F, nullptr, DF, 0, p.bfl(F, K), y.dFEAT, F, 0);
+  p.lin(2, DWP, 0, K, y.pWePadT, npad, nullptr, DF, off_u, CH_ACCUM | p.bfl(npad, K), y.dFEAT, F, off_u);      // padded rows only see [h_u | h_intent]
   {
     ChainOp& o = p.add(CH_MASKCOPY, 3);
     o.in_off = DF.off + off_int; o.in_ld = DF.ld; o.aux_off = MASK.off; o.aux_ld = MASK.ld; o.out_off = DH.off; o.out_ld = DH.ld;
@@ -1402,9 +1405,9 @@ static void head_bwd_a(Run& r, const float* d_weights, const float* d_ens) {
   }
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
-    p.lin(3, DF, w.feat_off, w.d, w.pXvT, w.d, nullptr, G1[t], 0, 0, y.dHB[t][0], w.d, 0);      // dxbar
+    p.lin(3, DF, w.feat_off, w.d, w.pXvT, w.d, nullptr, G1[t], 0, p.bfl(w.d, w.d), y.dHB[t][0], w.d, 0);      // dxbar
   }
-  p.lin(4, DH, 0, D.d_int, y.pIntT, I, nullptr, DI, 0, 0, y.dINTENT, I, 0);
+  p.lin(4, DH, 0, D.d_int, y.pIntT, I, nullptr, DI, 0, p.bfl(I, D.d_int), y.dINTENT, I, 0);
   chain_run(r, p);
 }
 
@@ -1418,6 +1421,7 @@ static void head_bwd_a_leaves(Run& r, int leaf_tag) {
   TowerBufs &ti = y.tw[0], &ts = y.tw[1];
   const int off_u = ti.d + ts.d, npad = D.d_u + D.d_int;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   const int S = cdiv(y.B, 16);
   const int o_we = 0, o_be = o_we + K * F, o_wi = o_be + K, o_bi = o_wi + D.d_int * I, o_v0 = o_bi + D.d_int, o_v1 = o_v0 + ti.d * ti.d,
             stride = (int)rup_sz((size_t)o_v1 + ts.d * ts.d, 64);
@@ -1429,8 +1433,8 @@ static void head_bwd_a_leaves(Run& r, int leaf_tag) {
     p.load(0, y.FEAT, F, 0, F, FE, 0, FE.width);
     p.load(0, y.dWV, K, 0, K, DWV, 0, DWV.width);
     p.load(0, y.dWPAD, K, 0, K, DWP, 0, DWP.width);
-    p.wgrad(1, DWV, 0, K, FE, 0, F, slab + o_we, F, 0, stride, slab + o_be);
-    p.wgrad(2, DWP, 0, K, FE, off_u, npad, slab + o_we, F, off_u, stride, slab + o_be, true);      // padded rows only see [h_u | h_intent]
+    p.wgrad(1, DWV, 0, K, FE, 0, F, slab + o_we, F, 0, stride, slab + o_be, false, p.bfl(F, K));
+    p.wgrad(2, DWP, 0, K, FE, off_u, npad, slab + o_we, F, off_u, stride, slab + o_be, true, p.bfl(npad, K));      // padded rows only see [h_u | h_intent]
     const int a = r.acc(INTEL_P_WE_W), ab = r.acc(INTEL_P_WE_B);
     redq_push(r.ctx->rq, slab + o_we, stride, S, K, F, r.G(INTEL_P_WE_W), F, a);
     redq_push(r.ctx->rq, slab + o_be, stride, S, 1, K, r.G(INTEL_P_WE_B), K, ab);
@@ -1439,7 +1443,7 @@ static void head_bwd_a_leaves(Run& r, int leaf_tag) {
     ChainTile IN = p.tile(I), DH = p.tile(D.d_int);
     p.load(0, y.INTENTS, I, 0, I, IN, 0, IN.width);
     p.load(0, y.dHINT, D.d_int, 0, D.d_int, DH, 0, DH.width);
-    p.wgrad(1, DH, 0, D.d_int, IN, 0, I, slab + o_wi, I, 0, stride, slab + o_bi);
+    p.wgrad(1, DH, 0, D.d_int, IN, 0, I, slab + o_wi, I, 0, stride, slab + o_bi, false, p.bfl(I, D.d_int));
     const int a = r.acc(INTEL_P_INTENT_W), ab = r.acc(INTEL_P_INTENT_B);
     redq_set_tag(r.ctx->rq, 0);            // the intent-embedding slot is shared with the encoders' branches: final flush
     redq_push(r.ctx->rq, slab + o_wi, stride, S, D.d_int, I, r.G(INTEL_P_INTENT_W), I, a);
@@ -1452,7 +1456,7 @@ static void head_bwd_a_leaves(Run& r, int leaf_tag) {
     ChainTile XB = p.tile(w.d), DFt = p.tile(w.d);
     p.load(0, w.XBAR, w.d, 0, w.d, XB, 0);
     p.load(0, y.dFEAT, F, w.feat_off, w.d, DFt, 0);
-    p.wgrad(1, DFt, 0, w.d, XB, 0, w.d, slab + (t == 0 ? o_v0 : o_v1), w.d, 0, stride);      // pooled = xbar Wv^T
+    p.wgrad(1, DFt, 0, w.d, XB, 0, w.d, slab + (t == 0 ? o_v0 : o_v1), w.d, 0, stride, nullptr, false, p.bfl(w.d, w.d));      // pooled = xbar Wv^T
     redq_push(r.ctx->rq, slab + (t == 0 ? o_v0 : o_v1), stride, S, w.d, w.d, r.G(w.xbase + 2), w.d, r.acc(w.xbase + 2));
   }
   if (p.a.nops) chain_run(r, p);
@@ -1464,6 +1468,7 @@ static void head_bwd_b(Run& r, const float* d_intents) {
   Layout& y = r.y;
   const int I = D.intent_num, Pin = y.Pin;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   ChainTile DA = p.tile(I), DB = p.tile(I), DC = p.tile(I), Y = p.tile(I), DL = p.tile(I), DP = p.tile(Pin);
   ChainTile G2[2] = {p.tile(y.tw[0].d), p.tile(y.tw[1].d)}, G3[2] = {p.tile(y.tw[0].d), p.tile(y.tw[1].d)};
   p.load(0, y.dINTENT, I, 0, I, DA, 0, DA.width);
@@ -1471,7 +1476,7 @@ static void head_bwd_b(Run& r, const float* d_intents) {
   for (int t = 0; t < 2; ++t) {
     TowerBufs& w = y.tw[t];
     p.load(0, y.dHB[t][1], w.d, 0, w.d, G2[t], 0);
-    p.lin(1, G2[t], 0, w.d, w.pXk, w.d, nullptr, G3[t], 0, 0, y.dHB[t][2], w.d, 0);            // dQV
+    p.lin(1, G2[t], 0, w.d, w.pXk, w.d, nullptr, G3[t], 0, p.bfl(w.d, w.d), y.dHB[t][2], w.d, 0);            // dQV
     p.lin(2, G3[t], 0, w.d, w.pXqT, I, nullptr, t == 0 ? DB : DC, 0);
   }
   {
@@ -1480,14 +1485,14 @@ static void head_bwd_b(Run& r, const float* d_intents) {
     o.out_off = DL.off; o.out_ld = DL.ld; o.N = I; o.NP = DL.width; o.gadd = d_intents;
     o.gout = y.dLOGITS; o.gld = I; o.gcol = 0;
   }
-  p.lin(4, DL, 0, I, y.pPredT, Pin, nullptr, DP, 0, 0, y.dPREDIN, Pin, 0);
+  p.lin(4, DL, 0, I, y.pPredT, Pin, nullptr, DP, 0, p.bfl(Pin, I), y.dPREDIN, Pin, 0);
   const bool gru_ext = D.encoder == INTEL_ENC_GRU4REC && y.enc[0].gru.ext_proj && y.enc[1].gru.ext_proj;
   if (gru_ext) {
     // GRU4Rec: d(h_last) = d(vec) Wout, d(vec) = the encoder's columns of d(pred_layer input)
     for (int e = 0; e < 2; ++e) {
       EncBufs& n = y.enc[e];
       ChainTile DH = p.tile(D.gru_hidden);
-      p.lin(5, DP, n.predin_off, n.dm, n.gru.pWoutT, D.gru_hidden, nullptr, DH, 0, 0, n.gru.dHa, D.gru_hidden, 0);
+      p.lin(5, DP, n.predin_off, n.dm, n.gru.pWoutT, D.gru_hidden, nullptr, DH, 0, p.bfl(D.gru_hidden, n.dm), n.gru.dHa, D.gru_hidden, 0);
     }
   }
   chain_run(r, p);
@@ -1500,6 +1505,7 @@ static void head_bwd_b_leaves(Run& r) {
   Layout& y = r.y;
   const int I = D.intent_num, Pin = y.Pin;
   ChainPlan p;
+  p.bf16 = r.D.dtype == INTEL_DTYPE_BF16;
   const int S = cdiv(y.B, 16);
   int off = 0;
   int o_k[2], o_q[2];
@@ -1520,7 +1526,7 @@ static void head_bwd_b_leaves(Run& r) {
       ChainTile QVt = p.tile(w.d), G2 = p.tile(w.d);
       p.load(0, w.QV, w.d, 0, w.d, QVt, 0);
       p.load(0, y.dHB[t][1], w.d, 0, w.d, G2, 0);
-      p.wgrad(1, QVt, 0, w.d, G2, 0, w.d, slab + o_k[t], w.d, 0, stride);
+      p.wgrad(1, QVt, 0, w.d, G2, 0, w.d, slab + o_k[t], w.d, 0, stride, nullptr, false, p.bfl(w.d, w.d));
       redq_push(r.ctx->rq, slab + o_k[t], stride, S, w.d, w.d, r.G(w.xbase + 1), w.d, r.acc(w.xbase + 1));
     }
     if (r.G(w.xbase + 0)) {          // QV = intent Wq^T
@@ -1536,7 +1542,7 @@ static void head_bwd_b_leaves(Run& r) {
     ChainTile PR = p.tile(Pin), DL = p.tile(I);
     p.load(0, y.PREDIN, Pin, 0, Pin, PR, 0, PR.width);
     p.load(0, y.dLOGITS, I, 0, I, DL, 0, DL.width);
-    p.wgrad(1, DL, 0, I, PR, 0, Pin, slab + o_wp, Pin, 0, stride, slab + o_bp);
+    p.wgrad(1, DL, 0, I, PR, 0, Pin, slab + o_wp, Pin, 0, stride, slab + o_bp, false, p.bfl(Pin, I));
     const int a = r.acc(INTEL_P_PRED_W), ab = r.acc(INTEL_P_PRED_B);
     redq_push(r.ctx->rq, slab + o_wp, stride, S, I, Pin, r.G(INTEL_P_PRED_W), Pin, a);
     redq_push(r.ctx->rq, slab + o_bp, stride, S, 1, I, r.G(INTEL_P_PRED_B), I, ab);
@@ -1549,7 +1555,7 @@ static void head_bwd_b_leaves(Run& r) {
       ChainTile HC = p.tile(Hd), DV = p.tile(n.dm);
       p.load(0, n.gru.HCUR, Hd, 0, Hd, HC, 0);
       p.load(0, y.dPREDIN, Pin, n.predin_off, n.dm, DV, 0, DV.width);
-      p.wgrad(1, DV, 0, n.dm, HC, 0, Hd, slab + o_go[e], Hd, 0, stride);
+      p.wgrad(1, DV, 0, n.dm, HC, 0, Hd, slab + o_go[e], Hd, 0, stride, nullptr, false, p.bfl(Hd, n.dm));
       redq_push(r.ctx->rq, slab + o_go[e], stride, S, n.dm, Hd, r.G(ws), Hd, r.acc(ws));
     }
   }

@@ -103,6 +103,6 @@ def test_bf16_mode_kernels():
         loss, _, _ = LS.IntListloss(args)(out, batch)
         loss.backward()
     assert bool(torch.isfinite(loss))
-    kt.check(['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'wgrad_tr_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel'],
-             ['attn_seq_bwd_fused_kernel', 'attn_seq_fwd_kernel'], 'bf16 mode, Tmall shape')
+    kt.check(['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'wgrad_tr_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel', 'chain_kernel'],
+             ['attn_seq_bwd_fused_kernel', 'attn_seq_fwd_kernel'], 'bf16 mode, Tmall shape')      # (round 5: the session head's chains in bf16 mode too, their 64 / 128-deep links rounding like the bf16 pipe)
     assert kt.count['tower_fwd_fused_kernel'] == 2 and kt.count['tower_bwd_fused_kernel'] == 2, kt.count
