@@ -333,6 +333,12 @@ def main():
     def one_step(i):
         return eng.train_step(batches[i % nbatches])
     loss = None
+    # The synthetic corpus and the resident batches are a few million Python objects; a generation-2 collection that walks them costs the host
+    # 40 - 90 ms, and when one falls into a 20-step timed block it IS the result (LifeData shape, lazy table: 3.3 -> 5.5 ms per step).  Everything
+    # built so far is long-lived: collect once, then keep it out of the collector's generations.
+    import gc
+    gc.collect()
+    gc.freeze()
     for i in range(a.warmup):
         loss = one_step(i)
     torch.cuda.synchronize()
