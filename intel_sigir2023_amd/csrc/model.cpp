@@ -1276,14 +1276,18 @@ static bool head_fused_ok(const IntelDesc& D, const Layout& y, int train) {
   // the two directions decide independently.  The BACKWARD chains pay where the step is launch-bound (the reference's hyper-parameters at
   // its batch of 512: +8.5 % sessions/s same-box).  With more sessions per step the kernel-per-op head's launches hide under the towers'
   // kernels while a chain launch holds whole CUs (measured same-box, round 4, both directions on: Tmall shape 1024 / 2048 / 4096 sessions
-  // -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress 1024 +-0): they stop at 768 sessions per step.  The FORWARD chains run at any batch
+  // -0.5 / -2.7 / -1.8 %, LifeData 2048 -2.5 %, stress 1024 +-0): they stopped at 768 sessions per step.  Round 5: part of that loss was the two
+  // weight-gradient chain launches queued behind the ITEM tower -- the backward's longest branch, with the table's Adam sweep behind it; they now go
+  // behind the score tower (intel_backward: leaves_behind_score).  Forced on against off after that, two boxes (profiles/r05_threshold_sweep.txt and
+  // the run before it): 1024 sessions +2.6 / +0.3 %, 2048 +1.0 / -0.5 %, 3072 -0.4 %, 4096 -1.6 / -1.4 %: the limit moves to 1024, no further.
+  // The FORWARD chains run at any batch
   // size (evaluation +2 ... +7 %, the training forward at the headline +0.5 %).  INTEL_HEAD_FUSED=2 forces the backward chains on too.
   // With BOTH towers on the one-kernel 32-wide path (tower32.hip) there are no tower launches to hide the head's under: the backward chains pay
   // up to 4096 sessions (published hyper-parameters, same-box: GRU4Rec encoders 1024 sessions +4 %, 4096 +-0, 8192 -5 %; BERT4Rec encoders
   // 1024 / 2048 / 4096: +2 / +4 / +5.5 %).
   const int force = mode == 2;
   const bool tw32_both = D.layers > 0 && tower32_supported(y.L, y.tw[0].d, D.heads, D.layers, 1) && tower32_supported(y.L, y.tw[1].d, D.heads, D.layers, 1);
-  const int bwd_limit = !tw32_both ? 768 : (D.encoder == INTEL_ENC_BERT4REC ? (1 << 30) : 4096);      // (BERT4Rec encoders: still +5 / +4 / +1.3 % at 6144 / 8192 / 16 384 sessions)
+  const int bwd_limit = !tw32_both ? 1024 : (D.encoder == INTEL_ENC_BERT4REC ? (1 << 30) : 4096);      // (BERT4Rec encoders: still +5 / +4 / +1.3 % at 6144 / 8192 / 16 384 sessions)
   if (train == 1 && y.B > bwd_limit && !force) return false;
   if ((D.d_u % 16) || (D.d_int % 16) || (D.d_c % 4)) return false;
   // LDS tiles of the largest of the four chains (16 sessions x (width + 4) floats per tile)
@@ -2085,6 +2089,20 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
     r.ok((int)hipEventRecord(c->ev_x[2], r.st));
     r.ok((int)hipStreamWaitEvent(c->side[0], c->ev_x[2], 0));
     r.ok((int)hipStreamWaitEvent(c->side[1], c->ev_x[0], 0));
+    // The weight gradients of the head's links (two chain launches, nothing in this backward reads them; reduced right there: tag 5, the shared
+    // intent-embedding slot stays for the final flush) go behind the SHORTER tower branch.  With both towers on the one-kernel 32-wide path that is
+    // the item tower's stream (round 4); with 64 / 128-wide towers the item tower's branch is the backward's longest and carries the table's Adam
+    // sweep behind it -- the two launches and their reduction there pushed the sweep out by ~150 us (the whole of the -1.8 % that kept the backward
+    // chains off at the headline's batch): behind the score tower they end a millisecond before anything waits for them.
+    const bool leaves_behind_score = !(D.layers > 0 && tower32_supported(L, y.tw[0].d, D.heads, D.layers, 1) && tower32_supported(L, y.tw[1].d, D.heads, D.layers, 1));
+    auto chain_leaves = [&](Run& q) {
+      redq_set_tag(c->rq, 5);
+      if (!q.rc) head_bwd_a_leaves(q, 5);
+      q.ok((int)hipStreamWaitEvent(q.st, c->ev_x[2], 0));
+      if (!q.rc) head_bwd_b_leaves(q);
+      if (!q.rc) q.ok(redq_flush_tag(c->rq, 5, q.st));
+      redq_set_tag(c->rq, 0);
+    };
     {   // score tower: it needs its pooling backward only (the tower kernels leave room for the chain launches: tower32.hip)
       redq_set_tag(c->rq, 1);
       Run t3 = s2;
@@ -2103,20 +2121,14 @@ void backward_impl(Run& r, const float* d_weights, const float* d_ens, const flo
         t3.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, 0, D.d_c, bt.context_mh, B, r.G(INTEL_P_CTX_EMB), nullptr, 0, 0, t3.st));
       if (!t3.rc && r.G(INTEL_P_UID_EMB))
         t3.ok(launch_scatter_add_rows(y.dPREDIN, y.Pin, D.d_c, D.d_u, bt.u_id_c, B, r.G(INTEL_P_UID_EMB), nullptr, 0, 0, t3.st));
+      if (leaves_behind_score) chain_leaves(t3);
       r.ok(t3.rc);
     }
     redq_set_tag(c->rq, 2);
     item_tower_bwd(s1, y.tmp[0].dXa);
     if (!s1.rc) s1.ok(redq_flush_tag(c->rq, 2, s1.st));
     redq_set_tag(c->rq, 0);
-    // ... and the weight gradients of the head's links behind the item tower (two chain launches off the critical chain), reduced right
-    // there (tag 5; the shared intent-embedding slot stays for the final flush)
-    redq_set_tag(c->rq, 5);
-    if (!s1.rc) head_bwd_a_leaves(s1, 5);
-    s1.ok((int)hipStreamWaitEvent(s1.st, c->ev_x[2], 0));
-    if (!s1.rc) head_bwd_b_leaves(s1);
-    if (!s1.rc) s1.ok(redq_flush_tag(c->rq, 5, s1.st));
-    redq_set_tag(c->rq, 0);
+    if (!leaves_behind_score) chain_leaves(s1);
     r.ok(s1.rc);
     if (r.rc) return;
     redq_set_tag(c->rq, 3);

@@ -48,6 +48,16 @@ def test_headline_widths_short_lists(L, B):
     assert kt.count['tower_fwd_fused_kernel'] == 1 and kt.count['attn_seq_bwd_fused_kernel'] == 2, kt.count
 
 
+@pytest.mark.parametrize('B,bwd_chains', [(1000, True), (1100, False)])
+def test_backward_chain_launches_stop_at_1024_sessions(B, bwd_chains):
+    """64 / 128-wide towers: the session head's BACKWARD runs as chain launches up to 1024 sessions per step (head_fused_ok; 768 before the
+    weight-gradient chains moved behind the score tower in round 5), as one launch per link above; the forward chains run at any batch.  Parity on both sides."""
+    kt, desc = _run(dict(W64, L=7, B=B, I=30, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=5, model_num=3, loss='IntListloss',
+                         cross_attention=1, cal_diversity=0), 9600 + B)
+    kt.check(['chain_kernel', 'tower_fwd_fused_kernel'], ['tw32_fwd_kernel'], desc)
+    assert (kt.count['chain_kernel'] > 2) == bwd_chains, (kt.count['chain_kernel'], desc)      # two forward chain launches in either case
+
+
 def test_headline_widths_two_layers_two_heads():
     kt, desc = _run(dict(W64, L=50, B=9, I=30, num_heads=2, num_layers=2, encoder='BERT4Rec', history_max=20, model_num=3, loss='IntListloss',
                          cross_attention=1, cal_diversity=1), 9200)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box sweeps that justify the batch thresholds left in the policy layer: every line is one bench.py run of 100 timed steps,
 # the two settings of a threshold alternate three times at every batch size, all in ONE gpurun call (box-to-box spread is +-3 %).
-#   1. backward chain launches (csrc/model.cpp head_fused_ok: <= 768 sessions with 64/128-wide towers, <= 4096 with 32-wide towers + GRU4Rec,
+#   1. backward chain launches (csrc/model.cpp head_fused_ok: <= 1024 sessions with 64/128-wide towers (the sweep under profiles/ was measured with the limit at 768),, <= 4096 with 32-wide towers + GRU4Rec,
 #      any batch with 32-wide towers + BERT4Rec): INTEL_HEAD_FUSED=1 (the policy) against 2 (backward chains at any batch)
 #   2. length-ordered GRU workgroups (default: from 1024 sessions): INTEL_GRU_ORDER_MIN_B=1 (always ordered) against 1000000 (never)
 # usage (GPU box): bash tools/threshold_sweep.sh > gpurun_out/threshold_sweep.txt
@@ -19,7 +19,7 @@ PY
 }
 if [ "$1" != "gru" ]; then
 echo "== backward chain launches: policy (INTEL_HEAD_FUSED=1) vs always (=2)"
-for b in 512 768 1024 2048; do
+for b in 768 1024 2048 3072 4096; do
   for rep in 1 2 3; do
     run "tmall (128/64-wide) B=$b" "--workload tmall --batch $b" INTEL_HEAD_FUSED=1
     run "tmall (128/64-wide) B=$b" "--workload tmall --batch $b" INTEL_HEAD_FUSED=2
