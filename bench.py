@@ -263,6 +263,41 @@ def short_line(workload, B, over, steps, warmup, dev):
     return out
 
 
+def self_launch(n, argv):
+    """Start the N ranks of `bench.py --gpus N` as children (python -m torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1), relay
+    rank 0's JSON line and check that it really is an N-rank line.  Returns the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:          # a free port for the rendezvous
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '8')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if p.returncode != 0:
+        print('bench.py: the %d-rank launch exited with code %d' % (n, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    try:
+        d = json.loads(line)
+    except Exception:
+        print('bench.py: the %d-rank launch printed no JSON line' % n, file=sys.stderr)
+        return 1
+    if d.get('n_gpus') != n or d.get('rccl_ranks') != n:
+        print('bench.py: asked for %d GPUs, the line says n_gpus=%s rccl_ranks=%s' % (n, d.get('n_gpus'), d.get('rccl_ranks')), file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -288,15 +323,32 @@ def main():
     ap.add_argument('--cpu_budget', type=float, default=24.0)
     ap.add_argument('--shapes', action='store_true', help='also report per-GEMM-shape timings')
     ap.add_argument('--encoder', type=str, default='', help='override the sequence encoder: BERT4Rec | GRU4Rec')
+    ap.add_argument('--dry_launch', action='store_true', help='stop after the process group is up: rank 0 prints {"dry_launch": true, "n_gpus": N, '
+                    '"rccl_ranks": N, "backend": ...}; checks the N-rank launch path without a GPU (tests/test_bench_launch_cpu.py)')
     a = ap.parse_args()
+
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher.  Nothing in this process has touched the GPU yet (torch is not even imported), the
+        # N ranks are CHILD processes (never an exec), rank 0's JSON line is relayed and checked
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
 
     import torch
     from intel_sigir2023_amd import _lib, parallel, synth
     from intel_sigir2023_amd.engine import IntELEngine
     from intel_sigir2023_amd.model import IntEL
     rank, world, local_rank = parallel.init_distributed()
-    if world != a.gpus and rank == 0:
-        print('warning: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (a.gpus, world), file=sys.stderr)
+    if world != a.gpus:
+        # a line that says n_gpus = WORLD_SIZE under --gpus N would be read as an N-GPU measurement
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (plain `python bench.py --gpus N` launches its own N ranks; under torch.distributed.run '
+                         'pass the same N as --nproc-per-node)' % (a.gpus, world))
+    ranks_seen = parallel.count_ranks()      # one all-reduce of ones through the group that will carry the gradients (1 without a group)
+    if ranks_seen != a.gpus:
+        raise SystemExit('bench.py: the process group reports %d ranks, --gpus %d' % (ranks_seen, a.gpus))
+    if a.dry_launch:
+        if rank == 0:
+            print(json.dumps({'dry_launch': True, 'n_gpus': world, 'rccl_ranks': ranks_seen, 'backend': parallel.backend_name()}))
+        parallel.barrier()
+        return
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback in the product path)')
     dev = torch.device('cuda', local_rank)
@@ -430,7 +482,7 @@ def main():
                   % (a.loss, {'tmall': 'Tmall-shape', 'lifedata': 'LifeData-shape'}.get(a.workload, a.workload), Lmax, f['model_num'], f['i_emb_size'] + f['im_emb_size'], f['s_emb_size']),
         'value': round(world * B * a.steps / max(el, 1e-9), 1), 'unit': 'sessions/s', 'n_gpus': world, 'steps': a.steps,
         'warmup': a.warmup, 'ms_per_step': round(1e3 * el / max(1, a.steps), 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic', 'rccl_ranks': ranks_seen, 'backend': parallel.backend_name(),
         'config': {'workload': '%s: %d items, list=%d, K=%d rankers, I=%d intents, H=%d, emb %d/%d/%d/%d (id/meta/score/ctx), %s, %d heads x %d tied '
                                'layers, %s, %s loss, cal_diversity=%d, %s item ids, %d resident batches'
                                % (a.workload, cinfo['items'], Lmax, f['model_num'], cinfo['I'], w['batch']['H'], f['i_emb_size'], f['im_emb_size'],

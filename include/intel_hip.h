@@ -462,6 +462,13 @@ int intel_op_linear_dgrad(const float* dy, int M, int N, const float* w, int K, 
 /* dw[N,K] = dy^T x, db[N] = colsum(dy) (db may be NULL). */
 int intel_op_linear_wgrad(const float* dy, const float* x, int M, int N, int K, float* dw, float* db,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The two products of a [d -> d] nn.Linear's backward in ONE pass over the rows (d = 64 / 128, fp32 mode; csrc/pair.hip):
+ * dx[M,d] = (dy @ w) [* (x > 0) when relu_mask: x is the relu output that fed the linear], dw[d,d] = dy^T x, db[d] = colsum(dy)
+ * -- what torch autograd computes for `y = linear(x)` (models/IntEL/IntEL.py:186-187,195-196) as two separate kernels.
+ * workspace: intel_op_linear_bwd_workspace_bytes(M, d) bytes. */
+size_t intel_op_linear_bwd_workspace_bytes(int M, int d);
+int intel_op_linear_bwd(const float* dy, const float* x, int M, int d, const float* w, int relu_mask, float* dx, float* dw,
+                        float* db, void* workspace, size_t workspace_bytes, void* stream);
 /* softmax(QK^T/sqrt(dk)) V per (session, head) on a packed [B*T, 3*d] QKV buffer
  * (modules/layers.py:50-60); key_len NULL = all T rows are keys. */
 int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,

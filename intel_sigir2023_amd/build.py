@@ -75,14 +75,34 @@ def _build_locked(verbose):
     stamp = _stamp()
     hipcc = _hipcc()
 
+    hdr = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join('..', '..', 'include', 'intel_hip.h')]:
+        if f.endswith('.h'):
+            with open(os.path.join(CSRC, f), 'rb') as fh:
+                hdr.update(f.encode())
+                hdr.update(fh.read())
+    hdr.update(' '.join(FLAGS).encode())
+
     def compile_one(src):
+        # per-object stamp (source + every header + flags): an edit to one .hip recompiles that file only
         obj = os.path.join(OBJ, os.path.basename(src) + '.o')
+        h = hdr.copy()
+        with open(src, 'rb') as fh:
+            h.update(fh.read())
+        want = h.hexdigest()
+        try:
+            if os.path.exists(obj) and open(obj + '.stamp').read() == want:
+                return obj
+        except OSError:
+            pass
         cmd = [hipcc] + FLAGS + ['-x', 'hip', '-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
         if verbose and r.stderr.strip():
             print(r.stderr)
+        with open(obj + '.stamp', 'w') as fh:
+            fh.write(want)
         return obj
     with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources()))

@@ -62,6 +62,41 @@ extern "C" int intel_op_linear_wgrad(const float* dy, const float* x, int M, int
   return launch_wgrad(dy, N, x, K, M, N, K, dw, K, db, 0, (float*)workspace, st);
 }
 
+// workspace: fp32 packed transposed weight | its three-plane image | reduce arena
+static size_t op_linear_bwd_parts(int M, int d, size_t* pk, size_t* img) {
+  *pk = rup_sz(packed_floats(d, d) * sizeof(float), 256);
+  *img = rup_sz(packed_b3_bytes(d, d), 256);
+  return *pk + *img + (linear_bwd_pair_slab_floats(M, d) + 64) * sizeof(float);
+}
+extern "C" size_t intel_op_linear_bwd_workspace_bytes(int M, int d) {
+  size_t pk, img;
+  return op_linear_bwd_parts(M, d, &pk, &img);
+}
+extern "C" int intel_op_linear_bwd(const float* dy, const float* x, int M, int d, const float* w, int relu_mask, float* dx, float* dw,
+                                   float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  INTEL_CHECK_ARG(dy && x && w && dx && workspace, "op_linear_bwd: null argument");
+  INTEL_CHECK_ARG(linear_bwd_pair_supported(M, d), "op_linear_bwd: unsupported shape M=%d d=%d (d = 64 / 128, fp32 mode)", M, d);
+  size_t pk, img;
+  INTEL_CHECK_ARG(workspace_bytes >= op_linear_bwd_parts(M, d, &pk, &img), "op_linear_bwd: workspace too small");
+  float* Bp = (float*)workspace;
+  void* B3 = (char*)workspace + pk;
+  float* arena = (float*)((char*)workspace + pk + img);
+  int rc = launch_pack_b(w, d, d, d, 1, Bp, 0, st);      // dx[m][k] = sum_n dy[m][n] w[n][k]
+  if (rc) return rc;
+  rc = launch_pack_b3(Bp, d, d, B3, st);
+  if (rc) return rc;
+  rc = pack_b3_flush(st);
+  if (rc) return rc;
+  ReduceQueue* q = redq_create();
+  INTEL_CHECK_ARG(q != nullptr, "op_linear_bwd: out of memory");
+  redq_reset(q, arena, linear_bwd_pair_slab_floats(M, d) + 64);
+  rc = launch_linear_bwd_pair(dy, d, x, d, M, d, B3, relu_mask, dx, d, dw, db, 0, 0, q, st);
+  if (rc == 0) rc = redq_flush(q, st);
+  redq_destroy(q);
+  return rc;
+}
+
 extern "C" int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,
                                   float* lse, void* stream) {
   return launch_attn_fwd(qkv, B, T, d, heads, key_len, out, lse, (hipStream_t)stream);

@@ -156,6 +156,15 @@ int launch_tower_bwd_fused(const float* X, const float* A, const float* LSE, con
                            const void* W1_b3, const void* W2T_b3, const void* W1T_b3, const void* WqkvT_b3, const float* b1, float* dQKV, float* dX,
                            float* const* grads, const int* accumulate, ReduceQueue* q, hipStream_t st, int a16 = 0, int dqkv16 = 0);
 
+// ---- one nn.Linear's backward in one pass over its rows (pair.hip): data gradient + weight gradient from ONE staging of dY ----
+// d x d linears of the towers (d = 64 / 128), fp32 mode (six plane products):  dXout[M, d] = (dY WT) [* (X > 0)],  dW[d, d] (+)= dY^T X,
+// db[d] (+)= colsum(dY).  WT_b3: the three-plane image (launch_pack_b3) of the packed TRANSPOSED weight (launch_pack_b(.., trans = 1)).  dW / db are valid
+// after the queue's flush (NULL = not wanted).  INTEL_PAIR_BWD=0 turns the path off.
+bool linear_bwd_pair_supported(int M, int d);
+size_t linear_bwd_pair_slab_floats(int M, int d);      // arena floats one launch takes from the reduce queue
+int launch_linear_bwd_pair(const float* dY, int lddy, const float* X, int ldx, int M, int d, const void* WT_b3, int relu_mask, float* dXout, int ldo,
+                           float* dW, float* db, int acc_w, int acc_b, ReduceQueue* q, hipStream_t st);
+
 // ---- the whole tied tower at the reference's own 32-wide shapes, one kernel per direction (tower32.hip) ---------------------------
 // d = 32, 1-2 heads, L <= 128, any number of tied layers; raw (unpacked) reference weights W [32, 32], vectors [32].  No activation stash:
 // the backward recomputes the forward from the tower input.  INTEL_TOWER32=0 turns the path off.

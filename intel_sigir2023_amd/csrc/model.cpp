@@ -405,7 +405,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     a += 6 * Wf(B, mx, mx);                                               // cross attention q / k / v of both towers
     a += 2 * rup_sz(xatt_ln_bwd_slab_floats(B, (int)dmax), 64);           // LayerNorm partials of the fused tower tails
     a += 2 * rup_sz(tower32_slab_floats(B), 64);                          // parameter-gradient slabs of the one-kernel 32-wide towers
-    a += (size_t)D.layers * (rup_sz(tower_bwd_slab_floats(B, d_i), 64) + rup_sz(tower_bwd_slab_floats(B, d_s), 64));      // ... of the one-kernel backward middles (tower_bwd.hip)
+    if (tower_bwd_fused_supported(L, d_i, D.heads)) a += (size_t)D.layers * rup_sz(tower_bwd_slab_floats(B, d_i), 64);      // ... of the one-kernel backward middles (tower_bwd.hip)
+    if (tower_bwd_fused_supported(L, d_s, D.heads)) a += (size_t)D.layers * rup_sz(tower_bwd_slab_floats(B, d_s), 64);
+    a += (size_t)D.layers * 2 * (rup_sz(linear_bwd_pair_slab_floats(M, d_i), 64) + rup_sz(linear_bwd_pair_slab_floats(M, d_s), 64));      // ... of the one-pass linear backwards (pair.hip)
     if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
                                 rup_sz((size_t)d_i * d_i + (size_t)d_s * d_s + (size_t)(d_i + d_s) * I + (size_t)I * y.Pin + I, 64) + 64 +
@@ -610,7 +612,10 @@ void pack_all(Run& r) {
       RUN(launch_pack_b3(w.pW1, w.d, w.d, w.b3W1, r.st));
     }
     if (fwdf) RUN(launch_pack_b3(w.pW2, w.d, w.d, w.b3W2, r.st));
-    if (bwdf) {
+    // the one-pass linear backward (pair.hip) streams the transposed feed-forward weights as images too (tower_bwd decides with the same predicate)
+    const bool pairf = r.train && D.layers > 0 && !bwdf && gemm_planes() == 3 && linear_bwd_pair_supported(y.M, w.d) &&
+                       !tower32_supported(y.L, w.d, D.heads, D.layers, r.train);
+    if (bwdf || pairf) {
       RUN(launch_pack_b3(w.pW1T, w.d, w.d, w.b3W1T, r.st));
       RUN(launch_pack_b3(w.pW2T, w.d, w.d, w.b3W2T, r.st));
     }
@@ -865,6 +870,17 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
       if (!r.ok(wgrad_batch_flush(r.st))) return nullptr;
       float* t = dX; dX = dXalt; dXalt = t;
       continue;
+    } else if (!h16 && gemm_planes() == 3 && linear_bwd_pair_supported(M, d)) {
+      // each feed-forward linear's backward in ONE pass over the rows (pair.hip): dZ / dF1 are staged once for the data and the weight gradient,
+      // the relu output is read once (operand + mask)
+      float* gw2 = r.G(pb + T_W2); float* gb2 = r.G(pb + T_B2);
+      const int aw2 = r.acc(pb + T_W2), ab2 = r.acc(pb + T_B2);
+      if (!r.ok(launch_linear_bwd_pair(dZd, d, b.R1, d, M, d, w.b3W2T, 1, r.T->dF1, d, gw2, gb2, aw2, ab2, r.ctx->rq, r.st))) return nullptr;
+      if (r.ctx->fwd_dropout) wgrad_batch_begin();
+      float* gw1 = r.G(pb + T_W1); float* gb1 = r.G(pb + T_B1);
+      const int aw1 = r.acc(pb + T_W1), ab1 = r.acc(pb + T_B1);
+      if (!r.ok(launch_linear_bwd_pair(r.T->dF1, d, b.A, d, M, d, w.b3W1T, 0, r.T->dA, d, gw1, gb1, aw1, ab1, r.ctx->rq, r.st))) return nullptr;
+      if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st, nullptr, h16))) return nullptr;
     } else {
     wgrad(r, dZd, d, b.R1, d, M, d, d, pb + T_W2, pb + T_B2, h16 ? 2 : 0);
     if (r.ctx->fwd_dropout) wgrad_batch_begin();

@@ -7,6 +7,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace planes {
 
@@ -104,6 +105,30 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ const uint4* launder(const uint4* p) {
   asm volatile("" : "+s"(p));
   return p;
+}
+
+// ---- transposing LDS reads (shared by tower_bwd.hip and pair.hip) ----
+typedef short tb_s16x4 __attribute__((ext_vector_type(4)));
+typedef short tb_s16x8 __attribute__((ext_vector_type(8)));
+
+// The operand of a product whose reduction runs over the ROWS of a row-major plane image: lane (p, j) gets column ct*16 + p at the eight rows
+// 32 kb + 8 j + {0, 2, 4, 6, 1, 3, 5, 7} from two transposing reads (ds_read_b64_tr_b16: lane 4q + pp of a 16-lane group names row q, columns
+// 4pp .. 4pp+3 of the group's 4 x 16 block and receives column p of its four rows).  Both operands of a product use the same row order.  The 32 lanes
+// one LDS cycle services touch rows {0, 2, .. 14} + half of a 32-row block: with a pitch of D + 8 bf16 (68 / 36 dwords) they cover all 64 banks once.
+// P8 = false: rows 32 kb + 8 j + {0, 2, 4, 6, 1, 3, 5, 7} (conflict-free at a pitch of D + 8 bf16: 68 / 36 dwords); P8 = true: rows 32 kb + 4 j + {0 .. 3}
+// and 32 kb + 16 + 4 j + {0 .. 3} -- the order in which an S-type accumulator pair (two 16-row tiles) holds its rows, so that probabilities / dS values go
+// from the accumulators straight into the other operand (conflict-free at a pitch of D + 16 bf16: 72 / 40 dwords: eight consecutive rows cover all banks)
+template <int LD, bool P8 = false>
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* plane, int kb, int ct, int p, int j) {
+  const int q = p >> 2, pp = p & 3;
+  const __bf16* a0 = plane + (P8 ? (32 * kb + 4 * j + q) : (32 * kb + 8 * j + 2 * q)) * LD + ct * 16 + 4 * pp;
+  const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0));
+  const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tb_s16x4*)(a0 + (P8 ? 16 : 1) * LD));
+  return __builtin_bit_cast(bf16x8, tb_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+
+__device__ __forceinline__ float sum8(const bf16x8& v) {
+  return (((float)v[0] + (float)v[1]) + ((float)v[2] + (float)v[3])) + (((float)v[4] + (float)v[5]) + ((float)v[6] + (float)v[7]));
 }
 
 }  // namespace planes

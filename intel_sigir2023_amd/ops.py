@@ -43,6 +43,20 @@ def linear_wgrad(dy, x, want_bias=True):
     return dw, db
 
 
+def linear_bwd(dy, x, w, relu_mask=False, want_bias=True):
+    """Both products of a [d -> d] nn.Linear's backward in one pass over the rows (csrc/pair.hip): dx = (dy @ w) [* (x > 0)], dw = dy^T x,
+    db = colsum(dy)."""
+    M, d = dy.shape
+    dx = torch.empty(M, d, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(d, d, dtype=torch.float32, device=dy.device)
+    db = torch.empty(d, dtype=torch.float32, device=dy.device) if want_bias else None
+    nb = L.lib().intel_op_linear_bwd_workspace_bytes(M, d)
+    ws = _ws(nb, dy.device)
+    L.check(L.lib().intel_op_linear_bwd(L.ptr(dy), L.ptr(x), M, d, L.ptr(w), 1 if relu_mask else 0, L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb,
+                                        L.stream_ptr(dy.device)), 'intel_op_linear_bwd')
+    return dx, dw, db
+
+
 def attention(qkv, B, T, d, heads, key_len=None):
     out = torch.empty(B * T, d, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)

@@ -200,3 +200,19 @@ def allreduce_max_float(x, device):
     if world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def backend_name():
+    """'nccl' (= RCCL on ROCm), 'gloo' (CPU tests), or 'none' without a process group."""
+    return dist.get_backend() if dist.is_initialized() else 'none'
+
+
+def count_ranks():
+    """How many ranks the collectives really span: an all-reduce of ones through the group (1 without a group).  bench.py refuses to print a line
+    whose n_gpus the group does not confirm."""
+    if not dist.is_initialized():
+        return 1
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.ones(1, dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
