@@ -20,11 +20,11 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15      # FLOP/s dense bf16 MFMA
-B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel')
+B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel', 'linear_bwd_pair_kernel')
 FUSED_KERNELS = ('tower_fwd_fused_kernel', 'tower_bwd_fused_kernel')
-MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8g_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
-                'attn_fwd_kernel', 'attn_bwd_dq_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_kv_kernel',
-                'attn_seq_bwd_q_kernel', 'attn_seq_bwd_fused_kernel', 'attn_bwd_dq_ds_kernel', 'tw32_fwd_kernel', 'tw32_bwd_kernel')      # exact fp32 MFMAs (v_mfma_f32_16x16x4_f32)
+MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
+                'attn_fwd_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'attn_bwd_dq_ds_kernel',
+                'tw32_fwd_kernel', 'tw32_bwd_kernel', 'enc32_fwd_kernel', 'enc32_bwd_kernel')      # exact fp32 MFMAs (v_mfma_f32_16x16x4_f32)
 
 
 def feed_throughput(w, cinfo, B, dev, reps=20):
@@ -169,6 +169,23 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
                       % (workload, best, physical, stages['B512']['full_step']['steps'], stages['B4096']['full_step']['steps'], total)}
 
 
+def pmc_stale(prof_shapes, psteps, pmc_kernels):
+    """Does the committed PMC summary (tools/pmc_summary.py) describe the step THIS build runs?  The library's kernels of the live profile and their
+    launches per step must equal the file's (torch's own kernels, which only the file sees, aside).  Returns None when they match, else what differs --
+    `roofline.traffic` is then withheld instead of quoting bytes of a step that no longer exists."""
+    if not pmc_kernels:
+        return {'reason': 'no PMC summary'}
+    live = {}
+    for k, v in prof_shapes.items():
+        base = k.split('[')[0].strip('()').split('<')[0]
+        live[base] = live.get(base, 0) + v['launches']
+    live = {k: round(n / psteps, 2) for k, n in live.items()}
+    foreign = ('at::', 'rocprim', '__amd_rocclr', 'void at::', 'softmax_warp')
+    filed = {k: v['launches_per_step'] for k, v in pmc_kernels.items() if not k.startswith(foreign) and 'elementwise_kernel' not in k}
+    diff = {k: [live.get(k), filed.get(k)] for k in sorted(set(live) | set(filed)) if live.get(k) is None or filed.get(k) is None or abs(live[k] - filed[k]) > 0.34}
+    return {'reason': 'kernel set / launches per step differ from the PMC summary', 'live_vs_file': diff} if diff else None
+
+
 def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_shape, planes=6.0):
     """`roofline` object for the kernel with the largest total time among the profiled launches: achieved = algorithmic bytes
     (or flops) / launch duration (HIP events on the launch stream), traffic = HBM bytes per launch from the committed PMC passes."""
@@ -214,9 +231,13 @@ def price_dominant_kernel(prof_shapes, psteps, pmc_kernels, pmc_source, exact_sh
         ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
         roof = {'bound': 'hbm', 'achieved': round(ach, 2), 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': round(ach / (HBM_PEAK / 1e9), 5), 'traffic': None}
-    if pmc_kernels and name in pmc_kernels and exact_shape:
-        roof['traffic'] = pmc_kernels[name]['hbm_bytes_per_launch']
-        roof['traffic_source'] = pmc_source
+    if pmc_kernels and exact_shape:
+        stale = pmc_stale(prof_shapes, psteps, pmc_kernels)
+        if stale is None and name in pmc_kernels:
+            roof['traffic'] = pmc_kernels[name]['hbm_bytes_per_launch']
+            roof['traffic_source'] = pmc_source
+        elif stale is not None:
+            roof['traffic_stale'] = dict(stale, source=pmc_source)
     roof.update({'kernel': name, 'launches_per_step': dom['launches'] / psteps, 'avg_launch_ms': round(avg_ms, 5),
                  'share_of_kernel_time': round(dom['ms'] / tot, 4),
                  'algorithmic_per_launch': (dom['flops'] if roof['bound'] == 'mfma' else dom['bytes']) / dom['launches']})
@@ -511,6 +532,11 @@ def main():
             src = sorted(os.path.relpath(f, ROOT) for f in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_traffic%s.json' % ('_bf16' if a.dtype == 'bf16' else ''))))[-1]
             j = json.load(open(os.path.join(ROOT, src)))
             pmc, pmc_eval = j.get('kernels'), j.get('kernels_eval', j.get('kernels'))
+            try:
+                from intel_sigir2023_amd import build as _b
+                res['pmc_file'] = {'source': src, 'commit': j.get('commit'), 'csrc_stamp_matches_this_build': j.get('csrc_stamp') == _b._stamp()}
+            except Exception:
+                pass
             src += ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x2 on gfx950), bytes per launch'
         except Exception:
             pass
@@ -548,7 +574,7 @@ def main():
               'fp32_equivalent_TFLOPs': round(sum(v['flops'] for v in prof.values()) / psteps / step_s / 1e12, 1),
               'note': 'algorithmic = %d B/session x %d sessions + %.2f GB of Adam streams (dense table sweep: 24 B/parameter, other parameters 32)' % (bytes_train, B, adam_b / 1e9)}
         try:
-            if exact and world == 1:
+            if exact and world == 1 and 'traffic_stale' not in roof:
                 jj = json.load(open(os.path.join(ROOT, src.split(' ')[0])))
                 sr['pmc_GB_per_step'] = jj['hbm_GB_per_train_step']
                 sr['traffic_ratio'] = round(jj['hbm_GB_per_train_step'] * 1e9 / alg_b, 2)

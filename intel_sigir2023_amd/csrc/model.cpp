@@ -2553,7 +2553,12 @@ static int backward_entry(IntelCtx* ctx, const void* const* params, const IntelB
   // The caller's table stream (intel_set_table_stream) is promised the finished item-id table gradient.  The four-branch schedule
   // hands it over as early as possible; every other way through a one-call backward (INTEL_STREAMS=0) does it
   // here, after everything: without this wait the caller's optimizer sweep raced the backward (found by the A/B switch tests)
-  if (r.rc == 0 && phase == 0 && ctx->table_stream && ctx->streams != 1) {
+  // Four-branch schedule too (round 6): the table stream is released early by the backward (item tower + item-history encoder done), but the optimizer's
+  // sweep of the 1 M-row table is HBM-bound on the whole chip and starved the backward's LAST launch -- the batched slab reduction every dense Adam
+  // group waits for (279 us under the sweep against ~25 alone: tools/rocprof_timeline.py) -- and with it the packing and the head of the next forward.
+  // The sweep now starts behind that reduction: +0.5 ... +1.2 % sessions/s same-box at the headline.  INTEL_TABLE_AFTER_FLUSH=0: the early release.
+  static const int table_after_flush = [] { const char* e = getenv("INTEL_TABLE_AFTER_FLUSH"); return e ? atoi(e) : 1; }();
+  if (r.rc == 0 && phase == 0 && ctx->table_stream && (ctx->streams != 1 || table_after_flush)) {
     if (!ctx->ev_tab && hipEventCreateWithFlags(&ctx->ev_tab, hipEventDisableTiming) != hipSuccess) {
       intel_set_error("intel_backward: event creation failed");
       return INTEL_E_STATE;

@@ -21,11 +21,23 @@ struct AdamArgs {
 // lr / bias_correction1, lerp weight 1 - beta1, addcmul value 1 - beta2; each becomes a float only where a tensor op consumes it).  The C ABI
 // carries lr and the betas as floats: (double)0.999f is 0.99900001287..., and 1.f - 0.999f is 1.3e-5 off float(0.001) -- a systematic 6e-6 on
 // sqrt(v) that tests/test_trajectory_gpu.py sees against the reference at t = 1.  The decimal value the caller meant is recovered by printing
-// the float with 7 significant digits (exact for every hyper-parameter given with <= 7 digits; any other float is reproduced to its own precision).
+// the float with 7 significant digits -- accepted ONLY when that decimal rounds back to the very float (true of every hyper-parameter written with <= 7
+// digits); any other float (a scheduled lr with more digits) is taken as the double it is.  The last value per call site is cached: three
+// snprintf / strtod pairs per Adam launch were measurable host time at the published batch of 512.
 static double adam_decimal(float x) {
+  static thread_local float last_x[4] = {0.f, 0.f, 0.f, 0.f};
+  static thread_local double last_v[4] = {0.0, 0.0, 0.0, 0.0};
+  static thread_local int next = 0;
+  for (int i = 0; i < 4; ++i)
+    if (last_x[i] == x && last_v[i] != 0.0) return last_v[i];
   char buf[48];
   snprintf(buf, sizeof(buf), "%.7g", (double)x);
-  return strtod(buf, nullptr);
+  double v = strtod(buf, nullptr);
+  if ((float)v != x) v = (double)x;
+  last_x[next] = x;
+  last_v[next] = v;
+  next = (next + 1) & 3;
+  return v;
 }
 static void adam_scalars(float lr, float beta1, float beta2, int step, float* step_size, float* inv_bc2_sqrt, float* omb1, float* omb2) {
   const double b1 = adam_decimal(beta1), b2 = adam_decimal(beta2);

@@ -44,7 +44,7 @@ struct PairCfg {
   static constexpr int CTW = D / 16;                     // 16-column tiles
   static constexpr int RS = NW / CTW;                    // row splits of the data gradient over the waves
   static constexpr int RT = (TR / 16) / RS;              // its row tiles per wave
-  static constexpr int LDP = D + 8, PLANE = TR * LDP;    // bf16 row pitch / plane elements
+  static constexpr int LDP = D + 16, PLANE = TR * LDP;   // bf16 row pitch / plane elements (72 / 40 dwords: the b128 row reads AND the transposing reads in the P8 row order are conflict-free)
   static constexpr size_t IMG = (size_t)3 * PLANE * 2;
   static constexpr size_t STAGE = 2 * IMG;               // P(dY) | P(X)
   static constexpr size_t SMEM = 2 * STAGE;
@@ -57,7 +57,9 @@ struct PairCfg {
   static_assert((NW / WPG) * WNT == CTW, "dW tiles");
 };
 
-template <int D, bool MASK>
+// ABL (debug builds, tools/pair_bench.py with INTEL_PAIR_ABL): 1 = no data-gradient products, 2 = no weight-gradient products, 4 = no output store,
+// 8 = no tile requests after the prologue, 16 = no split / plane stores after the prologue
+template <int D, bool MASK, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
   using C = PairCfg<D>;
   constexpr int NT = C::NT, TR = C::TR, KB = C::KB, KBT = C::KBT, CTW = C::CTW, RT = C::RT, LDP = C::LDP, PLANE = C::PLANE, NJ = C::NJ;
@@ -144,8 +146,8 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
     const int cur = it & 1;
     // (1) the next tile's rows (requested one iteration ago) -> plane registers; they go to the other stage (its readers finished before the last
     // barrier) behind the data gradient's products; (2) the tile after it leaves HBM
-    split_tile(t + G);
-    load_tile(t + 2 * G);
+    if (!(ABL & 16)) split_tile(t + G);
+    if (!(ABL & 8)) load_tile(t + 2 * G);
     const __bf16* pY = reinterpret_cast<const __bf16*>(smem_raw + (size_t)cur * C::STAGE);
     const __bf16* pX = reinterpret_cast<const __bf16*>(smem_raw + (size_t)cur * C::STAGE + C::IMG);
     // (3a) data gradient: acc[rt] (lane (p, j): row (rt0 + rt) * 16 + p, columns col .. col + 3) = dY[row][:] . W[:][column]; the fragments of
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
 #pragma unroll
         for (int q = 0; q < 3; ++q) f[0][rt][q] = *reinterpret_cast<const bf16x8*>(frag + rt * 16 * LDP + q * PLANE);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
+      for (int kb = 0; kb < ((ABL & 1) ? 0 : KB); ++kb) {
         if (kb + 1 < KB) {
 #pragma unroll
           for (int rt = 0; rt < RT; ++rt)
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, g[rt][0], acc[rt], 0, 0, 0);
       }
-      store_planes(cur ^ 1);
+      if (!(ABL & 16)) store_planes(cur ^ 1);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const int lr = (rt0 + rt) * 16 + p;
@@ -195,21 +197,21 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
           for (int r = 0; r < 4; ++r) x[r] = (float)hv[r] > 0.f ? x[r] : 0.f;
         }
         const long long row = (long long)t * TR + lr;
-        if (row < a.M) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = x;
+        if (row < a.M && (!(ABL & 4) || x[0] == 123.456f)) *reinterpret_cast<f32x4*>(a.out + (size_t)row * a.ldo + col) = x;
       }
     }
     // (3b) weight gradient: accW[n][k] (lane (p, j): dW[(nt0 + n) * 16 + 4j + r][(kt0 + k) * 16 + p]) += sum over the tile's rows of dY[row][.] X[row][.]
 #pragma unroll
-    for (int kb = 0; kb < TR / 32; ++kb) {
+    for (int kb = 0; kb < ((ABL & 2) ? 0 : TR / 32); ++kb) {
       bf16x8 y[WNT][3];
 #pragma unroll
       for (int n = 0; n < WNT; ++n) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) y[n][q] = tr_frag<LDP>(pY + q * PLANE, kb, nt0 + n, p, j);
+        for (int q = 0; q < 3; ++q) y[n][q] = tr_frag<LDP, true>(pY + q * PLANE, kb, nt0 + n, p, j);
       }
       bf16x8 x[2][3];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) x[0][q] = tr_frag<LDP>(pX + q * PLANE, kb, kt0, p, j);
+      for (int q = 0; q < 3; ++q) x[0][q] = tr_frag<LDP, true>(pX + q * PLANE, kb, kt0, p, j);
       if (kt0 == 0) {
 #pragma unroll
         for (int n = 0; n < WNT; ++n) dbp[n] += (sum8(y[n][2]) + sum8(y[n][1])) + sum8(y[n][0]);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
       for (int k = 0; k < WKT; ++k) {
         if (k + 1 < WKT) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) x[(k + 1) & 1][q] = tr_frag<LDP>(pX + q * PLANE, kb, kt0 + k + 1, p, j);
+          for (int q = 0; q < 3; ++q) x[(k + 1) & 1][q] = tr_frag<LDP, true>(pX + q * PLANE, kb, kt0 + k + 1, p, j);
         }
         auto& g = x[k & 1];
 #pragma unroll
@@ -259,14 +261,14 @@ int pair_grid(int ntiles) {
   return ntiles < g ? ntiles : g;
 }
 
-template <int D, bool MASK>
+template <int D, bool MASK, int ABL = 0>
 int launch_one(PairArgs& a, int grid, hipStream_t st) {
   using C = PairCfg<D>;
   static_assert(C::SMEM <= 160 * 1024, "LDS budget");
-  allow_lds((linear_bwd_pair_kernel<D, MASK>), C::SMEM);
+  allow_lds((linear_bwd_pair_kernel<D, MASK, ABL>), C::SMEM);
   const double flops = 4.0 * a.M * D * D;
   const double bytes = 12.0 * a.M * D;      // dY, X in; dXout out
-  LAUNCH_S(a.M, D, D, flops, bytes, (linear_bwd_pair_kernel<D, MASK>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
+  LAUNCH_S(a.M, D, D, flops, bytes, (linear_bwd_pair_kernel<D, MASK, ABL>), dim3(grid), dim3(C::NT), C::SMEM, st, a);
   INTEL_CHECK_LAUNCH();
   return 0;
 }
@@ -303,6 +305,24 @@ int launch_linear_bwd_pair(const float* dY, int lddy, const float* X, int ldx, i
   a.slabs = redq_alloc(q, (size_t)grid * slab);
   INTEL_CHECK_ARG(a.slabs != nullptr, "linear_bwd_pair: reduce arena exhausted");
   int rc;
+#ifdef INTEL_DEBUG
+  static const int abl = INTEL_DEBUG_ENV("INTEL_PAIR_ABL", 0);
+  if (abl && d == 128) {
+    switch (abl) {
+      case 1: return launch_one<128, true, 1>(a, grid, st);
+      case 2: return launch_one<128, true, 2>(a, grid, st);
+      case 3: return launch_one<128, true, 3>(a, grid, st);
+      case 4: return launch_one<128, true, 4>(a, grid, st);
+      case 8: return launch_one<128, true, 8>(a, grid, st);
+      case 16: return launch_one<128, true, 16>(a, grid, st);
+      case 24: return launch_one<128, true, 24>(a, grid, st);
+      case 28: return launch_one<128, true, 28>(a, grid, st);
+      case 31: return launch_one<128, true, 31>(a, grid, st);
+      case 27: return launch_one<128, true, 27>(a, grid, st);
+      default: break;
+    }
+  }
+#endif
   if (d == 128) rc = relu_mask ? launch_one<128, true>(a, grid, st) : launch_one<128, false>(a, grid, st);
   else rc = relu_mask ? launch_one<64, true>(a, grid, st) : launch_one<64, false>(a, grid, st);
   if (rc) return rc;

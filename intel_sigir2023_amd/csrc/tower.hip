@@ -137,6 +137,13 @@ struct TowerFwdArgs {
   float* XH;                 // [B*L, D] LayerNorm x-hat
   float* RSTD;               // [B*L]
   unsigned long long* dbg;   // INTEL_TOWER_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
+  // The first layer's input built INSIDE the kernel (X == NULL, template parameter INP; inference): the session's <= 64 rows go from the embedding tables
+  // straight into the plane image, the [B*L, D] input tensor never exists in HBM.  INP = 1 (item tower, IntEL.py:170-173): columns 0 .. d0-1 =
+  // tab0[idx0[row]], columns d0 .. D-1 = tab1[idx1[row]] (a negative id = a zero row, as gather_rows); INP = 2 (score tower, IntEL.py:176-178):
+  // x[c] = scb[c] + sum_k sc[row][k] scW[c][k] -- the fmaf chain of linear_smallk_kernel, so the rows carry the same bits as the kernel-per-op input
+  const float* tab0; const int* idx0; int d0;
+  const float* tab1; const int* idx1;
+  const float* sc; int sck; const float* scW; const float* scb;
 };
 
 template <int D, int NP = 3>
@@ -186,7 +193,7 @@ __device__ __forceinline__ void stash_rows16(const __bf16* src, int nmat, __bf16
   }
 }
 
-template <int D, int DK, bool TRAIN, int NP = 3>
+template <int D, int DK, bool TRAIN, int NP = 3, int INP = 0>
 __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_SIMD)) void tower_fwd_fused_kernel(TowerFwdArgs a) {
   using C = TowerCfg<D, NP>;
   constexpr int NW = C::NW, NT = C::NT, KB = C::KB, LDP = C::LDP, PLANE = C::PLANE, LQ = C::LQ, NJ = C::NJ;
@@ -217,11 +224,31 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     trow[jj] = i / (D / 4);
     tcol[jj] = (i - trow[jj] * (D / 4)) * 4;
   }
+  // one input value of the in-kernel score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending)
+  auto score_x = [&](const float* srow, int c) {
+    float v = a.scb[c];
+    for (int k = 0; k < a.sck; ++k) v = __builtin_fmaf(srow[k], a.scW[c * a.sck + k], v);
+    return v;
+  };
   auto load_x = [&](int b) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const int row = min(trow[jj], L - 1);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
+      f32x4 v;
+      if constexpr (INP == 1) {           // two gathered tables side by side
+        const size_t g = (size_t)b * L + row;
+        const bool first = tcol[jj] < a.d0;
+        const int id = first ? a.idx0[g] : a.idx1[g];
+        const float* src = first ? a.tab0 + (size_t)max(id, 0) * a.d0 + tcol[jj] : a.tab1 + (size_t)max(id, 0) * (D - a.d0) + (tcol[jj] - a.d0);
+        v = *reinterpret_cast<const f32x4*>(src);
+        if (id < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else if constexpr (INP == 2) {    // the K-wide linear of the base scores
+        const float* srow = a.sc + ((size_t)b * L + row) * a.sck;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = score_x(srow, tcol[jj] + e);
+      } else {
+        v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
+      }
       pre[jj] = trow[jj] < L ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -559,7 +586,20 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
       for (int rr = 0; rr < RPW; ++rr) {
         const int row = min(wave * RPW + rr, L - 1);
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) res[rr][cc] = a.X[((size_t)b * L + row) * D + lane + 64 * cc];
+        for (int cc = 0; cc < CPL; ++cc) {
+          const int c = lane + 64 * cc;
+          if constexpr (INP == 1) {       // (the rows are L2-hot: this session's phase 0 gathered them)
+            const size_t g = (size_t)b * L + row;
+            const bool first = c < a.d0;
+            const int id = first ? a.idx0[g] : a.idx1[g];
+            const float v = first ? a.tab0[(size_t)max(id, 0) * a.d0 + c] : a.tab1[(size_t)max(id, 0) * (D - a.d0) + (c - a.d0)];
+            res[rr][cc] = id < 0 ? 0.f : v;
+          } else if constexpr (INP == 2) {
+            res[rr][cc] = score_x(a.sc + ((size_t)b * L + row) * a.sck, c);
+          } else {
+            res[rr][cc] = a.X[((size_t)b * L + row) * D + c];
+          }
+        }
       }
     };
     if (NP != 1) load_res();
@@ -652,12 +692,15 @@ int fused_mode() {
   return m;
 }
 
-template <int D, int DK, bool TRAIN, int NP = 3>
+template <int D, int DK, bool TRAIN, int NP = 3, int INP = 0>
 int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   using C = TowerCfg<D, NP>;
   const size_t smem = C::SMEM;
-  if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1>(a, st);      // bf16 mode
-  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP>), smem);
+  if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1, INP>(a, st);      // bf16 mode
+  if constexpr (!TRAIN && INP == 0) {      // inference with the input built in the kernel (TowerInput: no X)
+    if (!a.X) return a.sc ? launch_one<D, DK, TRAIN, NP, 2>(a, st) : launch_one<D, DK, TRAIN, NP, 1>(a, st);
+  }
+  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), smem);
   // resident workgroups per CU: LDS (160 KB) and wave slots (NW waves each, WAVES_PER_SIMD per SIMD by the launch bounds)
   int per_cu = (int)((160 * 1024) / smem);
   if (per_cu > 4 * C::WAVES_PER_SIMD / C::NW) per_cu = 4 * C::WAVES_PER_SIMD / C::NW;
@@ -668,6 +711,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
+  if (INP == 2) bytes = 4.0 * M * (a.sck + (a.out ? D : 0));      // the base scores in, the output out
   if (TRAIN) bytes += 4.0 * M * D * (((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0)) * (a.qkv16 ? 0.5 : 1.0) + (a.XH ? 1.0 : 0.0));
   static const int dbg_on = INTEL_DEBUG_ENV("INTEL_TOWER_DBG", 0);      // phase clocks: debug builds only (common.h)
   TowerFwdArgs aa = a;
@@ -677,7 +721,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
     (void)hipMemsetAsync(dbg_buf, 0, 8 * sizeof(unsigned long long), st);
     aa.dbg = dbg_buf;
   }
-  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN, NP>), dim3(grid), dim3(C::NT), smem, st, aa);
+  LAUNCH_S(a.B * a.L, D, DK, flops, bytes, (tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), dim3(grid), dim3(C::NT), smem, st, aa);
   INTEL_CHECK_LAUNCH();
   if (dbg_on) {          // tools/tower_probe.py
     unsigned long long h[8];
@@ -709,11 +753,26 @@ bool tower_fused_supported(int L, int d, int heads) {
 
 int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,
-                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16) {
+                           float* QKV, float* A, float* LSE, float* R1, float* XH, float* RSTD, hipStream_t st, int qkv16, const TowerInput* in) {
   if (B <= 0) return 0;
   INTEL_CHECK_ARG(tower_fused_supported(L, d, heads), "tower_fwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
   TowerFwdArgs a;
   a.X = X; a.B = B; a.L = L; a.heads = heads;
+  a.tab0 = a.tab1 = a.sc = a.scW = a.scb = nullptr; a.idx0 = a.idx1 = nullptr; a.d0 = 0; a.sck = 0;
+  if (in) {
+    INTEL_CHECK_ARG(!train && !X, "tower_fwd_fused: the in-kernel input is the inference path's (no X, train = 0)");
+    if (in->scores) {
+      INTEL_CHECK_ARG(in->score_W && in->score_b && in->K >= 1 && in->K <= 16, "tower_fwd_fused: score input needs W, b and 1 <= K <= 16");
+      a.sc = in->scores; a.sck = in->K; a.scW = in->score_W; a.scb = in->score_b;
+    } else {
+      INTEL_CHECK_ARG(in->tab0 && in->idx0 && in->d0 > 0 && in->d0 % 4 == 0 && in->d0 <= d && (in->d0 == d || (in->tab1 && in->idx1)),
+                      "tower_fwd_fused: gathered input needs tab0 / idx0 (width d0 %% 4 == 0) and, for d0 < d, tab1 / idx1");
+      a.tab0 = in->tab0; a.idx0 = in->idx0; a.d0 = in->d0;
+      a.tab1 = in->d0 == d ? in->tab0 : in->tab1; a.idx1 = in->d0 == d ? in->idx0 : in->idx1;
+    }
+  } else {
+    INTEL_CHECK_ARG(X != nullptr, "tower_fwd_fused: no input");
+  }
   a.Wqkv = reinterpret_cast<const uint4*>(Wqkv_b3); a.W1 = reinterpret_cast<const uint4*>(W1_b3); a.W2 = reinterpret_cast<const uint4*>(W2_b3);
   a.b1 = b1; a.b2 = b2; a.gamma = gamma; a.beta = beta; a.out = out;
   a.qkv16 = (qkv16 && gemm_planes() == 1) ? 1 : 0;

@@ -208,7 +208,7 @@ class IntELEngine(object):
         table gradient -> every rank runs torch.optim.Adam's dense update on ITS 1/world row range only (parameter, both moments,
         28 B per parameter of HBM traffic instead of world x that) -> all-gather of the updated rows.  Over xGMI the two collectives
         move what the ring all-reduce of the dense exchange moves ((world-1)/world of the table each way); the sweep's HBM traffic
-        and the moments' memory are divided by world.  Rows are padded to a multiple of world through staging buffers; every
+        and the moments' memory are divided by world.  Rows are padded to a multiple of world inside the flat buckets themselves (_flatten: no staging copy); every
         replica ends the step with the same table bits (the owner's arithmetic is the dense sweep's, adam_kernel)."""
         lib = L.lib()
         w, r = parallel.world_size(), parallel.rank()
@@ -292,22 +292,29 @@ class IntELEngine(object):
 
     def _param_cache(self):
         """(slot items, detached parameters, parameter-pointer array, gradient-pointer array), built once: the engine owns the flat buckets
-        the parameters and gradients are views of (_flatten), so the pointers are the same every step.  Re-validated by the address of EVERY
-        parameter and gradient tensor."""
+        the parameters and gradients are views of (_flatten), so the pointers are the same every step.  Invalidated explicitly where the
+        buckets are rebuilt (_flatten); on the hot path only a cheap key is checked (first / last parameter address, the bucket addresses,
+        counts), the full key -- the address of EVERY parameter and gradient tensor, ~400 data_ptr() calls -- every 256th step and whenever the
+        cheap one moved."""
         c = getattr(self, '_pcache', None)
-        items = c[0] if c is not None else self.model.slot_items()
 
-        def key_of(items):      # every parameter's and every gradient's address (~200 ints): a re-assigned middle parameter or a swapped gradient tensor rebuilds the arrays
+        def cheap_key(items):
+            return (len(items), items[0][2].data_ptr(), items[-1][2].data_ptr(), len(self.grad_by_slot)) + tuple(t.data_ptr() for t in self.flat.values()) + \
+                   tuple(t.data_ptr() for t in self.gflat.values())
+
+        def full_key(items):
             return (tuple(p.data_ptr() for _, _, p in items), tuple((s, g.data_ptr()) for s, g in sorted(self.grad_by_slot.items())))
-        key = key_of(items)
-        if c is None or c[4] != key:
-            items = self.model.slot_items()
-            params = [p.detach() for _, _, p in items]
-            for t in params:
-                L.require_gpu(t)
-            parr = self.model._param_array({s: t.contiguous() for (s, _, _), t in zip(items, params)})
-            garr = self.model._param_array(self.grad_by_slot)
-            c = self._pcache = (items, params, parr, garr, key_of(items))
+        if c is not None:
+            self._pcache_age = getattr(self, '_pcache_age', 0) + 1
+            if c[5] == cheap_key(c[0]) and (self._pcache_age % 256 or c[4] == full_key(c[0])):
+                return c[0], c[1], c[2], c[3]
+        items = self.model.slot_items()
+        params = [p.detach() for _, _, p in items]
+        for t in params:
+            L.require_gpu(t)
+        parr = self.model._param_array({s: t.contiguous() for (s, _, _), t in zip(items, params)})
+        garr = self.model._param_array(self.grad_by_slot)
+        c = self._pcache = (items, params, parr, garr, full_key(items), cheap_key(items))
         return c[0], c[1], c[2], c[3]
 
     # ---- flat parameter / gradient / moment buckets -------------------------------------------------
@@ -406,8 +413,17 @@ class IntELEngine(object):
         sort_ev = self._sort_scatter_ids(ib, keep)
         if self._table_ev is not None:      # the previous step's table sweep may still run: only the forward's item-id gathers wait for it
             lib.intel_set_table_wait_event(model._context(), C.c_void_p(self._table_ev.cuda_event))
-            self._table_ev_keep, self._table_ev = self._table_ev, None
-        weights, ens, intents = model.run_forward(ib, keep, params, train=True, items=items, parr=parr)
+            self._table_ev_keep = self._table_ev
+            try:
+                weights, ens, intents = model.run_forward(ib, keep, params, train=True, items=items, parr=parr)
+            except BaseException:
+                # the forward may not have enqueued its waits: take the one-shot event back and order EVERY later reader behind the sweep
+                lib.intel_set_table_wait_event(model._context(), None)
+                self._table_sync()
+                raise
+            self._table_ev = None           # handed over: the forward's gathers are ordered behind the sweep
+        else:
+            weights, ens, intents = model.run_forward(ib, keep, params, train=True, items=items, parr=parr)
         model._generation = getattr(model, '_generation', 0) + 1
         st = L.stream_ptr(dev)
         nb = lib.intel_loss_workspace_bytes(B, Lmax, K)

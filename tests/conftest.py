@@ -48,7 +48,13 @@ def _dispatch_trace(request):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if not (_EXPECT or _FORBID) or not _SEEN:
+    if not (_EXPECT or _FORBID):
+        return
+    if not _SEEN:
+        # nothing was recorded: no gpu-marked test ran in this child, or the profiler saw no launch -- exactly the silent case the check exists for
+        if _EXPECT:
+            print('\nDISPATCH CHECK FAILED: expected kernels %s but the session recorded no launch at all' % _EXPECT)
+            session.exitstatus = 1
         return
     missing = [k for k in _EXPECT if k not in _SEEN]
     extra = [k for k in _FORBID if k in _SEEN]

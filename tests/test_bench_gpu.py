@@ -20,7 +20,8 @@ def _line(out):
 
 
 def test_default_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    # (--cpu_budget: the CPU baseline's bounded sample, 24 s by default, is 6 s here -- the line's fields are what is checked)
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2', '--cpu_budget', '6'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
@@ -36,13 +37,16 @@ def test_default_line_has_the_contract_fields():
 
 
 def test_two_rank_launch_line_runs_end_to_end():
+    # plain `python bench.py --gpus 2`: bench.py starts its own two ranks (torch.distributed.run as a child process), relays rank 0's line and checks
+    # that the process group really spans two ranks (`rccl_ranks`)
     env = dict(os.environ, INTEL_SINGLE_DEVICE='1', INTEL_DIST_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', '29517',
-           'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no_cpu_baseline', '--no_feed', '--no_bf16_line']
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--no_cpu_baseline', '--no_feed', '--no_bf16_line']
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['config']['global_batch'] == 2 * j['config']['per_gpu_batch'] and j['config']['parallelism'] == 'dp2'
+    assert j['n_gpus'] == 2 and j['rccl_ranks'] == 2 and j['backend'] == 'gloo' and j['scaling'] == 'weak' and j['config']['global_batch'] == 2 * j['config']['per_gpu_batch'] and j['config']['parallelism'] == 'dp2'
     assert j['value'] > 0 and abs(j['value'] - j['config']['global_batch'] / (j['ms_per_step'] * 1e-3)) <= 1e-3 * j['value']
     # data parallel: the line says which exchange form ran and what it cost / how much of it stayed exposed (HIP events around every collective)
     ex = j['exchange']

@@ -111,6 +111,68 @@ def test_bf16_forward_and_gradients_track_fp32(name):
     assert worst < 0.15, (wk, worst)                          # every gradient tensor within 15 % in norm
 
 
+@pytest.mark.parametrize('name', ['tmall64', 'stress', 'lifedata'])
+def test_bf16_gradients_against_the_reference_fixtures(name):
+    """A check that does NOT go through the emulating oracle (which restates the build's own rounding points: a bug shared by build and emulation
+    is invisible to it): the bf16 build's loss and parameter gradients against the fp32 REFERENCE's, as the fixtures hold them
+    (tests/golden/make_golden.py ran the unmodified reference).  One bf16 rounding is 2^-9 of an operand; a gradient tensor is a sum of products
+    of rounded operands over the batch's rows, so the bar is per TENSOR: direction (cosine >= 0.995) and size (norm within 8 %) of every tensor
+    that is not negligible, and the loss within 2e-3 -- a wrong tile, a dropped term or a stale operand is O(1) off in at least one tensor."""
+    from intel_sigir2023_amd import loss as LS
+    from intel_sigir2023_amd.model import IntEL
+    from tests.helpers import grad_projection
+    fx = Fixture(name)
+    dev = _dev()
+    a = dict(fx.args)
+    a['dtype'] = 'bf16'
+    args = make_args(a, dev)
+    args.cal_diversity = 1
+    model = IntEL(args, make_corpus(fx.shape))
+    model.load_state_dict(fx.state_dict(), strict=True)
+    model = model.to(dev).train()
+    batch = fx.batch(dev)
+    tag = 'bpr' if fx.detail == 'bpr' else 'pl'      # (the tmall64 fixture keeps the IntBPRloss gradients, with the reference's tie-breaking draw)
+    if tag == 'bpr':
+        batch['bpr_noise'] = torch.from_numpy(fx['bpr/noise']).to(dev)
+    out = model(batch)
+    loss, _, _ = (LS.IntBPRloss if tag == 'bpr' else LS.IntListloss)(args)(out, batch)
+    loss.backward()
+    ref_loss = float(fx['int%s/loss' % tag])
+    assert abs(float(loss) - ref_loss) < 2e-3 * max(1.0, abs(ref_loss)), (float(loss), ref_loss)
+    named = dict(model.named_parameters())
+    report = []
+    if fx.detail == 'proj':      # the large fixtures keep two random projections per gradient tensor instead of the tensor
+        for k, ref in fx.group('gradproj_pl').items():
+            g = named[k].grad
+            got = grad_projection(np.zeros(tuple(named[k].shape), np.float32) if g is None else g.cpu().numpy())
+            report.append((k, abs(got[0] - ref[0]) / max(1e-6, ref[1]), abs(got[1] - ref[1]) / max(1e-6, ref[1])))
+        worst = max(report, key=lambda t: max(t[1], t[2]))
+        print('bf16 gradients vs the reference (projections): worst %s %.3e / %.3e of the tensor norm' % worst)
+        assert max(worst[1], worst[2]) < 8e-2, worst
+        return
+    rows = fx.group('grad_%s_rows' % tag)
+    refs = fx.group('grad_' + tag)
+    gmax = max(float(np.linalg.norm(r)) for r in refs.values())
+    for k, ref in refs.items():
+        if 'k_linear.bias' in k or float(np.linalg.norm(ref)) < 1e-4 * gmax:
+            continue            # analytically zero (attention key bias) or negligible: rounding noise in any arithmetic
+        g = named[k].grad
+        g = torch.zeros_like(named[k]) if g is None else g
+        g = g.cpu()
+        if k in rows:
+            g = g[torch.from_numpy(rows[k])]
+        g = g.numpy().astype(np.float64).ravel()
+        r = ref.astype(np.float64).ravel()
+        cos = float(g @ r / max(1e-30, np.linalg.norm(g) * np.linalg.norm(r)))
+        size = float(abs(np.linalg.norm(g) - np.linalg.norm(r)) / np.linalg.norm(r))
+        report.append((k, cos, size))
+    wc = min(report, key=lambda t: t[1])
+    wsz = max(report, key=lambda t: t[2])
+    print('bf16 gradients vs the reference: worst direction %s cos %.5f, worst size %s %.3e (of %d tensors)' % (wc[0], wc[1], wsz[0], wsz[2], len(report)))
+    assert wc[1] >= 0.995, wc
+    assert wsz[2] <= 8e-2, wsz
+
+
 @pytest.mark.parametrize('name', ['tmall64', 'stress', 'lifedata', 'default'])
 def test_bf16_forward_matches_the_emulating_oracle(name):
     """oracle.forward_bf16 restates WHAT the mode computes: the reference's forward with both operands of a product rounded

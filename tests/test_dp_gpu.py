@@ -106,15 +106,30 @@ def _run_tmall(rank, world, port, out_dir, exchange='auto', tag=''):
         torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse'), (4, 'dense'), (2, 'sharded'), (4, 'sharded')])
+_BASE = {}
+
+
+def _baseline(fn, *args):
+    """The single-process run a data-parallel case is compared with, computed ONCE per configuration for the whole module (every case used to
+    spawn its own copy: ~3 s of process start each, a quarter of this file's wall time)."""
+    key = (fn.__name__,) + tuple(args)
+    if key not in _BASE:
+        with tempfile.TemporaryDirectory() as d:
+            mp.spawn(fn, args=(1, _free_port(), d) + tuple(args), nprocs=1, join=True)
+            files = [x for x in os.listdir(d) if x.endswith('.pt')]
+            assert len(files) == 1, files
+            _BASE[key] = torch.load(os.path.join(d, files[0]))
+    return _BASE[key]
+
+
+@pytest.mark.parametrize('world,exchange', [(2, 'dense'), (2, 'sparse'), (4, 'sparse'), (2, 'sharded'), (4, 'sharded')])
 def test_n_rank_engine_equals_single_process_at_tmall_shape(world, exchange):
     """N ranks on the contiguous shards of a 64-session Tmall-shape batch == one process on the whole batch: losses (mean of the
     shard means), replicas bit-identical, parameters after two Adam steps."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run_tmall, args=(1, _free_port(), d), nprocs=1, join=True)
+        one = _baseline(_run_tmall)
         mp.spawn(_run_tmall, args=(world, _free_port(), d, exchange), nprocs=world, join=True)
-        one = torch.load(os.path.join(d, 'tm_w1_r0.pt'))
         ranks = [torch.load(os.path.join(d, 'tm_w%d_r%d.pt' % (world, r))) for r in range(world)]
     for s in range(2):
         assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
@@ -136,9 +151,8 @@ def test_n_rank_engine_equals_single_process(world, exchange, schedule):
     world 4 = one session per rank of the 4-session fixture batch."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
+        one = _baseline(_run)
         mp.spawn(_run, args=(world, _free_port(), d, exchange, 'gloo', False, '1', '', schedule), nprocs=world, join=True)
-        one = torch.load(os.path.join(d, 'w1_r0.pt'))
         ranks = [torch.load(os.path.join(d, 'w%d_r%d.pt' % (world, r))) for r in range(world)]
     for s in range(2):
         assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
@@ -159,9 +173,8 @@ def test_lazy_table_adam_data_parallel(exchange, backend):
     assert torch.cuda.is_available()
     world = 2 if backend == 'gloo' else 1
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run, args=(1, _free_port(), d), nprocs=1, join=True)
+        one = _baseline(_run)
         mp.spawn(_run, args=(world, _free_port(), d, exchange, backend, False, '1', '_lazy', 'wide', '1'), nprocs=world, join=True)
-        one = torch.load(os.path.join(d, 'w1_r0.pt'))
         ranks = [torch.load(os.path.join(d, 'w%d_r%d_lazy.pt' % (world, r))) for r in range(world)]
     for s in range(2):
         assert abs(sum(r['losses'][s] for r in ranks) / world - one['losses'][s]) < 2e-5
@@ -179,9 +192,8 @@ def test_seeded_bpr_noise_is_keyed_by_global_session():
     negatives, the losses and the parameters after 2 steps agree -- and the two shards do NOT repeat each other's draws."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', True), nprocs=1, join=True)
+        one = _baseline(_run, 'auto', 'gloo', True)
         mp.spawn(_run, args=(2, _free_port(), d, 'dense', 'gloo', True), nprocs=2, join=True)
-        one = torch.load(os.path.join(d, 'w1_r0.pt'))
         ranks = [torch.load(os.path.join(d, 'w2_r%d.pt' % r)) for r in range(2)]
     for s in range(2):
         whole = one['selects'][s]
@@ -206,9 +218,8 @@ def test_rccl_world1_runs_every_collective_branch(exchange, overlap, schedule):
     for bit)."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_run, args=(1, _free_port(), d, 'auto', 'gloo', False, overlap, '', schedule), nprocs=1, join=True)      # the same backward schedule: the comparison isolates the collectives (the two schedules round differently: chain launches only in the one-call form)
+        one = _baseline(_run, 'auto', 'gloo', False, overlap, '', schedule)      # the same backward schedule: the comparison isolates the collectives (the two schedules round differently: chain launches only in the one-call form)
         mp.spawn(_run, args=(1, _free_port(), d, exchange, 'nccl', False, overlap, '_nccl', schedule), nprocs=1, join=True)
-        one = torch.load(os.path.join(d, 'w1_r0.pt'))
         got = torch.load(os.path.join(d, 'w1_r0_nccl.pt'))
     assert one['losses'][0] == got['losses'][0]
     assert abs(one['losses'][1] - got['losses'][1]) < 1e-6

@@ -22,7 +22,8 @@ from oracle import intel_oracle as O
 from tests.helpers import relu_flip_forgiven_error
 
 import os
-FORCE = eval(os.environ['FUZZ_FORCE']) if os.environ.get('FUZZ_FORCE') else None      # debugging: a dict that pins flags of the drawn case, e.g. "{'num_layers': 1}"
+import ast
+FORCE = ast.literal_eval(os.environ['FUZZ_FORCE']) if os.environ.get('FUZZ_FORCE') else None      # debugging: a dict that pins flags of the drawn case, e.g. "{'num_layers': 1}"
 VERBOSE = os.environ.get('FUZZ_VERBOSE') == '1'      # every parameter above 0.3 of its tolerance, with the magnitudes
 
 

@@ -44,13 +44,18 @@ for d in (128, 64):
     t_d = timeit(lambda: L.check(lib.intel_op_linear_dgrad(L.ptr(dy), M, d, L.ptr(w), d, L.ptr(dx), L.ptr(ws2), nb2, st)))
     t_w = timeit(lambda: L.check(lib.intel_op_linear_wgrad(L.ptr(dy), L.ptr(x), M, d, d, L.ptr(dw), L.ptr(db), L.ptr(ws2), nb2, st)))
     print('d=%d M=%d  dgrad (pack + kernel): %.1f us   wgrad (kernel + reduce): %.1f us   sum %.1f us' % (d, M, t_d, t_w, t_d + t_w))
-    # per-kernel from the library's profiler
-    lib.intel_prof_timeline()
-    lib.intel_prof_enable(1)
-    for _ in range(5):
-        L.check(lib.intel_op_linear_bwd(L.ptr(dy), L.ptr(x), M, d, L.ptr(w), 1, L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb, st))
-        L.check(lib.intel_op_linear_dgrad(L.ptr(dy), M, d, L.ptr(w), d, L.ptr(dx), L.ptr(ws2), nb2, st))
-        L.check(lib.intel_op_linear_wgrad(L.ptr(dy), L.ptr(x), M, d, d, L.ptr(dw), L.ptr(db), L.ptr(ws2), nb2, st))
-    torch.cuda.synchronize()
-    print(lib.intel_prof_collect().decode()[:3000])
-    lib.intel_prof_enable(0)
+    # kernel-only times from the library's profiler (HIP events around each launch), one variant at a time
+    def kernel_us(fn, n=10):
+        lib.intel_prof_collect()
+        lib.intel_prof_enable(1)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        import json
+        r = json.loads(lib.intel_prof_collect().decode())
+        lib.intel_prof_enable(0)
+        return {k.split('[')[0].strip('()').split('<')[0]: round(1e3 * v['ms'] / v['launches'], 1) for k, v in r.items()}
+    for mask in (1, 0, 1, 0):
+        print('d=%d mask=%d kernels (us):' % (d, mask), kernel_us(lambda: L.check(lib.intel_op_linear_bwd(L.ptr(dy), L.ptr(x), M, d, L.ptr(w), mask, L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb, st))))
+    print('d=%d separate kernels (us):' % d, kernel_us(lambda: (L.check(lib.intel_op_linear_dgrad(L.ptr(dy), M, d, L.ptr(w), d, L.ptr(dx), L.ptr(ws2), nb2, st)),
+                                                              L.check(lib.intel_op_linear_wgrad(L.ptr(dy), L.ptr(x), M, d, d, L.ptr(dw), L.ptr(db), L.ptr(ws2), nb2, st)))))

@@ -58,6 +58,15 @@ def main():
         esteps = int(sys.argv[7])
         eout, eper = summarise(sys.argv[5], sys.argv[6], esteps)
         res.update({'eval_steps': esteps, 'hbm_GB_per_eval_step': round(eper / 1e9, 3), 'kernels_eval': eout})
+    # what was measured: the commit the caller names (INTEL_COMMIT: the GPU box has no .git) and the hash of the kernel sources of the build that ran
+    import os
+    res['commit'] = os.environ.get('INTEL_COMMIT', 'unknown')
+    try:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+        from intel_sigir2023_amd import build as _b
+        res['csrc_stamp'] = _b._stamp()
+    except Exception:
+        res['csrc_stamp'] = 'unknown'
     json.dump(res, open(sys.argv[4], 'w'), indent=1, sort_keys=True)
     print('HBM traffic per training step: %.2f GB' % (per_step / 1e9))
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]['hbm_bytes_per_launch'] * kv[1]['launches'])[:14]:
