@@ -718,10 +718,19 @@ static Tower32Dropout tower32_dropout(const Run& r, int tower) {
   return d;
 }
 
-void tower_fwd(Run& r, TowerBufs& w) {
+// inference: may the first layer build its input inside the one-kernel layer (tower.hip: TowerInput) instead of reading a materialised X0?
+static bool tower_input_in_kernel(const Run& r, const TowerBufs& w) {
+  static const int on = [] { const char* e = getenv("INTEL_TOWER_GATHER"); return (e && e[0] == '0') ? 0 : 1; }();
+  const IntelDesc& D = r.D;
+  return on && !r.train && D.layers > 0 && !tower32_supported(r.y.L, w.d, D.heads, D.layers, r.train) && tower_fused_supported(r.y.L, w.d, D.heads) &&
+         tower_fused_wanted(0, w.d);
+}
+
+// in: the first layer's input is built in the kernel (inference; tower_input_in_kernel) -- w.X0 is then never written nor read
+void tower_fwd(Run& r, TowerBufs& w, const TowerInput* in = nullptr) {
   const IntelDesc& D = r.D;
   const int M = r.y.M, d = w.d, B = r.y.B, L = r.y.L, pb = w.pbase;
-  const float* X = w.X0;
+  const float* X = in ? nullptr : w.X0;
   const int tw_i = &w == &r.y.tw[0] ? 0 : 1;
   // the reference's own widths (32-wide towers): ALL tied layers in one kernel, nothing stashed (tower32.hip)
   r.ctx->tw32[tw_i] = D.layers > 0 && tower32_supported(L, d, D.heads, D.layers, r.train);
@@ -749,8 +758,13 @@ void tower_fwd(Run& r, TowerBufs& w) {
     const bool tail = l == D.layers - 1 && tail_fusable(r.ctx, D, L, d, r.train);      // x-hat / rstd only
     RUN(launch_tower_fwd_fused(X, B, L, d, D.heads, w.b3Wqkv, w.b3W1, w.b3W2, r.P(pb + T_B1), r.P(pb + T_B2), r.P(pb + T_LNG),
                                r.P(pb + T_LNB), tail ? nullptr : b.Xout, r.train, slim ? nullptr : b.QKV, b.A, b.LSE, slim ? nullptr : b.R1, b.XH, b.RSTD, r.st,
-                               r.ctx->tw_qkv16[tw_i]));
+                               r.ctx->tw_qkv16[tw_i], l == 0 ? in : nullptr));
     X = b.Xout;
+  }
+  if (in && !fused) {
+    intel_set_error("tower_fwd: in-kernel input without the one-kernel layer");
+    r.ok(INTEL_E_STATE);
+    return;
   }
   for (int l = 0; !fused && l < D.layers; ++l) {
     TowerLayerBufs& b = w.layer[l];
@@ -1690,6 +1704,14 @@ void forward_impl(Run& r, const IntelOut* out) {
     encoder_branch(b1, 1);
     // item tower
     wait_table(b2);
+    if (!lazy_gather && tower_input_in_kernel(r, ti) && D.d_id % 4 == 0) {
+      // inference: the candidate rows go from the tables straight into the first layer's LDS tile (IntEL.py:170-173 inside tower.hip)
+      TowerInput in;
+      in.tab0 = r.P(INTEL_P_IID_EMB); in.idx0 = bt.i_id_s; in.d0 = D.d_id;
+      if (D.d_im > 0) { in.tab1 = r.P(INTEL_P_ITEM_EMB); in.idx1 = bt.i_class_c; }
+      wait_pack(b2);
+      tower_fwd(b2, ti, &in);
+    } else
     if (b2.ok(lazy_gather ? launch_gather_rows_lazy(r.ctx->lazy, r.ctx->lazy_upto, bt.i_id_s, M, ti.X0, ti.d, 0, b2.st, nullptr, nullptr)
                           : launch_gather_rows(r.P(INTEL_P_IID_EMB), D.d_id, bt.i_id_s, M, ti.X0, ti.d, 0, 0, b2.st)) &&
         (D.d_im == 0 || b2.ok(launch_gather_rows(r.P(INTEL_P_ITEM_EMB), D.d_im, bt.i_class_c, M, ti.X0, ti.d, D.d_id, 0, b2.st)))) {
@@ -1697,6 +1719,12 @@ void forward_impl(Run& r, const IntelOut* out) {
       tower_fwd(b2, ti);
     }
     // score tower
+    if (tower_input_in_kernel(r, ts) && K <= 16) {
+      TowerInput in;      // inference: the score embedding (IntEL.py:176-178) is computed where the first layer stages its tile
+      in.scores = bt.scores; in.K = K; in.score_W = r.P(INTEL_P_SCORE_W); in.score_b = r.P(INTEL_P_SCORE_B);
+      wait_pack(b3);
+      tower_fwd(b3, ts, &in);
+    } else
     {
       GemmEpilogue es;
       es.bias = r.P(INTEL_P_SCORE_B);

@@ -116,3 +116,35 @@ def test_bf16_mode_kernels():
     kt.check(['tower_fwd_fused_kernel', 'tower_bwd_fused_kernel', 'wgrad_tr_kernel', 'enc_block_fwd_kernel', 'enc_block_bwd_kernel', 'chain_kernel'],
              ['attn_seq_bwd_fused_kernel', 'attn_seq_fwd_kernel'], 'bf16 mode, Tmall shape')      # (round 5: the session head's chains in bf16 mode too, their 64 / 128-deep links rounding like the bf16 pipe)
     assert kt.count['tower_fwd_fused_kernel'] == 2 and kt.count['tower_bwd_fused_kernel'] == 2, kt.count
+
+
+@pytest.mark.parametrize('L,B,heads', [(50, 19, 1), (64, 3, 2), (7, 40, 1)])
+def test_inference_builds_the_tower_inputs_inside_the_one_kernel_layer(L, B, heads):
+    """Evaluation at the benchmarked widths: the candidate rows go from the embedding tables (item tower: id | class embeddings, IntEL.py:170-173) and
+    from the base scores (score tower: the K-wide score embedding, IntEL.py:176-178) straight into the first layer's LDS tile (tower.hip: TowerInput) --
+    no gather_rows / linear_smallk launch for the towers, no [B*L, d] input tensor -- and the outputs still equal the oracle's forward."""
+    from intel_sigir2023_amd import synth
+    from intel_sigir2023_amd.model import IntEL
+    from oracle import intel_oracle as O
+    dev = torch.device('cuda:0')
+    name = 'gather%d_%d' % (L, heads)
+    synth.WORKLOADS[name] = dict(flags=dict(synth.WORKLOADS['tmall']['flags'], num_heads=heads), corpus=dict(items=3000, users=300, classes=40, ctx=50, I=30),
+                                 batch=dict(L=L, H=20))
+    torch.manual_seed(L + heads)
+    args = synth.make_args(name, dev)
+    corpus, c = synth.make_corpus(name)
+    model = IntEL(args, corpus).to(dev).eval()
+    batch = synth.make_batch(name, B, dev, seed=L, ragged=True)
+    with KernelTrace() as kt, torch.no_grad():
+        out = model(batch)
+    kt.check(['tower_fwd_fused_kernel'], ['tw32_fwd_kernel', 'attn_seq_fwd_kernel'])
+    assert kt.count['tower_fwd_fused_kernel'] == 2, kt.count
+    # what is left of the row kernels belongs to the encoders: the context / item-id gathers of the two histories and the intent linear of the session history
+    assert kt.count.get('gather_rows_kernel', 0) <= 2 and kt.count.get('linear_smallk_kernel', 0) <= 1, kt.count
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.Config(**{k: v for k, v in vars(args).items() if k not in ('device', 'dtype')})
+    with torch.no_grad():
+        ref = O.forward(sd, synth.to_reference_layout(batch, c['I']), cfg)
+    for k in ('weights', 'ens_score', 'intents'):
+        err = float((out[k].cpu() - ref[k]).abs().max())
+        assert err <= 3e-5 * max(1.0, float(ref[k].abs().max())), (k, err)

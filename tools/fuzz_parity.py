@@ -27,7 +27,7 @@ FORCE = ast.literal_eval(os.environ['FUZZ_FORCE']) if os.environ.get('FUZZ_FORCE
 VERBOSE = os.environ.get('FUZZ_VERBOSE') == '1'      # every parameter above 0.3 of its tolerance, with the magnitudes
 
 
-def one_case(rng, idx, dev, big=None, force=None, dry=False, trace=None, dtype='f32'):
+def one_case(rng, idx, dev, big=None, force=None, dry=False, trace=None, dtype='f32', keep=None):
     """big: None = decided per case (about one case in 25), True / False = forced.  A 'big' case is the reference's own tower widths
     (16/16/32/32, script/IntEL.sh:15,21) at lists of 50 / 90 with more than 32 768 candidate rows per batch: the far side of the
     row-count thresholds of the short-list attention backward and the batched small weight gradients."""
@@ -140,6 +140,8 @@ def one_case(rng, idx, dev, big=None, force=None, dry=False, trace=None, dtype='
         return O.int_mse_loss(ref, ref_batch, cfg)
 
     worst, bad = compare(ref, rl, sd, taps, not bf)
+    if keep is not None:      # tools/bf16_cloud.py: the case's objects for a closer look
+        keep.update(model=model, batch=batch, ref_batch=ref_batch, cfg=cfg, loss_name=loss_name, noise=noise.cpu(), desc=desc, worst=worst, bad=bad)
     if worst > 1.0 and not bf:
         # A hidden unit whose pre-activation is ZERO at rounding-noise level in the oracle sits on the kink of the relu: both one-sided derivatives
         # are legitimate, the two implementations may take different ones entry by entry, and at a handful of rows per batch the difference reaches
