@@ -1718,13 +1718,8 @@ void forward_impl(Run& r, const IntelOut* out) {
       wait_pack(b2);
       tower_fwd(b2, ti);
     }
-    // score tower
-    if (tower_input_in_kernel(r, ts) && K <= 16) {
-      TowerInput in;      // inference: the score embedding (IntEL.py:176-178) is computed where the first layer stages its tile
-      in.scores = bt.scores; in.K = K; in.score_W = r.P(INTEL_P_SCORE_W); in.score_b = r.P(INTEL_P_SCORE_B);
-      wait_pack(b3);
-      tower_fwd(b3, ts, &in);
-    } else
+    // score tower (its K-wide input linear stays a launch of its own: computed inside the one-kernel layer -- TowerInput.scores, tower.hip INP = 2 -- the
+    // layer ran 137 -> 183 us per launch at the headline shape for the 21 us the linear takes; kept in tower.hip for shapes where that trade differs)
     {
       GemmEpilogue es;
       es.bias = r.P(INTEL_P_SCORE_B);

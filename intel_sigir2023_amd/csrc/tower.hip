@@ -224,37 +224,86 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     trow[jj] = i / (D / 4);
     tcol[jj] = (i - trow[jj] * (D / 4)) * 4;
   }
-  // one input value of the in-kernel score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending)
-  auto score_x = [&](const float* srow, int c) {
-    float v = a.scb[c];
-    for (int k = 0; k < a.sck; ++k) v = __builtin_fmaf(srow[k], a.scW[c * a.sck + k], v);
-    return v;
+  // INP = 2, the in-kernel score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending).  A thread stages the same four columns
+  // of every tile (tcol does not depend on the piece: NT is a multiple of D / 4) and normalises the same columns lane, lane + 64: their weight rows
+  // and biases stay in registers for the whole sweep (K <= SCK_MAX)
+  constexpr int SCK_MAX = 8, CPLR = D / 64;
+  float scw[INP == 2 ? 4 : 1][SCK_MAX], scb4[4], scwr[INP == 2 ? CPLR : 1][SCK_MAX], scbr[CPLR];
+  if constexpr (INP == 2) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      scb4[e] = a.scb[tcol[0] + e];
+#pragma unroll
+      for (int k = 0; k < SCK_MAX; ++k) scw[e][k] = k < a.sck ? a.scW[(tcol[0] + e) * a.sck + k] : 0.f;
+    }
+#pragma unroll
+    for (int cc = 0; cc < CPLR; ++cc) {
+      scbr[cc] = a.scb[lane + 64 * cc];
+#pragma unroll
+      for (int k = 0; k < SCK_MAX; ++k) scwr[cc][k] = k < a.sck ? a.scW[(lane + 64 * cc) * a.sck + k] : 0.f;
+    }
+  }
+  // INP = 1: the session's ids are staged in LDS one session ahead of its rows (ids[slot][table][row], three slots): a row load whose address waits
+  // for an id load in the same phase is two dependent HBM round trips on the wave's critical path (measured: -10 % evaluation sessions/s)
+  int* ids = reinterpret_cast<int*>(smem_raw + C::SMEM);
+  auto load_id = [&](int bb) {      // threads 0 .. 127: (table tid >> 6, row tid & 63) of session bb
+    const size_t g = (size_t)bb * L + min(tid & 63, L - 1);
+    return (tid >> 6) == 0 ? a.idx0[g] : a.idx1[g];
   };
-  auto load_x = [&](int b) {
+  int idreg = 0;
+  // Nothing in load_x may LOOK at a loaded value: a select on it (padding rows, negative ids) or arithmetic (the score linear) makes the wave wait for the
+  // load where it is issued -- the random table rows of INP = 1 take an HBM round trip, not the Infinity-Cache hit of a tile the gather kernel just
+  // wrote (measured: +40 us per launch).  The raw values stay in registers; stage_x applies the masks / the linear when the tile goes to LDS.
+  float psc[INP == 2 ? NJ : 1][SCK_MAX];
+  auto load_x = [&](int b, int slot) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const int row = min(trow[jj], L - 1);
-      f32x4 v;
       if constexpr (INP == 1) {           // two gathered tables side by side
-        const size_t g = (size_t)b * L + row;
         const bool first = tcol[jj] < a.d0;
-        const int id = first ? a.idx0[g] : a.idx1[g];
+        const int id = ids[slot * 128 + (first ? 0 : 64) + row];
         const float* src = first ? a.tab0 + (size_t)max(id, 0) * a.d0 + tcol[jj] : a.tab1 + (size_t)max(id, 0) * (D - a.d0) + (tcol[jj] - a.d0);
-        v = *reinterpret_cast<const f32x4*>(src);
-        if (id < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
-      } else if constexpr (INP == 2) {    // the K-wide linear of the base scores
+        pre[jj] = *reinterpret_cast<const f32x4*>(src);
+      } else if constexpr (INP == 2) {    // the K-wide row of base scores
         const float* srow = a.sc + ((size_t)b * L + row) * a.sck;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = score_x(srow, tcol[jj] + e);
+        for (int k = 0; k < SCK_MAX; ++k)
+          if (k < a.sck) psc[jj][k] = srow[k];
       } else {
-        v = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
+        pre[jj] = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
       }
-      pre[jj] = trow[jj] < L ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  };
+  // piece jj of the tile being staged (session slot `slot` of the id table): the input values, padding rows (and rows with a negative id) zeroed
+  auto stage_x = [&](int jj, int slot) {
+    f32x4 v;
+    bool live = trow[jj] < L;
+    if constexpr (INP == 2) {             // the score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = scb4[e];
+#pragma unroll
+        for (int k = 0; k < SCK_MAX; ++k)
+          if (k < a.sck) x = __builtin_fmaf(psc[jj][k], scw[e][k], x);
+        v[e] = x;
+      }
+    } else {
+      v = pre[jj];
+      if constexpr (INP == 1) live = live && ids[slot * 128 + (tcol[jj] < a.d0 ? 0 : 64) + min(trow[jj], L - 1)] >= 0;
+    }
+    return live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   int b = blockIdx.x;
   if (b >= a.B) return;
-  load_x(b);
+  if constexpr (INP == 1) {
+    if (tid < 128) {
+      ids[tid] = load_id(b);
+      if (b + (int)gridDim.x < a.B) idreg = load_id(b + gridDim.x);
+    }
+    __syncthreads();
+  }
+  int it = 0;
+  load_x(b, 0);
   unsigned long long tstamp = 0;
   const bool probe = a.dbg != nullptr && blockIdx.x == 0 && tid == 0;
   auto mark = [&](int ph) {
@@ -265,12 +314,15 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     }
   };
   mark(-1);
-  for (; b < a.B; b += gridDim.x) {
+  for (; b < a.B; b += gridDim.x, ++it) {
     // ---- phase 0: X -> planes
+    if constexpr (INP == 1) {      // the next session's ids (requested an iteration ago) -> their slot; the barrier below publishes them
+      if (tid < 128) ids[((it + 1) % 3) * 128 + tid] = idreg;
+    }
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       bf16x4 h, m, l;
-      split4(pre[jj], h, m, l);
+      split4(stage_x(jj, it % 3), h, m, l);
       const int off = trow[jj] * LDP + tcol[jj];
       store_planes<NP, PLANE>(planes + off, h, m, l);
     }
@@ -354,7 +406,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
       }
     }
     // the next session's rows travel while this one is computed
-    if (b + (int)gridDim.x < a.B) load_x(b + gridDim.x);
+    // (INP = 1: the gathered rows are random 256-byte HBM reads -- slower to return than a streamed tile -- and vector-memory results come back in issue
+    // order: requested here, the W1 fragments below would queue behind them; they are requested after those fragments instead)
+    if (INP != 1 && b + (int)gridDim.x < a.B) load_x(b + gridDim.x, (it + 1) % 3);
     mark(1);
     lds_barrier();
     mark(6);
@@ -369,6 +423,10 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
       for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) bw1[kb][pl] = Bimg[((size_t)kb * 3 + pl) * 64];
+    }
+    if constexpr (INP == 1) {
+      if (b + (int)gridDim.x < a.B) load_x(b + gridDim.x, (it + 1) % 3);
+      if (tid < 128 && b + 2 * (int)gridDim.x < a.B) idreg = load_id(b + 2 * gridDim.x);
     }
     for (int pair = wave; pair < 4 * HEADS; pair += NW) {
       const int tile = pair & 3, h = pair >> 2;
@@ -588,14 +646,18 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) {
           const int c = lane + 64 * cc;
-          if constexpr (INP == 1) {       // (the rows are L2-hot: this session's phase 0 gathered them)
-            const size_t g = (size_t)b * L + row;
+          if constexpr (INP == 1) {       // (the rows are L2-hot: this session's phase 0 gathered them; the ids sit in LDS)
             const bool first = c < a.d0;
-            const int id = first ? a.idx0[g] : a.idx1[g];
+            const int id = ids[(it % 3) * 128 + (first ? 0 : 64) + row];
             const float v = first ? a.tab0[(size_t)max(id, 0) * a.d0 + c] : a.tab1[(size_t)max(id, 0) * (D - a.d0) + (c - a.d0)];
             res[rr][cc] = id < 0 ? 0.f : v;
           } else if constexpr (INP == 2) {
-            res[rr][cc] = score_x(a.sc + ((size_t)b * L + row) * a.sck, c);
+            const float* srow = a.sc + ((size_t)b * L + row) * a.sck;      // (wave-uniform row: scalar loads)
+            float x = scbr[cc];
+#pragma unroll
+            for (int k = 0; k < SCK_MAX; ++k)
+              if (k < a.sck) x = __builtin_fmaf(srow[k], scwr[cc][k], x);
+            res[rr][cc] = x;
           } else {
             res[rr][cc] = a.X[((size_t)b * L + row) * D + c];
           }
@@ -695,12 +757,13 @@ int fused_mode() {
 template <int D, int DK, bool TRAIN, int NP = 3, int INP = 0>
 int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   using C = TowerCfg<D, NP>;
-  const size_t smem = C::SMEM;
+  const size_t smem = C::SMEM + (INP == 1 ? 3 * 128 * sizeof(int) : 0);      // INP = 1: three slots of 2 x 64 ids
+  static_assert(C::SMEM + 3 * 128 * sizeof(int) <= 160 * 1024, "LDS budget");
   if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1, INP>(a, st);      // bf16 mode
   if constexpr (!TRAIN && INP == 0) {      // inference with the input built in the kernel (TowerInput: no X)
     if (!a.X) return a.sc ? launch_one<D, DK, TRAIN, NP, 2>(a, st) : launch_one<D, DK, TRAIN, NP, 1>(a, st);
   }
-  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), smem);
+  allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), smem);      // (smem: + the id slots of the in-kernel gather, below)
   // resident workgroups per CU: LDS (160 KB) and wave slots (NW waves each, WAVES_PER_SIMD per SIMD by the launch bounds)
   int per_cu = (int)((160 * 1024) / smem);
   if (per_cu > 4 * C::WAVES_PER_SIMD / C::NW) per_cu = 4 * C::WAVES_PER_SIMD / C::NW;
@@ -762,7 +825,7 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
   if (in) {
     INTEL_CHECK_ARG(!train && !X, "tower_fwd_fused: the in-kernel input is the inference path's (no X, train = 0)");
     if (in->scores) {
-      INTEL_CHECK_ARG(in->score_W && in->score_b && in->K >= 1 && in->K <= 16, "tower_fwd_fused: score input needs W, b and 1 <= K <= 16");
+      INTEL_CHECK_ARG(in->score_W && in->score_b && in->K >= 1 && in->K <= 8, "tower_fwd_fused: score input needs W, b and 1 <= K <= 8");
       a.sc = in->scores; a.sck = in->K; a.scW = in->score_W; a.scb = in->score_b;
     } else {
       INTEL_CHECK_ARG(in->tab0 && in->idx0 && in->d0 > 0 && in->d0 % 4 == 0 && in->d0 <= d && (in->d0 == d || (in->tab1 && in->idx1)),
