@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 MODEL = ['tests/test_model_gpu.py', '-k', 'forward or grads']
 ENGINE = ['tests/test_engine_gpu.py', '-k', 'synthetic_workloads or adam']
-FUZZ = ['tests/test_model_gpu.py', 'tests/test_fuzz_gpu.py', '-k', 'forward or grads or random_configs']      # + random shapes (1 - 2 heads, 1 - 2 tied layers)
+FUZZ = ['tests/test_model_gpu.py', 'tests/test_fuzz_gpu.py::test_random_configs_match_oracle_autograd[0]', '-k', 'forward or grads or random_configs']      # + six random shapes (1 - 2 heads, 1 - 2 tied layers)
 BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode's forward / gradient parity against its emulating oracle
 
 # Independent switches share a child run (round 6: 25 single-switch runs of ~4 s process start each were a quarter of the GPU suite's wall time).  A group
