@@ -257,18 +257,10 @@ class IntELEngine(object):
                 sample = keep['i_id_s'].reshape(-1)[:16384]
                 self._dup_share = 1.0 - float(torch.unique(sample).numel()) / float(sample.numel())
             mode = '1' if self._dup_share > 0.2 else '0'
-        # The item-CLASS ids always repeat (a few hundred classes under B * L candidate rows: 573 rows per class at the headline shape, every one a float
-        # atomic on the same 256 bytes): their scatter takes the sorted form whenever a class is hit >= 8 times per step on average (round 6;
-        # INTEL_SCATTER_SORTED=0 keeps every scatter unsorted)
-        cls = keep.get('i_class_c')
-        emb = getattr(self.model, 'item_embeddings', None)
-        sort_cls = self._sorted_scatter != '0' and cls is not None and emb is not None and emb.weight.shape[0] * 8 <= cls.numel()
-        keys = ([('iid', keep['i_id_s']), ('hisitem', keep['his_item_id'])] if mode == '1' else []) + ([('cls', cls)] if sort_cls else [])
-        for key in ('iid', 'hisitem', 'cls'):
-            if key not in [k for k, _ in keys]:
+        if mode != '1':
+            for key in ('iid', 'hisitem'):
                 setattr(ib, key + '_sort_ids', None)
                 setattr(ib, key + '_sort_rows', None)
-        if not keys:
             return None
         dev = self.device
         if self._sort_side is None:
@@ -276,7 +268,7 @@ class IntELEngine(object):
         side, cur = self._sort_side, torch.cuda.current_stream(dev)
         side.wait_stream(cur)               # also orders the reuse of last step's index buffers after that step's backward
         with torch.cuda.stream(side):
-            for key, src in keys:
+            for key, src in (('iid', keep['i_id_s']), ('hisitem', keep['his_item_id'])):
                 v, i = torch.sort(src.reshape(-1))
                 keep[key + '_sort_ids'], keep[key + '_sort_rows'] = v, i.to(torch.int32)
                 setattr(ib, key + '_sort_ids', v.data_ptr())
