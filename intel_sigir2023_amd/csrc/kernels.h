@@ -137,12 +137,10 @@ bool tower_fused_wanted(int train, int d);
 // W*_b3: bf16 three-plane images (launch_pack_b3) of the packed [d -> 3d] / [d -> d] / [d -> d] weights.  out may be NULL
 // (x-hat / rstd only); train = 0: none of the stash pointers is written.
 // in (inference, X == NULL): the first layer's input built inside the kernel -- two row gathers side by side (tab0[idx0] | tab1[idx1]: the item tower's
-// id / class embeddings, IntEL.py:170-173) or the K-wide linear of the base scores (the score tower's input, IntEL.py:176-178); the [B*L, d] input tensor
-// then never exists in HBM
+// id / class embeddings, IntEL.py:170-173); the [B*L, d] input tensor then never exists in HBM
 struct TowerInput {
   const float* tab0 = nullptr; const int* idx0 = nullptr; int d0 = 0;      // columns 0 .. d0-1 (idx < 0: a zero row)
   const float* tab1 = nullptr; const int* idx1 = nullptr;                  // columns d0 .. d-1 (unused when d0 == d)
-  const float* scores = nullptr; int K = 0; const float* score_W = nullptr; const float* score_b = nullptr;      // [B*L, K], [d, K], [d]
 };
 int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const void* Wqkv_b3, const void* W1_b3, const void* W2_b3,
                            const float* b1, const float* b2, const float* gamma, const float* beta, float* out, int train,

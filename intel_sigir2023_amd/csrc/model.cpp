@@ -1718,8 +1718,8 @@ void forward_impl(Run& r, const IntelOut* out) {
       wait_pack(b2);
       tower_fwd(b2, ti);
     }
-    // score tower (its K-wide input linear stays a launch of its own: computed inside the one-kernel layer -- TowerInput.scores, tower.hip INP = 2 -- the
-    // layer ran 137 -> 183 us per launch at the headline shape for the 21 us the linear takes; kept in tower.hip for shapes where that trade differs)
+    // score tower (its K-wide input linear stays a launch of its own: computed inside the one-kernel layer, the layer ran 137 -> 183 us per launch at the
+    // headline shape for the 21 us the linear takes -- measured and dropped)
     {
       GemmEpilogue es;
       es.bias = r.P(INTEL_P_SCORE_B);

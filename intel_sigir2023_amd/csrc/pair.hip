@@ -252,10 +252,10 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
   }
 }
 
-// workgroups of one launch: one per CU (104 / 110 KB of LDS); INTEL_PAIR_CUS=n caps it (a tower that is not on the step's critical chain may leave CUs
-// to the branches that are)
+// workgroups of one launch: one per CU (110 KB of LDS).  (Fewer -- 128, 192 -- to leave CUs to the backward's other branches, as the separate weight-gradient
+// kernel does: 3.27 - 3.32 ms per step either way, inside the spread; INTEL_PAIR_CUS in debug builds)
 int pair_grid(int ntiles) {
-  static const int cap = [] { const char* e = getenv("INTEL_PAIR_CUS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1 << 30; }();
+  static const int cap = [] { const int v = INTEL_DEBUG_ENV("INTEL_PAIR_CUS", 0); return v > 0 ? v : 1 << 30; }();
   int g = num_cus();
   if (g > cap) g = cap;
   return ntiles < g ? ntiles : g;

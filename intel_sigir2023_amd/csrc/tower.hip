@@ -139,11 +139,10 @@ struct TowerFwdArgs {
   unsigned long long* dbg;   // INTEL_TOWER_DBG=1: per-phase shader-clock totals of workgroup 0's thread 0 (NULL otherwise)
   // The first layer's input built INSIDE the kernel (X == NULL, template parameter INP; inference): the session's <= 64 rows go from the embedding tables
   // straight into the plane image, the [B*L, D] input tensor never exists in HBM.  INP = 1 (item tower, IntEL.py:170-173): columns 0 .. d0-1 =
-  // tab0[idx0[row]], columns d0 .. D-1 = tab1[idx1[row]] (a negative id = a zero row, as gather_rows); INP = 2 (score tower, IntEL.py:176-178):
-  // x[c] = scb[c] + sum_k sc[row][k] scW[c][k] -- the fmaf chain of linear_smallk_kernel, so the rows carry the same bits as the kernel-per-op input
+  // tab0[idx0[row]], columns d0 .. D-1 = tab1[idx1[row]] (a negative id = a zero row, as gather_rows).  (The score tower's K-wide input linear was
+  // tried inside the kernel as well and dropped: 137 -> 183 us per launch for the 21 us the separate linear takes.)
   const float* tab0; const int* idx0; int d0;
   const float* tab1; const int* idx1;
-  const float* sc; int sck; const float* scW; const float* scb;
 };
 
 template <int D, int NP = 3>
@@ -224,25 +223,6 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     trow[jj] = i / (D / 4);
     tcol[jj] = (i - trow[jj] * (D / 4)) * 4;
   }
-  // INP = 2, the in-kernel score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending).  A thread stages the same four columns
-  // of every tile (tcol does not depend on the piece: NT is a multiple of D / 4) and normalises the same columns lane, lane + 64: their weight rows
-  // and biases stay in registers for the whole sweep (K <= SCK_MAX)
-  constexpr int SCK_MAX = 8, CPLR = D / 64;
-  float scw[INP == 2 ? 4 : 1][SCK_MAX], scb4[4], scwr[INP == 2 ? CPLR : 1][SCK_MAX], scbr[CPLR];
-  if constexpr (INP == 2) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      scb4[e] = a.scb[tcol[0] + e];
-#pragma unroll
-      for (int k = 0; k < SCK_MAX; ++k) scw[e][k] = k < a.sck ? a.scW[(tcol[0] + e) * a.sck + k] : 0.f;
-    }
-#pragma unroll
-    for (int cc = 0; cc < CPLR; ++cc) {
-      scbr[cc] = a.scb[lane + 64 * cc];
-#pragma unroll
-      for (int k = 0; k < SCK_MAX; ++k) scwr[cc][k] = k < a.sck ? a.scW[(lane + 64 * cc) * a.sck + k] : 0.f;
-    }
-  }
   // INP = 1: the session's ids are staged in LDS one session ahead of its rows (ids[slot][table][row], three slots): a row load whose address waits
   // for an id load in the same phase is two dependent HBM round trips on the wave's critical path (measured: -10 % evaluation sessions/s)
   int* ids = reinterpret_cast<int*>(smem_raw + C::SMEM);
@@ -251,10 +231,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
     return (tid >> 6) == 0 ? a.idx0[g] : a.idx1[g];
   };
   int idreg = 0;
-  // Nothing in load_x may LOOK at a loaded value: a select on it (padding rows, negative ids) or arithmetic (the score linear) makes the wave wait for the
+  // Nothing in load_x may LOOK at a loaded value: a select on it (padding rows, negative ids) makes the wave wait for the
   // load where it is issued -- the random table rows of INP = 1 take an HBM round trip, not the Infinity-Cache hit of a tile the gather kernel just
-  // wrote (measured: +40 us per launch).  The raw values stay in registers; stage_x applies the masks / the linear when the tile goes to LDS.
-  float psc[INP == 2 ? NJ : 1][SCK_MAX];
+  // wrote (measured: +40 us per launch).  The raw values stay in registers; stage_x applies the masks when the tile goes to LDS.
   auto load_x = [&](int b, int slot) {
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
@@ -264,11 +243,6 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
         const int id = ids[slot * 128 + (first ? 0 : 64) + row];
         const float* src = first ? a.tab0 + (size_t)max(id, 0) * a.d0 + tcol[jj] : a.tab1 + (size_t)max(id, 0) * (D - a.d0) + (tcol[jj] - a.d0);
         pre[jj] = *reinterpret_cast<const f32x4*>(src);
-      } else if constexpr (INP == 2) {    // the K-wide row of base scores
-        const float* srow = a.sc + ((size_t)b * L + row) * a.sck;
-#pragma unroll
-        for (int k = 0; k < SCK_MAX; ++k)
-          if (k < a.sck) psc[jj][k] = srow[k];
       } else {
         pre[jj] = *reinterpret_cast<const f32x4*>(a.X + ((size_t)b * L + row) * D + tcol[jj]);
       }
@@ -276,22 +250,9 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
   };
   // piece jj of the tile being staged (session slot `slot` of the id table): the input values, padding rows (and rows with a negative id) zeroed
   auto stage_x = [&](int jj, int slot) {
-    f32x4 v;
     bool live = trow[jj] < L;
-    if constexpr (INP == 2) {             // the score linear: the fmaf chain of linear_smallk_kernel (bias first, k ascending)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float x = scb4[e];
-#pragma unroll
-        for (int k = 0; k < SCK_MAX; ++k)
-          if (k < a.sck) x = __builtin_fmaf(psc[jj][k], scw[e][k], x);
-        v[e] = x;
-      }
-    } else {
-      v = pre[jj];
-      if constexpr (INP == 1) live = live && ids[slot * 128 + (tcol[jj] < a.d0 ? 0 : 64) + min(trow[jj], L - 1)] >= 0;
-    }
-    return live ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (INP == 1) live = live && ids[slot * 128 + (tcol[jj] < a.d0 ? 0 : 64) + min(trow[jj], L - 1)] >= 0;
+    return live ? pre[jj] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   int b = blockIdx.x;
   if (b >= a.B) return;
@@ -651,13 +612,6 @@ __global__ __launch_bounds__((TowerCfg<D, NP>::NT), (TowerCfg<D, NP>::WAVES_PER_
             const int id = ids[(it % 3) * 128 + (first ? 0 : 64) + row];
             const float v = first ? a.tab0[(size_t)max(id, 0) * a.d0 + c] : a.tab1[(size_t)max(id, 0) * (D - a.d0) + (c - a.d0)];
             res[rr][cc] = id < 0 ? 0.f : v;
-          } else if constexpr (INP == 2) {
-            const float* srow = a.sc + ((size_t)b * L + row) * a.sck;      // (wave-uniform row: scalar loads)
-            float x = scbr[cc];
-#pragma unroll
-            for (int k = 0; k < SCK_MAX; ++k)
-              if (k < a.sck) x = __builtin_fmaf(srow[k], scwr[cc][k], x);
-            res[rr][cc] = x;
           } else {
             res[rr][cc] = a.X[((size_t)b * L + row) * D + c];
           }
@@ -761,7 +715,7 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   static_assert(C::SMEM + 3 * 128 * sizeof(int) <= 160 * 1024, "LDS budget");
   if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1, INP>(a, st);      // bf16 mode
   if constexpr (!TRAIN && INP == 0) {      // inference with the input built in the kernel (TowerInput: no X)
-    if (!a.X) return a.sc ? launch_one<D, DK, TRAIN, NP, 2>(a, st) : launch_one<D, DK, TRAIN, NP, 1>(a, st);
+    if (!a.X) return launch_one<D, DK, TRAIN, NP, 1>(a, st);
   }
   allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), smem);      // (smem: + the id slots of the in-kernel gather, below)
   // resident workgroups per CU: LDS (160 KB) and wave slots (NW waves each, WAVES_PER_SIMD per SIMD by the launch bounds)
@@ -774,7 +728,6 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   // algorithmic work: 5 D x D linears per row + the two attention products; bytes: X in, the output (or x-hat) out, the stash
   const double flops = 2.0 * M * D * D * 5 + 4.0 * (double)a.B * a.L * a.L * D;
   double bytes = 4.0 * M * D * (1.0 + (a.out ? 1.0 : 0.0));
-  if (INP == 2) bytes = 4.0 * M * (a.sck + (a.out ? D : 0));      // the base scores in, the output out
   if (TRAIN) bytes += 4.0 * M * D * (((a.QKV ? 3.0 : 0.0) + (a.A ? 1.0 : 0.0) + (a.R1 ? 1.0 : 0.0)) * (a.qkv16 ? 0.5 : 1.0) + (a.XH ? 1.0 : 0.0));
   static const int dbg_on = INTEL_DEBUG_ENV("INTEL_TOWER_DBG", 0);      // phase clocks: debug builds only (common.h)
   TowerFwdArgs aa = a;
@@ -821,18 +774,13 @@ int launch_tower_fwd_fused(const float* X, int B, int L, int d, int heads, const
   INTEL_CHECK_ARG(tower_fused_supported(L, d, heads), "tower_fwd_fused: unsupported shape L=%d d=%d heads=%d", L, d, heads);
   TowerFwdArgs a;
   a.X = X; a.B = B; a.L = L; a.heads = heads;
-  a.tab0 = a.tab1 = a.sc = a.scW = a.scb = nullptr; a.idx0 = a.idx1 = nullptr; a.d0 = 0; a.sck = 0;
+  a.tab0 = a.tab1 = nullptr; a.idx0 = a.idx1 = nullptr; a.d0 = 0;
   if (in) {
     INTEL_CHECK_ARG(!train && !X, "tower_fwd_fused: the in-kernel input is the inference path's (no X, train = 0)");
-    if (in->scores) {
-      INTEL_CHECK_ARG(in->score_W && in->score_b && in->K >= 1 && in->K <= 8, "tower_fwd_fused: score input needs W, b and 1 <= K <= 8");
-      a.sc = in->scores; a.sck = in->K; a.scW = in->score_W; a.scb = in->score_b;
-    } else {
-      INTEL_CHECK_ARG(in->tab0 && in->idx0 && in->d0 > 0 && in->d0 % 4 == 0 && in->d0 <= d && (in->d0 == d || (in->tab1 && in->idx1)),
-                      "tower_fwd_fused: gathered input needs tab0 / idx0 (width d0 %% 4 == 0) and, for d0 < d, tab1 / idx1");
-      a.tab0 = in->tab0; a.idx0 = in->idx0; a.d0 = in->d0;
-      a.tab1 = in->d0 == d ? in->tab0 : in->tab1; a.idx1 = in->d0 == d ? in->idx0 : in->idx1;
-    }
+    INTEL_CHECK_ARG(in->tab0 && in->idx0 && in->d0 > 0 && in->d0 % 4 == 0 && in->d0 <= d && (in->d0 == d || (in->tab1 && in->idx1)),
+                    "tower_fwd_fused: gathered input needs tab0 / idx0 (width d0 %% 4 == 0) and, for d0 < d, tab1 / idx1");
+    a.tab0 = in->tab0; a.idx0 = in->idx0; a.d0 = in->d0;
+    a.tab1 = in->d0 == d ? in->tab0 : in->tab1; a.idx1 = in->d0 == d ? in->idx0 : in->idx1;
   } else {
     INTEL_CHECK_ARG(X != nullptr, "tower_fwd_fused: no input");
   }

@@ -3,7 +3,7 @@
 # branches), the PMC passes (each counter in its own run, kernel-trace only; training steps and evaluation steps
 # separately) and the other workloads.  Everything lands under gpurun_out/<tag>/; tools/pmc_summary.py and a copy into
 # profiles/ follow in the build container.
-tag=${1:-r05}
+tag=${1:-r06}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -52,6 +52,18 @@ timeout 600 python tools/ab_bench.py "--workload tmall_pub_mse --loss IntMSEloss
 timeout 600 python tools/ab_bench.py "--workload lifedata --batch 2048 --steps 30 --warmup 5 --no_bf16_line" INTEL_ATTN_P3=1,0,1,0 > $out/ab_attn_p3_lifedata.txt 2>&1 < /dev/null
 timeout 600 python tools/ab_bench.py "--workload stress --batch 1024 --steps 12 --warmup 3 --no_bf16_line" INTEL_ATTN_P3=1,0,1,0 > $out/ab_attn_p3_stress.txt 2>&1 < /dev/null
 ( timeout 300 python tools/attn_bench.py long; INTEL_ATTN_P3=0 timeout 300 python tools/attn_bench.py long ) > $out/attn_bench_long.txt 2>&1 < /dev/null
+# round 6: the one-pass linear backward (pair.hip), the table sweep behind the backward's last reduction, the in-kernel gather of the inference tower --
+# same-box A/B lines (alternating, 100 steps), the kernel alone against the two it replaces, its SQ counters, and the step as the hardware queues ran it
+timeout 600 python tools/ab_bench.py "--steps 100 --warmup 10 --no_roofline" INTEL_PAIR_BWD=a,0,a,0 > $out/ab_pair_bwd.txt 2>&1 < /dev/null
+timeout 600 python tools/ab_bench.py "--steps 100 --warmup 10 --no_roofline" INTEL_TABLE_AFTER_FLUSH=1,0,1,0 > $out/ab_table_after_flush.txt 2>&1 < /dev/null
+timeout 600 python tools/ab_bench.py "--steps 40 --warmup 5 --eval_steps 60" INTEL_TOWER_GATHER=1,0,1,0 > $out/ab_tower_gather.txt 2>&1 < /dev/null
+timeout 300 python tools/pair_bench.py 204800 > $out/pair_bench.txt 2>&1 < /dev/null
+timeout 600 tools/pmc_kernel.sh $tag/pair_pmc linear_bwd_pair -- python3 tools/pair_bench.py 204800 > $out/pair_pmc.txt 2>&1 < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --steps 8 --warmup 3 --eval_steps 0 $PMCARGS > $out/trace.log 2>&1 < /dev/null
+python3 tools/rocprof_timeline.py $out/trace 3 > $out/rocprof_timeline_f32_train.txt 2>&1
+INTEL_PAIR_BWD=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/trace_nopair -- python3 bench.py --steps 8 --warmup 3 --eval_steps 0 $PMCARGS > $out/trace_nopair.log 2>&1 < /dev/null
+python3 tools/rocprof_timeline.py $out/trace_nopair 3 > $out/rocprof_timeline_f32_train_nopair.txt 2>&1
+rm -rf $out/trace $out/trace_nopair
 if [ "$2" != "quick" ]; then
 timeout 600 python bench.py --workload tmall_pub --steps 300 --warmup 30 --no_cpu_baseline > $out/bench_tmall_pub_long.json 2>/dev/null < /dev/null
 timeout 600 python bench.py --workload tmall_pub_mse --loss IntMSEloss --steps 300 --warmup 30 --no_cpu_baseline --no_bf16_line --no_feed > $out/bench_tmall_pub_mse.json 2>/dev/null < /dev/null

@@ -60,7 +60,13 @@ def main():
         res.update({'eval_steps': esteps, 'hbm_GB_per_eval_step': round(eper / 1e9, 3), 'kernels_eval': eout})
     # what was measured: the commit the caller names (INTEL_COMMIT: the GPU box has no .git) and the hash of the kernel sources of the build that ran
     import os
-    res['commit'] = os.environ.get('INTEL_COMMIT', 'unknown')
+    res['commit'] = os.environ.get('INTEL_COMMIT')
+    if not res['commit']:
+        try:
+            import subprocess
+            res['commit'] = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], stdout=subprocess.PIPE, text=True, check=True).stdout.strip()
+        except Exception:
+            res['commit'] = 'unknown'
     try:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
         from intel_sigir2023_amd import build as _b
