@@ -20,9 +20,9 @@ def _line(out):
 
 
 def test_default_line_has_the_contract_fields():
-    # (--cpu_budget: the CPU baseline's bounded sample, 24 s by default, is 6 s here and the four short lines of the other workloads are left out -- the
+    # (--cpu_budget: the CPU baseline's bounded sample, 24 s by default, is 6 s here and the four short lines of the other workloads, the bf16-mode line and the feed measurement are left out -- the
     # line's contract fields are what is checked)
-    r = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2', '--cpu_budget', '6', '--no_workloads'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2', '--cpu_budget', '6', '--no_workloads', '--no_bf16_line', '--no_feed'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
