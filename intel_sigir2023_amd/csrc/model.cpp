@@ -722,7 +722,7 @@ static Tower32Dropout tower32_dropout(const Run& r, int tower) {
 static bool tower_input_in_kernel(const Run& r, const TowerBufs& w) {
   static const int on = [] { const char* e = getenv("INTEL_TOWER_GATHER"); return (e && e[0] == '0') ? 0 : 1; }();
   const IntelDesc& D = r.D;
-  return on && !r.train && D.layers > 0 && !tower32_supported(r.y.L, w.d, D.heads, D.layers, r.train) && tower_fused_supported(r.y.L, w.d, D.heads) &&
+  return on && !r.train && gemm_planes() == 3 && D.layers > 0 && !tower32_supported(r.y.L, w.d, D.heads, D.layers, r.train) && tower_fused_supported(r.y.L, w.d, D.heads) &&
          tower_fused_wanted(0, w.d);
 }
 

@@ -713,9 +713,16 @@ int launch_one(const TowerFwdArgs& a, hipStream_t st) {
   using C = TowerCfg<D, NP>;
   const size_t smem = C::SMEM + (INP == 1 ? 3 * 128 * sizeof(int) : 0);      // INP = 1: three slots of 2 x 64 ids
   static_assert(C::SMEM + 3 * 128 * sizeof(int) <= 160 * 1024, "LDS budget");
-  if (NP == 3 && gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1, INP>(a, st);      // bf16 mode
+  if constexpr (NP == 3 && INP == 0) {
+    if (gemm_planes() == 1) return launch_one<D, DK, TRAIN, 1, 0>(a, st);      // bf16 mode
+  }
   if constexpr (!TRAIN && INP == 0) {      // inference with the input built in the kernel (TowerInput: no X)
-    if (!a.X) return launch_one<D, DK, TRAIN, NP, 1>(a, st);
+    if (!a.X) {
+      // fp32 mode only: the bf16 mode's variants run four waves per SIMD on 128 registers and the gather's addressing spilled 2 - 7 of them
+      if constexpr (NP == 3) return launch_one<D, DK, TRAIN, NP, 1>(a, st);
+      intel_set_error("tower_fwd_fused: the in-kernel input is the fp32 mode's");
+      return -1;
+    }
   }
   allow_lds((tower_fwd_fused_kernel<D, DK, TRAIN, NP, INP>), smem);      // (smem: + the id slots of the in-kernel gather, below)
   // resident workgroups per CU: LDS (160 KB) and wave slots (NW waves each, WAVES_PER_SIMD per SIMD by the launch bounds)
