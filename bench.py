@@ -20,7 +20,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12            # B/s   (MI355X_MICROARCH.md: HBM3E 8 TB/s spec)
 F32_MFMA_PEAK = 157.3e12     # FLOP/s (fp32-input MFMA = fp32 vector peak)
 BF16_MFMA_PEAK = 2.5e15      # FLOP/s dense bf16 MFMA
-B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel', 'linear_bwd_pair_kernel')
+B3_KERNELS = ('gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel', 'linear_bwd_pair_kernel', 'linear_bwd_qkv_kernel')
 FUSED_KERNELS = ('tower_fwd_fused_kernel', 'tower_bwd_fused_kernel')
 MFMA_KERNELS = ('gemm_rows_kernel', 'gemm_rows_w8_kernel', 'gemm_rows_w8k_kernel', 'wgrad_pipe_kernel',
                 'attn_fwd_kernel', 'attn_bwd_dkv_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'attn_bwd_dq_ds_kernel',

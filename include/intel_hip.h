@@ -469,6 +469,14 @@ int intel_op_linear_wgrad(const float* dy, const float* x, int M, int N, int K, 
 size_t intel_op_linear_bwd_workspace_bytes(int M, int d);
 int intel_op_linear_bwd(const float* dy, const float* x, int M, int d, const float* w, int relu_mask, float* dx, float* dw,
                         float* db, void* workspace, size_t workspace_bytes, void* stream);
+/* The backward of a fused q/k/v projection (nb = 3; nb = 2: k/v only) in ONE pass over the rows (d = 64 / 128 with nb = 3, d = 128 with nb = 2; fp32 mode;
+ * csrc/pair.hip): dy [M, nb*d] = [dq | dk | dv], w [nb*d, d] = the nb weights stacked (torch layout [out, in] each), x [M, d] the projection's input,
+ * res [M, d] an optional residual gradient:  dx = dy @ w (+ res),  dw [nb*d, d] = dy^T x,  db [nb*d] = colsum(dy) (db may be NULL)
+ * -- torch autograd of q, k, v = Linear(x) x 3 (modules/layers.py:44-48 under loss.backward()).
+ * workspace: intel_op_linear_bwd_qkv_workspace_bytes(M, d, nb) bytes. */
+size_t intel_op_linear_bwd_qkv_workspace_bytes(int M, int d, int nb);
+int intel_op_linear_bwd_qkv(const float* dy, const float* x, const float* res, int M, int d, int nb, const float* w, float* dx, float* dw,
+                            float* db, void* workspace, size_t workspace_bytes, void* stream);
 /* softmax(QK^T/sqrt(dk)) V per (session, head) on a packed [B*T, 3*d] QKV buffer
  * (modules/layers.py:50-60); key_len NULL = all T rows are keys. */
 int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,

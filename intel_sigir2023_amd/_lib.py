@@ -132,7 +132,7 @@ EXPORTS = [
     'intel_last_error', 'intel_abi_version', 'intel_abi_sizes', 'intel_create', 'intel_destroy', 'intel_set_concurrency', 'intel_set_params_unchanged', 'intel_set_table_stream', 'intel_set_table_wait_event', 'intel_side_stream', 'intel_set_dropout', 'intel_set_iid_grad_row_flags', 'intel_workspace_bytes',
     'intel_forward', 'intel_backward', 'intel_backward_phase', 'intel_bpr_loss', 'intel_bpr_loss_seeded', 'intel_list_loss', 'intel_mse_loss', 'intel_intent_loss',
     'intel_loss_workspace_bytes', 'intel_loss_total', 'intel_adam_step', 'intel_adam_step_pair', 'intel_adam_step_rows', 'intel_ndcg', 'intel_eval_metrics', 'intel_op_linear',
-    'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_linear_bwd', 'intel_op_linear_bwd_workspace_bytes', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
+    'intel_op_linear_dgrad', 'intel_op_linear_wgrad', 'intel_op_linear_bwd', 'intel_op_linear_bwd_workspace_bytes', 'intel_op_linear_bwd_qkv', 'intel_op_linear_bwd_qkv_workspace_bytes', 'intel_op_attention', 'intel_op_attention_bwd', 'intel_op_attention_bwd_workspace_bytes',
     'intel_op_add_layernorm', 'intel_op_workspace_bytes', 'intel_prof_enable', 'intel_prof_collect', 'intel_prof_timeline', 'intel_feed_collate', 'intel_feed_abi_sizes', 'intel_rows_take', 'intel_rows_add', 'intel_rows_compact', 'intel_rows_compact_scratch_ints', 'intel_rows_mark',
     'intel_lazy_table_sizeof', 'intel_adam_lazy_step', 'intel_adam_lazy_catchup', 'intel_adam_lazy_flush', 'intel_set_lazy_table',
 ]
@@ -184,6 +184,8 @@ def _declare(l):
     sig('intel_op_linear_wgrad', i, [vp, vp, i, i, i, vp, vp, vp, sz, vp])
     sig('intel_op_linear_bwd', i, [vp, vp, i, i, vp, i, vp, vp, vp, vp, sz, vp])
     sig('intel_op_linear_bwd_workspace_bytes', sz, [i, i])
+    sig('intel_op_linear_bwd_qkv', i, [vp, vp, vp, i, i, i, vp, vp, vp, vp, vp, sz, vp])
+    sig('intel_op_linear_bwd_qkv_workspace_bytes', sz, [i, i, i])
     sig('intel_op_attention', i, [vp, i, i, i, i, vp, vp, vp, vp])
     sig('intel_op_attention_bwd', i, [vp, vp, vp, vp, i, i, i, i, vp, vp, vp, vp])
     sig('intel_op_attention_bwd_workspace_bytes', sz, [i, i, i, i])

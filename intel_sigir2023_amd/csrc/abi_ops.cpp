@@ -97,6 +97,50 @@ extern "C" int intel_op_linear_bwd(const float* dy, const float* x, int M, int d
   return rc;
 }
 
+// workspace: fp32 packed stacked transposed weights | their three-plane image | reduce arena
+static size_t op_linear_bwd_qkv_parts(int M, int d, int nb, size_t* pk, size_t* img) {
+  *pk = rup_sz(packed_floats(nb * rup(d, 16), d) * sizeof(float), 256);
+  *img = rup_sz(packed_b3_bytes(nb * rup(d, 16), d), 256);
+  return *pk + *img + (linear_bwd_qkv_slab_floats(M, d, nb) + 64) * sizeof(float);
+}
+extern "C" size_t intel_op_linear_bwd_qkv_workspace_bytes(int M, int d, int nb) {
+  size_t pk, img;
+  return op_linear_bwd_qkv_parts(M, d, nb, &pk, &img);
+}
+extern "C" int intel_op_linear_bwd_qkv(const float* dy, const float* x, const float* res, int M, int d, int nb, const float* w, float* dx, float* dw,
+                                       float* db, void* workspace, size_t workspace_bytes, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  INTEL_CHECK_ARG(dy && x && w && dx && workspace, "op_linear_bwd_qkv: null argument");
+  INTEL_CHECK_ARG(linear_bwd_qkv_supported(M, d, nb), "op_linear_bwd_qkv: unsupported shape M=%d d=%d nb=%d (d = 64 / 128 with 3 blocks, 128 with 2; fp32 mode)", M, d, nb);
+  size_t pk, img;
+  INTEL_CHECK_ARG(workspace_bytes >= op_linear_bwd_qkv_parts(M, d, nb, &pk, &img), "op_linear_bwd_qkv: workspace too small");
+  float* Bp = (float*)workspace;
+  void* B3 = (char*)workspace + pk;
+  float* arena = (float*)((char*)workspace + pk + img);
+  const int nt = rup(d, 16) / 16;
+  int rc = 0;
+  for (int c = 0; c < nb && !rc; ++c)      // dx[m][k] = sum_c sum_n dy[m][c*d + n] w[c*d + n][k]: the nb weights stacked along the reduction index
+    rc = launch_pack_b(w + (size_t)c * d * d, d, d, d, 1, Bp, 0, st, c * nt, nb * nt);
+  if (rc) return rc;
+  rc = launch_pack_b3(Bp, nb * rup(d, 16), d, B3, st);
+  if (rc) return rc;
+  rc = pack_b3_flush(st);
+  if (rc) return rc;
+  ReduceQueue* q = redq_create();
+  INTEL_CHECK_ARG(q != nullptr, "op_linear_bwd_qkv: out of memory");
+  redq_reset(q, arena, linear_bwd_qkv_slab_floats(M, d, nb) + 64);
+  float *pw[3], *pb[3];
+  int acc[3] = {0, 0, 0};
+  for (int c = 0; c < nb; ++c) {
+    pw[c] = dw ? dw + (size_t)c * d * d : nullptr;
+    pb[c] = db ? db + (size_t)c * d : nullptr;
+  }
+  rc = launch_linear_bwd_qkv(dy, nb * d, x, d, res, d, M, d, nb, B3, dx, d, pw, db ? pb : nullptr, acc, q, st);
+  if (rc == 0) rc = redq_flush(q, st);
+  redq_destroy(q);
+  return rc;
+}
+
 extern "C" int intel_op_attention(const float* qkv, int B, int T, int d, int heads, const int* key_len, float* out,
                                   float* lse, void* stream) {
   return launch_attn_fwd(qkv, B, T, d, heads, key_len, out, lse, (hipStream_t)stream);

@@ -171,6 +171,14 @@ size_t linear_bwd_pair_slab_floats(int M, int d);      // arena floats one launc
 int launch_linear_bwd_pair(const float* dY, int lddy, const float* X, int ldx, int M, int d, const void* WT_b3, int relu_mask, float* dXout, int ldo,
                            float* dW, float* db, int acc_w, int acc_b, ReduceQueue* q, hipStream_t st);
 
+// the fused q/k/v projection's backward in one pass (pair.hip): dXout[M, d] = dY[M, nb*d] WT (+ res), dW[c][d, d] (+)= dY[:, c*d:(c+1)*d]^T X, db[c] (+)= colsum
+// (nb = 3: [dQ | dK | dV]; nb = 2 at d = 128: the pruned last encoder block's [dK | dV]).  WT_b3: the three-plane image of the stacked transposed weights
+// (k extent nb*d, n extent d: what gemm_rows_b3k takes).  dW / db: nb pointers each (NULL entries = not wanted; db may be NULL); valid after the queue's flush
+bool linear_bwd_qkv_supported(int M, int d, int nb);
+size_t linear_bwd_qkv_slab_floats(int M, int d, int nb);
+int launch_linear_bwd_qkv(const float* dY, int lddy, const float* X, int ldx, const float* res, int ldr, int M, int d, int nb, const void* WT_b3, float* dXout, int ldo,
+                          float* const* dW, float* const* db, const int* acc, ReduceQueue* q, hipStream_t st);
+
 // ---- the whole tied tower at the reference's own 32-wide shapes, one kernel per direction (tower32.hip) ---------------------------
 // d = 32, 1-2 heads, L <= 128, any number of tied layers; raw (unpacked) reference weights W [32, 32], vectors [32].  No activation stash:
 // the backward recomputes the forward from the tower input.  INTEL_TOWER32=0 turns the path off.

@@ -408,6 +408,9 @@ void make_layout(const IntelDesc& D, int B, int L, int H, int Hi, char* base, La
     if (tower_bwd_fused_supported(L, d_i, D.heads)) a += (size_t)D.layers * rup_sz(tower_bwd_slab_floats(B, d_i), 64);      // ... of the one-kernel backward middles (tower_bwd.hip)
     if (tower_bwd_fused_supported(L, d_s, D.heads)) a += (size_t)D.layers * rup_sz(tower_bwd_slab_floats(B, d_s), 64);
     a += (size_t)D.layers * 2 * (rup_sz(linear_bwd_pair_slab_floats(M, d_i), 64) + rup_sz(linear_bwd_pair_slab_floats(M, d_s), 64));      // ... of the one-pass linear backwards (pair.hip)
+    a += (size_t)D.layers * (rup_sz(linear_bwd_qkv_slab_floats(M, d_i, 3), 64) + rup_sz(linear_bwd_qkv_slab_floats(M, d_s, 3), 64));
+    if (D.encoder == INTEL_ENC_BERT4REC)
+      a += (size_t)D.enc_layers * (rup_sz(linear_bwd_qkv_slab_floats(B * H, dm0, 3), 64) + rup_sz(linear_bwd_qkv_slab_floats(B * Hi, dm1, 3), 64));
     if (D.encoder == INTEL_ENC_BERT4REC && D.enc_layers <= 2 && (dm0 == 32 || dm1 == 32)) a += 2 * rup_sz(enc32_slab_floats(B, D.enc_layers), 64);      // ... and encoders
     a += (size_t)cdiv(B, 16) * (rup_sz((size_t)K * y.F + K + (size_t)D.d_int * I + D.d_int + (size_t)d_i * d_i + (size_t)d_s * d_s, 64) + 64 +
                                 rup_sz((size_t)d_i * d_i + (size_t)d_s * d_s + (size_t)(d_i + d_s) * I + (size_t)I * y.Pin + I, 64) + 64 +
@@ -558,6 +561,28 @@ void wgrad_split(Run& r, const float* dY, int lddy, const float* X, int ldx, int
     if (b_slots[p] >= 0) r.acc(b_slots[p]);
   }
   RUN(launch_wgrad(dY, lddy, X, ldx, M, n * Nsub, K, nullptr, K, nullptr, 0, nullptr, r.st, r.ctx->rq, &sp));
+}
+
+// the backward of a fused q/k/v (or k/v) projection in ONE pass where pair.hip covers the shape: dXout = dY WT (+ res), dW[p] / db[p] (+)= ...; returns false
+// when the shape is not covered (the caller then runs wgrad_split + the K > 128 row GEMM)
+bool qkv_bwd_one_pass(Run& r, const float* dY, const float* X, const float* res, int M, int d, int nb, const void* WT_b3, float* dXout, const int* w_slots,
+                      const int* b_slots) {
+  if (gemm_planes() != 3 || !linear_bwd_qkv_supported(M, d, nb)) return false;
+  float *gw[3] = {nullptr, nullptr, nullptr}, *gb[3] = {nullptr, nullptr, nullptr};
+  int ac[3] = {0, 0, 0};
+  bool any_b = false;
+  for (int p = 0; p < nb; ++p) {
+    gw[p] = r.G(w_slots[p]);
+    gb[p] = b_slots[p] >= 0 ? r.G(b_slots[p]) : nullptr;
+    if (!gw[p]) return false;      // (a frozen weight: the separate kernels handle the mixed case)
+    any_b = any_b || gb[p];
+  }
+  for (int p = 0; p < nb; ++p) {
+    ac[p] = r.acc(w_slots[p]);
+    if (b_slots[p] >= 0) r.acc(b_slots[p]);
+  }
+  r.ok(launch_linear_bwd_qkv(dY, nb * d, X, d, res, d, M, d, nb, WT_b3, dXout, d, gw, any_b ? gb : nullptr, ac, r.ctx->rq, r.st));
+  return true;
 }
 
 // ---- weight packing -------------------------------------------------------------------------
@@ -909,16 +934,17 @@ float* tower_bwd(Run& r, TowerBufs& w, float* dX, float* dXalt, bool last_ln_don
     if (r.rc) return nullptr;
     if (!r.ok(launch_attn_bwd(b.QKV, b.A, r.T->dA, b.LSE, B, L, d, D.heads, nullptr, r.T->dQKV, r.T->DSUM, r.st, nullptr, h16))) return nullptr;
     }
-    {
-      const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
+    const int ws[3] = {pb + T_WQ, pb + T_WK, pb + T_WV}, bs[3] = {-1, -1, -1};
+    // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual) and the q/k/v weight gradients: one pass over the rows where pair.hip covers the shape (fp32 mode, widths 64 / 128)
+    if (h16 || !qkv_bwd_one_pass(r, r.T->dQKV, Xin, dZ, M, d, 3, w.b3WqkvT, dXalt, ws, bs)) {
       wgrad_split(r, r.T->dQKV, 3 * d, Xin, d, M, d, d, 3, ws, bs, h16);
+      // A has row stride 3d; the packed k extent is 3*rup(d,16).
+      GemmEpilogue er;
+      er.res = dZ; er.ldres = d;
+      er.b3 = w.b3WqkvT;
+      er.a_bf16 = h16;
+      lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     }
-    // dXin = dQKV @ [Wq;Wk;Wv] + dZ (residual).  A has row stride 3d; the packed k extent is 3*rup(d,16).
-    GemmEpilogue er;
-    er.res = dZ; er.ldres = d;
-    er.b3 = w.b3WqkvT;
-    er.a_bf16 = h16;
-    lin(r, r.T->dQKV, 3 * d, M, 3 * d, w.pWqkvT, d, dXalt, d, er);   // d % 16 == 0 (check_desc)
     if (r.rc) return nullptr;
     if (!r.ok(wgrad_batch_flush(r.st))) return nullptr;      // (dZ, dF1, dQKV and the stashes are still this layer's)
     float* t = dX; dX = dXalt; dXalt = t;
@@ -1134,11 +1160,14 @@ float* bert_bwd_blocks(Run& r, int e) {
       {
         const int ws[2] = {enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
         const int bs[2] = {enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
-        wgrad_split(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, 2, ws, bs);
+        // dE = dKV [Wk;Wv] (d(x_last) joins inside the block kernel) and the k / v weight + bias gradients: one pass where pair.hip covers the shape
+        if (!qkv_bwd_one_pass(r, r.T->dQKV, Xin, nullptr, rows, dm, 2, q.b3WkvT, dX, ws, bs)) {
+          wgrad_split(r, r.T->dQKV, 2 * dm, Xin, dm, rows, dm, dm, 2, ws, bs);
+          GemmEpilogue e0;
+          e0.b3 = q.b3WkvT;
+          lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);
+        }
       }
-      GemmEpilogue e0;
-      e0.b3 = q.b3WkvT;
-      lin(r, r.T->dQKV, 2 * dm, rows, 2 * dm, q.pWkvT, dm, dX, dm, e0);          // dE = dKV [Wk;Wv]; d(x_last) joins inside the block kernel
       if (r.rc) return nullptr;
     }
     for (int l = L - 2; l >= 0; --l) {
@@ -1161,12 +1190,15 @@ float* bert_bwd_blocks(Run& r, int e) {
       {
         const int ws[3] = {enc_blk_slot(e, l, INTEL_ENC_WQ), enc_blk_slot(e, l, INTEL_ENC_WK), enc_blk_slot(e, l, INTEL_ENC_WV)};
         const int bs[3] = {enc_blk_slot(e, l, INTEL_ENC_BQ), enc_blk_slot(e, l, INTEL_ENC_BK), enc_blk_slot(e, l, INTEL_ENC_BV)};
-        wgrad_split(r, r.T->dQKV, 3 * dm, Xin, dm, rows, dm, dm, 3, ws, bs);
+        // (dZ1 = the residual into the block input)
+        if (!qkv_bwd_one_pass(r, r.T->dQKV, Xin, r.T->dA, rows, dm, 3, k.b3WqkvT, dXalt, ws, bs)) {
+          wgrad_split(r, r.T->dQKV, 3 * dm, Xin, dm, rows, dm, dm, 3, ws, bs);
+          GemmEpilogue er;
+          er.res = r.T->dA; er.ldres = dm;
+          er.b3 = k.b3WqkvT;
+          lin(r, r.T->dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);
+        }
       }
-      GemmEpilogue er;
-      er.res = r.T->dA; er.ldres = dm;          // dZ1: the residual into the block input
-      er.b3 = k.b3WqkvT;
-      lin(r, r.T->dQKV, 3 * dm, rows, 3 * dm, k.pWqkvT, dm, dXalt, dm, er);
       if (r.rc) return nullptr;
       float* t = dX; dX = dXalt; dXalt = t;
     }

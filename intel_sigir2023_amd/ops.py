@@ -57,6 +57,22 @@ def linear_bwd(dy, x, w, relu_mask=False, want_bias=True):
     return dx, dw, db
 
 
+def linear_bwd_qkv(dy, x, w, res=None, want_bias=False):
+    """The backward of a fused q/k/v projection in one pass over the rows (csrc/pair.hip): dy [M, nb*d], w [nb*d, d] stacked, x [M, d]:
+    dx = dy @ w (+ res), dw = dy^T x, db = colsum(dy)."""
+    M, n = dy.shape
+    d = x.shape[1]
+    nb = n // d
+    dx = torch.empty(M, d, dtype=torch.float32, device=dy.device)
+    dw = torch.empty(n, d, dtype=torch.float32, device=dy.device)
+    db = torch.empty(n, dtype=torch.float32, device=dy.device) if want_bias else None
+    nbytes = L.lib().intel_op_linear_bwd_qkv_workspace_bytes(M, d, nb)
+    ws = _ws(nbytes, dy.device)
+    L.check(L.lib().intel_op_linear_bwd_qkv(L.ptr(dy), L.ptr(x), L.ptr(res), M, d, nb, L.ptr(w), L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nbytes,
+                                            L.stream_ptr(dy.device)), 'intel_op_linear_bwd_qkv')
+    return dx, dw, db
+
+
 def attention(qkv, B, T, d, heads, key_len=None):
     out = torch.empty(B * T, d, dtype=torch.float32, device=qkv.device)
     lse = torch.empty(B * heads * T, dtype=torch.float32, device=qkv.device)

@@ -37,15 +37,17 @@ def _run(force, idx):
 def test_headline_widths_short_lists(L, B):
     """Tmall-shape widths, lists <= 64, histories <= 32, fp32: the 64-wide score tower's forward as one-kernel layers (tower.hip), the 128-wide item
     tower and both backward passes on the kernel-per-op pipeline (policy: tower_fused_wanted, tower_bwd_fused_wanted -- the one-kernel backward is
-    the bf16 mode's) with each feed-forward linear's data + weight gradient in one pass (pair.hip), fused BERT4Rec blocks, forward chain launches, the pooling with the folded LayerNorm tail, weight gradients / row GEMMs on
+    the bf16 mode's) with each feed-forward linear's and each fused q/k/v projection's data + weight gradient in one pass (pair.hip: no K > 128 row GEMM left), fused BERT4Rec blocks, forward chain launches, the pooling with the folded LayerNorm tail, weight gradients / row GEMMs on
     the bf16 pipe."""
     kt, desc = _run(dict(W64, L=L, B=B, I=30, num_heads=1, num_layers=1, encoder='BERT4Rec', history_max=20, model_num=3, loss='IntBPRloss',
                          cross_attention=1, cal_diversity=0), 9100 + L)
     kt.check(['tower_fwd_fused_kernel', 'attn_seq_fwd_kernel', 'attn_seq_bwd_fused_kernel', 'enc_block_fwd_kernel', 'enc_last_fwd_kernel',
               'enc_block_bwd_kernel', 'enc_last_bwd_kernel', 'chain_kernel', 'xatt_pool_fwd_reg_kernel', 'xatt_pool_ln_bwd_reg_kernel', 'wgrad_b3_kernel',
-              'gemm_rows_b3k_kernel', 'linear_bwd_pair_kernel'],
-             ['attn_fwd_kernel', 'tw32_fwd_kernel', 'enc32_fwd_kernel', 'gru_seq_fwd_kernel', 'tower_bwd_fused_kernel'], desc)
-    assert kt.count['tower_fwd_fused_kernel'] == 1 and kt.count['attn_seq_bwd_fused_kernel'] == 2 and kt.count['linear_bwd_pair_kernel'] == 4, kt.count
+              'linear_bwd_pair_kernel', 'linear_bwd_qkv_kernel'],
+             ['attn_fwd_kernel', 'tw32_fwd_kernel', 'enc32_fwd_kernel', 'gru_seq_fwd_kernel', 'tower_bwd_fused_kernel', 'gemm_rows_b3k_kernel'], desc)
+    # (q/k/v one-pass backward: one per tower + per encoder one for the full block and one for the pruned last block's k/v)
+    assert kt.count['tower_fwd_fused_kernel'] == 1 and kt.count['attn_seq_bwd_fused_kernel'] == 2 and kt.count['linear_bwd_pair_kernel'] == 4 and \
+        kt.count['linear_bwd_qkv_kernel'] == 6, kt.count
 
 
 @pytest.mark.parametrize('B,bwd_chains', [(1000, True), (1100, False)])

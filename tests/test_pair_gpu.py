@@ -63,3 +63,27 @@ def test_linear_bwd_pair_matches_the_separate_kernels_bitwise_in_dx():
     assert float((dx - dx2).abs().max()) <= 2e-6 * float(dx2.abs().max())
     assert float((dw - dw2).abs().max()) <= 2e-5 * float(dw2.abs().max())
     assert float((db - db2).abs().max()) <= 2e-5 * float(db2.abs().max())
+
+
+# the fused q/k/v projection's backward (nb = 3; nb = 2 at d = 128): 32-row tiles at d = 128, 64-row tiles at d = 64 -- one tile, ragged tiles, more tiles than workgroups
+@pytest.mark.parametrize('M,d,nb', [(32, 128, 3), (64, 64, 3), (1, 128, 3), (1, 64, 3), (50, 128, 3), (50, 64, 3), (333, 64, 3), (4099, 128, 3), (20480, 128, 3), (40000, 64, 3),
+                                    (33, 128, 2), (4099, 128, 2), (9000, 128, 2)])
+@pytest.mark.parametrize('with_res,with_bias', [(True, False), (False, True)])
+def test_linear_bwd_qkv(M, d, nb, with_res, with_bias):
+    from intel_sigir2023_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 17 + d + nb)
+    x = torch.randn(M, d, generator=g)
+    w = torch.randn(nb * d, d, generator=g) / d ** 0.5
+    dy = torch.randn(M, nb * d, generator=g)
+    res = torch.randn(M, d, generator=g) if with_res else None
+    with KernelTrace() as kt:
+        dx, dw, db = ops.linear_bwd_qkv(dy.to(dev), x.to(dev), w.to(dev), res=None if res is None else res.to(dev), want_bias=with_bias)
+    kt.check(present=['linear_bwd_qkv_kernel'], absent=['wgrad_b3_kernel', 'gemm_rows_b3k_kernel'])
+    ref = dy.double() @ w.double()
+    if res is not None:
+        ref = ref + res.double()
+    _close(dx, ref, 2e-5, 'dx')
+    _close(dw, dy.double().t() @ x.double(), 5e-5, 'dw')
+    if with_bias:
+        _close(db, dy.double().sum(0), 5e-5, 'db')

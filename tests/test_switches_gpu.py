@@ -24,15 +24,15 @@ BF16 = ['tests/test_bf16_gpu.py', '-k', 'emulating_oracle']      # the bf16 mode
 CASES = [
     # everything on the kernel-per-op pipeline with exact-fp32 MFMA products: fp32-MFMA row GEMMs and weight gradients, general attention (lists /
     # histories > 64) on exact fp32 MFMAs, 32-wide towers / BERT4Rec encoders kernel-per-op instead of the one-kernel forms (tower32.hip), the session head
-    # as one launch per link (chain.hip), separate data / weight gradient kernels instead of the one-pass linear backward (pair.hip), the kernel-per-op
+    # as one launch per link (chain.hip), separate data / weight gradient kernels instead of the one-pass linear / q-k-v backwards (pair.hip), the kernel-per-op
     # encoder backward on the fused forward's stash, packing on the caller's stream, 64 partial slabs per weight gradient
     ({'INTEL_GEMM_B3': '0', 'INTEL_WGRAD_B3': '0', 'INTEL_ATTN_P3': '0', 'INTEL_TOWER32': '0', 'INTEL_ENC32': '0', 'INTEL_HEAD_FUSED': '0', 'INTEL_PAIR_BWD': '0',
       'INTEL_ENC_FUSED_BWD': '0', 'INTEL_PACK_SIDE': '0', 'INTEL_WGRAD_SLABS': '64'}, MODEL, ['wgrad_pipe_kernel', 'attn_fwd_kernel', 'attn_bwd_dkv_kernel'],
      ['gemm_rows_b3_kernel', 'gemm_rows_b3k_kernel', 'wgrad_b3_kernel', 'wgrad_b3_batch_kernel', 'attn_fwd_p3_kernel', 'attn_bwd_dkv_p3_kernel', 'attn_bwd_dq_ds_p3_kernel',
-      'tw32_fwd_kernel', 'tw32_bwd_kernel', 'enc32_fwd_kernel', 'enc32_bwd_kernel', 'chain_kernel', 'linear_bwd_pair_kernel', 'enc_block_bwd_kernel', 'enc_last_bwd_kernel']),
+      'tw32_fwd_kernel', 'tw32_bwd_kernel', 'enc32_fwd_kernel', 'enc32_bwd_kernel', 'chain_kernel', 'linear_bwd_pair_kernel', 'linear_bwd_qkv_kernel', 'enc_block_bwd_kernel', 'enc_last_bwd_kernel']),
     # the default (bf16-pipe) kernels, one switch family at a time where a group above would hide them: the b3 GEMMs with the kernel-per-op 32-wide paths
     ({'INTEL_TOWER32': '0', 'INTEL_ENC32': '0', 'INTEL_HEAD_FUSED': '0', 'INTEL_PAIR_BWD': '0'}, MODEL, ['wgrad_b3_kernel', 'gemm_rows_b3_kernel'],
-     ['tw32_fwd_kernel', 'tw32_bwd_kernel', 'enc32_fwd_kernel', 'enc32_bwd_kernel', 'chain_kernel', 'linear_bwd_pair_kernel']),
+     ['tw32_fwd_kernel', 'tw32_bwd_kernel', 'enc32_fwd_kernel', 'enc32_bwd_kernel', 'chain_kernel', 'linear_bwd_pair_kernel', 'linear_bwd_qkv_kernel']),
     # flash-style general attention for every shape, encoders on the padded [B, H] rows, the whole step on the caller's stream, IntEL.forward through
     # torch.ops.intel_mi355x.intel_forward
     ({'INTEL_ATTN_SEQ': '0', 'INTEL_ENC_FUSED': '0', 'INTEL_PACK_HISTORY': '0', 'INTEL_STREAMS': '0', 'INTEL_MODEL_OP': '1'}, MODEL, ['attn_fwd_kernel'],

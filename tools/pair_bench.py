@@ -59,3 +59,39 @@ for d in (128, 64):
         print('d=%d mask=%d kernels (us):' % (d, mask), kernel_us(lambda: L.check(lib.intel_op_linear_bwd(L.ptr(dy), L.ptr(x), M, d, L.ptr(w), mask, L.ptr(dx), L.ptr(dw), L.ptr(db), L.ptr(ws), nb, st))))
     print('d=%d separate kernels (us):' % d, kernel_us(lambda: (L.check(lib.intel_op_linear_dgrad(L.ptr(dy), M, d, L.ptr(w), d, L.ptr(dx), L.ptr(ws2), nb2, st)),
                                                               L.check(lib.intel_op_linear_wgrad(L.ptr(dy), L.ptr(x), M, d, d, L.ptr(dw), L.ptr(db), L.ptr(ws2), nb2, st)))))
+
+# ---- the fused q/k/v projection's backward (linear_bwd_qkv_kernel) against wgrad_b3 (three column blocks) + gemm_rows_b3k
+for d, nb in ((128, 3), (64, 3)):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(M, d, generator=g).to(dev)
+    dy = torch.randn(M, nb * d, generator=g).to(dev)
+    res = torch.randn(M, d, generator=g).to(dev)
+    w = (torch.randn(nb * d, d, generator=g) / d ** 0.5).to(dev)
+    lib = L.lib()
+    dx = torch.empty(M, d, device=dev); dw = torch.empty(nb * d, d, device=dev)
+    nb_ws = lib.intel_op_linear_bwd_qkv_workspace_bytes(M, d, nb)
+    ws = torch.empty(nb_ws, dtype=torch.uint8, device=dev)
+    nb2 = lib.intel_op_workspace_bytes(M, nb * d, nb * d)
+    ws2 = torch.empty(nb2, dtype=torch.uint8, device=dev)
+    st = L.stream_ptr(dev)
+
+    def kernel_us(fn, n=10):
+        import json
+        lib.intel_prof_collect()
+        lib.intel_prof_enable(1)
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        r = json.loads(lib.intel_prof_collect().decode())
+        lib.intel_prof_enable(0)
+        return {k.split('[')[0].strip('()').split('<')[0]: round(1e3 * v['ms'] / v['launches'], 1) for k, v in r.items()}
+    one = lambda: L.check(lib.intel_op_linear_bwd_qkv(L.ptr(dy), L.ptr(x), L.ptr(res), M, d, nb, L.ptr(w), L.ptr(dx), L.ptr(dw), None, L.ptr(ws), nb_ws, st))
+    for _ in range(3):
+        one()
+    print('qkv d=%d nb=%d one pass (us):' % (d, nb), kernel_us(one))
+    print('qkv d=%d nb=%d one pass (us):' % (d, nb), kernel_us(one))
+    sep = lambda: (L.check(lib.intel_op_linear_dgrad(L.ptr(dy), M, nb * d, L.ptr(w), d, L.ptr(dx), L.ptr(ws2), nb2, st)),
+                   L.check(lib.intel_op_linear_wgrad(L.ptr(dy), L.ptr(x), M, nb * d, d, L.ptr(dw), None, L.ptr(ws2), nb2, st)))
+    for _ in range(3):
+        sep()
+    print('qkv d=%d nb=%d separate kernels (us; the dgrad here is the exact-fp32 K > 128 kernel -- the model uses gemm_rows_b3k with a weight image):' % (d, nb), kernel_us(sep))
