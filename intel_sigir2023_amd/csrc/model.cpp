@@ -456,6 +456,8 @@ bool ensure_streams(IntelCtx* c) {
     // (tried for the encoder / tower branches and dropped: streams restricted to disjoint CU sets with
     // hipExtStreamCreateWithCUMask and a higher stream priority for the encoder branches -- both open extra hardware queues,
     // and more than four active queues cost 1.5-4x)
+    // (round 6, the same three side streams created WITH priorities -- encoder branch high and / or tower branches low, no extra queue: 3.26 ms per
+    // step -> 3.29 - 3.41, every combination loses)
     for (int i = 0; i < 3; ++i) {
       ok = ok && hipStreamCreateWithFlags(&c->side[i], hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) == hipSuccess;

@@ -6,6 +6,8 @@ few rows switch, and a weight-gradient tensor summed over 300 rows moves by seve
 parameter multiplied by (1 + eps * N(0, 1)), eps = the size of the build's own last-bit deviations, its gradients form a CLOUD.  A correct build lies
 inside that cloud (its distance to the nearest member is no larger than the members' distances to each other); a structural error (wrong tile, stale
 operand, dropped term) is O(1) away from every member.
+When the cloud does not contain the build (its members' flips are random; a specific unit a few 1e-4 of its row's scale from zero is not reached by 1e-6
+noise), flip_probe names the flip constructively instead.
 usage (GPU box): python tools/bf16_cloud.py <case index of `fuzz_parity.py N seed --dtype bf16`> [seed = 61616] [members = 24] [eps = 1e-6]"""
 import itertools
 import os
@@ -48,9 +50,62 @@ def cloud_check(model, batch, ref_batch, cfg, loss_name, noise, members=24, eps=
         if ratio > worst:
             worst, wk = ratio, k
     if verbose:
-        for k, a, b, c, r in sorted(rows, key=lambda t: -t[1])[:14]:
+        for k, a, b, c, r in sorted(rows, key=lambda t: -t[1])[:int(os.environ.get("CLOUD_ROWS", "14"))]:
             print('    %-52s to the unperturbed oracle %.3e  to the nearest member %.3e  cloud spread %.3e  (of |g|)  ratio %.2f' % (k, a, b, c, r))
     return worst, wk, rows
+
+
+def flip_probe(model, ref_batch, cfg, loss_name, noise, tries=6, verbose=True):
+    """Names the rounding flip behind an outlier that the parameter-noise cloud does not reach.  One relu unit of one row switching side shows up as ONE
+    element of the first feed-forward linear's bias gradient carrying the whole difference; the oracle's pre-ReLU activations are tapped (its own test
+    hook), the feed-forward block whose bias-gradient difference is the most concentrated gives the unit, the rows where that unit's pre-activation is
+    nearest zero are pushed across the kink one at a time, and the build is re-measured against each flipped oracle over ALL gradient tensors.  A build
+    that is one flip from the oracle lands at cloud-spread distance from one of them.
+    Returns (worst relative distance before, after, (block, layer, row index, unit, pre-activation / its row's largest))."""
+    from oracle import intel_oracle as O
+
+    def grads(nudge):
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+        taps = {'__nudge__': nudge} if nudge else {}
+        O._EMU['on'] = True
+        try:
+            ref = O.forward(sd, ref_batch, cfg, taps=taps)
+        finally:
+            O._EMU['on'] = False
+        rl = O.int_bpr_loss(ref, ref_batch, cfg, noise) if loss_name == 'IntBPRloss' else (O.int_list_loss(ref, ref_batch, cfg) if loss_name == 'IntListloss' else O.int_mse_loss(ref, ref_batch, cfg))
+        rl[0].backward()
+        return {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach() for k, v in sd.items() if v.is_floating_point()}, taps
+    named = {k: (p.grad if p.grad is not None else torch.zeros_like(p)).detach().cpu() for k, p in model.named_parameters()}
+
+    def worst(g):
+        return max((float((named[k] - g[k]).norm()) / float(g[k].norm()), k) for k in named if 'k_linear.bias' not in k and float(g[k].norm()) > 1e-12)
+    g0, taps = grads(None)
+    before = worst(g0)
+    pick = None
+    for key in taps:
+        if key != '__nudge__' and key + '.bias' in named:
+            d = named[key + '.bias'] - g0[key + '.bias']
+            score = float(d.abs().max()) / max(float(g0[key + '.bias'].norm()), 1e-30)      # one element's share of the tensor
+            if pick is None or score > pick[0]:
+                pick = (score, key, int(d.abs().argmax()))
+    _, key, u = pick
+    cands = []
+    for l, pre in enumerate(taps[key]):
+        rows = pre.reshape(-1, pre.shape[-1])
+        rel = rows[:, u].abs() / rows.abs().amax(dim=1).clamp_min(1e-30)
+        cands += [(float(rel[r]), l, r) for r in torch.argsort(rel)[:tries].tolist()]
+    best = (before[0], None)
+    for rel, l, r in sorted(cands)[:tries]:
+        pre = taps[key][l]
+        n = torch.zeros_like(pre).reshape(-1, pre.shape[-1])
+        n[r, u] = -2.0 * float(pre.reshape(-1, pre.shape[-1])[r, u])
+        g, _ = grads({key: {l: n.view_as(pre)}})
+        w = worst(g)
+        if verbose:
+            print('    %s layer %d row %d unit %d (pre-activation %.1e of its row\'s largest) pushed across the kink: worst tensor %.3e -> %.3e of |g| (%s)' % (key, l, r, u, rel, before[0], w[0], w[1]))
+        if w[0] < best[0]:
+            best = (w[0], (key, l, r, u, rel))
+    return before[0], best[0], best[1]
 
 
 def build_case(idx, seed, dev):
@@ -75,4 +130,7 @@ if __name__ == '__main__':
     h = build_case(idx, seed, torch.device('cuda:0'))
     print('case %d: %s; against the emulating oracle alone: %.2f of the sweep bar at %s' % (idx, h['desc'], h['worst'], h['bad']))
     worst, wk, _ = cloud_check(h['model'], h['batch'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], members, eps, verbose=True)
+    if worst > 1.0 and os.environ.get('CLOUD_FLIP', '1') != '0':
+        b, a, which = flip_probe(h['model'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'])
+        print('flip probe: worst tensor %.3e of |g| from the oracle, %.3e from the oracle with %s pushed across the relu kink' % (b, a, which))
     print('cloud check (%d members, eps %.0e): worst ratio %.2f at %s -> %s' % (members, eps, worst, wk, 'inside the cloud' if worst <= 1.0 else 'OUTSIDE'))
