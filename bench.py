@@ -138,7 +138,8 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
     # in the survey container) -- every candidate count runs one warmed B=512 full step, the fastest count is used for all stages
     t_start = time.perf_counter()
     b512 = synth.to_reference_layout(synth.make_batch(workload, 512, cpu, seed=99), cinfo['I'])
-    cand = sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= logical})
+    quick = budget_s < 10.0               # (the GPU suite's contract-field test: one thread count, B = 512 only)
+    cand = [min(16, logical)] if quick else sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= logical})
     sweep = {}
     for c in cand:
         torch.set_num_threads(c)
@@ -149,9 +150,9 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     total = time.perf_counter() - t_start
-    budget_s = max(8.0, budget_s - total)
+    budget_s = max(3.0 if quick else 8.0, budget_s - total)
     stages = {}
-    for B, share, max_n in ((512, 0.5, 40), (4096, 0.5, 6)):
+    for B, share, max_n in (((512, 1.0, 40),) if quick else ((512, 0.5, 40), (4096, 0.5, 6))):
         batch = b512 if B == 512 else synth.to_reference_layout(synth.make_batch(workload, B, cpu, seed=99), cinfo['I'])
         st = {}
         for kind, frac in (('fwd_loss', 0.2), ('fwd_loss_bwd', 0.3), ('full_step', 0.5)):
@@ -166,7 +167,7 @@ def cpu_baseline(args_ns, corpus, cinfo, workload, loss_name, budget_s=20.0):
             'sample': 'oracle/intel_oracle.py on synthetic %s sessions with the fastest torch thread count of the sweep (%d of %d physical '
                       'cores): B=512 and B=4096 per step, each warmed and timed as forward+loss, +autograd backward, full step with torch '
                       'Adam (%d / %d timed full steps), %.1f s of CPU work in total; value = full step at B=512'
-                      % (workload, best, physical, stages['B512']['full_step']['steps'], stages['B4096']['full_step']['steps'], total)}
+                      % (workload, best, physical, stages['B512']['full_step']['steps'], stages['B4096']['full_step']['steps'] if 'B4096' in stages else 0, total)}
 
 
 def pmc_stale(prof_shapes, psteps, pmc_kernels):

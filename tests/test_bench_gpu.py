@@ -20,7 +20,7 @@ def _line(out):
 
 
 def test_default_line_has_the_contract_fields():
-    # (--cpu_budget: the CPU baseline's bounded sample, 24 s by default, is 6 s here and the four short lines of the other workloads, the bf16-mode line and the feed measurement are left out -- the
+    # (--cpu_budget: the CPU baseline's bounded sample, 24 s by default -- thread sweep, B = 512 and B = 4096 -- is 6 s at one thread count and B = 512 here and the four short lines of the other workloads, the bf16-mode line and the feed measurement are left out -- the
     # line's contract fields are what is checked)
     r = subprocess.run([sys.executable, 'bench.py', '--steps', '4', '--warmup', '2', '--cpu_budget', '6', '--no_workloads', '--no_bf16_line', '--no_feed'], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -265,7 +265,8 @@ def test_sweep_case_274_lies_inside_the_oracles_own_cloud():
     rounding boundary fall the other way, two layers later a few relu units of a few of the 325 rows switch), and the build sits 1.3 % from the nearest
     member: it is one more sample of the cloud.  A structural error (wrong tile, stale LDS, dropped term) would be O(1) away from EVERY member.
     Asserted: the oracle's own cloud is wider than the sweep's bar on that tensor (the amplification is real, not a loose bar), and for every gradient
-    tensor the build's distance to the nearest of 24 members is no larger than the cloud's own spread (or the sweep's 5e-2 bar)."""
+    tensor the build's distance to the nearest of 12 members (24 in tools/bf16_cloud.py's own run, the numbers above) is no larger than the cloud's own spread (or the
+    sweep's 5e-2 bar)."""
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location('bf16_cloud', os.path.join(os.path.dirname(__file__), '..', 'tools', 'bf16_cloud.py'))
@@ -273,10 +274,10 @@ def test_sweep_case_274_lies_inside_the_oracles_own_cloud():
     spec.loader.exec_module(cloud)
     h = cloud.build_case(274, 61616, _dev())
     assert h['desc'].startswith('IntListloss B=5 L=65'), h['desc']
-    worst, wk, rows = cloud.cloud_check(h['model'], h['batch'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], members=24, eps=1e-6)
+    worst, wk, rows = cloud.cloud_check(h['model'], h['batch'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], members=12, eps=1e-6)
     by = {k: (d0, dn, sp, ratio) for k, d0, dn, sp, ratio in rows}
     d0, dn, sp, _ = by['s_attn_head.v_linear.weight']
-    print('case 274: s_attn_head.v_linear.weight %.3f of its norm from the unperturbed oracle, %.4f from the nearest of 24 members, cloud spread %.3f; worst ratio %.2f at %s'
+    print('case 274: s_attn_head.v_linear.weight %.3f of its norm from the unperturbed oracle, %.4f from the nearest of 12 members, cloud spread %.3f; worst ratio %.2f at %s'
           % (d0, dn, sp, worst, wk))
     assert worst <= 1.0, (wk, worst)        # every gradient tensor of the build: no farther from its nearest member than the members are from each other
     assert sp > 5e-2                        # the oracle disagrees with itself by more than the sweep's bar on this tensor (CPU-deterministic)
@@ -302,7 +303,7 @@ def test_sweep_case_348_is_one_relu_unit_from_the_oracle():
     spec.loader.exec_module(cloud)
     h = cloud.build_case(348, 62626, _dev())
     assert h['desc'].startswith('IntListloss B=3 L=33'), h['desc']
-    before, after, which = cloud.flip_probe(h['model'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], verbose=False)
+    before, after, which = cloud.flip_probe(h['model'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], tries=2, verbose=False)
     print('case 348: worst gradient tensor %.3e of its norm from the oracle, %.3e from the oracle with %s pushed across the relu kink' % (before, after, which))
     if before <= 5e-2:
         return      # the build's own last bits (float atomics in the embedding scatter) put the unit on the oracle's side this run: nothing to explain

@@ -71,10 +71,13 @@ def test_three_ranks_evaluate_every_session_of_uneven_batches():
     with the shard sizes as weights -- the dev / test numbers equal the single-process run's, which sees the same sessions."""
     assert torch.cuda.is_available()
     with tempfile.TemporaryDirectory() as d:
-        shutil.copytree(os.path.join(HERE, 'golden', 'minidata'), os.path.join(d, 'minidata'))
-        root = d + os.sep
-        mp.spawn(_run, args=(1, _free_port(), root, d, (), '18', '7'), nprocs=1, join=True)
-        mp.spawn(_run, args=(3, _free_port(), root, d, (), '18', '7'), nprocs=3, join=True)
+        for n in (1, 3):
+            shutil.copytree(os.path.join(HERE, 'golden', 'minidata'), os.path.join(d, 'data%d' % n, 'minidata'))
+        # the two runs side by side, each on its own copy of the corpus
+        ctxs = [mp.spawn(_run, args=(n, _free_port(), os.path.join(d, 'data%d' % n) + os.sep, d, (), '18', '7'), nprocs=n, join=False) for n in (1, 3)]
+        for c in ctxs:
+            while not c.join():
+                pass
         one = json.load(open(os.path.join(d, 'w1_r0.json')))
         three = [json.load(open(os.path.join(d, 'w3_r%d.json' % r))) for r in range(3)]
     assert three[0]['dev'] == three[1]['dev'] == three[2]['dev']
