@@ -59,6 +59,7 @@ timeout 600 python tools/ab_bench.py "--steps 100 --warmup 10 --no_roofline" INT
 timeout 600 python tools/ab_bench.py "--steps 40 --warmup 5 --eval_steps 60" INTEL_TOWER_GATHER=1,0,1,0 > $out/ab_tower_gather.txt 2>&1 < /dev/null
 timeout 300 python tools/pair_bench.py 204800 > $out/pair_bench.txt 2>&1 < /dev/null
 timeout 600 tools/pmc_kernel.sh $tag/pair_pmc linear_bwd_pair -- python3 tools/pair_bench.py 204800 > $out/pair_pmc.txt 2>&1 < /dev/null
+timeout 600 tools/pmc_kernel.sh $tag/qkv_pmc linear_bwd_qkv -- python3 tools/pair_bench.py 204800 > $out/qkv_pmc.txt 2>&1 < /dev/null
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/trace -- python3 bench.py --steps 8 --warmup 3 --eval_steps 0 $PMCARGS > $out/trace.log 2>&1 < /dev/null
 python3 tools/rocprof_timeline.py $out/trace 3 > $out/rocprof_timeline_f32_train.txt 2>&1
 INTEL_PAIR_BWD=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $out/trace_nopair -- python3 bench.py --steps 8 --warmup 3 --eval_steps 0 $PMCARGS > $out/trace_nopair.log 2>&1 < /dev/null

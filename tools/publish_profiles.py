@@ -70,7 +70,7 @@ if fl and wl:
 ff, wf = one('fetch_fusedbwd/**/*counter_collection.csv'), one('write_fusedbwd/**/*counter_collection.csv')
 if ff and wf:
     subprocess.run([sys.executable, 'tools/pmc_summary.py', ff, wf, '4', os.path.join(dst, '%s_pmc_traffic_fused_tower_bwd_forced.json' % rnd)], check=True, stdout=subprocess.DEVNULL)
-for name in ('ab_pair_bwd.txt', 'ab_table_after_flush.txt', 'ab_tower_gather.txt', 'pair_bench.txt', 'pair_pmc.txt', 'rocprof_timeline_f32_train.txt', 'rocprof_timeline_f32_train_nopair.txt', 'ab_tower_bwd_bf16.txt', 'ab_tower_bwd_f32.txt', 'ab_defer_table.txt', 'gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_enc32.txt', 'ab_attn_p3_lifedata.txt', 'ab_attn_p3_stress.txt', 'attn_bench_long.txt'):
+for name in ('ab_pair_bwd.txt', 'ab_table_after_flush.txt', 'ab_tower_gather.txt', 'pair_bench.txt', 'pair_pmc.txt', 'qkv_pmc.txt', 'rocprof_timeline_f32_train.txt', 'rocprof_timeline_f32_train_nopair.txt', 'ab_tower_bwd_bf16.txt', 'ab_tower_bwd_f32.txt', 'ab_defer_table.txt', 'gpu_bound_pub.txt', 'gpu_bound_tmall.txt', 'ab_pub.txt', 'ab_mse_enc32.txt', 'ab_attn_p3_lifedata.txt', 'ab_attn_p3_stress.txt', 'attn_bench_long.txt'):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, '%s_%s' % (rnd, name)))
