@@ -185,12 +185,27 @@ def one_case(rng, idx, dev, big=None, force=None, dry=False, trace=None, dtype='
     return worst, bad, desc
 
 
+def explain_bf16(h):
+    """A bf16-mode case over the bar: inside the oracle's own cloud, or one relu unit from the oracle?  Returns the sentence, or None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bf16_cloud', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'bf16_cloud.py'))
+    cloud = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cloud)
+    worst, wk, _ = cloud.cloud_check(h['model'], h['batch'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], members=12, eps=1e-6)
+    if worst <= 1.0:
+        return 'explained: inside the oracle\'s own parameter-noise cloud (12 members, 1e-6; worst ratio %.2f at %s)' % (worst, wk)
+    before, after, which = cloud.flip_probe(h['model'], h['ref_batch'], h['cfg'], h['loss_name'], h['noise'], tries=4, verbose=False)
+    if which is not None and after <= 2e-2 and which[4] < 2e-3:
+        return 'explained: ONE relu unit from the oracle -- %s layer %d row %d unit %d, pre-activation %.1e of its row\'s largest; flipped in the oracle: worst tensor %.3e -> %.3e of |g|' % (which[0], which[1], which[2], which[3], which[4], before, after)
+    return None
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = random.Random(seed)
     dev = torch.device('cuda:0')
-    fails = 0
+    fails = unexplained = 0
     only = None
     dtype = sys.argv[sys.argv.index('--dtype') + 1] if '--dtype' in sys.argv else 'f32'
     if '--only' in sys.argv:      # fuzz_parity.py N seed --only 56,136: the same cases as the full sweep draws, only these are run
@@ -199,8 +214,9 @@ def main():
         if only is not None and i not in only:
             one_case(rng, i, dev, dry=True, dtype=dtype)
             continue
+        hold = {} if dtype == 'bf16' else None
         try:
-            worst, bad, desc = one_case(rng, i, dev, dtype=dtype, force=FORCE)
+            worst, bad, desc = one_case(rng, i, dev, dtype=dtype, force=FORCE, keep=hold)
         except Exception as ex:      # an unsupported shape must fail loudly, not silently
             print('case %d ERROR %s: %s' % (i, type(ex).__name__, str(ex)[:300]))
             fails += 1
@@ -208,7 +224,17 @@ def main():
         ok = worst <= 1.0
         fails += 0 if ok else 1
         print('case %d %s worst=%.2f of tolerance%s  %s' % (i, 'ok  ' if ok else 'FAIL', worst, (' at ' + bad) if bad else '', desc))
-    print('fuzz: %d cases, %d failures' % (n, fails))
+        if not ok and hold:
+            # bf16 mode: a gradient over the structural bar is either a bug or ONE bf16 rounding amplified through relu kinks (tools/bf16_cloud.py) -- decided
+            # right here by the oracle itself: its own parameter-noise cloud, then the constructive one-unit flip
+            try:
+                why = explain_bf16(hold)
+            except Exception as ex:
+                why = None
+                print('    explanation failed: %s: %s' % (type(ex).__name__, str(ex)[:200]))
+            print('    case %d %s' % (i, why or 'UNEXPLAINED by the oracle\'s cloud or a single relu flip'))
+            unexplained += 0 if why else 1
+    print('fuzz: %d cases, %d failures' % (n, fails) + ((', %d of them unexplained' % unexplained) if dtype == 'bf16' else ''))
     sys.exit(1 if fails else 0)
 
 

@@ -44,6 +44,8 @@ if sweep:
 
 def one(pattern):
     fs = glob.glob(os.path.join(src, pattern), recursive=True)
+    if len(fs) > 1:      # rocprofv3 names its files by process id: a second collection merged into the same scratch directory leaves BOTH runs' files side by side
+        raise SystemExit('%d files match %s: stale files of an earlier collection -- rm -rf %s and collect again' % (len(fs), pattern, src))
     return fs[0] if fs else None
 
 
