@@ -16,7 +16,7 @@ for p in ('p1', 'p2', 'p3'):
         d = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
         for r in csv.DictReader(open(f)):
             if pat in r['Kernel_Name']:
-                k = r['Kernel_Name'].split('(')[0][-60:]
+                k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][-60:]
                 e = d[k][r['Counter_Name']]
                 e[0] += 1; e[1] += float(r['Counter_Value'])
         for k, cs in d.items():
