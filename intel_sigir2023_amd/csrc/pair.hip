@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
 // The same idea one size up: the gradient rows are NB * D wide (NB = 3: [dQ | dK | dV]; NB = 2: the pruned last encoder block's [dK | dV]).  The kernel-per-op
 // backward read them twice (wgrad_b3 over three column blocks, re-reading and re-splitting X for each; gemm_rows_b3k for dX) and split them twice.  Here a
 // TR-row tile of dQKV (76.8 KB as three planes at D = 128) and of X sit in LDS ONCE: the data gradient sweeps the 12 k-blocks with the transposed weight's
-// fragments streamed from the pre-split image in L2 one k-block ahead (144 registers of stationary weights do not fit), the weight gradient keeps all NB * D x D
+// fragments streamed from the pre-split image in L2 three k-blocks ahead (144 registers of stationary weights do not fit; ONE block ahead left every MFMA group waiting for its fragment: 426 -> 280 us at D = 128), the weight gradient keeps all NB * D x D
 // accumulators in registers (96 per lane at D = 128: 3 x 8 tiles per wave), the residual rows are requested at the top of the tile.  One LDS stage
 // (104 - 111 KB): the next tile's rows travel in registers under the products, two LDS-only barriers per tile.
 struct QkvArgs {
