@@ -67,6 +67,7 @@ __device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img
       for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) bw[(kb + 1) & 1][c][pl] = img[((size_t)((ct0 + c) * KBT + kb + 1) * 3 + pl) * 64];
+      __builtin_amdgcn_sched_barrier(0);      // (pins the requests here: the scheduler otherwise sinks them behind this block's MFMAs -- no lookahead at all)
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -105,6 +106,7 @@ __device__ __forceinline__ void gemm_planes_pre(const __bf16* frag, const uint4*
   for (int kb = 0; kb < KB; ++kb) {
     if (kb + 1 < KB) load_w<NP, CT>(bw[(kb + 1) & 1], img, ct0, kb + 1);
     if (kb == (KB >= 2 ? KB - 2 : 0)) tail_loads();
+    __builtin_amdgcn_sched_barrier(0);        // (pins the requests here: the scheduler otherwise sinks them behind this block's MFMAs -- no lookahead at all)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const __bf16* fp = frag + rt * 16 * LDP + kb * 32;

@@ -47,6 +47,7 @@ __device__ __forceinline__ void gemm_planes(const __bf16* frag, const uint4* img
         for (int pl = 0; pl < NP; ++pl) bw[(kb + 1) & 1][c][pl] = img[((size_t)((ct0 + c) * KBT + kb + 1) * 3 + pl) * 64];
     }
     if (kb == (KB >= 2 ? KB - 2 : 0)) tail_loads();
+    __builtin_amdgcn_sched_barrier(0);      // (pins the requests here: the scheduler otherwise sinks them behind this block's MFMAs -- no lookahead at all)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       const __bf16* fp = frag + rt * 16 * LDP + kb * 32;

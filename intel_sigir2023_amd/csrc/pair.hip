@@ -148,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_pair_kernel(PairArgs a) {
     // barrier) behind the data gradient's products; (2) the tile after it leaves HBM
     if (!(ABL & 16)) split_tile(t + G);
     if (!(ABL & 8)) load_tile(t + 2 * G);
+    __builtin_amdgcn_sched_barrier(0);      // (pins the requests at the top of the iteration: the scheduler otherwise sinks them behind the products, to the end of the loop body)
     const __bf16* pY = reinterpret_cast<const __bf16*>(smem_raw + (size_t)cur * C::STAGE);
     const __bf16* pX = reinterpret_cast<const __bf16*>(smem_raw + (size_t)cur * C::STAGE + C::IMG);
     // (3a) data gradient: acc[rt] (lane (p, j): row (rt0 + rt) * 16 + p, columns col .. col + 3) = dY[row][:] . W[:][column]; the fragments of
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(512, 2) void linear_bwd_qkv_kernel(QkvArgs a) {
         if (kb + LA < KB) {
 #pragma unroll
           for (int q = 0; q < 3; ++q) bw[kb + LA][q] = img[((kb + LA) * 3 + q) * 64];
+          __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks these requests to one k-block ahead of their use)
         }
         if (kb + 1 < KB) {
 #pragma unroll

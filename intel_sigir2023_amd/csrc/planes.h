@@ -102,9 +102,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // keeps loads of loop-invariant weight images where they are written (streamed from L2) instead of hoisted into registers
+// (the asm makes the pointer's address space unknown to the compiler -- its loads would become FLAT loads, which count on lgkmcnt as well and drag every
+// LDS read into their waits; laundering the address as an INTEGER and casting it to a global-address-space pointer keeps global_load)
+typedef const uint4 __attribute__((address_space(1)))* global_uint4_ptr;
 __device__ __forceinline__ const uint4* launder(const uint4* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+  unsigned long long u = (unsigned long long)p;
+  asm volatile("" : "+s"(u));
+  return (const uint4*)(global_uint4_ptr)u;
 }
 
 // ---- transposing LDS reads (shared by tower_bwd.hip and pair.hip) ----

@@ -60,8 +60,9 @@ __device__ __forceinline__ f32x4 mma6(const bf16x8& wh, const bf16x8& wm, const 
 // loop and keep 240 registers of weights live (spilling everything else).  Laundering the base pointer once per session
 // keeps the loads where they are written: streamed from L2, one k-block ahead of their MFMAs.
 __device__ __forceinline__ const uint4* per_session(const uint4* p) {
-  asm volatile("" : "+s"(p));
-  return p;
+  unsigned long long u = (unsigned long long)p;      // (as an integer, then a global-address-space pointer: global_load, not flat_load -- see planes.h: launder)
+  asm volatile("" : "+s"(u));
+  return (const uint4*)(const uint4 __attribute__((address_space(1)))*)u;
 }
 
 template <int NP, int PLANE>

@@ -130,6 +130,7 @@ __device__ __forceinline__ void lin(const __bf16* pl, const uint4* img, const WF
       for (int q = 0; q < NP; ++q) bw[(kb + 1) & 1][q] = img[((kb + 1) * 3 + q) * 64];
     }
     if (NEXT && WN != KB && kb == KB - 1) wload<NP, WN>(nimg, wn);
+    __builtin_amdgcn_sched_barrier(0);      // (pins the requests here: the scheduler otherwise sinks them behind this block's MFMAs -- no lookahead at all)
     uint4 cw[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) cw[q] = kb < WN ? w0.v[kb < WN ? kb : 0][q] : bw[kb & 1][q];
